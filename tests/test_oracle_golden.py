@@ -1,0 +1,145 @@
+"""Pin the CPU oracle (oracle/) to fixtures produced by running the reference (tools/gen_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import bcqp_oracle as bo
+from oracle import svm_oracle as so
+
+SOLVER_KW = {'pg': {}, 'fw': {}, 'ip': {}, 'as': {}}
+
+
+def _cmp_run(res, g, prefix, rtol=1e-9, atol=1e-12):
+    assert res['status'] == str(g[prefix + '_status'])
+    assert res['iter'] == int(g[prefix + '_iter'])
+    np.testing.assert_allclose(res['f_x'], float(g[prefix + '_f_x']), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(res['x'], g[prefix + '_x'], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(res['f_hist'], g[prefix + '_f_hist'], rtol=rtol, atol=atol)
+    if prefix + '_x_iters' in g.files:
+        for k, xk in zip(g[prefix + '_x_iters'], g[prefix + '_x_at']):
+            if int(k) in res['x_at']:
+                np.testing.assert_allclose(res['x_at'][int(k)], xk, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('tag', ['nd2', 'nd5', 'nd64'])
+@pytest.mark.parametrize('s', ['pg', 'fw', 'as', 'ip'])
+def test_reference_unit_problems(golden, tag, s):
+    g = golden('unit_problems.npz')
+    Q, q, ub, lb = (g[f'{tag}_{k}'] for k in ('Q', 'q', 'ub', 'lb'))
+    keep = range(0, 200)
+    res = bo.SOLVERS[s](Q, q, ub, lb=lb, keep_x=keep)
+    _cmp_run(res, g, f'{tag}_{s}')
+
+
+def test_reference_nd5_known_optimum(golden):
+    # x* and f* of the ndim=5, seed=7, lb=ub/4 problem
+    g = golden('unit_problems.npz')
+    x = bo.active_set(g['nd5_Q'], g['nd5_q'], g['nd5_ub'], lb=g['nd5_lb'])['x']  # AS is exact at its optimum
+    np.testing.assert_allclose(x, [2.076308289374, 2.77991879224, 9.753636925764, 8.950232049078, 2.977989511997],
+                               rtol=1e-9)
+
+
+def test_kernels(golden):
+    g = golden('kernels.npz')
+    X, Y = g['X'], g['Y']
+    tol = dict(rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(so.gram('linear', X), g['linear_XX'], **tol)
+    np.testing.assert_allclose(so.gram('linear', Y, X), g['linear_YX'], **tol)
+    np.testing.assert_allclose(so.gram('poly', X, None, 'scale', 1., 3), g['poly3_scale_c1_XX'], **tol)
+    np.testing.assert_allclose(so.gram('poly', Y, X, 'scale', 1., 3), g['poly3_scale_c1_YX'], **tol)
+    np.testing.assert_allclose(so.gram('poly', X), g['poly3_default_XX'], **tol)
+    np.testing.assert_allclose(so.gram('poly', X, None, 0.5, 2., 2), g['poly2_g05_c2_XX'], **tol)
+    np.testing.assert_allclose(so.gram('rbf', X), g['rbf_scale_XX'], **tol)
+    np.testing.assert_allclose(so.gram('rbf', Y, X), g['rbf_scale_YX'], **tol)
+    np.testing.assert_allclose(so.gram('rbf', X, None, 'auto'), g['rbf_auto_XX'], **tol)
+    np.testing.assert_allclose(so.gram('rbf', X, None, 0.37), g['rbf_g037_XX'], **tol)
+    assert so.resolve_gamma('scale', X) == float(g['gamma_scale_X'])
+    assert so.resolve_gamma('scale', Y) == float(g['gamma_scale_Y'])
+    assert np.all(np.diag(so.gram('rbf', X)) == 1.0)
+
+
+@pytest.mark.parametrize('s,prefix,kw', [
+    ('pg', 'pg', {}), ('fw', 'fw', {}), ('fw', 'fwt', {'t': 0.1}), ('ip', 'ip', {}), ('as', 'as', {'max_iter': 5000})])
+def test_traj_svc(golden, s, prefix, kw):
+    g = golden('traj_svc_rbf_n256.npz')
+    Q, q, ub = so.svc_dual(so.gram('rbf', g['X']), g['y'], float(g['C']))
+    np.testing.assert_allclose(Q, g['Q'], rtol=1e-13, atol=1e-15)
+    res = bo.SOLVERS[s](g['Q'], g['q'], g['ub'], keep_x=range(0, 5001), **kw)
+    _cmp_run(res, g, prefix)
+
+
+@pytest.mark.parametrize('s', ['pg', 'fw', 'ip', 'as'])
+def test_traj_svc_lb_warmstart(golden, s):
+    g = golden('traj_svc_rbf_n256.npz')
+    res = bo.SOLVERS[s](g['Q'], g['q'], g['ub'], lb=g['lbx0_lb'], x0=g['lbx0_x0'], max_iter=3000,
+                        keep_x=(1, 2, 3, 10, 100, 500, 1000))
+    _cmp_run(res, g, 'lbx0_' + s)
+
+
+@pytest.mark.parametrize('s,kw', [('pg', {}), ('fw', {}), ('ip', {})])
+def test_traj_svr(golden, s, kw):
+    g = golden('traj_svr_poly_n128.npz')
+    K = so.gram('poly', g['X'], None, 'scale', 1., 3)
+    Q, q, ub = so.svr_dual(K, g['y'], float(g['C']), float(g['epsilon']))
+    np.testing.assert_allclose(Q, g['Q'], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(q, g['q'], rtol=0, atol=0)
+    res = bo.SOLVERS[s](g['Q'], g['q'], g['ub'], keep_x=range(0, 1001), **kw)
+    _cmp_run(res, g, s)
+
+
+def test_traj_svr_active_set_singular(golden):
+    # the 2n x 2n SVR Hessian is singular: the reference falls into its minres branch (active_set.py:142-151);
+    # the restatement must take the same branch and reproduce the same (non-converged) trajectory
+    g = golden('traj_svr_poly_n128.npz')
+    res = bo.active_set(g['Q'], g['q'], g['ub'], max_iter=300, trace=True)
+    assert any(ev['used_minres'] for ev in res['trace'])
+    np.testing.assert_allclose(res['f_hist'], g['as_f_hist'][:301], rtol=1e-7, atol=1e-9)
+
+
+FIT_SVC = [(n, k, s) for n in (200, 600) for k in ('rbf', 'linear') for s in ('pg', 'fw', 'ip', 'as')
+           if not (k == 'linear' and s == 'as')]
+
+
+@pytest.mark.parametrize('n,kind,s', FIT_SVC)
+def test_fit_svc(golden, n, kind, s):
+    g = golden(f'fit_svc_n{n}.npz')
+    kw = {'max_iter': 5000} if s == 'as' else {}
+    res, post = so.fit_svc(g['X'], g['y'], s, kind=kind, **kw)
+    p = f'{kind}_{s}'
+    assert res['status'] == str(g[p + '_status']) and res['iter'] == int(g[p + '_iter'])
+    np.testing.assert_allclose(res['x'], g[p + '_alphas'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(res['f_hist'], g[p + '_loss_hist'], rtol=1e-9)
+    np.testing.assert_array_equal(post['support'], g[p + '_support'])
+    np.testing.assert_allclose(post['dual_coef'], g[p + '_dual_coef'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(post['intercept'], float(g[p + '_intercept']), rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(so.decision(kind, post, g['Xtest']), g[p + '_decision'], rtol=1e-8, atol=1e-10)
+    if kind == 'linear':
+        np.testing.assert_allclose(post['coef'], g[p + '_coef'], rtol=1e-8, atol=1e-11)
+
+
+FIT_SVR = [(n, k, s) for n in (150, 400) for k in ('poly', 'rbf', 'linear') for s in ('pg', 'fw', 'ip')]
+
+
+@pytest.mark.parametrize('n,kind,s', FIT_SVR)
+def test_fit_svr(golden, n, kind, s):
+    g = golden(f'fit_svr_n{n}.npz')
+    kk = dict(coef0=1., degree=3) if kind == 'poly' else {}
+    res, post = so.fit_svr(g['X'], g['y'], s, kind=kind, epsilon=float(g['epsilon']), **kk)
+    p = f'{kind}_{s}'
+    assert res['status'] == str(g[p + '_status']) and res['iter'] == int(g[p + '_iter'])
+    np.testing.assert_allclose(res['x'], g[p + '_alphas'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_array_equal(post['support'], g[p + '_support'])
+    np.testing.assert_allclose(post['dual_coef'], g[p + '_dual_coef'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(post['intercept'], float(g[p + '_intercept']), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(so.decision(kind, post, g['Xtest'], **kk), g[p + '_decision'], rtol=1e-7, atol=1e-9)
+
+
+def test_cfg5_squared_hinge_active_set(golden):
+    g = golden('cfg5_sqhinge_n300.npz')
+    X, y, C = g['X'], g['y'], float(g['C'])
+    Q, q, _ = so.svc_dual(so.gram('rbf', X), y, C)
+    Q += np.diag(np.ones(len(y)) / (2 * C))
+    ub = np.full(len(y), np.inf)
+    res = bo.active_set(Q, q, ub, x0=g['x0'], max_iter=5000, keep_x=(1, 2, 10, 50, 100))
+    _cmp_run(res, g, 'as')
+    res = bo.projected_gradient(Q, q, ub, x0=g['x0'], max_iter=1000, keep_x=(1, 2, 10, 100))
+    _cmp_run(res, g, 'pg')

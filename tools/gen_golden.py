@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference implementation.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box);
+the committed outputs are plain data: inputs and the reference's outputs on them.
+
+The reference's box-constrained solvers / SVC / SVR need only numpy + scipy + sklearn, but the
+package import chain also pulls `autograd`, `qpsolvers`, `wurlitzer`, `cvxpy`, `casadi`, which are
+not installed here and are never exercised on this path (`Quadratic` overrides jacobian/hessian,
+`x_star()` is not called).  They are satisfied by empty in-memory modules below; `autograd.numpy`
+is a namespace view of the real numpy, so every arithmetic operation is numpy's own.
+Nothing is written to /root/reference and no reference source is copied.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def _install_placeholders():
+    ag = types.ModuleType('autograd')
+    ag.jacobian = lambda f: (lambda *a, **k: (_ for _ in ()).throw(RuntimeError('autograd absent')))
+    ag.hessian = ag.jacobian
+    agn = types.ModuleType('autograd.numpy')
+    agn.__dict__.update({k: v for k, v in np.__dict__.items() if not k.startswith('__')})
+    ag.numpy = agn
+    sys.modules['autograd'] = ag
+    sys.modules['autograd.numpy'] = agn
+
+    def _absent(name):
+        def f(*a, **k):
+            raise RuntimeError(name + ' is not available in this container')
+        return f
+
+    qp = types.ModuleType('qpsolvers')
+    qp.solve_qp = _absent('qpsolvers')
+    sys.modules['qpsolvers'] = qp
+
+    wz = types.ModuleType('wurlitzer')
+    wz.pipes = lambda *a, **k: contextlib.nullcontext()
+    wz.STDOUT = object()
+    sys.modules['wurlitzer'] = wz
+
+    cp = types.ModuleType('cvxpy')
+    for nm in ('Variable', 'Problem', 'Minimize', 'sum_squares', 'sum', 'pos', 'multiply', 'square', 'abs'):
+        setattr(cp, nm, _absent('cvxpy'))
+    cperr = types.ModuleType('cvxpy.error')
+    cperr.SolverError = type('SolverError', (Exception,), {})
+    cperr.DCPError = type('DCPError', (Exception,), {})
+    cp.error = cperr
+    cp.SolverError = cperr.SolverError
+    cp.DCPError = cperr.DCPError
+    sys.modules['cvxpy'] = cp
+    sys.modules['cvxpy.error'] = cperr
+
+    ca = types.ModuleType('casadi')
+    ca.ldl = _absent('casadi')
+    ca.ldl_solve = _absent('casadi')
+    sys.modules['casadi'] = ca
+
+
+_install_placeholders()
+sys.path.insert(0, '/root/reference')
+
+from optiml.opti import Quadratic  # noqa: E402
+from optiml.opti.constrained import ProjectedGradient, FrankWolfe, ActiveSet, InteriorPoint  # noqa: E402
+from optiml.opti.utils import generate_box_constrained_quadratic  # noqa: E402
+from optiml.ml.svm import SVC, SVR  # noqa: E402
+from optiml.ml.svm.kernels import (LinearKernel, PolyKernel, GaussianKernel,  # noqa: E402
+                                   linear, gaussian)
+from optiml.ml.svm.losses import hinge, epsilon_insensitive  # noqa: E402
+
+from optiml_amd.datasets import make_blobs, make_regression  # noqa: E402
+
+SOLVERS = {'pg': ProjectedGradient, 'fw': FrankWolfe, 'as': ActiveSet, 'ip': InteriorPoint}
+
+
+class Recorder:
+    """Callback that snapshots (iter, f_x) every call and x at chosen iteration numbers."""
+
+    def __init__(self, keep_x_at=(), keep_all_x=False):
+        self.keep = set(keep_x_at)
+        self.keep_all = keep_all_x
+        self.f = []
+        self.x = {}
+
+    def __call__(self, opt):
+        self.f.append(float(opt.f_x))
+        if self.keep_all or opt.iter in self.keep:
+            self.x[opt.iter] = np.array(opt.x, dtype=float, copy=True)
+
+
+def run_solver(cls, Q, q, ub, lb=None, x0=None, keep=(), keep_all=False, **kw):
+    rec = Recorder(keep, keep_all)
+    opt = cls(quad=Quadratic(Q, q), ub=ub, lb=lb, x=None if x0 is None else x0.copy(), callback=rec, **kw)
+    opt.minimize()
+    out = {'x': np.array(opt.x, dtype=float), 'f_x': float(opt.f_x), 'iter': int(opt.iter),
+           'status': str(opt.status), 'f_hist': np.array(rec.f)}
+    if rec.x:
+        ks = sorted(rec.x)
+        out['x_iters'] = np.array(ks)
+        out['x_at'] = np.stack([rec.x[k] for k in ks])
+    return out
+
+
+def flat(prefix, d):
+    return {prefix + '_' + k: v for k, v in d.items()}
+
+
+def gen_unit_problems(out):
+    data = {}
+    # optiml/opti/constrained/tests/test_{projected_gradient,frank_wolfe,active_set,interior_point}.py
+    Q, q, ub = generate_box_constrained_quadratic(ndim=2)
+    data.update(nd2_Q=Q, nd2_q=q, nd2_ub=ub, nd2_lb=np.zeros_like(ub))
+    for s, cls in SOLVERS.items():
+        data.update(flat('nd2_' + s, run_solver(cls, Q, q, ub)))
+    # optiml/opti/constrained/tests/test_lower_bound.py
+    Q, q, ub = generate_box_constrained_quadratic(ndim=5, seed=7)
+    lb = ub / 4
+    data.update(nd5_Q=Q, nd5_q=q, nd5_ub=ub, nd5_lb=lb)
+    for s, cls in SOLVERS.items():
+        data.update(flat('nd5_' + s, run_solver(cls, Q, q, ub, lb=lb, keep_all=(s != 'fw'))))
+    # a larger generator instance with a non-trivial active set (same generator, other size/seed)
+    Q, q, ub = generate_box_constrained_quadratic(ndim=64, seed=11)
+    data.update(nd64_Q=Q, nd64_q=q, nd64_ub=ub, nd64_lb=np.zeros_like(ub))
+    for s, cls in SOLVERS.items():
+        data.update(flat('nd64_' + s, run_solver(cls, Q, q, ub, keep=(1, 2, 5, 10, 50, 100))))
+    np.savez_compressed(os.path.join(out, 'unit_problems.npz'), **data)
+
+
+def gen_kernels(out):
+    rs = np.random.RandomState(0)
+    X = 1.7 * rs.standard_normal((64, 8)) + 0.3
+    Y = 0.9 * rs.standard_normal((16, 8)) - 0.2
+    data = {'X': X, 'Y': Y}
+    data['linear_XX'] = linear(X)
+    data['linear_YX'] = linear(Y, X)
+    pk = PolyKernel(degree=3, gamma='scale', coef0=1.)
+    data['poly3_scale_c1_XX'] = pk(X)
+    data['poly3_scale_c1_YX'] = pk(Y, X)
+    data['poly3_default_XX'] = PolyKernel()(X)
+    data['poly2_g05_c2_XX'] = PolyKernel(degree=2, gamma=0.5, coef0=2.)(X)
+    data['rbf_scale_XX'] = gaussian(X)
+    data['rbf_scale_YX'] = gaussian(Y, X)
+    data['rbf_auto_XX'] = GaussianKernel(gamma='auto')(X)
+    data['rbf_g037_XX'] = GaussianKernel(gamma=0.37)(X)
+    data['gamma_scale_X'] = 1. / (X.shape[1] * X.var())
+    data['gamma_scale_Y'] = 1. / (Y.shape[1] * Y.var())
+    # float32 input: the reference (via sklearn's euclidean_distances) up-casts chunk-wise
+    X32 = X.astype(np.float32)
+    data['rbf_scale_XX_f32in'] = np.asarray(gaussian(X32), dtype=np.float64)
+    np.savez_compressed(os.path.join(out, 'kernels.npz'), **data)
+
+
+def gen_trajectories(out):
+    keep = (1, 2, 3, 10, 100, 500, 1000)
+    # --- SVC, RBF, n=256 (dual dim 256) — svm/_base.py:552-559,628-629
+    X, y = make_blobs(256, 16, seed=3)
+    C = 1.0
+    K = gaussian(X)
+    Q = K * np.outer(y, y)
+    Q += np.outer(y, y)
+    q = -np.ones(len(y))
+    ub = np.ones(len(y)) * C
+    data = {'X': X, 'y': y, 'C': C, 'Q': Q, 'q': q, 'ub': ub}
+    data.update(flat('pg', run_solver(ProjectedGradient, Q, q, ub, keep=keep)))
+    data.update(flat('fw', run_solver(FrankWolfe, Q, q, ub, keep=keep)))
+    data.update(flat('fwt', run_solver(FrankWolfe, Q, q, ub, keep=keep, t=0.1)))
+    data.update(flat('ip', run_solver(InteriorPoint, Q, q, ub, keep_all=True)))
+    data.update(flat('as', run_solver(ActiveSet, Q, q, ub, keep_all=True, max_iter=5000)))
+    # warm start + general lb (the ctor's x= and lb= arguments)
+    lb = 0.05 * ub
+    x0 = np.linspace(0.1, 0.9, len(y))
+    for s, cls in SOLVERS.items():
+        data.update(flat('lbx0_' + s, run_solver(cls, Q, q, ub, lb=lb, x0=x0, keep=keep, max_iter=3000)))
+    data['lbx0_lb'] = lb
+    data['lbx0_x0'] = x0
+    np.savez_compressed(os.path.join(out, 'traj_svc_rbf_n256.npz'), **data)
+
+    # --- SVR, poly(3, scale, coef0=1), n=128 (dual dim 256) — svm/_base.py:1096-1104,1178
+    X, y = make_regression(128, 8, seed=5)
+    eps_ins = 0.1
+    K = PolyKernel(degree=3, gamma='scale', coef0=1.)(X)
+    Q = np.vstack((np.hstack((K, -K)), np.hstack((-K, K))))
+    q = np.hstack((-y, y)) + eps_ins
+    ub = np.ones(2 * len(y)) * C
+    e = np.hstack((np.ones(len(y)), -np.ones(len(y))))
+    Q += np.outer(e, e)
+    data = {'X': X, 'y': y, 'C': C, 'epsilon': eps_ins, 'Q': Q, 'q': q, 'ub': ub}
+    data.update(flat('pg', run_solver(ProjectedGradient, Q, q, ub, keep=keep)))
+    data.update(flat('fw', run_solver(FrankWolfe, Q, q, ub, keep=keep)))
+    data.update(flat('ip', run_solver(InteriorPoint, Q, q, ub, keep_all=True)))
+    data.update(flat('as', run_solver(ActiveSet, Q, q, ub, keep_all=True, max_iter=5000)))
+    np.savez_compressed(os.path.join(out, 'traj_svr_poly_n128.npz'), **data)
+
+
+def _fit_record(est, Xtest):
+    opt = est.optimizer
+    rec = {'alphas': np.asarray(est.alphas_, dtype=float), 'support': np.asarray(est.support_),
+           'dual_coef': np.asarray(est.dual_coef_, dtype=float), 'intercept': float(est.intercept_),
+           'iter': int(opt.iter), 'status': str(opt.status), 'f_x': float(opt.f_x),
+           'loss_hist': np.asarray(est.train_loss_history, dtype=float),
+           'decision': np.asarray(est.decision_function(Xtest), dtype=float)}
+    if hasattr(est, 'coef_') and np.size(est.coef_):
+        rec['coef'] = np.asarray(est.coef_, dtype=float)
+    return rec
+
+
+def gen_fits(out):
+    for n, d in ((200, 6), (600, 10)):
+        X, y = make_blobs(n, d, seed=100 + n, sigma=6.0)
+        Xte, _ = make_blobs(32, d, seed=900 + n, sigma=6.0)
+        data = {'X': X, 'y': y, 'Xtest': Xte}
+        for kname, kern in (('rbf', gaussian), ('linear', linear)):
+            for s, cls in SOLVERS.items():
+                if kname == 'linear' and s == 'as' and n > 200:
+                    continue  # singular Q_AA -> minres-on-normal-equations path; kept to the small case
+                mi = 5000 if s == 'as' else 1000
+                est = SVC(loss=hinge, kernel=kern, C=1., reg_intercept=True, dual=True, optimizer=cls, max_iter=mi)
+                est.fit(X, y)
+                data.update(flat(f'{kname}_{s}', _fit_record(est, Xte)))
+                print(f'  svc n={n} {kname} {s}: iter={est.optimizer.iter} status={est.optimizer.status} '
+                      f'f={est.optimizer.f_x:.10f} nsv={len(est.support_)}')
+        np.savez_compressed(os.path.join(out, f'fit_svc_n{n}.npz'), **data)
+
+    for n, d in ((150, 5), (400, 8)):
+        X, y = make_regression(n, d, seed=200 + n)
+        Xte, _ = make_regression(32, d, seed=700 + n)
+        data = {'X': X, 'y': y, 'Xtest': Xte, 'epsilon': 0.1}
+        for kname, kern in (('poly', PolyKernel(degree=3, gamma='scale', coef0=1.)), ('rbf', gaussian),
+                            ('linear', linear)):
+            for s, cls in SOLVERS.items():
+                if kname == 'linear' and s == 'as' and n > 150:
+                    continue
+                mi = 5000 if s == 'as' else 1000
+                est = SVR(loss=epsilon_insensitive, epsilon=0.1, kernel=kern, C=1., reg_intercept=True, dual=True,
+                          optimizer=cls, max_iter=mi)
+                est.fit(X, y)
+                data.update(flat(f'{kname}_{s}', _fit_record(est, Xte)))
+                print(f'  svr n={n} {kname} {s}: iter={est.optimizer.iter} status={est.optimizer.status} '
+                      f'f={est.optimizer.f_x:.10f} nsv={len(est.support_)}')
+        np.savez_compressed(os.path.join(out, f'fit_svr_n{n}.npz'), **data)
+
+
+def gen_cfg5(out):
+    # BASELINE config 5 is not reachable through SVC.fit (svm/_base.py:771-774 raises); SURVEY 8(c) item 6
+    # drives ActiveSet directly on the squared-hinge dual: Q = K*yy' + yy' + I/(2C), q=-1, 0 <= x (ub=+inf).
+    n, d, C = 300, 8, 1.0
+    X, y = make_blobs(n, d, seed=42, sigma=6.0)
+    K = gaussian(X)
+    Q = K * np.outer(y, y)
+    Q += np.outer(y, y)
+    Q += np.diag(np.ones(n) / (2 * C))
+    q = -np.ones(n)
+    ub = np.full(n, np.inf)
+    x0 = np.ones(n)
+    data = {'X': X, 'y': y, 'C': C, 'x0': x0}
+    data.update(flat('as', run_solver(ActiveSet, Q, q, ub, x0=x0, keep=(1, 2, 10, 50, 100), max_iter=5000)))
+    data.update(flat('pg', run_solver(ProjectedGradient, Q, q, ub, x0=x0, keep=(1, 2, 10, 100), max_iter=1000)))
+    np.savez_compressed(os.path.join(out, 'cfg5_sqhinge_n300.npz'), **data)
+    print(f"  cfg5: AS iter={data['as_iter']} status={data['as_status']} f={data['as_f_x']:.10f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for fn in (gen_unit_problems, gen_kernels, gen_trajectories, gen_fits, gen_cfg5):
+        print(fn.__name__)
+        fn(args.out)
+    print('done ->', args.out)
+
+
+if __name__ == '__main__':
+    main()
