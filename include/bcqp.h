@@ -1,0 +1,145 @@
+/*
+ * bcqp.h — C ABI of the MI355X-native box-constrained dual-QP hot path (libbcqp_hip.so).
+ *
+ * The reference (dmeoli/optiml) is pure Python/NumPy and has NO FFI; its "operator API" for this
+ * path is the Python class surface.  Each entry point below replaces the NumPy/SciPy arithmetic of
+ * one reference site (paths relative to the reference checkout); the Python classes in
+ * optiml_amd/ keep the reference's names and ctor arguments and bind these symbols with ctypes
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ *   min 1/2 x'Qx + q'x   s.t.  lb <= x <= ub
+ *
+ * Conventions
+ *   - every function returns an int: 0 = ok, <0 = error class (BQ_ERR_*); the message of the last
+ *     error on the calling thread is returned by bq_last_error().
+ *   - host buffers are BORROWED for the duration of the call, never retained.
+ *   - device memory is owned by the opaque handles and released by the *_destroy functions.
+ *   - a bq_ctx is not thread-safe; every call returns after its HIP stream has been synchronised.
+ *   - all host-visible vectors are fp64.  `storage` selects the dtype of the resident Hessian /
+ *     Gram panel only (fp32 storage still accumulates in fp64).
+ *   - multi-GPU: one process per GPU; rank r owns a contiguous block of rows of the panel, all
+ *     n-vectors are replicated, and each product Q*v is completed by one all-gather of the row
+ *     blocks (RCCL over xGMI, or a caller-supplied exchange callback).
+ */
+#ifndef BCQP_H
+#define BCQP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BQ_OK 0
+#define BQ_ERR_HIP (-1)       /* a HIP runtime call failed */
+#define BQ_ERR_RCCL (-2)      /* RCCL missing or a collective failed */
+#define BQ_ERR_NOT_PD (-3)    /* Cholesky met a non-positive pivot (scipy: LinAlgError) */
+#define BQ_ERR_NONFINITE (-4) /* inf/nan where the reference would raise (e.g. IP with ub=inf) */
+#define BQ_ERR_BADARG (-5)
+#define BQ_ERR_NOMEM (-6)
+
+#define BQ_ABI_VERSION 1
+
+typedef struct bq_ctx bq_ctx;
+typedef struct bq_problem bq_problem;
+typedef struct bq_solver bq_solver;
+
+enum { BQ_F64 = 0, BQ_F32 = 1 };                                    /* panel storage dtype */
+enum { BQ_KERNEL_LINEAR = 0, BQ_KERNEL_POLY = 1, BQ_KERNEL_RBF = 2 };
+enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian structure */
+enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3 };                 /* solver kind */
+enum { BQ_STATUS_UNKNOWN = 0, BQ_STATUS_OPTIMAL = 1, BQ_STATUS_STOPPED = 2 };
+enum { BQ_GET_X = 0, BQ_GET_G = 1, BQ_GET_LP = 2, BQ_GET_LM = 3, BQ_GET_D = 4,
+       BQ_GET_MASK_L = 5, BQ_GET_MASK_U = 6 };
+
+/* One row per evaluation at the top of a solver iteration (what the reference's callback/verbose
+ * line sees).  r1/r2/r3 by solver:  PG: |proj grad|_2, step t, max_t;  FW: best lower bound, gap,
+ * step a;  IP: dual value p, gap, step;  AS: |L|+|U|, event (0 step / 1 release-L / 2 release-U /
+ * 3 optimal) , index or count. */
+typedef struct bq_iter_stat {
+    int64_t iter;
+    double f;
+    double r1, r2, r3;
+} bq_iter_stat;
+
+/* Exchange callback for multi-process runs without RCCL (tests; hosts without xGMI):
+ * on entry buf[r0*..] holds this rank's rows [row_begin,row_end) of an n-vector; on return the whole
+ * vector must be filled with every rank's rows.  Return 0 on success. */
+typedef int (*bq_exchange_fn)(void *user, double *buf, int64_t n, int64_t row_begin, int64_t row_end);
+
+int bq_abi_version(void);
+const char *bq_last_error(void);
+
+/* ---- context -------------------------------------------------------------------------------- */
+int bq_device_count(int *count);
+int bq_ctx_create(int device, bq_ctx **out);
+/* uid: 128-byte RCCL unique id, created on rank 0 by bq_comm_unique_id and broadcast by the caller */
+int bq_comm_unique_id(void *uid128);
+int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_ctx **out);
+int bq_ctx_create_exchange(int device, int rank, int world, bq_exchange_fn fn, void *user, bq_ctx **out);
+int bq_ctx_destroy(bq_ctx *ctx);
+int bq_ctx_info(const bq_ctx *ctx, int *device, int *rank, int *world, char *name, size_t name_cap);
+/* HIP-event timing of the dominant kernels (on the stream they run on).  which: 0 = Q*v panel
+ * product, 1 = Gram build, 2 = Cholesky factorisation, 3 = row-block exchange. */
+int bq_ctx_profile(bq_ctx *ctx, int enable);
+int bq_ctx_profile_read(bq_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
+/* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic) */
+int bq_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end);
+
+/* ---- the quadratic ("Quadratic", optiml/opti/_base.py:228-300) ------------------------------- */
+/* dense Q (n x n row-major fp64) and q: replaces the host copy at optiml/opti/_base.py:243 */
+int bq_problem_create_dense(bq_ctx *ctx, int64_t n, const double *Q, const double *q, int storage,
+                            bq_problem **out);
+/* kernel-structured Hessian built on the device from X (n x d row-major fp64):
+ *   K = kernel(X, X)                        optiml/ml/svm/kernels.py:49-51 / 91-95 / 125-129
+ *   BQ_SVC: Q = K*yy' + yy' (+ diag_add*I), dual dim n     optiml/ml/svm/_base.py:552-555, 628, 729-730
+ *   BQ_SVR: Q = [[K,-K],[-K,K]] + ee', dual dim 2n         optiml/ml/svm/_base.py:1096-1099, 1178
+ *   BQ_PLAIN: Q = K (+ diag_add*I)
+ * gamma must already be resolved ('scale'/'auto' are host-side scalars of X).  q has the dual dim. */
+int bq_problem_create_kernel(bq_ctx *ctx, int structure, int64_t n, int64_t d, const double *X,
+                             const double *y, int kernel, double gamma, double coef0, int degree,
+                             double diag_add, const double *q, int storage, bq_problem **out);
+int bq_problem_destroy(bq_problem *p);
+int bq_problem_dims(const bq_problem *p, int64_t *n_dual, int64_t *n_rows, int64_t *row_begin,
+                    int64_t *row_end);
+/* out = Q v (dual dim; every rank gets the full vector)       optiml/opti/_base.py:291 (minus q) */
+int bq_problem_matvec(bq_problem *p, const double *v, double *out);
+/* f = 1/2 x'Qx + q'x and (optionally, g != NULL) g = Qx + q   optiml/opti/_base.py:282, 291 */
+int bq_problem_eval(bq_problem *p, const double *x, double *f, double *g);
+/* out = K w with the raw Gram panel (kernel problems only; n-vectors)  svm/_base.py:877-880 */
+int bq_problem_gram_matvec(bq_problem *p, const double *w, double *out);
+/* copy rows [row0,row0+nrows) of this rank's resident panel (n columns each) to the host as fp64 */
+int bq_problem_panel_rows(bq_problem *p, int64_t row0, int64_t nrows, double *out);
+/* time `reps` launches of the panel product with HIP events; returns the mean in ms */
+int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms);
+
+/* ---- solvers (optiml/opti/constrained/, the four .py files) --------------------------------------------------- */
+/* lb/ub/x0: dual-dim fp64 host vectors (lb, x0 may be NULL: 0 and mid-box, constrained/_base.py:61-65).
+ * eps: stopping accuracy; max_iter: as the reference; fw_t: FrankWolfe trust radius in [0,1). */
+int bq_solver_create(bq_problem *p, int kind, const double *lb, const double *ub, const double *x0,
+                     double eps, int64_t max_iter, double fw_t, bq_solver **out);
+int bq_solver_destroy(bq_solver *s);
+/* advance by at most max_steps iterations, device-resident; stats receives one row per evaluated
+ * iteration (capacity stats_cap rows, at least max_steps+1).  *status is BQ_STATUS_UNKNOWN while the
+ * solver can continue. */
+int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stats, int64_t stats_cap,
+                  int64_t *n_stats, int *status);
+int bq_solver_state(const bq_solver *s, int64_t *iter, int *status, double *f_x);
+int bq_solver_get(bq_solver *s, int what, double *out);
+
+/* ---- prediction (optiml/ml/svm/_base.py:284-287) ------------------------------- */
+/* out[t] = sum_m coef[m] * kernel(SV[m], Xt[t]) + intercept   (SV: m x d, Xt: t x d, row-major fp64) */
+int bq_decision_function(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m,
+                         int64_t d, const double *SV, const double *coef, double intercept, int64_t t,
+                         const double *Xt, double *out);
+
+/* dense Gram matrix out (m x t, row-major) = kernel(A (m x d), B (t x d)); B == NULL means B is A (t ignored)
+ * — the kernel functors' __call__, optiml/ml/svm/kernels.py:49-51 / 91-95 / 125-129 */
+int bq_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
+                   const double *A, int64_t t, const double *B, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCQP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of libbcqp_hip.so (C ABI declared in include/bcqp.h).
+
+There is no CPU fallback: if the shared library is missing, or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libbcqp_hip.so')
+
+OK = 0
+ERR_HIP, ERR_RCCL, ERR_NOT_PD, ERR_NONFINITE, ERR_BADARG, ERR_NOMEM = -1, -2, -3, -4, -5, -6
+F64, F32 = 0, 1
+KERNEL_LINEAR, KERNEL_POLY, KERNEL_RBF = 0, 1, 2
+PLAIN, SVC, SVR = 0, 1, 2
+PG, FW, AS, IP = 0, 1, 2, 3
+STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
+GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U = range(7)
+PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
+ABI_VERSION = 1
+
+
+class IterStat(C.Structure):
+    _fields_ = [('iter', C.c_int64), ('f', C.c_double), ('r1', C.c_double), ('r2', C.c_double), ('r3', C.c_double)]
+
+
+STAT_DTYPE = np.dtype([('iter', np.int64), ('f', np.float64), ('r1', np.float64), ('r2', np.float64),
+                       ('r3', np.float64)])
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_int64)
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); every symbol include/bcqp.h declares
+PROTOTYPES = {
+    'bq_abi_version': (C.c_int, []),
+    'bq_last_error': (C.c_char_p, []),
+    'bq_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'bq_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    'bq_comm_unique_id': (C.c_int, [_vp]),
+    'bq_ctx_create_rccl': (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    'bq_ctx_create_exchange': (C.c_int, [C.c_int, C.c_int, C.c_int, EXCHANGE_FN, _vp, C.POINTER(_vp)]),
+    'bq_ctx_destroy': (C.c_int, [_vp]),
+    'bq_ctx_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    'bq_ctx_profile': (C.c_int, [_vp, C.c_int]),
+    'bq_ctx_profile_read': (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i64), C.c_int]),
+    'bq_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    'bq_problem_create_dense': (C.c_int, [_vp, _i64, _dp, _dp, C.c_int, C.POINTER(_vp)]),
+    'bq_problem_create_kernel': (C.c_int, [_vp, C.c_int, _i64, _i64, _dp, _dp, C.c_int, C.c_double, C.c_double,
+                                           C.c_int, C.c_double, _dp, C.c_int, C.POINTER(_vp)]),
+    'bq_problem_destroy': (C.c_int, [_vp]),
+    'bq_problem_dims': (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'bq_problem_matvec': (C.c_int, [_vp, _dp, _dp]),
+    'bq_problem_eval': (C.c_int, [_vp, _dp, _dp, _dp]),
+    'bq_problem_gram_matvec': (C.c_int, [_vp, _dp, _dp]),
+    'bq_problem_panel_rows': (C.c_int, [_vp, _i64, _i64, _dp]),
+    'bq_problem_time_matvec': (C.c_int, [_vp, C.c_int, _dp]),
+    'bq_solver_create': (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.c_double, _i64, C.c_double, C.POINTER(_vp)]),
+    'bq_solver_destroy': (C.c_int, [_vp]),
+    'bq_solver_run': (C.c_int, [_vp, _i64, C.POINTER(IterStat), _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    'bq_solver_state': (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), _dp]),
+    'bq_solver_get': (C.c_int, [_vp, C.c_int, _dp]),
+    'bq_decision_function': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _dp,
+                                       C.c_double, _i64, _dp, _dp]),
+    'bq_gram_matrix': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _i64, _dp, _dp]),
+}
+
+
+class BcqpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f'libbcqp_hip error {code}: {message}')
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build the HIP library first (python -m optiml_amd.build, needs hipcc). '
+            'optiml_amd has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale: also loud
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bq_abi_version() != ABI_VERSION:
+        raise RuntimeError('libbcqp_hip.so ABI version mismatch: rebuild it')
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().bq_last_error()
+        raise BcqpError(rc, msg.decode('utf-8', 'replace') if msg else '?')
+
+
+def as_f64(a, n=None, name='array'):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.size != n:
+        raise ValueError(f'{name} has {a.size} elements, expected {n}')
+    return a
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)

@@ -1,0 +1,78 @@
+"""Build libbcqp_hip.so (the HIP/C-ABI library) in-tree with hipcc for gfx950.
+
+    python -m optiml_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so is written to optiml_amd/lib/ so that it travels with
+the source snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+OBJDIR = os.path.join(HERE, 'lib', 'obj')
+LIBNAME = 'libbcqp_hip.so'
+ARCH = 'gfx950'
+
+CXXFLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-ffp-contract=on', '-Wall',
+            '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hs.append(os.path.join(os.path.dirname(HERE), 'include', 'bcqp.h'))
+    return hs
+
+
+def lib_path():
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, obj):
+    cmd = ['hipcc', '-x', 'hip', '-c', src, '-o', obj] + CXXFLAGS
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+    return r.stderr
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    objs = []
+    for src in _sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src) + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for (src, _), warn in zip(jobs, ex.map(lambda a: _compile(*a), jobs)):
+                if verbose and warn.strip():
+                    print(warn, file=sys.stderr)
+    target = lib_path()
+    if jobs or _stale(target, objs):
+        cmd = ['hipcc', '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', target] + objs + ['-ldl']
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return target
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

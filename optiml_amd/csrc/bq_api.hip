@@ -1,0 +1,663 @@
+// C-ABI entry points (include/bcqp.h): contexts, the device-resident quadratic, solver drivers.
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+
+#include "bq_common.h"
+
+static thread_local std::string g_last_error;
+
+void bq_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char *bq_last_error(void) { return g_last_error.c_str(); }
+extern "C" int bq_abi_version(void) { return BQ_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int bq_device_count(int *count) {
+    BQ_ARG(count != nullptr, "count is NULL");
+    BQ_HIP(hipGetDeviceCount(count));
+    return BQ_OK;
+}
+
+static int ctx_new(int device, bq_ctx **out) {
+    BQ_ARG(out != nullptr, "out is NULL");
+    int ndev = 0;
+    BQ_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        bq_set_error("device %d out of range (%d visible)", device, ndev);
+        return BQ_ERR_BADARG;
+    }
+    BQ_HIP(hipSetDevice(device));
+    bq_ctx *c = new bq_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    BQ_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    BQ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_create(int device, bq_ctx **out) { return ctx_new(device, out); }
+
+int bq_comm_init_rccl(bq_ctx *ctx, const void *uid128);  // bq_comm.cpp
+void bq_comm_destroy(bq_ctx *ctx);
+
+extern "C" int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_ctx **out) {
+    BQ_ARG(world >= 1 && rank >= 0 && rank < world, "rank/world");
+    BQ_ARG(uid128 != nullptr, "uid is NULL");
+    bq_ctx *c = nullptr;
+    BQ_TRY(ctx_new(device, &c));
+    c->rank = rank;
+    c->world = world;
+    int rc = bq_comm_init_rccl(c, uid128);
+    if (rc != BQ_OK) {
+        bq_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_create_exchange(int device, int rank, int world, bq_exchange_fn fn, void *user, bq_ctx **out) {
+    BQ_ARG(world >= 1 && rank >= 0 && rank < world, "rank/world");
+    BQ_ARG(fn != nullptr || world == 1, "exchange callback is NULL");
+    bq_ctx *c = nullptr;
+    BQ_TRY(ctx_new(device, &c));
+    c->rank = rank;
+    c->world = world;
+    c->comm_kind = world > 1 ? BQ_COMM_CALLBACK : BQ_COMM_NONE;
+    c->exch_fn = fn;
+    c->exch_user = user;
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_destroy(bq_ctx *c) {
+    if (c == nullptr) return BQ_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    bq_comm_destroy(c);
+    for (auto &slot : c->prof)
+        for (auto &pr : slot.pending) {
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_info(const bq_ctx *c, int *device, int *rank, int *world, char *name, size_t cap) {
+    BQ_ARG(c != nullptr, "ctx is NULL");
+    if (device) *device = c->device;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (name && cap) snprintf(name, cap, "%s", c->name);
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_profile(bq_ctx *c, int enable) {
+    BQ_ARG(c != nullptr, "ctx is NULL");
+    c->profiling = enable != 0;
+    return BQ_OK;
+}
+
+int bq_prof_begin(bq_ctx *c, int which, hipEvent_t *e0, hipEvent_t *e1) {
+    *e0 = *e1 = nullptr;
+    if (!c->profiling) return BQ_OK;
+    for (hipEvent_t *e : {e0, e1}) {
+        if (!c->event_pool.empty()) {
+            *e = c->event_pool.back();
+            c->event_pool.pop_back();
+        } else {
+            BQ_HIP(hipEventCreate(e));
+        }
+    }
+    BQ_HIP(hipEventRecord(*e0, c->stream));
+    (void)which;
+    return BQ_OK;
+}
+
+int bq_prof_end(bq_ctx *c, int which, hipEvent_t e0, hipEvent_t e1) {
+    if (e0 == nullptr) return BQ_OK;
+    BQ_HIP(hipEventRecord(e1, c->stream));
+    c->prof[which].pending.emplace_back(e0, e1);
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_profile_read(bq_ctx *c, int which, double *total_ms, int64_t *launches, int reset) {
+    BQ_ARG(c != nullptr && which >= 0 && which < BQ_PROF_COUNT, "ctx/which");
+    BQ_HIP(hipStreamSynchronize(c->stream));
+    bq_prof_slot &s = c->prof[which];
+    for (auto &pr : s.pending) {
+        float ms = 0.f;
+        BQ_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        s.total_ms += ms;
+        s.launches += 1;
+        c->event_pool.push_back(pr.first);
+        c->event_pool.push_back(pr.second);
+    }
+    s.pending.clear();
+    if (total_ms) *total_ms = s.total_ms;
+    if (launches) *launches = s.launches;
+    if (reset) {
+        s.total_ms = 0.0;
+        s.launches = 0;
+    }
+    return BQ_OK;
+}
+
+static int64_t row_block_size(int64_t n, int world) {
+    const int64_t per = (n + world - 1) / world;
+    return bq_round_up(per > 0 ? per : 1, 128);  // tile-aligned for the Gram kernel
+}
+
+extern "C" int bq_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end) {
+    BQ_ARG(n >= 0 && world >= 1 && rank >= 0 && rank < world, "n/rank/world");
+    const int64_t blk = row_block_size(n, world);
+    int64_t b = (int64_t)rank * blk;
+    if (b > n) b = n;
+    int64_t e = b + blk;
+    if (e > n) e = n;
+    if (begin) *begin = b;
+    if (end) *end = e;
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the quadratic
+// ---------------------------------------------------------------------------------------------
+__global__ void f64_to_f32_rows_kernel(const double *__restrict__ src, int64_t rows, int64_t n, float *__restrict__ dst,
+                                       int64_t ld) {
+    const int64_t r = blockIdx.y;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        dst[r * ld + j] = (float)src[r * n + j];
+    (void)rows;
+}
+
+static int problem_alloc_common(bq_problem *p, const double *q_host) {
+    bq_ctx *c = p->ctx;
+    const int64_t nblk = p->ldN / BQ_VEC_TILE;
+    BQ_HIP(hipMalloc(&p->q, sizeof(double) * p->ldN));
+    BQ_HIP(hipMemsetAsync(p->q, 0, sizeof(double) * p->ldN, c->stream));
+    BQ_HIP(hipMemcpyAsync(p->q, q_host, sizeof(double) * p->N, hipMemcpyHostToDevice, c->stream));
+    BQ_HIP(hipMalloc(&p->w, sizeof(double) * p->ld));
+    BQ_HIP(hipMemsetAsync(p->w, 0, sizeof(double) * p->ld, c->stream));
+    const int64_t slen = bq_round_up(p->blk * c->world, BQ_PAD);
+    BQ_HIP(hipMalloc(&p->s, sizeof(double) * slen));
+    BQ_HIP(hipMemsetAsync(p->s, 0, sizeof(double) * slen, c->stream));
+    BQ_HIP(hipMalloc(&p->va, sizeof(double) * p->ldN));
+    BQ_HIP(hipMalloc(&p->vb, sizeof(double) * p->ldN));
+    BQ_HIP(hipMemsetAsync(p->va, 0, sizeof(double) * p->ldN, c->stream));
+    BQ_HIP(hipMemsetAsync(p->vb, 0, sizeof(double) * p->ldN, c->stream));
+    BQ_HIP(hipMalloc(&p->partials, sizeof(double) * BQ_MAX_PARTIAL_Q * nblk));
+    BQ_HIP(hipMalloc(&p->scal, sizeof(double) * 16));
+    return BQ_OK;
+}
+
+static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
+    bq_ctx *c = p->ctx;
+    p->n = n;
+    p->N = N;
+    p->ld = bq_round_up(n, BQ_PAD);
+    p->ldN = bq_round_up(N, BQ_PAD);
+    p->blk = row_block_size(n, c->world);
+    BQ_TRY(bq_row_block(n, c->rank, c->world, &p->r0, &p->r1));
+    const size_t esz = p->storage == BQ_F64 ? 8 : 4;
+    const int64_t rows = p->r1 - p->r0;
+    const size_t bytes = (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld * esz;
+    hipError_t e = hipMalloc(&p->panel, bytes);
+    if (e != hipSuccess) {
+        bq_set_error("cannot allocate the %lld x %lld panel (%.1f GB): %s", (long long)rows, (long long)p->ld,
+                     bytes / 1e9, hipGetErrorString(e));
+        return BQ_ERR_NOMEM;
+    }
+    BQ_HIP(hipMemsetAsync(p->panel, 0, bytes, c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_destroy(bq_problem *p) {
+    if (p == nullptr) return BQ_OK;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    for (void *ptr : {(void *)p->panel, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
+                      (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal})
+        if (ptr) hipFree(ptr);
+    delete p;
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, const double *q, int storage,
+                                       bq_problem **out) {
+    BQ_ARG(c && Q && q && out, "NULL argument");
+    BQ_ARG(n >= 2, "Q is too small");  // optiml/opti/_base.py:249-250
+    BQ_ARG(storage == BQ_F64 || storage == BQ_F32, "storage");
+    BQ_HIP(hipSetDevice(c->device));
+    bq_problem *p = new bq_problem();
+    p->ctx = c;
+    p->structure = BQ_PLAIN;
+    p->storage = storage;
+    int rc = problem_layout(p, n, n);
+    if (rc == BQ_OK) rc = problem_alloc_common(p, q);
+    if (rc != BQ_OK) {
+        bq_problem_destroy(p);
+        return rc;
+    }
+    const int64_t rows = p->r1 - p->r0;
+    if (rows > 0) {
+        if (storage == BQ_F64) {
+            hipError_t e = hipMemcpy2DAsync(p->panel, p->ld * 8, Q + p->r0 * n, n * 8, n * 8, rows,
+                                            hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) {
+                bq_set_error("panel upload failed: %s", hipGetErrorString(e));
+                bq_problem_destroy(p);
+                return BQ_ERR_HIP;
+            }
+        } else {
+            const int64_t chunk = std::max<int64_t>(1, (int64_t)(256ll << 20) / (n * 8));
+            double *tmp = nullptr;
+            hipError_t e = hipMalloc(&tmp, sizeof(double) * chunk * n);
+            for (int64_t r = 0; e == hipSuccess && r < rows; r += chunk) {
+                const int64_t cr = std::min(chunk, rows - r);
+                e = hipMemcpyAsync(tmp, Q + (p->r0 + r) * n, sizeof(double) * cr * n, hipMemcpyHostToDevice, c->stream);
+                if (e != hipSuccess) break;
+                dim3 grid((unsigned)std::min<int64_t>((n + 255) / 256, 1024), (unsigned)cr);
+                f64_to_f32_rows_kernel<<<grid, 256, 0, c->stream>>>(tmp, cr, n, (float *)p->panel + r * p->ld, p->ld);
+                e = hipStreamSynchronize(c->stream);
+            }
+            if (tmp) hipFree(tmp);
+            if (e != hipSuccess) {
+                bq_set_error("panel upload failed: %s", hipGetErrorString(e));
+                bq_problem_destroy(p);
+                return BQ_ERR_HIP;
+            }
+        }
+    }
+    BQ_HIP(hipStreamSynchronize(c->stream));
+    *out = p;
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int64_t d, const double *X,
+                                        const double *y, int kernel, double gamma, double coef0, int degree,
+                                        double diag_add, const double *q, int storage, bq_problem **out) {
+    BQ_ARG(c && X && q && out, "NULL argument");
+    BQ_ARG(structure == BQ_PLAIN || structure == BQ_SVC || structure == BQ_SVR, "structure");
+    BQ_ARG(structure != BQ_SVC || y != nullptr, "labels required for BQ_SVC");
+    BQ_ARG(kernel == BQ_KERNEL_LINEAR || kernel == BQ_KERNEL_POLY || kernel == BQ_KERNEL_RBF, "kernel");
+    BQ_ARG(n >= 2 && d >= 1, "n/d");
+    BQ_ARG(storage == BQ_F64 || storage == BQ_F32, "storage");
+    BQ_ARG(kernel != BQ_KERNEL_POLY || degree > 0, "degree must be > 0");
+    BQ_HIP(hipSetDevice(c->device));
+    bq_problem *p = new bq_problem();
+    p->ctx = c;
+    p->structure = structure;
+    p->storage = storage;
+    p->kernel = kernel;
+    p->add_one = structure != BQ_PLAIN;
+    p->gamma = gamma;
+    p->coef0 = coef0;
+    p->degree = degree;
+    p->diag_add = diag_add;
+    p->d = d;
+    int rc = problem_layout(p, n, structure == BQ_SVR ? 2 * n : n);
+    if (rc == BQ_OK) rc = problem_alloc_common(p, q);
+    if (rc != BQ_OK) {
+        bq_problem_destroy(p);
+        return rc;
+    }
+    auto fail = [&](hipError_t e) {
+        bq_set_error("kernel problem setup failed: %s", hipGetErrorString(e));
+        bq_problem_destroy(p);
+        return BQ_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&p->X, sizeof(double) * n * d)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(p->X, X, sizeof(double) * n * d, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e);
+    if (structure == BQ_SVC) {
+        if ((e = hipMalloc(&p->sgn, sizeof(double) * p->ld)) != hipSuccess) return fail(e);
+        if ((e = hipMemsetAsync(p->sgn, 0, sizeof(double) * p->ld, c->stream)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(p->sgn, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e);
+    }
+    rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld);
+    if (rc != BQ_OK) {
+        bq_problem_destroy(p);
+        return rc;
+    }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail(e);
+    *out = p;
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_dims(const bq_problem *p, int64_t *n_dual, int64_t *n_rows, int64_t *rb, int64_t *re) {
+    BQ_ARG(p != nullptr, "problem is NULL");
+    if (n_dual) *n_dual = p->N;
+    if (n_rows) *n_rows = p->n;
+    if (rb) *rb = p->r0;
+    if (re) *re = p->r1;
+    return BQ_OK;
+}
+
+static int upload_padded(bq_problem *p, const double *host, double *dev, int64_t len, int64_t padded) {
+    BQ_HIP(hipMemsetAsync(dev, 0, sizeof(double) * padded, p->ctx->stream));
+    BQ_HIP(hipMemcpyAsync(dev, host, sizeof(double) * len, hipMemcpyHostToDevice, p->ctx->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_matvec(bq_problem *p, const double *v, double *out) {
+    BQ_ARG(p && v && out, "NULL argument");
+    BQ_HIP(hipSetDevice(p->ctx->device));
+    BQ_TRY(upload_padded(p, v, p->va, p->N, p->ldN));
+    BQ_TRY(bq_problem_apply(p, p->va, p->vb, nullptr));
+    BQ_HIP(hipMemcpyAsync(out, p->vb, sizeof(double) * p->N, hipMemcpyDeviceToHost, p->ctx->stream));
+    BQ_HIP(hipStreamSynchronize(p->ctx->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_eval(bq_problem *p, const double *x, double *f, double *g) {
+    BQ_ARG(p && x && f, "NULL argument");
+    BQ_HIP(hipSetDevice(p->ctx->device));
+    BQ_TRY(upload_padded(p, x, p->va, p->N, p->ldN));
+    BQ_TRY(bq_problem_apply(p, p->va, p->vb, nullptr));
+    BQ_TRY(bq_vec_eval_f(p, p->va, p->vb, g ? p->vb : nullptr, p->scal));
+    BQ_HIP(hipMemcpyAsync(f, p->scal, sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
+    if (g) BQ_HIP(hipMemcpyAsync(g, p->vb, sizeof(double) * p->N, hipMemcpyDeviceToHost, p->ctx->stream));
+    BQ_HIP(hipStreamSynchronize(p->ctx->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_gram_matvec(bq_problem *p, const double *w, double *out) {
+    BQ_ARG(p && w && out, "NULL argument");
+    BQ_ARG(p->kernel >= 0, "not a kernel-structured problem");
+    bq_ctx *c = p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    BQ_HIP(hipMemsetAsync(p->w, 0, sizeof(double) * p->ld, c->stream));
+    BQ_HIP(hipMemcpyAsync(p->w, w, sizeof(double) * p->n, hipMemcpyHostToDevice, c->stream));
+    BQ_TRY(bq_launch_gemv(c, p->panel, p->storage, false, p->r1 - p->r0, p->ld, p->w, p->s + p->r0, nullptr));
+    if (c->world > 1) BQ_TRY(bq_exchange_rows(c, p->s, p->n, p->blk, p->r0, p->r1));
+    BQ_HIP(hipMemcpyAsync(out, p->s, sizeof(double) * p->n, hipMemcpyDeviceToHost, c->stream));
+    BQ_HIP(hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_panel_rows(bq_problem *p, int64_t row0, int64_t nrows, double *out) {
+    BQ_ARG(p && out, "NULL argument");
+    BQ_ARG(row0 >= p->r0 && row0 + nrows <= p->r1 && nrows >= 0, "rows outside this rank's block");
+    bq_ctx *c = p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    if (nrows == 0) return BQ_OK;
+    const int64_t lr = row0 - p->r0;
+    if (p->storage == BQ_F64) {
+        BQ_HIP(hipMemcpy2DAsync(out, p->n * 8, (const double *)p->panel + lr * p->ld, p->ld * 8, p->n * 8, nrows,
+                                hipMemcpyDeviceToHost, c->stream));
+        BQ_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        std::vector<float> tmp((size_t)nrows * p->n);
+        BQ_HIP(hipMemcpy2DAsync(tmp.data(), p->n * 4, (const float *)p->panel + lr * p->ld, p->ld * 4, p->n * 4, nrows,
+                                hipMemcpyDeviceToHost, c->stream));
+        BQ_HIP(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms) {
+    BQ_ARG(p && mean_ms && reps > 0, "argument");
+    bq_ctx *c = p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    BQ_HIP(hipEventCreate(&e0));
+    BQ_HIP(hipEventCreate(&e1));
+    const bool prof = c->profiling;
+    c->profiling = false;
+    int rc = bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w, p->s + p->r0, nullptr);  // warm
+    hipEventRecord(e0, c->stream);
+    for (int i = 0; rc == BQ_OK && i < reps; ++i)
+        rc = bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w, p->s + p->r0, nullptr);
+    hipEventRecord(e1, c->stream);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    c->profiling = prof;
+    BQ_TRY(rc);
+    BQ_HIP(e);
+    *mean_ms = (double)ms / reps;
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// solvers
+// ---------------------------------------------------------------------------------------------
+static int alloc_vec(bq_solver *s, double **v) {
+    BQ_HIP(hipMalloc(v, sizeof(double) * s->ldN));
+    BQ_HIP(hipMemsetAsync(*v, 0, sizeof(double) * s->ldN, s->p->ctx->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_destroy(bq_solver *s) {
+    if (s == nullptr) return BQ_OK;
+    hipSetDevice(s->p->ctx->device);
+    hipStreamSynchronize(s->p->ctx->stream);
+    for (void *ptr : {(void *)s->x, (void *)s->g, (void *)s->d, (void *)s->Qd, (void *)s->lb, (void *)s->ub,
+                      (void *)s->lp, (void *)s->lm, (void *)s->rhs, (void *)s->hd, (void *)s->dlp, (void *)s->dlm,
+                      (void *)s->mL, (void *)s->mU, (void *)s->partials, (void *)s->sc, (void *)s->stats})
+        if (ptr) hipFree(ptr);
+    if (s->chol) bq_chol_ws_destroy(s->chol);
+    if (s->as_ws) free(s->as_ws);
+    delete s;
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const double *ub, const double *x0,
+                                double eps, int64_t max_iter, double fw_t, bq_solver **out) {
+    BQ_ARG(p && ub && out, "NULL argument");
+    BQ_ARG(kind == BQ_PG || kind == BQ_FW || kind == BQ_AS || kind == BQ_IP, "solver kind");
+    BQ_ARG(max_iter > 0, "max_iter must be > 0");             // optiml/opti/_base.py:73-74
+    BQ_ARG(fw_t >= 0.0 && fw_t < 1.0, "t has to lie in [0, 1)");  // frank_wolfe.py:84-85
+    if ((kind == BQ_IP || kind == BQ_AS) && p->ctx->world > 1) {
+        bq_set_error("InteriorPoint/ActiveSet factorise the whole Hessian: use a single-rank context (replicas only)");
+        return BQ_ERR_BADARG;
+    }
+    bq_ctx *c = p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    bq_solver *s = new bq_solver();
+    s->p = p;
+    s->kind = kind;
+    s->N = p->N;
+    s->ldN = p->ldN;
+    s->nblk = p->ldN / BQ_VEC_TILE;
+    int rc = BQ_OK;
+    for (double **v : {&s->x, &s->g, &s->d, &s->Qd, &s->lb, &s->ub})
+        if (rc == BQ_OK) rc = alloc_vec(s, v);
+    if (rc == BQ_OK && kind == BQ_IP)
+        for (double **v : {&s->lp, &s->lm, &s->rhs, &s->hd, &s->dlp, &s->dlm})
+            if (rc == BQ_OK) rc = alloc_vec(s, v);
+    if (rc != BQ_OK) {
+        bq_solver_destroy(s);
+        return rc;
+    }
+    std::vector<double> h((size_t)s->N);
+    auto up = [&](double *dev, const double *src) {
+        return hipMemcpyAsync(dev, src, sizeof(double) * s->N, hipMemcpyHostToDevice, c->stream);
+    };
+    hipError_t e = up(s->ub, ub);
+    if (e == hipSuccess && lb) e = up(s->lb, lb);
+    if (e == hipSuccess) {
+        if (x0) {
+            e = up(s->x, x0);
+        } else {
+            for (int64_t i = 0; i < s->N; ++i) h[i] = ((lb ? lb[i] : 0.0) + ub[i]) / 2;  // constrained/_base.py:65
+            e = up(s->x, h.data());
+        }
+    }
+    if (e == hipSuccess) e = hipMalloc(&s->partials, sizeof(double) * BQ_MAX_PARTIAL_Q * s->nblk);
+    if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_scal));
+    if (e == hipSuccess) {
+        memset(&s->host, 0, sizeof(bq_scal));
+        s->host.max_iter = max_iter;
+        s->host.eps = eps;
+        s->host.fw_t = fw_t;
+        s->host.status = BQ_STATUS_UNKNOWN;
+        s->host.best_lb = -INFINITY;
+        s->host.f = NAN;
+        e = hipMemcpyAsync(s->sc, &s->host, sizeof(bq_scal), hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        bq_set_error("solver setup failed: %s", hipGetErrorString(e));
+        bq_solver_destroy(s);
+        return BQ_ERR_HIP;
+    }
+    if (kind == BQ_IP || kind == BQ_AS) {
+        rc = bq_chol_ws_create(c, s->N, &s->chol);
+        if (rc != BQ_OK) {
+            bq_solver_destroy(s);
+            return rc;
+        }
+    }
+    *out = s;
+    return BQ_OK;
+}
+
+static int solver_first(bq_solver *s) {
+    switch (s->kind) {
+        case BQ_PG:
+        case BQ_FW:
+            return bq_pgfw_start(s);
+        case BQ_IP:
+            return bq_ip_start(s);
+        default:
+            return bq_as_start(s);
+    }
+}
+
+static int solver_iterate(bq_solver *s) {
+    switch (s->kind) {
+        case BQ_PG:
+        case BQ_FW:
+            return bq_pgfw_iterate(s);
+        case BQ_IP:
+            return bq_ip_iterate(s);
+        default:
+            return bq_as_iterate(s);
+    }
+}
+
+extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stats, int64_t stats_cap, int64_t *n_stats,
+                             int *status) {
+    BQ_ARG(s && n_stats && status, "NULL argument");
+    BQ_ARG(max_steps > 0, "max_steps must be > 0");
+    BQ_ARG(stats == nullptr || stats_cap >= max_steps, "stats capacity must be >= max_steps");
+    bq_ctx *c = s->p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    *n_stats = 0;
+    *status = s->host.status;
+    if (s->host.done) return BQ_OK;
+    if (s->stats_cap < max_steps) {
+        if (s->stats) BQ_HIP(hipFree(s->stats));
+        s->stats = nullptr;
+        BQ_HIP(hipMalloc(&s->stats, sizeof(bq_iter_stat) * max_steps));
+        s->stats_cap = max_steps;
+    }
+    const long long base = s->host.iter;
+    long long hdr[2] = {base, (long long)max_steps};
+    BQ_HIP(hipMemcpyAsync(&s->sc->stat_base, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
+    if (!s->initialised) {
+        BQ_TRY(solver_first(s));
+        s->initialised = true;
+    }
+    const int64_t poll = s->N >= 16384 ? 1 : 8;
+    for (int64_t k = 0; k < max_steps; ++k) {
+        BQ_TRY(solver_iterate(s));
+        if ((k + 1) % poll == 0 && k + 1 < max_steps) {
+            BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));
+            BQ_HIP(hipStreamSynchronize(c->stream));
+            if (s->host.done) break;
+        }
+    }
+    BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));
+    BQ_HIP(hipStreamSynchronize(c->stream));
+    if (s->host.status < 0) {  // a kernel flagged a numerical failure (codes mirror BQ_ERR_*)
+        bq_set_error(s->host.status == BQ_ERR_NOT_PD ? "Cholesky met a non-positive pivot"
+                                                     : "non-finite values in the solver state");
+        return s->host.status;
+    }
+    int64_t rows = s->host.iter - base + (s->host.done ? 1 : 0);
+    if (rows > max_steps) rows = max_steps;
+    if (rows < 0) rows = 0;
+    if (stats && rows > 0) {
+        BQ_HIP(hipMemcpyAsync(stats, s->stats, sizeof(bq_iter_stat) * rows, hipMemcpyDeviceToHost, c->stream));
+        BQ_HIP(hipStreamSynchronize(c->stream));
+    }
+    *n_stats = rows;
+    *status = s->host.status;
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_state(const bq_solver *s, int64_t *iter, int *status, double *f_x) {
+    BQ_ARG(s != nullptr, "solver is NULL");
+    if (iter) *iter = s->host.iter;
+    if (status) *status = s->host.status;
+    if (f_x) *f_x = s->host.f;
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_get(bq_solver *s, int what, double *out) {
+    BQ_ARG(s && out, "NULL argument");
+    bq_ctx *c = s->p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    const double *src = nullptr;
+    switch (what) {
+        case BQ_GET_X: src = s->x; break;
+        case BQ_GET_G: src = s->g; break;
+        case BQ_GET_D: src = s->d; break;
+        case BQ_GET_LP: src = s->lp; break;
+        case BQ_GET_LM: src = s->lm; break;
+        default: break;
+    }
+    if (what == BQ_GET_MASK_L || what == BQ_GET_MASK_U) {
+        const unsigned char *m = what == BQ_GET_MASK_L ? s->mL : s->mU;
+        BQ_ARG(m != nullptr, "masks exist for ActiveSet only");
+        std::vector<unsigned char> tmp((size_t)s->N);
+        BQ_HIP(hipMemcpyAsync(tmp.data(), m, (size_t)s->N, hipMemcpyDeviceToHost, c->stream));
+        BQ_HIP(hipStreamSynchronize(c->stream));
+        for (int64_t i = 0; i < s->N; ++i) out[i] = tmp[i] ? 1.0 : 0.0;
+        return BQ_OK;
+    }
+    BQ_ARG(src != nullptr, "vector not available for this solver");
+    BQ_HIP(hipMemcpyAsync(out, src, sizeof(double) * s->N, hipMemcpyDeviceToHost, c->stream));
+    BQ_HIP(hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}
+
+extern "C" int bq_decision_function(bq_ctx *c, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
+                                    const double *SV, const double *coef, double intercept, int64_t t,
+                                    const double *Xt, double *out) {
+    BQ_ARG(c && SV && coef && Xt && out, "NULL argument");
+    BQ_ARG(m >= 1 && d >= 1 && t >= 1, "m/d/t");
+    BQ_HIP(hipSetDevice(c->device));
+    return bq_launch_decision(c, kernel, gamma, coef0, degree, m, d, SV, coef, intercept, t, Xt, out);
+}
+
+extern "C" int bq_gram_matrix(bq_ctx *c, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
+                              const double *A, int64_t t, const double *B, double *out) {
+    BQ_ARG(c && A && out, "NULL argument");
+    BQ_ARG(m >= 1 && d >= 1 && (B == nullptr || t >= 1), "m/d/t");
+    BQ_HIP(hipSetDevice(c->device));
+    return bq_launch_gram_matrix(c, kernel, gamma, coef0, degree, m, d, A, t, B, out);
+}

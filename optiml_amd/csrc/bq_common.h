@@ -1,0 +1,172 @@
+// Internal declarations shared by the HIP translation units of libbcqp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bcqp.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+void bq_set_error(const char *fmt, ...);
+
+#define BQ_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            bq_set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return BQ_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define BQ_TRY(expr)              \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != BQ_OK) return _rc; \
+    } while (0)
+
+#define BQ_ARG(cond, msg)                 \
+    do {                                  \
+        if (!(cond)) {                    \
+            bq_set_error("bad argument: %s", msg); \
+            return BQ_ERR_BADARG;         \
+        }                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// layout constants
+// ---------------------------------------------------------------------------------------------
+// Every device vector and every panel row is padded to a multiple of BQ_PAD elements and the pad is
+// kept at zero, so the streaming kernels never need a column tail.
+constexpr int64_t BQ_PAD = 1024;
+constexpr int BQ_VEC_BLOCK = 256;                 // threads per block in the O(n) kernels
+constexpr int BQ_VEC_ITEMS = 4;                   // elements per thread
+constexpr int BQ_VEC_TILE = BQ_VEC_BLOCK * BQ_VEC_ITEMS;  // 1024 elements per block == BQ_PAD
+constexpr int BQ_MAX_PARTIAL_Q = 8;               // reduced quantities per kernel
+
+static inline int64_t bq_round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
+
+enum { BQ_PROF_MATVEC = 0, BQ_PROF_GRAM = 1, BQ_PROF_CHOL = 2, BQ_PROF_EXCH = 3, BQ_PROF_COUNT = 4 };
+enum { BQ_COMM_NONE = 0, BQ_COMM_RCCL = 1, BQ_COMM_CALLBACK = 2 };
+
+struct bq_prof_slot {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct bq_ctx {
+    int device = 0, rank = 0, world = 1;
+    int num_cu = 256;
+    char name[128] = {0};
+    hipStream_t stream = nullptr;
+    int comm_kind = BQ_COMM_NONE;
+    void *nccl_comm = nullptr;
+    bq_exchange_fn exch_fn = nullptr;
+    void *exch_user = nullptr;
+    double *pinned = nullptr;  // host staging for the callback exchange
+    size_t pinned_cap = 0;
+    bool profiling = false;
+    bq_prof_slot prof[BQ_PROF_COUNT];
+    std::vector<hipEvent_t> event_pool;
+};
+
+struct bq_problem {
+    bq_ctx *ctx = nullptr;
+    int structure = BQ_PLAIN, storage = BQ_F64, kernel = -1;
+    bool add_one = false;  // panel holds K and the Hessian entry is +-(K+1)
+    int64_t n = 0;         // panel columns (= samples for kernel problems)
+    int64_t N = 0;         // dual dimension (n, or 2n for BQ_SVR)
+    int64_t ld = 0;        // padded leading dimension of the panel (elements)
+    int64_t ldN = 0;       // padded length of dual-dim vectors
+    int64_t r0 = 0, r1 = 0, blk = 0;  // my rows [r0,r1) and the per-rank block size
+    void *panel = nullptr;
+    double *q = nullptr;    // ldN
+    double *sgn = nullptr;  // ld (labels, BQ_SVC) or null
+    double *X = nullptr;    // n x d (kernel problems)
+    int64_t d = 0;
+    double gamma = 0, coef0 = 0, diag_add = 0;
+    int degree = 0;
+    double *w = nullptr;   // ld: panel-product input
+    double *s = nullptr;   // world*blk (>= n): panel-product output, gathered
+    double *va = nullptr, *vb = nullptr;  // ldN scratch for the host-vector entry points
+    double *partials = nullptr;           // BQ_MAX_PARTIAL_Q * nblocks(ldN)
+    double *scal = nullptr;               // a few device scalars for the host-vector entry points
+};
+
+// device-resident scalar state of a solver; one instance per solver, read back in one copy
+struct bq_scal {
+    long long iter, max_iter, stat_base, stat_cap;
+    int status, done, fw_clip, pad0;
+    double eps, fw_t;
+    double f, ng, gd, max_t, den, t;          // PG / FW
+    double low, best_lb, gap;                  // FW
+    double p, mu, xr, step;                    // IP
+    double aux[8];
+};
+
+struct bq_chol_ws;
+
+struct bq_solver {
+    bq_problem *p = nullptr;
+    int kind = BQ_PG;
+    int64_t N = 0, ldN = 0, nblk = 0;
+    double *x = nullptr, *g = nullptr, *d = nullptr, *Qd = nullptr, *lb = nullptr, *ub = nullptr;
+    double *lp = nullptr, *lm = nullptr, *rhs = nullptr, *hd = nullptr, *dlp = nullptr, *dlm = nullptr;  // IP
+    unsigned char *mL = nullptr, *mU = nullptr;                                                         // AS
+    double *partials = nullptr;
+    bq_scal *sc = nullptr;
+    bq_iter_stat *stats = nullptr;
+    int64_t stats_cap = 0;
+    bq_scal host;  // mirror after the last run
+    bool initialised = false;  // the one-time start-up product has run
+    bool started = false;      // an evaluation has run, so a pending step may exist
+    bq_chol_ws *chol = nullptr;
+    void *as_ws = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// cross-file launchers (each defined next to its kernels)
+// ---------------------------------------------------------------------------------------------
+// bq_ctx.cpp / bq_api.hip
+int bq_prof_begin(bq_ctx *ctx, int which, hipEvent_t *e0, hipEvent_t *e1);
+int bq_prof_end(bq_ctx *ctx, int which, hipEvent_t e0, hipEvent_t e1);
+int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0, int64_t r1);
+
+// bq_gemv.hip: s[r0 + i] = sum_j elem(panel[i][j]) * w[j], i in [0, nrows)
+int bq_launch_gemv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nrows, int64_t ld,
+                   const double *w, double *s_rows, const int *done_flag);
+
+// bq_gram.hip: panel rows [r0,r1) of kernel(X, X) (n x n), written in `storage` dtype with row pitch ld
+int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r0, int64_t r1, int kernel,
+                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld);
+// rectangular cross-Gram fused with a coefficient contraction (decision function)
+int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
+                       const double *SV, const double *coef, double intercept, int64_t t, const double *Xt,
+                       double *out);
+
+int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
+                          const double *A, int64_t t, const double *B, double *out);
+
+// bq_vec.hip
+int bq_vec_prep(bq_problem *p, const double *v, const int *done_flag);                  // v (ldN) -> p->w (ld)
+int bq_vec_finish(bq_problem *p, const double *v, double *out, const int *done_flag);   // p->s (+v) -> out (ldN)
+int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *done_flag);  // out = Q v, all ranks
+int bq_vec_eval_f(bq_problem *p, const double *x, const double *Qx, double *g_out, double *f_dev);
+
+int bq_solver_alloc_common(bq_solver *s);
+int bq_pgfw_start(bq_solver *s);
+int bq_pgfw_iterate(bq_solver *s);
+int bq_ip_start(bq_solver *s);
+int bq_ip_iterate(bq_solver *s);
+int bq_as_start(bq_solver *s);
+int bq_as_iterate(bq_solver *s);
+
+// bq_chol.hip
+int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out);
+void bq_chol_ws_destroy(bq_chol_ws *ws);

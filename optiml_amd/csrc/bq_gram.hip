@@ -1,0 +1,351 @@
+// Gram-panel build on fp64 matrix cores: K[r0:r1, :] = kernel(X[r0:r1], X)   (one-time, MFMA-bound).
+//
+// Replaces optiml/ml/svm/kernels.py:49-51 (linear), :91-95 (poly), :125-129 (gaussian; the squared
+// distances follow sklearn's euclidean_distances formula -2xy' + |x|^2 + |y|^2, clamped at 0, zero diagonal
+// when both arguments are the same matrix).
+//
+// Data flow: X (n x d, row-major) is transposed once into a k-major, zero-padded image Xt[dp][np] so that a
+// 128-row tile of one k-slice is 1 KiB contiguous: global loads are coalesced 16-byte loads and the LDS image
+// [k][row] needs no transposition.  One 256-thread workgroup (4 waves, 2x2) owns a 128x128 output tile; each
+// wave accumulates a 64x64 block as 4x4 v_mfma_f64_16x16x4_f64 tiles (128 accumulator VGPRs), stepping K in
+// chunks of 16 through double-buffered LDS (row pitch 144 doubles: the four k-slices a wave reads in one
+// ds_read_b64 land on disjoint bank halves).  The kernel epilogue applies the RBF / polynomial map and
+// stores in the panel's storage dtype.
+#include "bq_common.h"
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GT = 128;        // output tile edge
+constexpr int GK = 16;         // k-chunk
+constexpr int GP = GT + 16;    // LDS row pitch in doubles
+
+__global__ void transpose_pad_kernel(const double *__restrict__ X, int64_t n, int64_t d, double *__restrict__ Xt,
+                                     int64_t np, int64_t dp) {
+    __shared__ double tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int64_t r = r0 + j, k = k0 + tx;
+        tile[j][tx] = (r < n && k < d) ? X[r * d + k] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int64_t k = k0 + j, r = r0 + tx;
+        if (k < dp && r < np) Xt[k * np + r] = tile[tx][j];
+    }
+}
+
+__global__ void row_norms_kernel(const double *__restrict__ X, int64_t n, int64_t d, double *__restrict__ out,
+                                 int64_t np) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    double s = 0.0;
+    if (i < n) {
+        const double *row = X + i * d;
+        for (int64_t k = 0; k < d; ++k) s = fma(row[k], row[k], s);
+    }
+    out[i] = s;
+}
+
+template <typename T> __device__ __forceinline__ void store_elem(T *p, double v);
+template <> __device__ __forceinline__ void store_elem<double>(double *p, double v) { *p = v; }
+template <> __device__ __forceinline__ void store_elem<float>(float *p, double v) { *p = (float)v; }
+
+struct gram_params {
+    const double *At, *Bt;   // k-major padded images: At[dp][mp], Bt[dp][np]
+    const double *a2, *b2;   // squared row norms (padded)
+    int64_t m, n;            // valid rows of A / rows of B (output is m_rows x n)
+    int64_t mp, np, dp;
+    int64_t arow0;           // first A row this launch covers (global index), rows [arow0, arow1)
+    int64_t arow1;
+    int64_t brow_off;        // global index of B row 0 (for the same-matrix diagonal test)
+    int same;                // A and B are the same matrix -> exact zero distance on the diagonal
+    int kernel, degree;
+    double gamma, coef0;
+    int64_t ld;              // output pitch (elements)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double As[2][GK][GP];
+    __shared__ __attribute__((aligned(16))) double Bs[2][GK][GP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;  // wave position in the 2x2 arrangement
+    // tiles of the same A-row block are adjacent in blockIdx -> they share the A slice in L2
+    const int64_t tiles_n = (P.n + GT - 1) / GT;
+    const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int64_t arow = P.arow0 + tm * GT;  // global A row of tile row 0
+    const int64_t bcol = tn * GT;
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    // staging map: 16 k-slices x 64 double2 per tile = 1024 double2, 4 per thread
+    d2_t ra[4], rb[4];
+    auto gload = [&](int64_t kc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tid + 256 * u;
+            const int k = j >> 6, c2 = j & 63;
+            ra[u] = *reinterpret_cast<const d2_t *>(P.At + (kc + k) * P.mp + arow + 2 * c2);
+            rb[u] = *reinterpret_cast<const d2_t *>(P.Bt + (kc + k) * P.np + bcol + 2 * c2);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tid + 256 * u;
+            const int k = j >> 6, c2 = j & 63;
+            *reinterpret_cast<d2_t *>(&As[buf][k][2 * c2]) = ra[u];
+            *reinterpret_cast<d2_t *>(&Bs[buf][k][2 * c2]) = rb[u];
+        }
+    };
+
+    const int64_t nchunks = P.dp / GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < nchunks) gload((c + 1) * GK);
+#pragma unroll
+        for (int kk = 0; kk < GK / 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = As[buf][kk * 4 + fk][wr * 64 + t * 16 + fr];
+                b[t] = Bs[buf][kk * 4 + fk][wc * 64 + t * 16 + fr];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) {
+            lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const int ccol = lane & 15, crow = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;  // global A row
+            if (gi >= P.arow1) continue;
+            const double ai = P.a2[gi];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
+                if (gj >= P.n) continue;
+                const double dot = acc[i][j][v];
+                double kv;
+                if (P.kernel == BQ_KERNEL_RBF) {
+                    double dist = -2.0 * dot;
+                    dist += ai;
+                    dist += P.b2[gj];
+                    dist = fmax(dist, 0.0);
+                    if (P.same && gi == gj + P.brow_off) dist = 0.0;
+                    kv = exp(-P.gamma * dist);
+                } else if (P.kernel == BQ_KERNEL_POLY) {
+                    const double base = P.gamma * dot + P.coef0;
+                    kv = pow(base, (double)P.degree);
+                } else {
+                    kv = dot;
+                }
+                store_elem<T>(out + (gi - P.arow0) * P.ld + gj, kv);
+            }
+        }
+    }
+}
+
+struct gram_images {
+    double *At = nullptr, *a2 = nullptr;
+    int64_t mp = 0, dp = 0;
+};
+
+static int make_image(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, gram_images *img) {
+    img->mp = bq_round_up(n, GT);
+    img->dp = bq_round_up(d, GK);
+    BQ_HIP(hipMalloc(&img->At, sizeof(double) * img->mp * img->dp));
+    BQ_HIP(hipMalloc(&img->a2, sizeof(double) * img->mp));
+    dim3 grid((unsigned)((img->mp + 31) / 32), (unsigned)((img->dp + 31) / 32));
+    transpose_pad_kernel<<<grid, 256, 0, ctx->stream>>>(Xdev, n, d, img->At, img->mp, img->dp);
+    row_norms_kernel<<<(unsigned)((img->mp + 255) / 256), 256, 0, ctx->stream>>>(Xdev, n, d, img->a2, img->mp);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
+static void free_image(gram_images *img) {
+    if (img->At) hipFree(img->At);
+    if (img->a2) hipFree(img->a2);
+    img->At = img->a2 = nullptr;
+}
+
+static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int64_t m_rows0, int64_t m_rows1,
+                    int64_t n, bool same, int kernel, double gamma, double coef0, int degree, void *out,
+                    int storage, int64_t ld) {
+    gram_params P;
+    P.At = A.At;
+    P.Bt = B.At;
+    P.a2 = A.a2;
+    P.b2 = B.a2;
+    P.m = m_rows1 - m_rows0;
+    P.n = n;
+    P.mp = A.mp;
+    P.np = B.mp;
+    P.dp = A.dp;
+    P.arow0 = m_rows0;
+    P.arow1 = m_rows1;
+    P.brow_off = 0;
+    P.same = same ? 1 : 0;
+    P.kernel = kernel;
+    P.degree = degree;
+    P.gamma = gamma;
+    P.coef0 = coef0;
+    P.ld = ld;
+    const int64_t tiles_m = (P.m + GT - 1) / GT, tiles_n = (n + GT - 1) / GT;
+    if (tiles_m * tiles_n <= 0) return BQ_OK;
+    BQ_ARG(tiles_m * tiles_n < (int64_t)2147483647, "Gram grid too large");
+    // the A tile of the last tile-row may run past arow1 but never past mp because arow0 is tile-aligned
+    BQ_ARG(m_rows0 % GT == 0 || m_rows0 + tiles_m * GT <= A.mp, "row block must keep tiles inside the padded image");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BQ_TRY(bq_prof_begin(ctx, BQ_PROF_GRAM, &e0, &e1));
+    dim3 grid((unsigned)(tiles_m * tiles_n));
+    if (storage == BQ_F64)
+        gram_mfma_kernel<double><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));
+    else
+        gram_mfma_kernel<float><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
+    BQ_HIP(hipGetLastError());
+    BQ_TRY(bq_prof_end(ctx, BQ_PROF_GRAM, e0, e1));
+    return BQ_OK;
+}
+
+int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r0, int64_t r1, int kernel,
+                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld) {
+    gram_images img;
+    // pad the image so that a tile starting at any r0 stays inside it
+    int rc = make_image(ctx, X, n, d, &img);
+    if (rc != BQ_OK) {
+        free_image(&img);
+        return rc;
+    }
+    if (r0 % GT != 0) {
+        // row blocks are handed out tile-aligned by bq_row_block; anything else needs a larger pad
+        free_image(&img);
+        bq_set_error("row block start %lld is not a multiple of %d", (long long)r0, GT);
+        return BQ_ERR_BADARG;
+    }
+    rc = run_gram(ctx, img, img, r0, r1, n, true, kernel, gamma, coef0, degree, panel, storage, ld);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    free_image(&img);
+    if (rc != BQ_OK) return rc;
+    BQ_HIP(e);
+    return BQ_OK;
+}
+
+// out[t] = sum_m coef[m] * kernel(SV[m], Xt[t]) + intercept : the m x t cross-Gram goes through the same MFMA
+// kernel (A = Xt rows, B = SV rows -> panel t x m), then the panel product with coef.
+int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
+                       const double *SV, const double *coef, double intercept, int64_t t, const double *Xt,
+                       double *out) {
+    gram_images A, B;
+    double *dSV = nullptr, *dXt = nullptr, *panel = nullptr, *w = nullptr, *s = nullptr;
+    const int64_t ld = bq_round_up(m, BQ_PAD);
+    int rc = BQ_OK;
+    auto cleanup = [&]() {
+        free_image(&A);
+        free_image(&B);
+        if (dSV) hipFree(dSV);
+        if (dXt) hipFree(dXt);
+        if (panel) hipFree(panel);
+        if (w) hipFree(w);
+        if (s) hipFree(s);
+    };
+#define DEC_HIP(e)                                                          \
+    do {                                                                    \
+        hipError_t _e = (e);                                                \
+        if (_e != hipSuccess) {                                             \
+            bq_set_error("%s failed: %s", #e, hipGetErrorString(_e));       \
+            cleanup();                                                      \
+            return BQ_ERR_HIP;                                              \
+        }                                                                   \
+    } while (0)
+    DEC_HIP(hipMalloc(&dSV, sizeof(double) * m * d));
+    DEC_HIP(hipMalloc(&dXt, sizeof(double) * t * d));
+    DEC_HIP(hipMalloc(&panel, sizeof(double) * t * ld));
+    DEC_HIP(hipMalloc(&w, sizeof(double) * ld));
+    DEC_HIP(hipMalloc(&s, sizeof(double) * t));
+    DEC_HIP(hipMemcpyAsync(dSV, SV, sizeof(double) * m * d, hipMemcpyHostToDevice, ctx->stream));
+    DEC_HIP(hipMemcpyAsync(dXt, Xt, sizeof(double) * t * d, hipMemcpyHostToDevice, ctx->stream));
+    DEC_HIP(hipMemsetAsync(panel, 0, sizeof(double) * t * ld, ctx->stream));
+    DEC_HIP(hipMemsetAsync(w, 0, sizeof(double) * ld, ctx->stream));
+    DEC_HIP(hipMemcpyAsync(w, coef, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = make_image(ctx, dXt, t, d, &A)) != BQ_OK || (rc = make_image(ctx, dSV, m, d, &B)) != BQ_OK) {
+        cleanup();
+        return rc;
+    }
+    // kernel(SV, Xt)[m][t] == kernel(Xt, SV)[t][m] for all three kernels (gamma is passed in resolved)
+    rc = run_gram(ctx, A, B, 0, t, m, false, kernel, gamma, coef0, degree, panel, BQ_F64, ld);
+    if (rc == BQ_OK) rc = bq_launch_gemv(ctx, panel, BQ_F64, false, t, ld, w, s, nullptr);
+    if (rc != BQ_OK) {
+        cleanup();
+        return rc;
+    }
+    DEC_HIP(hipMemcpyAsync(out, s, sizeof(double) * t, hipMemcpyDeviceToHost, ctx->stream));
+    DEC_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < t; ++i) out[i] += intercept;
+    cleanup();
+#undef DEC_HIP
+    return BQ_OK;
+}
+
+// Dense Gram matrix kernel(A, B) (m x t) for host callers (the Kernel functors' __call__): B == nullptr means
+// B is A (exact zero distance on the diagonal, as sklearn does when Y is X).
+int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
+                          const double *A, int64_t t, const double *B, double *out) {
+    gram_images ia, ib;
+    double *dA = nullptr, *dB = nullptr, *panel = nullptr;
+    const bool same = (B == nullptr);
+    if (same) t = m;
+    const int64_t ld = bq_round_up(t, BQ_PAD);
+    int rc = BQ_OK;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        free_image(&ia);
+        if (!same) free_image(&ib);
+        if (dA) hipFree(dA);
+        if (dB) hipFree(dB);
+        if (panel) hipFree(panel);
+    };
+    do {
+        if ((e = hipMalloc(&dA, sizeof(double) * m * d)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(dA, A, sizeof(double) * m * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if (!same) {
+            if ((e = hipMalloc(&dB, sizeof(double) * t * d)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(dB, B, sizeof(double) * t * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        }
+        if ((e = hipMalloc(&panel, sizeof(double) * m * ld)) != hipSuccess) break;
+        if ((rc = make_image(ctx, dA, m, d, &ia)) != BQ_OK) break;
+        if (!same && (rc = make_image(ctx, dB, t, d, &ib)) != BQ_OK) break;
+        if ((rc = run_gram(ctx, ia, same ? ia : ib, 0, m, t, same, kernel, gamma, coef0, degree, panel, BQ_F64, ld)) != BQ_OK) break;
+        if ((e = hipMemcpy2DAsync(out, t * 8, panel, ld * 8, t * 8, m, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    cleanup();
+    if (rc != BQ_OK) return rc;
+    if (e != hipSuccess) {
+        bq_set_error("gram matrix failed: %s", hipGetErrorString(e));
+        return BQ_ERR_HIP;
+    }
+    return BQ_OK;
+}

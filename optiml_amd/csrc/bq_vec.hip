@@ -1,0 +1,380 @@
+// O(n) kernels of the dual-QP solvers: fused vector updates, masks and deterministic reductions.
+//
+// Every vector is replicated on every rank and padded with zeros to a multiple of 1024; block b always owns
+// elements [1024 b, 1024 (b+1)), lane t the elements b*1024 + j*256 + t.  Reductions are two-stage with a fixed
+// order (4 items per lane -> shuffle tree -> 4 waves -> partials[b] -> one block sums the partials strided by
+// 256 + the same tree), so the iterates are bit-identical for any GPU count.  The scalar state of a solver lives
+// in one device struct (bq_scal); "decide"/"step" kernels are single-block and keep the host out of the loop:
+// once `done` is set every later kernel of the run returns immediately.
+//
+// Reference sites: projected_gradient.py:82-129, frank_wolfe.py:96-151, interior_point.py:180-267
+// (all under optiml/opti/constrained/), objective/gradient optiml/opti/_base.py:282,291.
+#include "bq_common.h"
+
+#include <cmath>
+
+#define ACT_TOL 1e-12
+#define CURV_TOL 1e-16
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wmin(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+// all threads of a 256-thread block get the result
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    v = wsum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_min(double v, double *sh) {
+    v = wmin(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double final_sum(const double *part, int64_t nblk, double *sh) {
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) a += part[i];
+    return block_sum(a, sh);
+}
+__device__ __forceinline__ double final_min(const double *part, int64_t nblk, double *sh) {
+    double a = INFINITY;
+    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) a = fmin(a, part[i]);
+    return block_min(a, sh);
+}
+
+#define VEC_LOOP(i)                                                             \
+    const int64_t _base = (int64_t)blockIdx.x * BQ_VEC_TILE + threadIdx.x;      \
+    _Pragma("unroll") for (int _j = 0; _j < BQ_VEC_ITEMS; ++_j)                 \
+        for (int64_t i = _base + (int64_t)_j * BQ_VEC_BLOCK, _once = 1; _once; _once = 0)
+
+static inline dim3 vec_grid(int64_t ldN) { return dim3((unsigned)(ldN / BQ_VEC_TILE)); }
+
+// ---------------------------------------------------------------------------------------------
+// Hessian application: prep (v -> panel input w), finish (gathered panel output s -> Q v)
+// ---------------------------------------------------------------------------------------------
+__global__ void prep_kernel(int structure, int64_t n, const double *__restrict__ v, const double *__restrict__ sgn,
+                            double *__restrict__ w, const int *done) {
+    if (done != nullptr && *done) return;
+    VEC_LOOP(i) {
+        double r = 0.0;
+        if (i < n) r = (structure == BQ_SVC) ? sgn[i] * v[i] : v[i] - v[n + i];
+        w[i] = r;
+    }
+}
+
+__global__ void finish_kernel(int structure, int64_t n, int64_t N, double diag_add, const double *__restrict__ s,
+                              const double *__restrict__ v, const double *__restrict__ sgn, double *__restrict__ out,
+                              const int *done) {
+    if (done != nullptr && *done) return;
+    VEC_LOOP(i) {
+        double r = 0.0;
+        if (i < N) {
+            if (structure == BQ_PLAIN)
+                r = s[i];
+            else if (structure == BQ_SVC)
+                r = sgn[i] * s[i];
+            else
+                r = (i < n) ? s[i] : -s[i - n];
+            if (diag_add != 0.0) r += diag_add * v[i];
+        }
+        out[i] = r;
+    }
+}
+
+int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *done) {
+    bq_ctx *ctx = p->ctx;
+    const double *w = v;
+    if (p->structure != BQ_PLAIN) {
+        prep_kernel<<<vec_grid(p->ld), BQ_VEC_BLOCK, 0, ctx->stream>>>(p->structure, p->n, v, p->sgn, p->w, done);
+        w = p->w;
+    }
+    BQ_TRY(bq_launch_gemv(ctx, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, w, p->s + p->r0, done));
+    if (ctx->world > 1) BQ_TRY(bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1));
+    finish_kernel<<<vec_grid(p->ldN), BQ_VEC_BLOCK, 0, ctx->stream>>>(p->structure, p->n, p->N, p->diag_add, p->s, v,
+                                                                      p->sgn, out, done);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
+// f = 1/2 x'(Qx) + q'x, g = Qx + q       (host-vector entry point bq_problem_eval)
+__global__ void evalf_partial_kernel(int64_t N, const double *__restrict__ x, const double *__restrict__ Qx,
+                                     const double *__restrict__ q, double *__restrict__ g, double *__restrict__ part,
+                                     int64_t nblk) {
+    __shared__ double sh[4];
+    double a = 0.0, b = 0.0;
+    VEC_LOOP(i) {
+        if (i < N) {
+            a += x[i] * Qx[i];
+            b += q[i] * x[i];
+            if (g != nullptr) g[i] = Qx[i] + q[i];
+        }
+    }
+    a = block_sum(a, sh);
+    b = block_sum(b, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = a;
+        part[nblk + blockIdx.x] = b;
+    }
+}
+__global__ void evalf_final_kernel(const double *part, int64_t nblk, double *f) {
+    __shared__ double sh[4];
+    double a = final_sum(part, nblk, sh);
+    double b = final_sum(part + nblk, nblk, sh);
+    if (threadIdx.x == 0) *f = 0.5 * a + b;
+}
+
+int bq_vec_eval_f(bq_problem *p, const double *x, const double *Qx, double *g_out, double *f_dev) {
+    const int64_t nblk = p->ldN / BQ_VEC_TILE;
+    evalf_partial_kernel<<<vec_grid(p->ldN), BQ_VEC_BLOCK, 0, p->ctx->stream>>>(p->N, x, Qx, p->q, g_out, p->partials, nblk);
+    evalf_final_kernel<<<1, BQ_VEC_BLOCK, 0, p->ctx->stream>>>(p->partials, nblk, f_dev);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Projected gradient and Frank-Wolfe
+// ---------------------------------------------------------------------------------------------
+struct vecs {
+    double *x, *g, *d, *Qd, *q, *lb, *ub;
+};
+
+// g = Qx + q from the product already in Qd (first evaluation only)
+__global__ void grad_init_kernel(int64_t N, vecs V) {
+    VEC_LOOP(i) {
+        if (i < N) V.g[i] = V.Qd[i] + V.q[i];
+    }
+}
+
+// apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and its reductions
+__global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *__restrict__ part,
+                                      int64_t nblk) {
+    if (sc->done) return;
+    __shared__ double sh[4];
+    const double t = do_update ? sc->t : 0.0;
+    double sd2 = 0.0, sgd = 0.0, sxg = 0.0, rmin = INFINITY;
+    VEC_LOOP(i) {
+        if (i < N) {
+            double xi = V.x[i], gi = V.g[i];
+            if (do_update) {
+                xi = xi + __dmul_rn(t, V.d[i]);
+                gi = gi + __dmul_rn(t, V.Qd[i]);
+                V.x[i] = xi;
+                V.g[i] = gi;
+            }
+            const double ubi = V.ub[i], lbi = V.lb[i];
+            double di = -gi;
+            if (ubi - xi <= ACT_TOL && di > 0.0) di = 0.0;
+            if (xi - lbi <= ACT_TOL && di < 0.0) di = 0.0;
+            V.d[i] = di;
+            sd2 += di * di;
+            sgd += gi * di;
+            sxg += xi * (gi + V.q[i]);
+            if (di > 0.0) rmin = fmin(rmin, (ubi - xi) / di);
+            if (di < 0.0) rmin = fmin(rmin, (lbi - xi) / di);
+        }
+    }
+    sd2 = block_sum(sd2, sh);
+    sgd = block_sum(sgd, sh);
+    sxg = block_sum(sxg, sh);
+    rmin = block_min(rmin, sh);
+    if (threadIdx.x == 0) {
+        part[0 * nblk + blockIdx.x] = sd2;
+        part[1 * nblk + blockIdx.x] = sgd;
+        part[2 * nblk + blockIdx.x] = sxg;
+        part[3 * nblk + blockIdx.x] = rmin;
+    }
+}
+
+__global__ void pg_decide_kernel(bq_scal *sc, const double *__restrict__ part, int64_t nblk, bq_iter_stat *stats) {
+    if (sc->done) return;
+    __shared__ double sh[4];
+    const double sd2 = final_sum(part + 0 * nblk, nblk, sh);
+    const double sgd = final_sum(part + 1 * nblk, nblk, sh);
+    const double sxg = final_sum(part + 2 * nblk, nblk, sh);
+    const double rmin = final_min(part + 3 * nblk, nblk, sh);
+    if (threadIdx.x == 0) {
+        const double f = 0.5 * sxg, ng = sqrt(sd2);
+        sc->f = f;
+        sc->ng = ng;
+        sc->gd = sgd;
+        sc->max_t = rmin;
+        const long long row = sc->iter - sc->stat_base;
+        if (row >= 0 && row < sc->stat_cap) {
+            bq_iter_stat st;
+            st.iter = sc->iter;
+            st.f = f;
+            st.r1 = ng;
+            st.r2 = NAN;
+            st.r3 = rmin;
+            stats[row] = st;
+        }
+        if (ng <= sc->eps) {
+            sc->status = BQ_STATUS_OPTIMAL;
+            sc->done = 1;
+        } else if (sc->iter >= sc->max_iter) {
+            sc->status = BQ_STATUS_STOPPED;
+            sc->done = 1;
+        }
+    }
+}
+
+__global__ void den_partial_kernel(int64_t N, const double *__restrict__ d, const double *__restrict__ Qd,
+                                   const bq_scal *sc, double *__restrict__ part) {
+    if (sc->done) return;
+    __shared__ double sh[4];
+    double a = 0.0;
+    VEC_LOOP(i) {
+        if (i < N) a += d[i] * Qd[i];
+    }
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
+// kind 0: PG  t = max_t if den <= 1e-16 else min(-g'd/den, max_t);  kind 1: FW  a = 1 if ... else min(-g'd/den, 1)
+__global__ void step_kernel(int kind, bq_scal *sc, const double *__restrict__ part, int64_t nblk, bq_iter_stat *stats) {
+    if (sc->done) return;
+    __shared__ double sh[4];
+    const double den = final_sum(part, nblk, sh);
+    if (threadIdx.x == 0) {
+        const double cap = (kind == 0) ? sc->max_t : 1.0;
+        const double t = (den <= CURV_TOL) ? cap : fmin(-sc->gd / den, cap);
+        sc->den = den;
+        sc->t = t;
+        const long long row = sc->iter - sc->stat_base;
+        if (row >= 0 && row < sc->stat_cap) {
+            if (kind == 0)
+                stats[row].r2 = t;
+            else
+                stats[row].r3 = t;
+        }
+        sc->iter += 1;
+    }
+}
+
+// FW: apply pending step, pick the vertex, form the (optionally trust-clipped) direction
+__global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *__restrict__ part,
+                                      int64_t nblk) {
+    if (sc->done) return;
+    __shared__ double sh[4];
+    const double a = do_update ? sc->t : 0.0;
+    const double tr = sc->fw_t;
+    double sgy = 0.0, sgd = 0.0, sxg = 0.0;
+    VEC_LOOP(i) {
+        if (i < N) {
+            double xi = V.x[i], gi = V.g[i];
+            if (do_update) {
+                xi = xi + __dmul_rn(a, V.d[i]);
+                gi = gi + __dmul_rn(a, V.Qd[i]);
+                V.x[i] = xi;
+                V.g[i] = gi;
+            }
+            const double ubi = V.ub[i], lbi = V.lb[i];
+            double yi = (gi < 0.0) ? ubi : lbi;
+            sgy += gi * (yi - xi);
+            if (tr > 0.0) {
+                const double rad = tr * (ubi - lbi);
+                yi = fmin(fmax(yi, xi - rad), xi + rad);
+            }
+            const double di = yi - xi;
+            V.d[i] = di;
+            sgd += gi * di;
+            sxg += xi * (gi + V.q[i]);
+        }
+    }
+    sgy = block_sum(sgy, sh);
+    sgd = block_sum(sgd, sh);
+    sxg = block_sum(sxg, sh);
+    if (threadIdx.x == 0) {
+        part[0 * nblk + blockIdx.x] = sgy;
+        part[1 * nblk + blockIdx.x] = sgd;
+        part[2 * nblk + blockIdx.x] = sxg;
+    }
+}
+
+__global__ void fw_decide_kernel(bq_scal *sc, const double *__restrict__ part, int64_t nblk, bq_iter_stat *stats) {
+    if (sc->done) return;
+    __shared__ double sh[4];
+    const double sgy = final_sum(part + 0 * nblk, nblk, sh);
+    const double sgd = final_sum(part + 1 * nblk, nblk, sh);
+    const double sxg = final_sum(part + 2 * nblk, nblk, sh);
+    if (threadIdx.x == 0) {
+        const double f = 0.5 * sxg;
+        const double low = f + sgy;
+        if (low > sc->best_lb) sc->best_lb = low;
+        const double gap = (f - sc->best_lb) / fmax(fabs(f), 1.0);
+        sc->f = f;
+        sc->low = low;
+        sc->gap = gap;
+        sc->gd = sgd;
+        const long long row = sc->iter - sc->stat_base;
+        if (row >= 0 && row < sc->stat_cap) {
+            bq_iter_stat st;
+            st.iter = sc->iter;
+            st.f = f;
+            st.r1 = sc->best_lb;
+            st.r2 = gap;
+            st.r3 = NAN;
+            stats[row] = st;
+        }
+        if (gap <= sc->eps) {
+            sc->status = BQ_STATUS_OPTIMAL;
+            sc->done = 1;
+        } else if (sc->iter >= sc->max_iter) {
+            sc->status = BQ_STATUS_STOPPED;
+            sc->done = 1;
+        }
+    }
+}
+
+static vecs solver_vecs(bq_solver *s) {
+    vecs V;
+    V.x = s->x;
+    V.g = s->g;
+    V.d = s->d;
+    V.Qd = s->Qd;
+    V.q = s->p->q;
+    V.lb = s->lb;
+    V.ub = s->ub;
+    return V;
+}
+
+int bq_pgfw_start(bq_solver *s) {
+    // g = Q x0 + q : the only full-gradient product of the run (later iterations update g incrementally)
+    hipStream_t st = s->p->ctx->stream;
+    BQ_TRY(bq_problem_apply(s->p, s->x, s->Qd, nullptr));
+    grad_init_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, solver_vecs(s));
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
+int bq_pgfw_iterate(bq_solver *s) {
+    hipStream_t st = s->p->ctx->stream;
+    const int *done = &s->sc->done;
+    const int upd = s->started ? 1 : 0;
+    vecs V = solver_vecs(s);
+    if (s->kind == BQ_PG) {
+        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk);
+        pg_decide_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, s->partials, s->nblk, s->stats);
+    } else {
+        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk);
+        fw_decide_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, s->partials, s->nblk, s->stats);
+    }
+    s->started = true;
+    BQ_TRY(bq_problem_apply(s->p, s->d, s->Qd, done));
+    den_partial_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->d, s->Qd, s->sc, s->partials);
+    step_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->kind == BQ_PG ? 0 : 1, s->sc, s->partials, s->nblk, s->stats);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}

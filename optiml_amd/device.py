@@ -1,0 +1,127 @@
+"""Device contexts: one HIP stream (and, for multi-GPU runs, one RCCL communicator) per process.
+
+One process drives one GPU.  `get_context()` returns the process-wide default context, created on first
+use on device LOCAL_RANK (or 0).  Multi-GPU runs call `init_distributed(comm)` first: rank r then owns a
+contiguous row block of every Gram/Hessian panel and each product Q v ends in one all-gather of the row
+blocks over RCCL/xGMI (exchange='rccl'), or through the communicator's host all-gather
+(exchange='host': tests and machines without RCCL).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ['Context', 'get_context', 'set_context', 'init_distributed', 'row_block', 'device_count']
+
+
+def device_count():
+    lib = _lib.load()
+    n = C.c_int(0)
+    _lib.check(lib.bq_device_count(C.byref(n)))
+    return n.value
+
+
+def row_block(n, rank, world):
+    """Rows [begin, end) of an n-row panel owned by `rank` (blocks are 128-row aligned)."""
+    lib = _lib.load()
+    b, e = C.c_int64(0), C.c_int64(0)
+    _lib.check(lib.bq_row_block(int(n), int(rank), int(world), C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+class Context:
+    def __init__(self, device=None, comm=None, exchange='rccl'):
+        lib = _lib.load()
+        self._lib = lib
+        self._h = C.c_void_p()
+        self._cb = None
+        self.comm = comm
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+            ndev = device_count()
+            if ndev > 0:
+                device %= ndev
+        self.device = device
+        if comm is None or comm.world_size == 1:
+            self.rank, self.world, self.exchange = 0, 1, 'none'
+            _lib.check(lib.bq_ctx_create(device, C.byref(self._h)))
+        elif exchange == 'rccl':
+            self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'rccl'
+            uid = C.create_string_buffer(128)
+            if comm.rank == 0:
+                _lib.check(lib.bq_comm_unique_id(uid))
+            raw = comm.broadcast_bytes(uid.raw, src=0)
+            uid = C.create_string_buffer(raw, 128)
+            _lib.check(lib.bq_ctx_create_rccl(device, comm.rank, comm.world_size, uid, C.byref(self._h)))
+        elif exchange == 'host':
+            self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'host'
+
+            def _exchange(user, buf, n, r0, r1):
+                try:
+                    view = np.ctypeslib.as_array(buf, shape=(n,))
+                    comm.allgather_rows(view, r0, r1)
+                    return 0
+                except Exception as exc:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            self._cb = _lib.EXCHANGE_FN(_exchange)
+            _lib.check(lib.bq_ctx_create_exchange(device, comm.rank, comm.world_size, self._cb, None, C.byref(self._h)))
+        else:
+            raise ValueError(f"unknown exchange '{exchange}' (use 'rccl' or 'host')")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError('context has been closed')
+        return self._h
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(128)
+        _lib.check(self._lib.bq_ctx_info(self.handle, None, None, None, buf, 128))
+        return buf.value.decode()
+
+    def profile(self, enable=True):
+        _lib.check(self._lib.bq_ctx_profile(self.handle, 1 if enable else 0))
+
+    def profile_read(self, which, reset=False):
+        """(total_ms, launches) of the HIP-event timers: which in _lib.PROF_*."""
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        _lib.check(self._lib.bq_ctx_profile_read(self.handle, which, C.byref(ms), C.byref(cnt), 1 if reset else 0))
+        return ms.value, cnt.value
+
+    def close(self):
+        if self._h:
+            self._lib.bq_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def get_context():
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default
+
+
+def set_context(ctx):
+    global _default
+    _default = ctx
+    return ctx
+
+
+def init_distributed(comm, exchange='rccl', device=None):
+    """Make the default context a multi-rank one (call once per process, before building problems)."""
+    return set_context(Context(device=device, comm=comm, exchange=exchange))

@@ -1,0 +1,258 @@
+"""sklearn-compatible SVC / SVR restricted to the box-constrained dual path, device-resident.
+
+Constructor arguments, validation and fitted attributes follow optiml/ml/svm/_base.py (SVM :187-282,
+SVC :366-419, SVR :907-963).  Only the branch
+
+    dual=True, reg_intercept=True, optimizer in {ProjectedGradient, FrankWolfe, ActiveSet, InteriorPoint}
+
+is implemented (SVC.fit :547-559, :619-636, :725, :867-880; SVR.fit :1091-1104, :1169-1186, :1277,
+:1423-1437): the Gram panel is built and kept in HBM, the Wolfe dual never exists as an n x n host matrix
+(`self.obj` is a lazy `KernelQuadratic`), and the support-vector / intercept post-processing uses one masked
+panel product instead of the reference's Python loop.  Every other configuration raises NotImplementedError
+(as the reference does for reg_intercept=False and for the squared losses with these optimizers).
+"""
+from abc import ABC
+
+import numpy as np
+
+from ... import _lib
+from ...device import get_context
+from ...opti import Optimizer, KernelQuadratic
+from ...opti.constrained import BoxConstrainedQuadraticOptimizer, ProjectedGradient
+from .kernels import Kernel, LinearKernel, gaussian, BaseEstimator
+from .losses import (Hinge, SquaredHinge, EpsilonInsensitive, SquaredEpsilonInsensitive,
+                     squared_hinge, squared_epsilon_insensitive)
+
+try:
+    from sklearn.base import ClassifierMixin, RegressorMixin
+except ImportError:  # pragma: no cover
+    class ClassifierMixin:
+        def score(self, X, y):
+            return float(np.mean(self.predict(X) == np.asarray(y)))
+
+    class RegressorMixin:
+        def score(self, X, y):
+            y = np.asarray(y, dtype=float)
+            r = y - self.predict(X)
+            return 1.0 - float(r @ r) / float(((y - y.mean()) ** 2).sum())
+
+__all__ = ['SVM', 'SVC', 'SVR']
+
+_OUT_OF_SCOPE = ('only dual=True with a box-constrained optimizer (ProjectedGradient, FrankWolfe, ActiveSet, '
+                 'InteriorPoint) is implemented by optiml_amd')
+
+
+class SVM(BaseEstimator, ABC):
+
+    def __init__(self, loss=None, kernel=gaussian, C=1, rho=1, mu=1, fit_intercept=True, intercept_scaling=1,
+                 reg_intercept=False, dual=False, optimizer=ProjectedGradient, master_solver='clarabel',
+                 learning_rate='auto', momentum_type='none', momentum=0.9, max_iter=1000, max_f_eval=15000,
+                 tol=1e-4, batch_size=None, shuffle=True, random_state=None, early_stopping=False,
+                 validation_split=0., patience=5, verbose=False, master_verbose=False, storage='f64'):
+        self.loss = loss
+        if not isinstance(kernel, Kernel):
+            raise TypeError(f'{kernel} is not an allowed kernel function')
+        self.kernel = kernel
+        if not C > 0:
+            raise ValueError('C must be > 0')
+        self.C = C
+        if not rho > 0:
+            raise ValueError('rho must be > 0')
+        self.rho = rho
+        if not mu > 0:
+            raise ValueError('mu must be > 0')
+        self.mu = mu
+        if not isinstance(fit_intercept, bool):
+            raise ValueError('fit_intercept mu be a boolean value')
+        self.fit_intercept = fit_intercept
+        self.intercept_scaling = intercept_scaling
+        if not isinstance(reg_intercept, bool):
+            raise ValueError('reg_intercept mu be a boolean value')
+        self.reg_intercept = reg_intercept
+        if not isinstance(dual, bool):
+            raise ValueError('dual must be a boolean value')
+        self.dual = dual
+        if not (isinstance(optimizer, str) or (isinstance(optimizer, type) and issubclass(optimizer, Optimizer))):
+            raise TypeError(f'{optimizer} is not an allowed optimization method')
+        self.optimizer = optimizer
+        self.master_solver = master_solver
+        self.learning_rate = learning_rate
+        self.max_iter = max_iter
+        self.max_f_eval = max_f_eval
+        self.momentum_type = momentum_type
+        self.momentum = momentum
+        if not tol > 0:
+            raise ValueError('tol must be > 0')
+        self.tol = tol
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.random_state = random_state
+        self.early_stopping = early_stopping
+        self.validation_split = validation_split
+        self.patience = patience
+        self.verbose = verbose
+        self.master_verbose = master_verbose
+        self.storage = storage
+        if not self.dual or isinstance(self.kernel, LinearKernel):
+            self.coef_ = np.zeros(0)
+        self.intercept_ = 0.
+        self.support_ = np.zeros(0)
+        self.support_vectors_ = np.zeros(0)
+        if self.dual:
+            self.alphas_ = np.zeros(0)
+            self.dual_coef_ = np.zeros(0)
+        if not isinstance(optimizer, str):
+            self.train_loss_history = []
+
+    def fit(self, X, y):
+        raise NotImplementedError
+
+    def decision_function(self, X):
+        X = np.ascontiguousarray(X, dtype=float)
+        if self.dual and not isinstance(self.kernel, LinearKernel):
+            # gamma='scale' resolves against the support vectors here, as in the reference (kernels.py:127 with
+            # kernel(self.support_vectors_, X), svm/_base.py:286) — not against the training set
+            sv = np.ascontiguousarray(self.support_vectors_, dtype=float)
+            kind, gamma, coef0, degree = self.kernel.device_spec(sv)
+            lib = _lib.load()
+            out = np.empty(X.shape[0])
+            coef = _lib.as_f64(self.dual_coef_, sv.shape[0], 'dual_coef_')
+            _lib.check(lib.bq_decision_function(get_context().handle, kind, gamma, coef0, degree, sv.shape[0],
+                                                sv.shape[1], _lib.ptr(sv), _lib.ptr(coef), float(self.intercept_),
+                                                X.shape[0], _lib.ptr(X), _lib.ptr(out)))
+            return out
+        return np.dot(X, self.coef_) + self.intercept_
+
+    def _store_train_info(self, opt):
+        self.train_loss_history.append(opt.f_x)
+
+    _store_train_info._bq_needs_state = False  # reads opt.f_x only: replayed from the device iteration records
+
+    def _check_bcqp(self):
+        if not self.dual or isinstance(self.optimizer, str) or not (
+                isinstance(self.optimizer, type) and issubclass(self.optimizer, BoxConstrainedQuadraticOptimizer)):
+            raise NotImplementedError(_OUT_OF_SCOPE)
+        if not self.reg_intercept:
+            # constrained optimizer with A x = 0 and 0 <= x <= ub is not available (svm/_base.py:621-624)
+            raise NotImplementedError('box-constrained optimizers need reg_intercept=True')
+
+    def _run(self, obj, ub):
+        hook = self._store_train_info
+        self.obj = obj
+        self.optimizer = self.optimizer(quad=obj, ub=ub, tol=self.tol, max_iter=self.max_iter,
+                                        callback=hook, verbose=self.verbose).minimize()
+        self.alphas_ = self.optimizer.x
+
+    def _intercept_sum(self, obj, sv, dual_coef, sv_y):
+        """sum_n ( y_n - sum_m dual_coef_m K[support_n, support_m] ) over the support set: one masked panel product."""
+        w = np.zeros(len(sv))
+        w[sv] = dual_coef
+        u = obj.device_problem().gram_matvec(w)
+        return float(np.sum(sv_y - u[sv]))
+
+
+class SVC(ClassifierMixin, SVM):
+
+    def __init__(self, loss=squared_hinge, kernel=gaussian, C=1, rho=1, mu=1, fit_intercept=True,
+                 intercept_scaling=1, reg_intercept=False, dual=False, optimizer=ProjectedGradient,
+                 master_solver='clarabel', learning_rate='auto', momentum_type='none', momentum=0.9, max_iter=1000,
+                 max_f_eval=15000, tol=1e-4, batch_size=None, shuffle=True, random_state=None, early_stopping=False,
+                 validation_split=0., patience=5, verbose=False, master_verbose=False, storage='f64'):
+        super(SVC, self).__init__(loss=loss, kernel=kernel, C=C, rho=rho, mu=mu, fit_intercept=fit_intercept,
+                                  intercept_scaling=intercept_scaling, reg_intercept=reg_intercept, dual=dual,
+                                  optimizer=optimizer, master_solver=master_solver, learning_rate=learning_rate,
+                                  momentum_type=momentum_type, momentum=momentum, max_iter=max_iter,
+                                  max_f_eval=max_f_eval, tol=tol, batch_size=batch_size, shuffle=shuffle,
+                                  random_state=random_state, early_stopping=early_stopping,
+                                  validation_split=validation_split, patience=patience, verbose=verbose,
+                                  master_verbose=master_verbose, storage=storage)
+        if not getattr(loss, '_loss_type', None) == 'classifier':
+            raise TypeError(f'{loss} is not an allowed SVC loss function')
+
+    def fit(self, X, y):
+        y = np.asarray(y)
+        self.classes_ = np.unique(y)
+        if len(self.classes_) > 2:
+            raise ValueError('use OneVsOneClassifier or OneVsRestClassifier from sklearn.multiclass '
+                             'to train a model over more than two labels')
+        # LabelBinarizer(neg_label=-1): the larger class label maps to +1 (svm/_base.py:419, 436-440)
+        y = np.where(y == self.classes_[-1], 1., -1.)
+        self._check_bcqp()
+        if self.loss == SquaredHinge:
+            # bcqp optimizer with 0 <= x <= +inf is not available (svm/_base.py:771-774)
+            raise NotImplementedError('squared hinge is not available with box-constrained optimizers')
+        if self.loss != Hinge:
+            raise TypeError(f'{self.loss} is not an allowed loss')
+        X = np.ascontiguousarray(X, dtype=float)
+        n = len(y)
+        obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage)
+        self._run(obj, np.ones(n) * self.C)
+
+        sv = self.alphas_ > 1e-6
+        self.support_ = np.arange(len(self.alphas_))[sv]
+        self.support_vectors_, sv_y, alphas = X[sv], y[sv], self.alphas_[sv]
+        self.dual_coef_ = alphas * sv_y
+        if isinstance(self.kernel, LinearKernel):
+            self.coef_ = np.dot(self.dual_coef_, self.support_vectors_)
+        self.intercept_ += self._intercept_sum(obj, sv, self.dual_coef_, sv_y)
+        self.intercept_ /= len(alphas)
+        return self
+
+    def predict(self, X):
+        return np.where(self.decision_function(X) > 0, self.classes_[-1], self.classes_[0])
+
+
+class SVR(RegressorMixin, SVM):
+
+    def __init__(self, loss=squared_epsilon_insensitive, epsilon=0.1, kernel=gaussian, C=1, rho=1, mu=1,
+                 fit_intercept=True, intercept_scaling=1, reg_intercept=False, dual=False,
+                 optimizer=ProjectedGradient, master_solver='clarabel', learning_rate='auto', momentum_type='none',
+                 momentum=0.9, max_iter=1000, max_f_eval=15000, tol=1e-4, batch_size=None, shuffle=True,
+                 random_state=None, early_stopping=False, validation_split=0., patience=5, verbose=False,
+                 master_verbose=False, storage='f64'):
+        super(SVR, self).__init__(loss=loss, kernel=kernel, C=C, rho=rho, mu=mu, fit_intercept=fit_intercept,
+                                  intercept_scaling=intercept_scaling, reg_intercept=reg_intercept, dual=dual,
+                                  optimizer=optimizer, master_solver=master_solver, learning_rate=learning_rate,
+                                  momentum_type=momentum_type, momentum=momentum, max_iter=max_iter,
+                                  max_f_eval=max_f_eval, tol=tol, batch_size=batch_size, shuffle=shuffle,
+                                  random_state=random_state, early_stopping=early_stopping,
+                                  validation_split=validation_split, patience=patience, verbose=verbose,
+                                  master_verbose=master_verbose, storage=storage)
+        if not getattr(loss, '_loss_type', None) == 'regressor':
+            raise TypeError(f'{loss} is not an allowed SVR loss function')
+        if not epsilon >= 0:
+            raise ValueError('epsilon must be >= 0')
+        self.epsilon = epsilon
+
+    def fit(self, X, y):
+        y = np.asarray(y, dtype=float)
+        targets = y.shape[1] if y.ndim > 1 else 1
+        if targets > 1:
+            raise ValueError('use sklearn.multioutput.MultiOutputRegressor '
+                             'to train a model over more than one target')
+        self._check_bcqp()
+        if self.loss == SquaredEpsilonInsensitive:
+            # bcqp optimizer with 0 <= x <= +inf is not available (svm/_base.py:1325-1328)
+            raise NotImplementedError('squared epsilon-insensitive is not available with box-constrained optimizers')
+        if self.loss != EpsilonInsensitive:
+            raise TypeError(f'{self.loss} is not an allowed loss')
+        X = np.ascontiguousarray(X, dtype=float)
+        n = len(y)
+        q = np.hstack((-y, y)) + self.epsilon
+        obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage)
+        self._run(obj, np.ones(2 * n) * self.C)
+
+        alphas_p, alphas_n = np.split(self.alphas_, 2)
+        sv = np.logical_or(alphas_p > 1e-6, alphas_n > 1e-6)
+        self.support_ = np.arange(len(alphas_p))[sv]
+        self.support_vectors_, sv_y, alphas_p, alphas_n = X[sv], y[sv], alphas_p[sv], alphas_n[sv]
+        self.dual_coef_ = alphas_p - alphas_n
+        if isinstance(self.kernel, LinearKernel):
+            self.coef_ = np.dot(self.dual_coef_, self.support_vectors_)
+        self.intercept_ += self._intercept_sum(obj, sv, self.dual_coef_, sv_y)
+        self.intercept_ -= self.epsilon   # subtracted once before the division, as svm/_base.py:1436-1437
+        self.intercept_ /= len(alphas_p)
+        return self
+
+    def predict(self, X):
+        return self.decision_function(X)

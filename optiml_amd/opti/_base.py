@@ -1,0 +1,284 @@
+"""Objective and optimizer bases of the box-constrained QP path (device-backed).
+
+Mirrors the interface of optiml/opti/_base.py: `Optimizer` (:9-181, non-Lagrangian part),
+`OptimizationFunction` (:184-225) and `Quadratic` (:228-300).  The arithmetic of
+`Quadratic.function/jacobian` (:282, :291) runs in libbcqp_hip.so on the Hessian resident in HBM.
+"""
+import ctypes as C
+from abc import ABC
+
+import numpy as np
+
+from .. import _lib
+from ..device import get_context
+
+__all__ = ['Optimizer', 'OptimizationFunction', 'Quadratic', 'KernelQuadratic']
+
+
+class OptimizationFunction(ABC):
+
+    def __init__(self, ndim=2):
+        self.ndim = ndim
+
+    def x_star(self):
+        return np.full(fill_value=np.nan, shape=self.ndim)
+
+    def f_star(self):
+        return np.inf
+
+    def args(self):
+        return ()
+
+    def function(self, x):
+        raise NotImplementedError
+
+    def jacobian(self, x):
+        raise NotImplementedError
+
+    def hessian(self, x):
+        raise NotImplementedError
+
+    def function_jacobian(self, *args, **kwargs):
+        return self.function(*args, **kwargs), self.jacobian(*args, **kwargs)
+
+    def __call__(self, *args, **kwargs):
+        return self.function(*args, **kwargs)
+
+
+class _DeviceProblem:
+    """Owner of one bq_problem handle (freed with the object)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._h = handle
+        self._lib = _lib.load()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def dims(self):
+        a, b, c, d = (C.c_int64(0) for _ in range(4))
+        _lib.check(self._lib.bq_problem_dims(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    def matvec(self, v):
+        N = self.dims()[0]
+        v = _lib.as_f64(v, N, 'v')
+        out = np.empty(N)
+        _lib.check(self._lib.bq_problem_matvec(self._h, _lib.ptr(v), _lib.ptr(out)))
+        return out
+
+    def eval(self, x, want_grad=True):
+        N = self.dims()[0]
+        x = _lib.as_f64(x, N, 'x')
+        f = C.c_double(0)
+        g = np.empty(N) if want_grad else None
+        _lib.check(self._lib.bq_problem_eval(self._h, _lib.ptr(x), C.byref(f), _lib.ptr(g)))
+        return f.value, g
+
+    def gram_matvec(self, w):
+        n = self.dims()[1]
+        w = _lib.as_f64(w, n, 'w')
+        out = np.empty(n)
+        _lib.check(self._lib.bq_problem_gram_matvec(self._h, _lib.ptr(w), _lib.ptr(out)))
+        return out
+
+    def panel_rows(self, row0=None, nrows=None):
+        _, n, r0, r1 = self.dims()
+        row0 = r0 if row0 is None else row0
+        nrows = r1 - row0 if nrows is None else nrows
+        out = np.empty((nrows, n))
+        _lib.check(self._lib.bq_problem_panel_rows(self._h, row0, nrows, _lib.ptr(out)))
+        return out
+
+    def time_matvec(self, reps=10):
+        ms = C.c_double(0)
+        _lib.check(self._lib.bq_problem_time_matvec(self._h, reps, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            self._lib.bq_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Quadratic(OptimizationFunction):
+    r"""f(x) = 1/2 x'Qx + q'x with a dense Hessian (same ctor and checks as optiml/opti/_base.py:230-256).
+
+    `storage='f32'` keeps the device copy of Q in fp32 (fp64 accumulation); the default is fp64.
+    """
+
+    def __init__(self, Q, q, storage='f64'):
+        Q = np.array(Q, dtype=float)
+        q = np.array(q, dtype=float)
+        n = len(Q)
+        super(Quadratic, self).__init__(n)
+        if n <= 1:
+            raise ValueError('Q is too small')
+        if Q.ndim != 2 or n != Q.shape[1]:
+            raise ValueError('Q is not square')
+        self.Q = Q
+        if q.size != n:
+            raise ValueError('q size does not match with Q')
+        self.q = q
+        self.storage = storage
+        self._dev = None
+
+    # -- device residency -------------------------------------------------------------------
+    def _build_problem(self, ctx):
+        lib = _lib.load()
+        h = C.c_void_p()
+        Qc = np.ascontiguousarray(self.Q)
+        _lib.check(lib.bq_problem_create_dense(ctx.handle, self.ndim, _lib.ptr(Qc), _lib.ptr(self.q.ravel()),
+                                               _lib.F32 if self.storage == 'f32' else _lib.F64, C.byref(h)))
+        return _DeviceProblem(ctx, h)
+
+    def device_problem(self, ctx=None):
+        ctx = ctx or get_context()
+        if self._dev is None or self._dev.ctx is not ctx:
+            self._dev = self._build_problem(ctx)
+        return self._dev
+
+    def release(self):
+        """Free the device copy (it is rebuilt on demand)."""
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None
+
+    # -- reference interface ------------------------------------------------------------------
+    def function(self, x):
+        return self.device_problem().eval(x, want_grad=False)[0]
+
+    def jacobian(self, x):
+        return self.device_problem().eval(x)[1]
+
+    def function_jacobian(self, x):
+        return self.device_problem().eval(x)
+
+    def hessian(self, x):
+        return self.Q
+
+
+class KernelQuadratic(Quadratic):
+    """Lazy form of the SVM dual Hessian: holds X (and labels), never builds the n x n matrix on the host.
+
+    structure 'svc': Q = K*yy' + yy' (+ diag*I), n variables      (optiml/ml/svm/_base.py:552-555, 628)
+    structure 'svr': Q = [[K,-K],[-K,K]] + ee', 2n variables      (optiml/ml/svm/_base.py:1096-1099, 1178)
+    structure 'plain': Q = K (+ diag*I)
+    `.Q` materialises the dense matrix from the device panel on demand (inspection / small problems only).
+    """
+
+    _STRUCT = {'plain': _lib.PLAIN, 'svc': _lib.SVC, 'svr': _lib.SVR}
+
+    def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64'):
+        X = np.ascontiguousarray(X, dtype=float)
+        if structure not in self._STRUCT:
+            raise ValueError(f'unknown structure {structure}')
+        n = X.shape[0]
+        N = 2 * n if structure == 'svr' else n
+        q = np.array(q, dtype=float)
+        OptimizationFunction.__init__(self, N)
+        if n <= 1:
+            raise ValueError('Q is too small')
+        if q.size != N:
+            raise ValueError('q size does not match with Q')
+        if structure == 'svc' and (y is None or len(y) != n):
+            raise ValueError('labels are required for the svc structure')
+        self.X, self.q, self.structure, self.kernel = X, q, structure, kernel
+        self.y = None if y is None else np.ascontiguousarray(y, dtype=float)
+        self.diag = float(diag)
+        self.storage = storage
+        self.kind, self.gamma, self.coef0, self.degree = kernel.device_spec(X)
+        self._dev = None
+
+    def _build_problem(self, ctx):
+        lib = _lib.load()
+        h = C.c_void_p()
+        n, d = self.X.shape
+        _lib.check(lib.bq_problem_create_kernel(
+            ctx.handle, self._STRUCT[self.structure], n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
+            self.gamma, self.coef0, self.degree, self.diag, _lib.ptr(self.q),
+            _lib.F32 if self.storage == 'f32' else _lib.F64, C.byref(h)))
+        return _DeviceProblem(ctx, h)
+
+    def gram(self):
+        """The n x n Gram matrix K held by this rank's panel (all of it on a single-rank context)."""
+        return self.device_problem().panel_rows()
+
+    @property
+    def Q(self):
+        dev = self.device_problem()
+        if dev.ctx.world != 1:
+            raise RuntimeError('materialising Q needs the whole panel: single-rank contexts only')
+        K = dev.panel_rows()
+        n = K.shape[0]
+        if self.structure == 'plain':
+            Q = K
+        elif self.structure == 'svc':
+            Q = (K + 1.0) * np.outer(self.y, self.y)
+        else:
+            P = K + 1.0
+            Q = np.vstack((np.hstack((P, -P)), np.hstack((-P, P))))
+        if self.diag:
+            Q = Q + self.diag * np.eye(Q.shape[0])
+        return Q
+
+
+class Optimizer(ABC):
+    """State and callback contract of optiml/opti/_base.py:9-181 (the part a plain Quadratic exercises)."""
+
+    def __init__(self, f, x=None, eps=1e-6, tol=1e-8, max_iter=1000, callback=None, callback_args=(),
+                 random_state=None, verbose=False):
+        if not isinstance(f, OptimizationFunction):
+            raise TypeError(f'{f} is not an allowed optimization function')
+        self.f = f
+        if x is None:
+            x = np.random.uniform if random_state is None else np.random.RandomState(random_state).uniform
+        if callable(x):
+            self.x = x(size=f.ndim)
+        else:
+            self.x = np.asarray(x, dtype=float)
+        self.f_x = np.nan
+        self.g_x = np.zeros(0)
+        self.eps = eps
+        self.tol = tol
+        if not max_iter > 0:
+            raise ValueError('max_iter must be > 0')
+        self.max_iter = max_iter
+        self.iter = 0
+        self.status = 'unknown'
+        if self.f.ndim <= 3:
+            self.x0_history = []
+            self.x1_history = []
+            self.f_x_history = []
+        self._callback = callback
+        self.callback_args = callback_args
+        self.random_state = random_state
+        self.verbose = verbose
+
+    def is_lagrangian_dual(self):
+        return False
+
+    def is_augmented_lagrangian_dual(self):
+        return False
+
+    def callback(self, args=()):
+        if self.f.ndim <= 3:
+            self.x0_history.append(self.x[0])
+            self.x1_history.append(self.x[1])
+            self.f_x_history.append(self.f_x)
+        if callable(self._callback):
+            self._callback(self, *args, *self.callback_args)
+
+    def is_verbose(self):
+        return self.verbose and not self.iter % self.verbose
+
+    def minimize(self):
+        raise NotImplementedError

@@ -1,0 +1,125 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds, loads, and exports every symbol that
+include/bcqp.h declares; pure-host entry points behave; the Python surface mirrors the reference's names."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from optiml_amd import build, _lib
+    build.build()           # hipcc cross-compiles without a GPU
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'bcqp.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(bq_[a-z0-9_]+)\s*\(', text)) - {'bq_exchange_fn'})
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from optiml_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/bcqp.h but not exported'
+        assert s in _lib.PROTOTYPES, f'{s} has no ctypes prototype'
+    assert set(_lib.PROTOTYPES) == set(syms)
+    assert lib.bq_abi_version() == _lib.ABI_VERSION
+
+
+@pytest.mark.parametrize('n', [2, 127, 128, 129, 2000, 100000, 250000])
+@pytest.mark.parametrize('world', [1, 2, 3, 4, 8])
+def test_row_blocks_partition_the_panel(lib, n, world):
+    from optiml_amd.device import row_block
+    from optiml_amd.dist import block_size, SocketComm
+    blocks = [row_block(n, r, world) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n
+    for (b0, e0), (b1, e1) in zip(blocks, blocks[1:]):
+        assert e0 == b1 and b0 <= e0
+    blk = block_size(n, world)
+    assert blk % 128 == 0 and blk * world >= n
+    for r, (b, e) in enumerate(blocks):
+        assert b == min(n, r * blk) and e == min(n, b + blk)
+        c = SocketComm.__new__(SocketComm)
+        c.rank, c.world_size = r, world
+        assert c.rows_of(n) == (b, e)
+
+
+def test_bad_arguments_are_reported_not_crashed(lib):
+    import ctypes as C
+    from optiml_amd import _lib
+    assert lib.bq_row_block(10, 3, 2, None, None) == _lib.ERR_BADARG
+    assert b'rank' in lib.bq_last_error()
+    with pytest.raises(_lib.BcqpError):
+        _lib.check(lib.bq_problem_matvec(None, None, None))
+
+
+def test_python_surface_matches_reference_names():
+    import optiml_amd.opti as opti
+    import optiml_amd.opti.constrained as con
+    import optiml_amd.ml.svm as svm
+    from optiml_amd.ml.svm import kernels, losses
+    for name in ('Optimizer', 'OptimizationFunction', 'Quadratic'):
+        assert hasattr(opti, name)
+    for name in ('BoxConstrainedQuadraticOptimizer', 'ProjectedGradient', 'ActiveSet', 'FrankWolfe', 'InteriorPoint'):
+        assert issubclass(getattr(con, name), con.BoxConstrainedQuadraticOptimizer)
+    for name in ('SVM', 'SVC', 'SVR'):
+        assert hasattr(svm, name)
+    for name in ('linear', 'poly', 'gaussian', 'LinearKernel', 'PolyKernel', 'GaussianKernel'):
+        assert hasattr(kernels, name)
+    for name in ('hinge', 'squared_hinge', 'epsilon_insensitive', 'squared_epsilon_insensitive'):
+        assert hasattr(losses, name)
+
+
+def test_constructor_validation_mirrors_reference():
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import ProjectedGradient, FrankWolfe, InteriorPoint
+    from optiml_amd.ml.svm import SVC, SVR
+    from optiml_amd.ml.svm.kernels import PolyKernel, GaussianKernel, gaussian
+    from optiml_amd.ml.svm.losses import hinge, squared_hinge, epsilon_insensitive
+    Q = np.eye(3)
+    quad = Quadratic(Q, np.zeros(3))
+    assert quad.ndim == 3 and quad.hessian(None) is quad.Q
+    with pytest.raises(ValueError):
+        Quadratic(np.eye(1), np.zeros(1))                       # opti/_base.py:249-250
+    with pytest.raises(ValueError):
+        Quadratic(np.eye(3), np.zeros(2))                       # opti/_base.py:255-256
+    with pytest.raises(TypeError):
+        ProjectedGradient(quad=object(), ub=np.ones(3))         # constrained/_base.py:59-60
+    with pytest.raises(ValueError):
+        ProjectedGradient(quad=quad, ub=np.ones(3), max_iter=0)  # opti/_base.py:73-74
+    with pytest.raises(ValueError):
+        FrankWolfe(quad=quad, ub=np.ones(3), t=1.0)             # frank_wolfe.py:84-85
+    opt = InteriorPoint(quad=quad, ub=np.array([2., 4., 6.]))
+    assert opt.eps == 1e-10 and opt.status == 'unknown' and opt.iter == 0 and np.isnan(opt.f_x)
+    np.testing.assert_array_equal(opt.x, [1., 2., 3.])           # mid-box start, constrained/_base.py:65
+    np.testing.assert_array_equal(opt.lb, np.zeros(3))
+    assert hasattr(opt, 'x0_history')                            # ndim <= 3, opti/_base.py:78-82
+    with pytest.raises(ValueError):
+        PolyKernel(degree=0)
+    with pytest.raises(ValueError):
+        GaussianKernel(gamma='bogus')
+    with pytest.raises(ValueError):
+        SVC(loss=hinge, C=0)
+    with pytest.raises(TypeError):
+        SVC(loss=epsilon_insensitive)
+    with pytest.raises(TypeError):
+        SVR(loss=hinge)
+    with pytest.raises(TypeError):
+        SVC(loss=hinge, kernel='rbf')
+    X = np.random.RandomState(0).standard_normal((8, 2))
+    y = np.array([0, 1] * 4)
+    with pytest.raises(NotImplementedError):                     # svm/_base.py:621-624
+        SVC(loss=hinge, kernel=gaussian, dual=True, reg_intercept=False, optimizer=ProjectedGradient).fit(X, y)
+    with pytest.raises(NotImplementedError):                     # svm/_base.py:771-774
+        SVC(loss=squared_hinge, kernel=gaussian, dual=True, reg_intercept=True, optimizer=ProjectedGradient).fit(X, y)
+    with pytest.raises(ValueError):                              # svm/_base.py:437-439
+        SVC(loss=hinge, dual=True, reg_intercept=True, optimizer=ProjectedGradient).fit(X, np.arange(8))
+    est = SVC(loss=hinge, dual=True, reg_intercept=True, optimizer=ProjectedGradient)
+    assert est.get_params()['C'] == 1 and est.train_loss_history == []
