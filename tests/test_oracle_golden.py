@@ -143,3 +143,17 @@ def test_cfg5_squared_hinge_active_set(golden):
     _cmp_run(res, g, 'as')
     res = bo.projected_gradient(Q, q, ub, x0=g['x0'], max_iter=1000, keep_x=(1, 2, 10, 100))
     _cmp_run(res, g, 'pg')
+
+
+def test_pg_is_sensitive_to_rounding(golden):
+    """Evidence for the PG parity policy: the reference formulation itself is chaotic.  A 1e-15 relative
+    perturbation of the start changes the iterates by > 1e-6 within 500 iterations (and the stopping iteration),
+    while the first ~120 iterations and the objective reached stay reproducible."""
+    g = golden('traj_svc_rbf_n256.npz')
+    Q, q, ub = g['Q'], g['q'], g['ub']
+    x0 = ub / 2 * (1 + 1e-15 * np.random.RandomState(0).standard_normal(len(ub)))
+    a = bo.projected_gradient(Q, q, ub, keep_x=(100, 500))
+    b = bo.projected_gradient(Q, q, ub, x0=x0, keep_x=(100, 500))
+    assert np.abs(a['x_at'][100] - b['x_at'][100]).max() < 1e-9
+    assert np.abs(a['x_at'][500] - b['x_at'][500]).max() > 1e-6
+    assert abs(a['f_x'] - b['f_x']) < 1e-5 * abs(a['f_x'])
