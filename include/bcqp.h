@@ -139,6 +139,12 @@ int bq_decision_function(bq_ctx *ctx, int kernel, double gamma, double coef0, in
 int bq_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                    const double *A, int64_t t, const double *B, double *out);
 
+/* x = A^-1 b for a dense symmetric positive definite A (n x n row-major fp64, lower triangle read):
+ * scipy.linalg.cho_solve(cho_factor(A), b) at optiml/opti/constrained/interior_point.py:235 and
+ * active_set.py:141.  BQ_ERR_NOT_PD mirrors LinAlgError.  factor_ms (optional): HIP-event time of the
+ * factorisation alone. */
+int bq_cholesky_solve(bq_ctx *ctx, int64_t n, const double *A, const double *b, double *x, double *factor_ms);
+
 #ifdef __cplusplus
 }
 #endif

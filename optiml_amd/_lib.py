@@ -67,6 +67,7 @@ PROTOTYPES = {
     'bq_decision_function': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _dp,
                                        C.c_double, _i64, _dp, _dp]),
     'bq_gram_matrix': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _i64, _dp, _dp]),
+    'bq_cholesky_solve': (C.c_int, [_vp, _i64, _dp, _dp, _dp, _dp]),
 }
 
 

@@ -581,7 +581,9 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
         BQ_TRY(solver_first(s));
         s->initialised = true;
     }
-    const int64_t poll = s->N >= 16384 ? 1 : 8;
+    // how often the host looks at the device `done` flag (kernels early-exit on it, so a late look is harmless;
+    // the factorising solvers are host-enqueued O(n^3) work per iteration, so they look every time)
+    const int64_t poll = (s->kind == BQ_IP || s->kind == BQ_AS || s->N >= 16384) ? 1 : 8;
     for (int64_t k = 0; k < max_steps; ++k) {
         BQ_TRY(solver_iterate(s));
         if ((k + 1) % poll == 0 && k + 1 < max_steps) {
@@ -660,4 +662,13 @@ extern "C" int bq_gram_matrix(bq_ctx *c, int kernel, double gamma, double coef0,
     BQ_ARG(m >= 1 && d >= 1 && (B == nullptr || t >= 1), "m/d/t");
     BQ_HIP(hipSetDevice(c->device));
     return bq_launch_gram_matrix(c, kernel, gamma, coef0, degree, m, d, A, t, B, out);
+}
+
+int bq_chol_solve_dense_impl(bq_ctx *ctx, int64_t n, const double *A, const double *b, double *x, double *factor_ms);
+
+extern "C" int bq_cholesky_solve(bq_ctx *c, int64_t n, const double *A, const double *b, double *x, double *factor_ms) {
+    BQ_ARG(c && A && b && x, "NULL argument");
+    BQ_ARG(n >= 1, "n");
+    BQ_HIP(hipSetDevice(c->device));
+    return bq_chol_solve_dense_impl(c, n, A, b, x, factor_ms);
 }

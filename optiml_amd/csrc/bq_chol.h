@@ -1,0 +1,19 @@
+// Factorisation workspace shared by the interior-point and active-set drivers.
+#pragma once
+#include "bq_common.h"
+
+struct bq_chol_ws {
+    bq_ctx *ctx = nullptr;
+    int64_t cap = 0;   // largest padded order the workspace can hold (multiple of 128)
+    int64_t ldh = 0;   // row pitch of H
+    double *H = nullptr;      // cap x ldh, row-major; lower triangle = matrix, then its Cholesky factor
+    double *Wt = nullptr;     // 128 x ldh k-major image of the current block column
+    double *LinvT = nullptr;  // per diagonal block: 128 x 128 image of the inverse triangular factor
+    double *rhs = nullptr;    // right-hand side / solution (padded)
+    double *tmp = nullptr;    // 128 scratch
+    int *info = nullptr;      // 0 = ok, else 1 + index of the first non-positive pivot
+};
+
+int bq_chol_factor(bq_chol_ws *ws, int64_t np);
+int bq_chol_solve(bq_chol_ws *ws, int64_t np);
+int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out);

@@ -1,0 +1,381 @@
+// Dense fp64 Cholesky (lower, in place, row-major) + triangular solves for the interior-point Newton system
+// and the active-set restricted system.  Replaces scipy's cho_factor / cho_solve at
+// optiml/opti/constrained/interior_point.py:235 and active_set.py:141.
+//
+// Blocked right-looking factorisation with 128-wide block columns:
+//   1. potrf_diag   one workgroup factors the 128x128 diagonal block in LDS (packed lower triangle, 66 KB) and
+//                   inverts the triangular factor next to it (another 66 KB); the inverse is kept per block (it
+//                   turns both TRSM and the two triangular solves into matrix products);
+//   2. trsm as GEMM the block column below the diagonal, X = A_ik L_kk^-T, on the shared fp64-MFMA 128x128 tile
+//                   kernel (operands as k-major images so global loads are coalesced);
+//   3. syrk         the trailing lower triangle, A_ij -= X_i X_j^T, one workgroup per 128x128 tile on the same
+//                   MFMA kernel — n^3/3 flops, the MFMA-bound bulk of every interior-point iteration.
+// The solves walk the block columns with one row-panel product + one 128x128 product per block (forward
+// left-looking, backward right-looking), all with fixed reduction orders.
+#include <cmath>
+
+#include "bq_chol.h"
+#include "bq_mfma_tile.h"
+
+constexpr int NB = 128;
+constexpr int TRI = NB * (NB + 1) / 2;  // packed lower triangle
+
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // j <= i
+
+// ---------------------------------------------------------------------------------------------
+// 1. diagonal block: factor + invert
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ H, int64_t ldh, int64_t k0,
+                                                         double *__restrict__ LinvT, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *Lp = smem;        // packed lower factor
+    double *Xp = smem + TRI;  // packed lower inverse
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        if (j <= i) Lp[tri(i, j)] = H[(k0 + i) * ldh + k0 + j];
+    }
+    __syncthreads();
+    bool ok = true;
+    for (int j = 0; j < NB; ++j) {
+        const double piv = Lp[tri(j, j)];
+        if (!(piv > 0.0)) {  // also catches NaN; identical in every thread -> uniform exit
+            if (tid == 0 && *info == 0) *info = (int)(k0 + j + 1);
+            ok = false;
+            break;
+        }
+        const double r = sqrt(piv);
+        __syncthreads();
+        for (int i = j + 1 + tid; i < NB; i += 256) Lp[tri(i, j)] /= r;
+        if (tid == 0) Lp[tri(j, j)] = r;
+        __syncthreads();
+        const int ti = tid >> 4, tk = tid & 15;
+        for (int i = j + 1 + ti; i < NB; i += 16) {
+            const double lij = Lp[tri(i, j)];
+            for (int k = j + 1 + tk; k <= i; k += 16) Lp[tri(i, k)] -= lij * Lp[tri(k, j)];
+        }
+        __syncthreads();
+    }
+    if (!ok) return;
+    // inverse of the lower-triangular factor, one column per thread (forward substitution on e_c)
+    if (tid < NB) {
+        const int c = tid;
+        for (int i = c; i < NB; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) s -= Lp[tri(i, k)] * Xp[tri(k, c)];
+            Xp[tri(i, c)] = s / Lp[tri(i, i)];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        if (j <= i) H[(k0 + i) * ldh + k0 + j] = Lp[tri(i, j)];
+        // image for the tile kernel: Bt[k][j] = Linv[j][k]  (zero above the diagonal of Linv)
+        const int k = i, jj = j;  // e enumerates (k, jj)
+        LinvT[k * NB + jj] = (k <= jj) ? Xp[tri(jj, k)] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2./3. block column: transpose to a k-major image, TRSM as GEMM, SYRK on the trailing triangle
+// ---------------------------------------------------------------------------------------------
+// Wt[kk][i] = H[i][k0 + kk] for i in [i0, np), kk < 128
+__global__ void panel_to_image_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0, int64_t i0, int64_t np,
+                                      double *__restrict__ Wt) {
+    __shared__ double tile[32][33];
+    const int64_t r0 = i0 + (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = r0 + j;
+        tile[j][tx] = (r < np) ? H[r * ldh + k0 + c0 + tx] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = r0 + tx;
+        if (r < np) Wt[(int64_t)(c0 + j) * ldh + r] = tile[tx][j];
+    }
+}
+
+// X = A_ik * Linv_kk^T for the row tiles below the diagonal block; written back in place
+__global__ __launch_bounds__(256, 2) void trsm_gemm_kernel(double *__restrict__ H, int64_t ldh, int64_t k0, int64_t i0,
+                                                           const double *__restrict__ Wt,
+                                                           const double *__restrict__ LinvT) {
+    __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
+    const int64_t arow = i0 + (int64_t)blockIdx.x * NB;
+    bq_d4 acc[4][4];
+    bq_tile_zero(acc);
+    bq_mfma_tile_128(Wt, ldh, arow, LinvT, NB, 0, NB, sm, acc);
+    bq_tile_foreach(acc, [&](int r, int c, double v) { H[(arow + r) * ldh + k0 + c] = v; });
+}
+
+// A_ij -= X_i X_j^T over the lower-triangular tiles (ti >= tj) of the trailing matrix starting at i0
+__global__ __launch_bounds__(256, 2) void syrk_kernel(double *__restrict__ H, int64_t ldh, int64_t i0,
+                                                      const double *__restrict__ Wt) {
+    __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
+    const int64_t b = blockIdx.x;
+    int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    while (ti * (ti + 1) / 2 > b) --ti;
+    const int64_t tj = b - ti * (ti + 1) / 2;
+    const int64_t arow = i0 + ti * NB, bcol = i0 + tj * NB;
+    bq_d4 acc[4][4];
+    bq_tile_zero(acc);
+    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, bcol, NB, sm, acc);
+    bq_tile_foreach(acc, [&](int r, int c, double v) {
+        double *p = H + (arow + r) * ldh + bcol + c;
+        *p -= v;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// triangular solves with the blocked factor (rhs overwritten by the solution)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wsum_c(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// tmp[r] = rhs[k0 + r] - sum_{c < k0} L[k0 + r][c] * rhs[c]      (one workgroup per row r)
+__global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0,
+                                                        const double *__restrict__ rhs, double *__restrict__ tmp) {
+    __shared__ double red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const double *row = H + (k0 + r) * ldh;
+    double a = 0.0;
+    for (int64_t c = 2 * tid; c < k0; c += 512) {  // k0 is a multiple of 128 -> pairs never straddle k0
+        const bq_d2 l = *reinterpret_cast<const bq_d2 *>(row + c);
+        const bq_d2 y = *reinterpret_cast<const bq_d2 *>(rhs + c);
+        a = fma(l.y, y.y, fma(l.x, y.x, a));
+    }
+    a = wsum_c(a);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) tmp[r] = rhs[k0 + r] - (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+// out[i] = sum_j M[i][j] in[j] with M = Linv (transpose == 0) or Linv^T (transpose == 1); LinvT[k][j] = Linv[j][k]
+__global__ __launch_bounds__(128) void diag_mv_kernel(const double *__restrict__ LinvT, int transpose,
+                                                      const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double v[NB];
+    __shared__ double M[NB][NB + 1];
+    const int i = threadIdx.x;
+    v[i] = in[i];
+    for (int e = i; e < NB * NB; e += NB) M[e >> 7][e & 127] = LinvT[e];
+    __syncthreads();
+    double s = 0.0;
+    if (transpose) {
+        for (int j = i; j < NB; ++j) s = fma(M[i][j], v[j], s);  // Linv^T[i][j] = LinvT[i][j], upper triangular
+    } else {
+        for (int j = 0; j <= i; ++j) s = fma(M[j][i], v[j], s);  // Linv[i][j] = LinvT[j][i], lower triangular
+    }
+    out[i] = s;
+}
+
+// rhs[c] -= sum_{r < 128} L[k0 + r][c] * x[r]  for c < k0
+__global__ __launch_bounds__(256) void bwd_update_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0,
+                                                         const double *__restrict__ xk, double *__restrict__ rhs) {
+    __shared__ double x[NB];
+    if (threadIdx.x < NB) x[threadIdx.x] = xk[threadIdx.x];
+    __syncthreads();
+    const int64_t c = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+    if (c >= k0) return;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < NB; ++r) {
+        const bq_d2 l = *reinterpret_cast<const bq_d2 *>(H + (k0 + r) * ldh + c);
+        a0 = fma(l.x, x[r], a0);
+        a1 = fma(l.y, x[r], a1);
+    }
+    rhs[c] -= a0;
+    rhs[c + 1] -= a1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------------------------
+int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
+    bq_chol_ws *ws = new bq_chol_ws();
+    ws->ctx = ctx;
+    ws->cap = bq_round_up(n, NB);
+    ws->ldh = ws->cap;
+    const int64_t nblk = ws->cap / NB;
+    hipError_t e = hipMalloc(&ws->H, sizeof(double) * ws->ldh * ws->cap);
+    if (e != hipSuccess) {
+        bq_set_error("cannot allocate the %lld x %lld factorisation workspace (%.1f GB): %s", (long long)ws->cap,
+                     (long long)ws->cap, 8e-9 * ws->ldh * ws->cap, hipGetErrorString(e));
+        delete ws;
+        return BQ_ERR_NOMEM;
+    }
+    if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * NB * ws->ldh);
+    if (e == hipSuccess) e = hipMalloc(&ws->LinvT, sizeof(double) * nblk * NB * NB);
+    if (e == hipSuccess) e = hipMalloc(&ws->rhs, sizeof(double) * (ws->cap + NB));
+    if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * NB);
+    if (e == hipSuccess) e = hipMalloc(&ws->info, sizeof(int));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 2 * TRI * (int)sizeof(double));
+    if (e != hipSuccess) {
+        bq_set_error("factorisation workspace setup failed: %s", hipGetErrorString(e));
+        bq_chol_ws_destroy(ws);
+        return BQ_ERR_HIP;
+    }
+    *out = ws;
+    return BQ_OK;
+}
+
+void bq_chol_ws_destroy(bq_chol_ws *ws) {
+    if (!ws) return;
+    for (void *p : {(void *)ws->H, (void *)ws->Wt, (void *)ws->LinvT, (void *)ws->rhs, (void *)ws->tmp, (void *)ws->info})
+        if (p) hipFree(p);
+    delete ws;
+}
+
+// factor the leading np x np block of ws->H (np multiple of 128, lower triangle valid) in place
+int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
+    bq_ctx *ctx = ws->ctx;
+    hipStream_t st = ctx->stream;
+    BQ_ARG(np % NB == 0 && np <= ws->cap, "factor size");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BQ_TRY(bq_prof_begin(ctx, BQ_PROF_CHOL, &e0, &e1));
+    BQ_HIP(hipMemsetAsync(ws->info, 0, sizeof(int), st));
+    const int64_t ldh = ws->ldh;
+    for (int64_t k0 = 0; k0 < np; k0 += NB) {
+        double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
+        potrf_diag_kernel<<<1, 256, 2 * TRI * sizeof(double), st>>>(ws->H, ldh, k0, LinvT, ws->info);
+        const int64_t i0 = k0 + NB;
+        if (i0 >= np) break;
+        const int64_t T = (np - i0) / NB;
+        dim3 tg((unsigned)((np - i0 + 31) / 32), NB / 32);
+        panel_to_image_kernel<<<tg, 256, 0, st>>>(ws->H, ldh, k0, i0, np, ws->Wt);
+        trsm_gemm_kernel<<<(unsigned)T, 256, 0, st>>>(ws->H, ldh, k0, i0, ws->Wt, LinvT);
+        panel_to_image_kernel<<<tg, 256, 0, st>>>(ws->H, ldh, k0, i0, np, ws->Wt);
+        syrk_kernel<<<(unsigned)(T * (T + 1) / 2), 256, 0, st>>>(ws->H, ldh, i0, ws->Wt);
+    }
+    BQ_HIP(hipGetLastError());
+    BQ_TRY(bq_prof_end(ctx, BQ_PROF_CHOL, e0, e1));
+    return BQ_OK;
+}
+
+// solve (L L^T) x = ws->rhs in place (ws->rhs padded to np, pad entries zero)
+int bq_chol_solve(bq_chol_ws *ws, int64_t np) {
+    hipStream_t st = ws->ctx->stream;
+    const int64_t ldh = ws->ldh;
+    for (int64_t k0 = 0; k0 < np; k0 += NB) {
+        const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
+        const double *src = ws->rhs + k0;
+        if (k0 > 0) {
+            fwd_panel_kernel<<<NB, 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp);
+            src = ws->tmp;
+        }
+        diag_mv_kernel<<<1, NB, 0, st>>>(LinvT, 0, src, ws->rhs + k0);
+    }
+    for (int64_t k0 = np - NB; k0 >= 0; k0 -= NB) {
+        const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
+        diag_mv_kernel<<<1, NB, 0, st>>>(LinvT, 1, ws->rhs + k0, ws->rhs + k0);
+        if (k0 > 0) bwd_update_kernel<<<(unsigned)((k0 / 2 + 255) / 256), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs + k0, ws->rhs);
+    }
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// H assembly: H[a][b] = Q[idx[a]][idx[b]] (+ hd[a] on the diagonal) for b <= a < m; identity on the pad
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64_t ldp, int64_t n,
+                               const double *__restrict__ sgn, double diag_add, const int *__restrict__ idx, int64_t m,
+                               int64_t np, const double *__restrict__ hd, double *__restrict__ H, int64_t ldh) {
+    const int64_t a0 = (int64_t)blockIdx.y * 32, b0 = (int64_t)blockIdx.x * 32;
+    if (b0 > a0 + 31) return;  // strictly-upper tile
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t b = b0 + tx;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t a = a0 + j;
+        if (a >= np || b > a) continue;
+        double v;
+        if (a >= m) {
+            v = (a == b) ? 1.0 : 0.0;
+        } else {
+            const int64_t i = idx ? idx[a] : a, jj = idx ? idx[b] : b;
+            if (structure == BQ_PLAIN) {
+                v = (double)panel[i * ldp + jj];
+            } else if (structure == BQ_SVC) {
+                v = sgn[i] * sgn[jj] * ((double)panel[i * ldp + jj] + 1.0);
+            } else {
+                const int64_t ii = i >= n ? i - n : i, jn = jj >= n ? jj - n : jj;
+                const double pv = (double)panel[ii * ldp + jn] + 1.0;
+                v = ((i >= n) == (jj >= n)) ? pv : -pv;
+            }
+            if (i == jj) {
+                if (diag_add != 0.0) v += diag_add;
+                if (hd) v += hd[a];
+            }
+        }
+        H[a * ldh + b] = v;
+    }
+}
+
+int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out) {
+    const int64_t np = bq_round_up(m > 0 ? m : 1, NB);
+    BQ_ARG(np <= ws->cap, "H larger than the workspace");
+    BQ_ARG(p->r0 == 0 && p->r1 == p->n, "the factorisation needs the whole panel on this rank");
+    dim3 grid((unsigned)((np + 31) / 32), (unsigned)((np + 31) / 32));
+    if (p->storage == BQ_F64)
+        build_h_kernel<double><<<grid, 256, 0, ws->ctx->stream>>>(p->structure, (const double *)p->panel, p->ld, p->n, p->sgn,
+                                                                 p->diag_add, idx, m, np, hd, ws->H, ws->ldh);
+    else
+        build_h_kernel<float><<<grid, 256, 0, ws->ctx->stream>>>(p->structure, (const float *)p->panel, p->ld, p->n, p->sgn,
+                                                                p->diag_add, idx, m, np, hd, ws->H, ws->ldh);
+    BQ_HIP(hipGetLastError());
+    *np_out = np;
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone entry: x = A^-1 b for a dense SPD host matrix (cho_factor + cho_solve), used by tests and benchmarks
+// ---------------------------------------------------------------------------------------------
+__global__ void pad_identity_kernel(double *H, int64_t ldh, int64_t n, int64_t np) {
+    const int64_t i = n + (int64_t)blockIdx.x;
+    for (int64_t j = threadIdx.x; j <= i; j += blockDim.x) H[i * ldh + j] = (i == j) ? 1.0 : 0.0;
+    (void)np;
+}
+
+int bq_chol_solve_dense_impl(bq_ctx *ctx, int64_t n, const double *A, const double *b, double *x, double *factor_ms) {
+    bq_chol_ws *ws = nullptr;
+    BQ_TRY(bq_chol_ws_create(ctx, n, &ws));
+    const int64_t np = bq_round_up(n, NB);
+    hipStream_t st = ctx->stream;
+    int rc = BQ_OK;
+    hipError_t e = hipMemcpy2DAsync(ws->H, ws->ldh * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && np > n) pad_identity_kernel<<<(unsigned)(np - n), 128, 0, st>>>(ws->H, ws->ldh, n, np);
+    if (e == hipSuccess) e = hipMemsetAsync(ws->rhs, 0, sizeof(double) * np, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws->rhs, b, sizeof(double) * n, hipMemcpyHostToDevice, st);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    if (e == hipSuccess) rc = bq_chol_factor(ws, np);
+    if (e == hipSuccess && rc == BQ_OK) e = hipEventRecord(e1, st);
+    if (e == hipSuccess && rc == BQ_OK) rc = bq_chol_solve(ws, np);
+    int info = 0;
+    if (e == hipSuccess && rc == BQ_OK) e = hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && rc == BQ_OK) e = hipMemcpyAsync(x, ws->rhs, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    float ms = 0.f;
+    if (e == hipSuccess && rc == BQ_OK && e0 && e1) e = hipEventElapsedTime(&ms, e0, e1);
+    if (factor_ms) *factor_ms = ms;
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    bq_chol_ws_destroy(ws);
+    if (rc != BQ_OK) return rc;
+    if (e != hipSuccess) {
+        bq_set_error("dense Cholesky solve failed: %s", hipGetErrorString(e));
+        return BQ_ERR_HIP;
+    }
+    if (info != 0) {
+        bq_set_error("%d-th leading minor of the array is not positive definite", info);
+        return BQ_ERR_NOT_PD;
+    }
+    return BQ_OK;
+}

@@ -13,12 +13,10 @@
 // stores in the panel's storage dtype.
 #include "bq_common.h"
 
-typedef double d2_t __attribute__((ext_vector_type(2)));
-typedef double d4_t __attribute__((ext_vector_type(4)));
+#include "bq_mfma_tile.h"
 
-constexpr int GT = 128;        // output tile edge
-constexpr int GK = 16;         // k-chunk
-constexpr int GP = GT + 16;    // LDS row pitch in doubles
+constexpr int GT = BQ_GT;
+constexpr int GK = BQ_GK;
 
 __global__ void transpose_pad_kernel(const double *__restrict__ X, int64_t n, int64_t d, double *__restrict__ Xt,
                                      int64_t np, int64_t dp) {
@@ -55,11 +53,9 @@ template <> __device__ __forceinline__ void store_elem<float>(float *p, double v
 struct gram_params {
     const double *At, *Bt;   // k-major padded images: At[dp][mp], Bt[dp][np]
     const double *a2, *b2;   // squared row norms (padded)
-    int64_t m, n;            // valid rows of A / rows of B (output is m_rows x n)
+    int64_t m, n;            // rows of A covered by this launch / rows of B (= output columns)
     int64_t mp, np, dp;
-    int64_t arow0;           // first A row this launch covers (global index), rows [arow0, arow1)
-    int64_t arow1;
-    int64_t brow_off;        // global index of B row 0 (for the same-matrix diagonal test)
+    int64_t arow0, arow1;    // global A rows [arow0, arow1) of this launch (arow0 tile-aligned)
     int same;                // A and B are the same matrix -> exact zero distance on the diagonal
     int kernel, degree;
     double gamma, coef0;
@@ -68,104 +64,32 @@ struct gram_params {
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) double As[2][GK][GP];
-    __shared__ __attribute__((aligned(16))) double Bs[2][GK][GP];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;  // wave position in the 2x2 arrangement
+    __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     // tiles of the same A-row block are adjacent in blockIdx -> they share the A slice in L2
     const int64_t tiles_n = (P.n + GT - 1) / GT;
     const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-    const int64_t arow = P.arow0 + tm * GT;  // global A row of tile row 0
-    const int64_t bcol = tn * GT;
-
-    d4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-
-    // staging map: 16 k-slices x 64 double2 per tile = 1024 double2, 4 per thread
-    d2_t ra[4], rb[4];
-    auto gload = [&](int64_t kc) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = tid + 256 * u;
-            const int k = j >> 6, c2 = j & 63;
-            ra[u] = *reinterpret_cast<const d2_t *>(P.At + (kc + k) * P.mp + arow + 2 * c2);
-            rb[u] = *reinterpret_cast<const d2_t *>(P.Bt + (kc + k) * P.np + bcol + 2 * c2);
+    const int64_t arow = P.arow0 + tm * GT, bcol = tn * GT;
+    bq_d4 acc[4][4];
+    bq_tile_zero(acc);
+    bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
+    bq_tile_foreach(acc, [&](int r, int c, double dot) {
+        const int64_t gi = arow + r, gj = bcol + c;
+        if (gi >= P.arow1 || gj >= P.n) return;
+        double kv;
+        if (P.kernel == BQ_KERNEL_RBF) {
+            double dist = -2.0 * dot;
+            dist += P.a2[gi];
+            dist += P.b2[gj];
+            dist = fmax(dist, 0.0);
+            if (P.same && gi == gj) dist = 0.0;
+            kv = exp(-P.gamma * dist);
+        } else if (P.kernel == BQ_KERNEL_POLY) {
+            kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+        } else {
+            kv = dot;
         }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = tid + 256 * u;
-            const int k = j >> 6, c2 = j & 63;
-            *reinterpret_cast<d2_t *>(&As[buf][k][2 * c2]) = ra[u];
-            *reinterpret_cast<d2_t *>(&Bs[buf][k][2 * c2]) = rb[u];
-        }
-    };
-
-    const int64_t nchunks = P.dp / GK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int fr = lane & 15, fk = lane >> 4;
-    for (int64_t c = 0; c < nchunks; ++c) {
-        const int buf = (int)(c & 1);
-        if (c + 1 < nchunks) gload((c + 1) * GK);
-#pragma unroll
-        for (int kk = 0; kk < GK / 4; ++kk) {
-            double a[4], b[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = As[buf][kk * 4 + fk][wr * 64 + t * 16 + fr];
-                b[t] = Bs[buf][kk * 4 + fk][wc * 64 + t * 16 + fr];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (c + 1 < nchunks) {
-            lstore(buf ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-    const int ccol = lane & 15, crow = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;  // global A row
-            if (gi >= P.arow1) continue;
-            const double ai = P.a2[gi];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
-                if (gj >= P.n) continue;
-                const double dot = acc[i][j][v];
-                double kv;
-                if (P.kernel == BQ_KERNEL_RBF) {
-                    double dist = -2.0 * dot;
-                    dist += ai;
-                    dist += P.b2[gj];
-                    dist = fmax(dist, 0.0);
-                    if (P.same && gi == gj + P.brow_off) dist = 0.0;
-                    kv = exp(-P.gamma * dist);
-                } else if (P.kernel == BQ_KERNEL_POLY) {
-                    const double base = P.gamma * dot + P.coef0;
-                    kv = pow(base, (double)P.degree);
-                } else {
-                    kv = dot;
-                }
-                store_elem<T>(out + (gi - P.arow0) * P.ld + gj, kv);
-            }
-        }
-    }
+        store_elem<T>(out + (gi - P.arow0) * P.ld + gj, kv);
+    });
 }
 
 struct gram_images {
@@ -206,7 +130,6 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
     P.dp = A.dp;
     P.arow0 = m_rows0;
     P.arow1 = m_rows1;
-    P.brow_off = 0;
     P.same = same ? 1 : 0;
     P.kernel = kernel;
     P.degree = degree;

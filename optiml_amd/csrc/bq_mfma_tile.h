@@ -1,0 +1,102 @@
+// 128x128 fp64 MFMA tile product shared by the Gram build, the Cholesky TRSM-as-GEMM and the SYRK update.
+//
+//   acc[i][j] (+)= sum_k A[arow + .][k] * B[bcol + .][k]      (both operands "row x k", i.e. C = A * B^T)
+//
+// Operands are k-major, zero-padded images: At[k][row] with pitch lda, Bt[k][row] with pitch ldb, so one k-slice
+// of a 128-row tile is 1 KiB contiguous (coalesced 16-byte loads) and the LDS image [k][row] needs no transpose.
+// 256 threads = 4 waves in a 2x2 arrangement; each wave owns a 64x64 block as 4x4 v_mfma_f64_16x16x4_f64 tiles
+// (64 fp64 accumulators = 128 VGPRs per lane).  K advances in chunks of 16 through double-buffered LDS; the row
+// pitch of 144 doubles puts the k-slices that one ds_read_b64 touches (lanes 0-15 / 16-31 of a 32-lane group) on
+// disjoint bank halves.  Lane maps of v_mfma_f64_16x16x4_f64: A/B operand: row = lane & 15, k = lane >> 4;
+// C/D: col = lane & 15, row = (lane >> 4) + 4 * reg.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+typedef double bq_d2 __attribute__((ext_vector_type(2)));
+typedef double bq_d4 __attribute__((ext_vector_type(4)));
+
+constexpr int BQ_GT = 128;          // tile edge
+constexpr int BQ_GK = 16;           // k-chunk
+constexpr int BQ_GP = BQ_GT + 16;   // LDS row pitch (doubles)
+
+struct bq_tile_smem {
+    double A[2][BQ_GK][BQ_GP];
+    double B[2][BQ_GK][BQ_GP];
+};
+
+// kdim must be a multiple of 16; arow/bcol multiples of 2 with arow+127 < lda, bcol+127 < ldb.
+__device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, int64_t lda, int64_t arow,
+                                                 const double *__restrict__ Bt, int64_t ldb, int64_t bcol,
+                                                 int64_t kdim, bq_tile_smem &sm, bq_d4 (&acc)[4][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    bq_d2 ra[4], rb[4];
+    auto gload = [&](int64_t kc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tid + 256 * u;
+            const int k = j >> 6, c2 = j & 63;
+            ra[u] = *reinterpret_cast<const bq_d2 *>(At + (kc + k) * lda + arow + 2 * c2);
+            rb[u] = *reinterpret_cast<const bq_d2 *>(Bt + (kc + k) * ldb + bcol + 2 * c2);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tid + 256 * u;
+            const int k = j >> 6, c2 = j & 63;
+            *reinterpret_cast<bq_d2 *>(&sm.A[buf][k][2 * c2]) = ra[u];
+            *reinterpret_cast<bq_d2 *>(&sm.B[buf][k][2 * c2]) = rb[u];
+        }
+    };
+    const int64_t nchunks = kdim / BQ_GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int buf = (int)(c & 1);
+        if (c + 1 < nchunks) gload((c + 1) * BQ_GK);
+#pragma unroll
+        for (int kk = 0; kk < BQ_GK / 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = sm.A[buf][kk * 4 + fk][wr * 64 + t * 16 + fr];
+                b[t] = sm.B[buf][kk * 4 + fk][wc * 64 + t * 16 + fr];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) {
+            lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+}
+
+// Visit every accumulator element of this lane: f(row_in_tile, col_in_tile, value)
+template <typename F>
+__device__ __forceinline__ void bq_tile_foreach(bq_d4 (&acc)[4][4], F &&f) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int ccol = lane & 15, crow = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f(wr * 64 + i * 16 + crow + 4 * v, wc * 64 + j * 16 + ccol, acc[i][j][v]);
+}
+
+__device__ __forceinline__ void bq_tile_zero(bq_d4 (&acc)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (bq_d4){0.0, 0.0, 0.0, 0.0};
+}

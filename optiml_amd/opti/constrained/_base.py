@@ -35,8 +35,16 @@ class _DeviceSolver:
     def run(self, max_steps):
         stats = np.zeros(max_steps, dtype=_lib.STAT_DTYPE)
         n, status = C.c_int64(0), C.c_int(0)
-        _lib.check(self._lib.bq_solver_run(self._h, max_steps, stats.ctypes.data_as(C.POINTER(_lib.IterStat)),
-                                           max_steps, C.byref(n), C.byref(status)))
+        try:
+            _lib.check(self._lib.bq_solver_run(self._h, max_steps, stats.ctypes.data_as(C.POINTER(_lib.IterStat)),
+                                               max_steps, C.byref(n), C.byref(status)))
+        except _lib.BcqpError as err:
+            # the exceptions scipy's cho_factor raises inside the reference solvers
+            if err.code == _lib.ERR_NOT_PD:
+                raise np.linalg.LinAlgError(str(err)) from None
+            if err.code == _lib.ERR_NONFINITE:
+                raise ValueError('array must not contain infs or NaNs') from None
+            raise
         return stats[:n.value], _lib.STATUS[status.value]
 
     def get(self, what):
