@@ -50,8 +50,11 @@ enum { BQ_KERNEL_LINEAR = 0, BQ_KERNEL_POLY = 1, BQ_KERNEL_RBF = 2 };
 enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian structure */
 enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3 };                 /* solver kind */
 enum { BQ_STATUS_UNKNOWN = 0, BQ_STATUS_OPTIMAL = 1, BQ_STATUS_STOPPED = 2 };
+/* BQ_GET_X / BQ_GET_G: the point (and gradient) the LAST ITERATION RECORD was evaluated at — what the
+ * reference's callback sees at the top of that iteration.  BQ_GET_X_NOW / BQ_GET_G_NOW: the current iterate
+ * (differs only for ActiveSet, whose loop body moves x after the record: active_set.py:156-160, 208). */
 enum { BQ_GET_X = 0, BQ_GET_G = 1, BQ_GET_LP = 2, BQ_GET_LM = 3, BQ_GET_D = 4,
-       BQ_GET_MASK_L = 5, BQ_GET_MASK_U = 6 };
+       BQ_GET_MASK_L = 5, BQ_GET_MASK_U = 6, BQ_GET_X_NOW = 7, BQ_GET_G_NOW = 8 };
 
 /* One row per evaluation at the top of a solver iteration (what the reference's callback/verbose
  * line sees).  r1/r2/r3 by solver:  PG: |proj grad|_2, step t, max_t;  FW: best lower bound, gap,

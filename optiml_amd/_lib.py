@@ -17,7 +17,7 @@ KERNEL_LINEAR, KERNEL_POLY, KERNEL_RBF = 0, 1, 2
 PLAIN, SVC, SVR = 0, 1, 2
 PG, FW, AS, IP = 0, 1, 2, 3
 STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
-GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U = range(7)
+GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW = range(9)
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
 ABI_VERSION = 1
 

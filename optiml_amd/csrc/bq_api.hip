@@ -387,7 +387,7 @@ extern "C" int bq_problem_gram_matvec(bq_problem *p, const double *w, double *ou
     BQ_HIP(hipMemsetAsync(p->w, 0, sizeof(double) * p->ld, c->stream));
     BQ_HIP(hipMemcpyAsync(p->w, w, sizeof(double) * p->n, hipMemcpyHostToDevice, c->stream));
     BQ_TRY(bq_launch_gemv(c, p->panel, p->storage, false, p->r1 - p->r0, p->ld, p->w, p->s + p->r0, nullptr));
-    if (c->world > 1) BQ_TRY(bq_exchange_rows(c, p->s, p->n, p->blk, p->r0, p->r1));
+    if (c->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_rows(c, p->s, p->n, p->blk, p->r0, p->r1));
     BQ_HIP(hipMemcpyAsync(out, p->s, sizeof(double) * p->n, hipMemcpyDeviceToHost, c->stream));
     BQ_HIP(hipStreamSynchronize(c->stream));
     return BQ_OK;
@@ -458,7 +458,7 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
                       (void *)s->mL, (void *)s->mU, (void *)s->partials, (void *)s->sc, (void *)s->stats})
         if (ptr) hipFree(ptr);
     if (s->chol) bq_chol_ws_destroy(s->chol);
-    if (s->as_ws) free(s->as_ws);
+    bq_as_free(s);
     delete s;
     return BQ_OK;
 }
@@ -625,8 +625,10 @@ extern "C" int bq_solver_get(bq_solver *s, int what, double *out) {
     BQ_HIP(hipSetDevice(c->device));
     const double *src = nullptr;
     switch (what) {
-        case BQ_GET_X: src = s->x; break;
-        case BQ_GET_G: src = s->g; break;
+        case BQ_GET_X: src = s->kind == BQ_AS ? bq_as_view(s, BQ_GET_X) : s->x; break;
+        case BQ_GET_G: src = s->kind == BQ_AS ? bq_as_view(s, BQ_GET_G) : s->g; break;
+        case BQ_GET_X_NOW: src = s->x; break;
+        case BQ_GET_G_NOW: src = s->g; break;
         case BQ_GET_D: src = s->d; break;
         case BQ_GET_LP: src = s->lp; break;
         case BQ_GET_LM: src = s->lm; break;

@@ -86,7 +86,7 @@ void bq_comm_destroy(bq_ctx *ctx) {
 
 // s holds world*blk doubles; rows [r0,r1) (this rank's block, r0 == rank*blk) are fresh on entry
 int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0, int64_t r1) {
-    if (ctx->world <= 1) return BQ_OK;
+    if (ctx->comm_kind == BQ_COMM_NONE) return BQ_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_EXCH, &e0, &e1));
     if (ctx->comm_kind == BQ_COMM_RCCL) {

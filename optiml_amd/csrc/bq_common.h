@@ -166,6 +166,8 @@ int bq_ip_start(bq_solver *s);
 int bq_ip_iterate(bq_solver *s);
 int bq_as_start(bq_solver *s);
 int bq_as_iterate(bq_solver *s);
+void bq_as_free(bq_solver *s);
+const double *bq_as_view(bq_solver *s, int what);
 
 // bq_chol.hip
 int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out);

@@ -270,6 +270,3 @@ int bq_ip_iterate(bq_solver *s) {
     return BQ_OK;
 }
 
-// ActiveSet lands next
-int bq_as_start(bq_solver *) { bq_set_error("ActiveSet not built yet"); return BQ_ERR_BADARG; }
-int bq_as_iterate(bq_solver *) { bq_set_error("ActiveSet not built yet"); return BQ_ERR_BADARG; }

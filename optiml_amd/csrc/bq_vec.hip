@@ -101,7 +101,7 @@ int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *don
         w = p->w;
     }
     BQ_TRY(bq_launch_gemv(ctx, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, w, p->s + p->r0, done));
-    if (ctx->world > 1) BQ_TRY(bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1));
+    if (ctx->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1));
     finish_kernel<<<vec_grid(p->ldN), BQ_VEC_BLOCK, 0, ctx->stream>>>(p->structure, p->n, p->N, p->diag_add, p->s, v,
                                                                       p->sgn, out, done);
     BQ_HIP(hipGetLastError());

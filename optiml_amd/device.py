@@ -44,7 +44,7 @@ class Context:
             if ndev > 0:
                 device %= ndev
         self.device = device
-        if comm is None or comm.world_size == 1:
+        if comm is None or (comm.world_size == 1 and exchange != 'rccl'):
             self.rank, self.world, self.exchange = 0, 1, 'none'
             _lib.check(lib.bq_ctx_create(device, C.byref(self._h)))
         elif exchange == 'rccl':

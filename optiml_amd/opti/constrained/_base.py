@@ -47,6 +47,12 @@ class _DeviceSolver:
             raise
         return stats[:n.value], _lib.STATUS[status.value]
 
+    def state(self):
+        """(iter, status, f_x) as of the end of the last run."""
+        it, st, f = C.c_int64(0), C.c_int(0), C.c_double(0)
+        _lib.check(self._lib.bq_solver_state(self._h, C.byref(it), C.byref(st), C.byref(f)))
+        return it.value, _lib.STATUS.get(st.value, 'unknown'), f.value
+
     def get(self, what):
         out = np.empty(self.N)
         _lib.check(self._lib.bq_solver_get(self._h, what, _lib.ptr(out)))
@@ -128,8 +134,12 @@ class BoxConstrainedQuadraticOptimizer(Optimizer, ABC):
                 if status != 'unknown':
                     self.status = status
                     break
-            self.x = solver.get(_lib.GET_X)
-            self.g_x = solver.get(_lib.GET_G)
+            self.x = solver.get(_lib.GET_X if stop else _lib.GET_X_NOW)
+            self.g_x = solver.get(_lib.GET_G if stop else _lib.GET_G_NOW)
+            if not stop:
+                # ActiveSet re-evaluates f after its last move (active_set.py:160); for the others this is the
+                # value of the last record
+                self.f_x = solver.state()[2]
             self._finalize(solver)
         finally:
             solver.close()

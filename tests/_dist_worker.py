@@ -1,0 +1,95 @@
+"""Rank program for the multi-process tests (started by tests/test_distributed.py, one process per rank).
+
+usage: python tests/_dist_worker.py MODE OUTDIR      with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the env
+  cpu-torch / cpu-socket : communicator primitives + a row-sharded product with the CPU oracle's Hessian (no GPU)
+  gpu-host               : every rank on GPU 0, row-block panels, host (gloo) exchange, PG + FW solves
+  gpu-rccl               : RCCL exchange (world size 1 on a one-GPU box exercises init / all-gather / destroy)
+"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def make_comm(kind):
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if kind == 'socket':
+        from optiml_amd.dist import SocketComm
+        return SocketComm(rank, world, os.environ.get('MASTER_ADDR', '127.0.0.1'),
+                          int(os.environ['MASTER_PORT']) + 1)
+    import torch.distributed as dist
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    from optiml_amd.dist import TorchComm
+    return TorchComm()
+
+
+def cpu_mode(kind, outdir):
+    from oracle import svm_oracle as so
+    from optiml_amd.datasets import make_blobs
+    comm = make_comm(kind)
+    blob = comm.broadcast_bytes(bytes(range(128)) if comm.rank == 0 else b'\0' * 128, src=0)
+    assert blob == bytes(range(128))
+    res = {}
+    for n in (300, 1000):
+        X, y = make_blobs(n, 5, seed=n)
+        Q, q, _ = so.svc_dual(so.gram('rbf', X), y, 1.0)
+        v = np.random.RandomState(1).standard_normal(n)
+        r0, r1 = comm.rows_of(n)
+        buf = np.zeros(n)
+        buf[r0:r1] = Q[r0:r1] @ v            # this rank's row block of the product
+        comm.allgather_rows(buf, r0, r1)
+        res[f'full_{n}'] = np.concatenate([Q[b:e] @ v for b, e in (comm.rows_of(n, r) for r in range(comm.world_size))])
+        res[f'gathered_{n}'] = buf
+    res['tmax'] = comm.max_float(float(comm.rank + 1))
+    comm.barrier()
+    np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)
+
+
+def gpu_mode(exchange, outdir):
+    from optiml_amd import device, _lib
+    from optiml_amd.datasets import make_blobs, make_regression
+    from optiml_amd.ml.svm.kernels import gaussian, PolyKernel
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import ProjectedGradient, FrankWolfe
+    comm = make_comm('torch')
+    ctx = device.init_distributed(comm, exchange=exchange, device=0)
+    assert ctx.world == comm.world_size
+    assert ctx.exchange == (exchange if (comm.world_size > 1 or exchange == 'rccl') else 'none')
+    res = {}
+    n = 700
+    X, y = make_blobs(n, 12, seed=5)
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
+    dev = quad.device_problem()
+    res['rows'] = np.array(dev.dims()[2:])
+    v = np.random.RandomState(2).standard_normal(n)
+    res['matvec'] = dev.matvec(v)
+    res['gram_matvec'] = dev.gram_matvec(v)
+    hist = []
+    cb = lambda o: hist.append(o.f_x)
+    cb._bq_needs_state = False
+    opt = ProjectedGradient(quad=quad, ub=np.ones(n), max_iter=60, callback=cb).minimize()
+    res['pg_x'], res['pg_hist'] = opt.x, np.array(hist)
+    Xr, yr = make_regression(300, 6, seed=9)
+    quad = KernelQuadratic(Xr, np.hstack((-yr, yr)) + 0.1, 'svr', PolyKernel(3, 'scale', 1.))
+    opt = FrankWolfe(quad=quad, ub=np.ones(600), max_iter=40).minimize()
+    res['fw_x'], res['fw_f'] = opt.x, opt.f_x
+    ms, cnt = ctx.profile_read(_lib.PROF_EXCH)
+    comm.barrier()
+    np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)
+
+
+if __name__ == '__main__':
+    mode, outdir = sys.argv[1], sys.argv[2]
+    if mode == 'cpu-torch':
+        cpu_mode('torch', outdir)
+    elif mode == 'cpu-socket':
+        cpu_mode('socket', outdir)
+    elif mode == 'gpu-host':
+        gpu_mode('host', outdir)
+    elif mode == 'gpu-rccl':
+        gpu_mode('rccl', outdir)
+    else:
+        raise SystemExit('unknown mode ' + mode)
