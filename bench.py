@@ -46,6 +46,26 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(workload, world):
+    """HBM bytes per launch of the panel-product kernel from the committed PMC passes (profiles/rNN/pmc_traffic_*.json,
+    produced by tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
+    command); None when no pass matches this workload."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', 'pmc_traffic_*.json'))):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        meta = rec.get('meta', {})
+        if meta.get('workload') != workload or int(meta.get('n_gpus', 1)) != world:
+            continue
+        for name, k in rec.get('kernels', {}).items():
+            if name.startswith('gemv_rows_kernel') or name.startswith('symv_'):
+                best = {'hbm_bytes': k['hbm_bytes'], 'source': os.path.relpath(path, REPO)}
+    return best
+
+
 def cpu_baseline(args):
     """The oracle (NumPy restatement of the reference: dense Q on the host, 3 products per PG iteration) timed on
     this host's cores at a bounded n, then scaled by (n_sample / n)^2 to the headline size (the per-iteration
@@ -144,17 +164,20 @@ def main():
         avg_ms = mv_ms / max(mv_cnt, 1)
         alg_bytes = (r1 - r0) * n * esz + 3 * n * 8          # panel rows once + read w, write s
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        workload = f'svc_hinge_rbf_{args.solver}_dual_n{n}_d{d}'
+        traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
         out = {
             'metric': 'dual_qp_iterations_per_sec', 'value': done / elapsed, 'unit': 'iter/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(done, 1),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64' if args.storage == 'f64' else 'f32-storage/f64-accumulate', 'data': 'synthetic',
-            'config': {'workload': f'svc_hinge_rbf_{args.solver}_dual_n{n}_d{d}', 'n': n, 'd': d, 'C': 1.0,
+            'config': {'workload': workload, 'n': n, 'd': d, 'C': 1.0,
                        'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange,
                        'rows_per_gpu': r1 - r0, 'device': ctx.name},
             'roofline': {'bound': 'hbm', 'kernel': 'gemv_rows_kernel (panel product Q*d)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'avg_launch_ms': avg_ms, 'launches': mv_cnt,
+                         'traffic': traffic['hbm_bytes'] if traffic else None,
+                         'traffic_source': traffic['source'] if traffic else None, 'avg_launch_ms': avg_ms, 'launches': mv_cnt,
                          'algorithmic_bytes_per_launch': alg_bytes},
             'steps_done': done, 'solver_status': status,
             'f_last': float(rows['f'][-1]) if done else None,

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench contract): one JSON line per run.
+
+    python tools/bench_extra.py ip   --n 16000 --d 128 --iters 3     # InteriorPoint iteration / Cholesky rate
+    python tools/bench_extra.py chol --n 8192                        # stand-alone dense Cholesky solve
+    python tools/bench_extra.py fit  --n 20000 --d 64 --solver pg    # SVC.fit wall time (BASELINE config 2 shape)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+FP64_MFMA_TF = 78.6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('what', choices=['ip', 'chol', 'fit'])
+    ap.add_argument('--n', type=int, default=8192)
+    ap.add_argument('--d', type=int, default=128)
+    ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--solver', default='pg')
+    ap.add_argument('--max-iter', type=int, default=1000)
+    a = ap.parse_args()
+    from optiml_amd import _lib, device
+    from optiml_amd.datasets import make_blobs
+    ctx = device.get_context()
+    out = {'what': a.what, 'n': a.n, 'd': a.d, 'device': ctx.name}
+    if a.what == 'chol':
+        from optiml_amd.linalg import cho_solve_spd
+        rs = np.random.RandomState(0)
+        A = rs.uniform(-1, 1, (a.n, a.n))
+        A = (A + A.T) / 2
+        A[np.diag_indices(a.n)] = a.n       # strictly diagonally dominant -> SPD
+        b = rs.standard_normal(a.n)
+        cho_solve_spd(A[:256, :256].copy(), b[:256])
+        x, ms = cho_solve_spd(A, b, return_factor_ms=True)
+        res = np.abs(A @ x - b).max()
+        out.update(factor_ms=ms, tflops=a.n ** 3 / 3 / (ms * 1e-3) / 1e12, resid=float(res))
+        out['frac_of_fp64_mfma_peak'] = out['tflops'] / FP64_MFMA_TF
+    elif a.what == 'ip':
+        from optiml_amd.ml.svm.kernels import gaussian
+        from optiml_amd.opti import KernelQuadratic
+        from optiml_amd.opti.constrained._base import _DeviceSolver
+        X, y = make_blobs(a.n, a.d, seed=0)
+        quad = KernelQuadratic(X, -np.ones(a.n), 'svc', gaussian, y=y)
+        ctx.profile(True)
+        dev = quad.device_problem(ctx)
+        ub = np.ones(a.n)
+        s = _DeviceSolver(dev, _lib.IP, np.zeros(a.n), ub, ub / 2, 1e-10, 10 ** 6)
+        s.run(1)
+        ctx.profile_read(_lib.PROF_CHOL, reset=True)
+        t0 = time.perf_counter()
+        rows, status = s.run(a.iters)
+        dt = time.perf_counter() - t0
+        ms, cnt = ctx.profile_read(_lib.PROF_CHOL, reset=True)
+        out.update(iters=len(rows), s_per_iter=dt / max(len(rows), 1), chol_ms=ms / max(cnt, 1),
+                   chol_tflops=a.n ** 3 / 3 / (ms / max(cnt, 1) * 1e-3) / 1e12, gap_last=float(rows['r2'][-1]))
+        out['chol_frac_of_fp64_mfma_peak'] = out['chol_tflops'] / FP64_MFMA_TF
+        s.close()
+    else:
+        from optiml_amd.ml.svm import SVC
+        from optiml_amd.ml.svm.kernels import gaussian
+        from optiml_amd.ml.svm.losses import hinge
+        from optiml_amd.opti.constrained import ProjectedGradient, FrankWolfe, InteriorPoint, ActiveSet
+        cls = {'pg': ProjectedGradient, 'fw': FrankWolfe, 'ip': InteriorPoint, 'as': ActiveSet}[a.solver]
+        X, y = make_blobs(a.n, a.d, seed=0)
+        t0 = time.perf_counter()
+        est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls,
+                  max_iter=a.max_iter).fit(X, y)
+        dt = time.perf_counter() - t0
+        o = est.optimizer
+        out.update(solver=a.solver, fit_s=dt, iters=o.iter, status=o.status, f=o.f_x, n_sv=int(len(est.support_)),
+                   iter_per_s=o.iter / dt, train_acc=float(est.score(X[:5000], y[:5000])))
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()
