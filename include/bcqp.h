@@ -66,10 +66,11 @@ typedef struct bq_iter_stat {
     double r1, r2, r3;
 } bq_iter_stat;
 
-/* Exchange callback for multi-process runs without RCCL (tests; hosts without xGMI):
- * on entry buf[r0*..] holds this rank's rows [row_begin,row_end) of an n-vector; on return the whole
- * vector must be filled with every rank's rows.  Return 0 on success. */
-typedef int (*bq_exchange_fn)(void *user, double *buf, int64_t n, int64_t row_begin, int64_t row_end);
+/* Exchange callback for multi-process runs without RCCL (tests; hosts without xGMI).  Return 0 on success.
+ *   op 0 (gather): on entry buf holds this rank's rows [row_begin,row_end) of an n-vector; on return the whole
+ *                  vector must be filled with every rank's rows            (row-block panels: dense Q)
+ *   op 1 (sum):    on return buf[0:n) must hold the element-wise sum over ranks   (symmetric tile panels) */
+typedef int (*bq_exchange_fn)(void *user, double *buf, int64_t n, int64_t row_begin, int64_t row_end, int op);
 
 int bq_abi_version(void);
 const char *bq_last_error(void);
@@ -87,8 +88,11 @@ int bq_ctx_info(const bq_ctx *ctx, int *device, int *rank, int *world, char *nam
  * product, 1 = Gram build, 2 = Cholesky factorisation, 3 = row-block exchange. */
 int bq_ctx_profile(bq_ctx *ctx, int enable);
 int bq_ctx_profile_read(bq_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
-/* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic) */
+/* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic): equal 128-aligned
+ * blocks for dense panels; bq_sym_row_block: the balanced triangular partition (256-aligned) of the symmetric
+ * kernel panels, whose ranks stream only the tiles on/below the diagonal */
 int bq_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end);
+int bq_sym_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end);
 
 /* ---- the quadratic ("Quadratic", optiml/opti/_base.py:228-300) ------------------------------- */
 /* dense Q (n x n row-major fp64) and q: replaces the host copy at optiml/opti/_base.py:243 */

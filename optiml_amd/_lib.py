@@ -29,7 +29,7 @@ class IterStat(C.Structure):
 STAT_DTYPE = np.dtype([('iter', np.int64), ('f', np.float64), ('r1', np.float64), ('r2', np.float64),
                        ('r3', np.float64)])
 
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_int64)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_int64, C.c_int)
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -49,6 +49,7 @@ PROTOTYPES = {
     'bq_ctx_profile': (C.c_int, [_vp, C.c_int]),
     'bq_ctx_profile_read': (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i64), C.c_int]),
     'bq_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    'bq_sym_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_problem_create_dense': (C.c_int, [_vp, _i64, _dp, _dp, C.c_int, C.POINTER(_vp)]),
     'bq_problem_create_kernel': (C.c_int, [_vp, C.c_int, _i64, _i64, _dp, _dp, C.c_int, C.c_double, C.c_double,
                                            C.c_int, C.c_double, _dp, C.c_int, C.POINTER(_vp)]),

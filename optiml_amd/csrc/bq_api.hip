@@ -177,6 +177,29 @@ extern "C" int bq_row_block(int64_t n, int rank, int world, int64_t *begin, int6
     return BQ_OK;
 }
 
+// Balanced triangular partition of nb tile rows: rank k owns [I_k, I_k+1) with I_k = round(nb * sqrt(k / G)), so every
+// rank streams about nb^2 / (2 G) tiles of the lower triangle.
+static void sym_tile_rows(int64_t nb, int rank, int world, int64_t *I0, int64_t *I1) {
+    auto cut = [&](int k) -> int64_t {
+        if (k <= 0) return 0;
+        if (k >= world) return nb;
+        int64_t v = (int64_t)std::llround((double)nb * std::sqrt((double)k / (double)world));
+        return v < 0 ? 0 : (v > nb ? nb : v);
+    };
+    *I0 = cut(rank);
+    *I1 = cut(rank + 1);
+}
+
+extern "C" int bq_sym_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end) {
+    BQ_ARG(n >= 0 && world >= 1 && rank >= 0 && rank < world, "n/rank/world");
+    const int64_t nb = (n + BQ_SYM_TILE - 1) / BQ_SYM_TILE;
+    int64_t I0, I1;
+    sym_tile_rows(nb, rank, world, &I0, &I1);
+    if (begin) *begin = std::min(n, I0 * BQ_SYM_TILE);
+    if (end) *end = std::min(n, I1 * BQ_SYM_TILE);
+    return BQ_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the quadratic
 // ---------------------------------------------------------------------------------------------
@@ -196,7 +219,10 @@ static int problem_alloc_common(bq_problem *p, const double *q_host) {
     BQ_HIP(hipMemcpyAsync(p->q, q_host, sizeof(double) * p->N, hipMemcpyHostToDevice, c->stream));
     BQ_HIP(hipMalloc(&p->w, sizeof(double) * p->ld));
     BQ_HIP(hipMemsetAsync(p->w, 0, sizeof(double) * p->ld, c->stream));
-    const int64_t slen = bq_round_up(p->blk * c->world, BQ_PAD);
+    const int64_t slen = bq_round_up(std::max(p->blk * c->world, p->nb * BQ_SYM_TILE), BQ_PAD);
+    if (p->symmetric) {
+        BQ_HIP(hipMalloc(&p->slab, sizeof(double) * p->nb * p->nb * BQ_SYM_TILE));
+    }
     BQ_HIP(hipMalloc(&p->s, sizeof(double) * slen));
     BQ_HIP(hipMemsetAsync(p->s, 0, sizeof(double) * slen, c->stream));
     BQ_HIP(hipMalloc(&p->va, sizeof(double) * p->ldN));
@@ -215,9 +241,18 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
     p->ld = bq_round_up(n, BQ_PAD);
     p->ldN = bq_round_up(N, BQ_PAD);
     p->blk = row_block_size(n, c->world);
-    BQ_TRY(bq_row_block(n, c->rank, c->world, &p->r0, &p->r1));
+    int64_t rows;
+    if (p->symmetric) {
+        p->nb = (n + BQ_SYM_TILE - 1) / BQ_SYM_TILE;
+        sym_tile_rows(p->nb, c->rank, c->world, &p->I0, &p->I1);
+        p->r0 = std::min(n, p->I0 * BQ_SYM_TILE);
+        p->r1 = std::min(n, p->I1 * BQ_SYM_TILE);
+        rows = (p->I1 - p->I0) * BQ_SYM_TILE;  // whole tiles, zero rows past n
+    } else {
+        BQ_TRY(bq_row_block(n, c->rank, c->world, &p->r0, &p->r1));
+        rows = p->r1 - p->r0;
+    }
     const size_t esz = p->storage == BQ_F64 ? 8 : 4;
-    const int64_t rows = p->r1 - p->r0;
     const size_t bytes = (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld * esz;
     hipError_t e = hipMalloc(&p->panel, bytes);
     if (e != hipSuccess) {
@@ -234,7 +269,7 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     for (void *ptr : {(void *)p->panel, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
-                      (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal})
+                      (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab})
         if (ptr) hipFree(ptr);
     delete p;
     return BQ_OK;
@@ -313,6 +348,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     p->degree = degree;
     p->diag_add = diag_add;
     p->d = d;
+    p->symmetric = true;  // Gram panels are symmetric: store and stream only the tiles on/below the diagonal
     int rc = problem_layout(p, n, structure == BQ_SVR ? 2 * n : n);
     if (rc == BQ_OK) rc = problem_alloc_common(p, q);
     if (rc != BQ_OK) {
@@ -332,7 +368,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
         if ((e = hipMemsetAsync(p->sgn, 0, sizeof(double) * p->ld, c->stream)) != hipSuccess) return fail(e);
         if ((e = hipMemcpyAsync(p->sgn, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e);
     }
-    rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld);
+    rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld, true);
     if (rc != BQ_OK) {
         bq_problem_destroy(p);
         return rc;
@@ -386,8 +422,7 @@ extern "C" int bq_problem_gram_matvec(bq_problem *p, const double *w, double *ou
     BQ_HIP(hipSetDevice(c->device));
     BQ_HIP(hipMemsetAsync(p->w, 0, sizeof(double) * p->ld, c->stream));
     BQ_HIP(hipMemcpyAsync(p->w, w, sizeof(double) * p->n, hipMemcpyHostToDevice, c->stream));
-    BQ_TRY(bq_launch_gemv(c, p->panel, p->storage, false, p->r1 - p->r0, p->ld, p->w, p->s + p->r0, nullptr));
-    if (c->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_rows(c, p->s, p->n, p->blk, p->r0, p->r1));
+    BQ_TRY(bq_panel_product(p, false, p->w, nullptr));
     BQ_HIP(hipMemcpyAsync(out, p->s, sizeof(double) * p->n, hipMemcpyDeviceToHost, c->stream));
     BQ_HIP(hipStreamSynchronize(c->stream));
     return BQ_OK;
@@ -423,10 +458,15 @@ extern "C" int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms) 
     BQ_HIP(hipEventCreate(&e1));
     const bool prof = c->profiling;
     c->profiling = false;
-    int rc = bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w, p->s + p->r0, nullptr);  // warm
+    auto local = [&]() {
+        return p->symmetric ? bq_launch_symv(c, p->panel, p->storage, p->add_one, p->I0, p->I1, p->nb, p->ld, p->w,
+                                             p->slab, p->s, nullptr)
+                            : bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w,
+                                             p->s + p->r0, nullptr);
+    };
+    int rc = local();  // warm
     hipEventRecord(e0, c->stream);
-    for (int i = 0; rc == BQ_OK && i < reps; ++i)
-        rc = bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w, p->s + p->r0, nullptr);
+    for (int i = 0; rc == BQ_OK && i < reps; ++i) rc = local();
     hipEventRecord(e1, c->stream);
     hipError_t e = hipEventSynchronize(e1);
     float ms = 0.f;
@@ -674,3 +714,4 @@ extern "C" int bq_cholesky_solve(bq_ctx *c, int64_t n, const double *A, const do
     BQ_HIP(hipSetDevice(c->device));
     return bq_chol_solve_dense_impl(c, n, A, b, x, factor_ms);
 }
+

@@ -298,13 +298,15 @@ __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64
             v = (a == b) ? 1.0 : 0.0;
         } else {
             const int64_t i = idx ? idx[a] : a, jj = idx ? idx[b] : b;
+            // kernel-built panels keep only the tiles on/below the diagonal: always read (max, min)
             if (structure == BQ_PLAIN) {
                 v = (double)panel[i * ldp + jj];
             } else if (structure == BQ_SVC) {
                 v = sgn[i] * sgn[jj] * ((double)panel[i * ldp + jj] + 1.0);
             } else {
                 const int64_t ii = i >= n ? i - n : i, jn = jj >= n ? jj - n : jj;
-                const double pv = (double)panel[ii * ldp + jn] + 1.0;
+                const int64_t hi = ii > jn ? ii : jn, lo = ii > jn ? jn : ii;
+                const double pv = (double)panel[hi * ldp + lo] + 1.0;
                 v = ((i >= n) == (jj >= n)) ? pv : -pv;
             }
             if (i == jj) {

@@ -14,6 +14,7 @@ typedef struct { char internal[128]; } nccl_uid_t;
 typedef void *nccl_comm_t;
 typedef int nccl_result_t;
 constexpr int NCCL_FLOAT64 = 8;  // ncclDouble / ncclFloat64 in rccl.h's ncclDataType_t
+constexpr int NCCL_SUM = 0;      // ncclSum in rccl.h's ncclRedOp_t
 
 struct rccl_api {
     void *handle = nullptr;
@@ -21,6 +22,7 @@ struct rccl_api {
     nccl_result_t (*CommInitRank)(nccl_comm_t *, int, nccl_uid_t, int) = nullptr;
     nccl_result_t (*CommDestroy)(nccl_comm_t) = nullptr;
     nccl_result_t (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+    nccl_result_t (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(nccl_result_t) = nullptr;
 };
 rccl_api g_rccl;
@@ -41,8 +43,9 @@ int load_rccl() {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.AllReduce) {
         bq_set_error("librccl.so lacks a required symbol");
         dlclose(h);
         return BQ_ERR_RCCL;
@@ -105,7 +108,7 @@ int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0,
             BQ_HIP(hipMemcpyAsync(ctx->pinned + r0, s + r0, sizeof(double) * (size_t)(r1 - r0), hipMemcpyDeviceToHost,
                                   ctx->stream));
         BQ_HIP(hipStreamSynchronize(ctx->stream));
-        int rc = ctx->exch_fn(ctx->exch_user, ctx->pinned, n, r0, r1);
+        int rc = ctx->exch_fn(ctx->exch_user, ctx->pinned, n, r0, r1, 0);
         if (rc != 0) {
             bq_set_error("exchange callback returned %d", rc);
             return BQ_ERR_RCCL;
@@ -114,6 +117,37 @@ int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0,
     } else {
         bq_set_error("multi-rank context without an exchange");
         return BQ_ERR_BADARG;
+    }
+    BQ_TRY(bq_prof_end(ctx, BQ_PROF_EXCH, e0, e1));
+    return BQ_OK;
+}
+
+// in-place all-reduce(sum) of v[0:count) — the exchange of the symmetric tile product (every rank holds partial
+// sums for every output block)
+int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count) {
+    if (ctx->comm_kind == BQ_COMM_NONE) return BQ_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BQ_TRY(bq_prof_begin(ctx, BQ_PROF_EXCH, &e0, &e1));
+    if (ctx->comm_kind == BQ_COMM_RCCL) {
+        nccl_result_t r = g_rccl.AllReduce(v, v, (size_t)count, NCCL_FLOAT64, NCCL_SUM, (nccl_comm_t)ctx->nccl_comm,
+                                           ctx->stream);
+        if (r != 0) return rccl_fail("ncclAllReduce", r);
+    } else {
+        const size_t bytes = sizeof(double) * (size_t)count;
+        if (ctx->pinned_cap < bytes) {
+            if (ctx->pinned) hipHostFree(ctx->pinned);
+            ctx->pinned = nullptr;
+            BQ_HIP(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+            ctx->pinned_cap = bytes;
+        }
+        BQ_HIP(hipMemcpyAsync(ctx->pinned, v, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        BQ_HIP(hipStreamSynchronize(ctx->stream));
+        int rc = ctx->exch_fn(ctx->exch_user, ctx->pinned, count, 0, count, 1);
+        if (rc != 0) {
+            bq_set_error("exchange callback returned %d", rc);
+            return BQ_ERR_RCCL;
+        }
+        BQ_HIP(hipMemcpyAsync(v, ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_EXCH, e0, e1));
     return BQ_OK;

@@ -84,7 +84,13 @@ struct bq_problem {
     int64_t N = 0;         // dual dimension (n, or 2n for BQ_SVR)
     int64_t ld = 0;        // padded leading dimension of the panel (elements)
     int64_t ldN = 0;       // padded length of dual-dim vectors
-    int64_t r0 = 0, r1 = 0, blk = 0;  // my rows [r0,r1) and the per-rank block size
+    int64_t r0 = 0, r1 = 0, blk = 0;  // my rows [r0,r1) and the per-rank block size (row-block mode)
+    // symmetric mode (kernel-built panels): only tiles on/below the diagonal are stored and streamed; this rank owns
+    // the 256-row tile rows [I0, I1) of nb, panel row 0 is global row I0*256
+    bool symmetric = false;
+    int64_t I0 = 0, I1 = 0, nb = 0;
+    double *slab = nullptr;   // nb x nb x 256 partial products
+    double *part = nullptr;   // nb*256: this rank's partial K w (all-reduced across ranks)
     void *panel = nullptr;
     double *q = nullptr;    // ldN
     double *sgn = nullptr;  // ld (labels, BQ_SVC) or null
@@ -137,6 +143,13 @@ struct bq_solver {
 int bq_prof_begin(bq_ctx *ctx, int which, hipEvent_t *e0, hipEvent_t *e1);
 int bq_prof_end(bq_ctx *ctx, int which, hipEvent_t e0, hipEvent_t e1);
 int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0, int64_t r1);
+int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count);  // all-reduce(sum) of a replicated-length vector
+
+// bq_symv.hip: symmetric tile product over tile rows [I0, I1) -> out (nb*256 partial sums)
+constexpr int64_t BQ_SYM_TILE = 256;
+int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
+                   int64_t ld, const double *w, double *slab, double *out, const int *done);
+int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done);  // -> p->s (complete on all ranks)
 
 // bq_gemv.hip: s[r0 + i] = sum_j elem(panel[i][j]) * w[j], i in [0, nrows)
 int bq_launch_gemv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nrows, int64_t ld,
@@ -144,7 +157,7 @@ int bq_launch_gemv(bq_ctx *ctx, const void *panel, int storage, bool add_one, in
 
 // bq_gram.hip: panel rows [r0,r1) of kernel(X, X) (n x n), written in `storage` dtype with row pitch ld
 int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r0, int64_t r1, int kernel,
-                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld);
+                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld, bool lower_tiles_only);
 // rectangular cross-Gram fused with a coefficient contraction (decision function)
 int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                        const double *SV, const double *coef, double intercept, int64_t t, const double *Xt,

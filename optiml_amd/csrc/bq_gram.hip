@@ -57,6 +57,7 @@ struct gram_params {
     int64_t mp, np, dp;
     int64_t arow0, arow1;    // global A rows [arow0, arow1) of this launch (arow0 tile-aligned)
     int same;                // A and B are the same matrix -> exact zero distance on the diagonal
+    int lower_only;          // skip tiles whose 256-tile lies strictly above the diagonal (symmetric panels)
     int kernel, degree;
     double gamma, coef0;
     int64_t ld;              // output pitch (elements)
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
     const int64_t tiles_n = (P.n + GT - 1) / GT;
     const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int64_t arow = P.arow0 + tm * GT, bcol = tn * GT;
+    if (P.lower_only && (bcol / BQ_SYM_TILE) > (arow / BQ_SYM_TILE)) return;
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
     bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
@@ -117,8 +119,9 @@ static void free_image(gram_images *img) {
 
 static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int64_t m_rows0, int64_t m_rows1,
                     int64_t n, bool same, int kernel, double gamma, double coef0, int degree, void *out,
-                    int storage, int64_t ld) {
+                    int storage, int64_t ld, bool lower_only = false) {
     gram_params P;
+    P.lower_only = lower_only ? 1 : 0;
     P.At = A.At;
     P.Bt = B.At;
     P.a2 = A.a2;
@@ -154,7 +157,7 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
 }
 
 int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r0, int64_t r1, int kernel,
-                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld) {
+                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld, bool lower_tiles_only) {
     gram_images img;
     // pad the image so that a tile starting at any r0 stays inside it
     int rc = make_image(ctx, X, n, d, &img);
@@ -168,7 +171,7 @@ int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r
         bq_set_error("row block start %lld is not a multiple of %d", (long long)r0, GT);
         return BQ_ERR_BADARG;
     }
-    rc = run_gram(ctx, img, img, r0, r1, n, true, kernel, gamma, coef0, degree, panel, storage, ld);
+    rc = run_gram(ctx, img, img, r0, r1, n, true, kernel, gamma, coef0, degree, panel, storage, ld, lower_tiles_only);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     free_image(&img);
     if (rc != BQ_OK) return rc;

@@ -1,0 +1,190 @@
+// Symmetric panel product: out = K w reading only the tiles on or below the diagonal — half the HBM bytes of the
+// row-block product for the (symmetric) Gram panels of the SVM dual.
+//
+// The panel is cut into 256 x 256 tiles (I, J), J <= I.  A work item is a STRIP: up to JG consecutive tiles of one
+// tile row, i.e. 256 rows x (JG * 2 KiB) contiguous bytes per row.  The workgroup streams the strip once (16-byte
+// non-temporal loads, lanes along the columns) and produces BOTH contributions the strip is responsible for:
+//   row part   S[I][J0][r]  = sum over the strip's columns of elem(K[I*T+r][c]) * w[c]        (to output block I)
+//   col parts  S[J][I][c]   = sum_r elem(K[I*T+r][J*T+c]) * w[I*T+r],  each J != I of the strip  (to output block J)
+// into a slab S[nb][nb][T]; a second kernel sums the slab entries of each output block in a fixed order ->
+// deterministic, no atomics.  Column sums are lane-local (a lane owns 4 columns of every tile); the row partials of a
+// step are accumulated over the whole strip and then reduced across the 64 lanes with a halving butterfly
+// (4 row sums in 7 shuffle-adds).  Slab traffic is about n^2*8/T*(1/2 + 1/(2 JG)) bytes each way (~1 % of the tile bytes).
+//
+// Multi-GPU: rank r owns the tile rows [I_r, I_r+1) of a balanced triangular partition and therefore produces
+// partial sums for every output block; the partial vectors are combined by one all-reduce(sum) per product.
+#include "bq_common.h"
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+constexpr int ST = 256;   // tile edge (== BQ_SYM_TILE)
+constexpr int JG = 4;     // tiles per strip
+constexpr int SR = 4;     // rows per wave and step
+
+template <typename T> struct ld2;
+template <> struct ld2<double> {
+    static __device__ __forceinline__ d2_t get(const double *p) {
+        return __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p));
+    }
+};
+template <> struct ld2<float> {
+    static __device__ __forceinline__ d2_t get(const float *p) {
+        f2_t v = __builtin_nontemporal_load(reinterpret_cast<const f2_t *>(p));
+        return (d2_t){(double)v.x, (double)v.y};
+    }
+};
+
+// strips of tile row I: g = 0 .. I / JG ; linear index over tile rows [I0, I1)
+__device__ __forceinline__ int64_t strips_before(int64_t I) {  // sum_{i < I} (i / JG + 1)
+    const int64_t qq = I / JG, rr = I % JG;
+    return JG * qq * (qq + 1) / 2 + rr * (qq + 1);
+}
+
+template <typename T, bool ADD_ONE>
+__global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict__ panel, int64_t ld, int64_t I0,
+                                                            int64_t nb, const double *__restrict__ w,
+                                                            double *__restrict__ slab, const int *__restrict__ done) {
+    if (done != nullptr && *done) return;
+    __shared__ double colred[4][ST];
+    // decode (I, g) from the linear strip index
+    const int64_t t = (int64_t)blockIdx.x + strips_before(I0);
+    int64_t I = (int64_t)sqrt(2.0 * (double)JG * (double)t);
+    if (I >= nb) I = nb - 1;
+    while (I > 0 && strips_before(I) > t) --I;
+    while (strips_before(I + 1) <= t) ++I;
+    const int64_t g = t - strips_before(I);
+    const int64_t J0 = g * JG;
+    const int nj = (int)((J0 + JG <= I + 1) ? JG : (I + 1 - J0));  // tiles in this strip (J <= I)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const T *rows = panel + ((I - I0) * ST + wv * 64) * ld + J0 * ST;  // panel row 0 is global row I0*ST
+    const double *wI = w + I * ST + wv * 64;
+    const int c0 = 2 * lane, c1 = 128 + 2 * lane;
+    d2_t wj0[JG], wj1[JG];
+    double ca[JG][4];
+#pragma unroll
+    for (int j = 0; j < JG; ++j) {
+        const double *wJ = w + (J0 + (j < nj ? j : 0)) * ST;
+        wj0[j] = *reinterpret_cast<const d2_t *>(wJ + c0);
+        wj1[j] = *reinterpret_cast<const d2_t *>(wJ + c1);
+        ca[j][0] = ca[j][1] = ca[j][2] = ca[j][3] = 0.0;
+    }
+    double *rowout = slab + (I * nb + J0) * ST + wv * 64;
+    const bool b5 = lane & 32, b4 = lane & 16;
+
+#pragma unroll 1
+    for (int step = 0; step < 64 / SR; ++step) {
+        double rp[SR];
+        double wi[SR];
+#pragma unroll
+        for (int k = 0; k < SR; ++k) {
+            rp[k] = 0.0;
+            wi[k] = wI[step * SR + k];
+        }
+#pragma unroll
+        for (int j = 0; j < JG; ++j) {
+            if (j < nj) {
+                d2_t a[SR], b[SR];
+#pragma unroll
+                for (int k = 0; k < SR; ++k) {
+                    const T *row = rows + (int64_t)(step * SR + k) * ld + j * ST;
+                    a[k] = ld2<T>::get(row + c0);
+                    b[k] = ld2<T>::get(row + c1);
+                }
+#pragma unroll
+                for (int k = 0; k < SR; ++k) {
+                    if (ADD_ONE) {
+                        a[k].x += 1.0;
+                        a[k].y += 1.0;
+                        b[k].x += 1.0;
+                        b[k].y += 1.0;
+                    }
+                    rp[k] = fma(b[k].y, wj1[j].y, fma(b[k].x, wj1[j].x, fma(a[k].y, wj0[j].y, fma(a[k].x, wj0[j].x, rp[k]))));
+                    ca[j][0] = fma(a[k].x, wi[k], ca[j][0]);
+                    ca[j][1] = fma(a[k].y, wi[k], ca[j][1]);
+                    ca[j][2] = fma(b[k].x, wi[k], ca[j][2]);
+                    ca[j][3] = fma(b[k].y, wi[k], ca[j][3]);
+                }
+            }
+        }
+        // halving butterfly: 4 row partials x 64 lanes -> one full row sum per 16-lane group
+        double u[2], s1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double send = b5 ? rp[i] : rp[i + 2];
+            const double keep = b5 ? rp[i + 2] : rp[i];
+            u[i] = keep + __shfl_xor(send, 32, 64);
+        }
+        {
+            const double send = b4 ? u[0] : u[1];
+            const double keep = b4 ? u[1] : u[0];
+            s1 = keep + __shfl_xor(send, 16, 64);
+        }
+        s1 += __shfl_xor(s1, 8, 64);
+        s1 += __shfl_xor(s1, 4, 64);
+        s1 += __shfl_xor(s1, 2, 64);
+        s1 += __shfl_xor(s1, 1, 64);
+        if ((lane & 15) == 0) rowout[step * SR + (b5 ? 2 : 0) + (b4 ? 1 : 0)] = s1;
+    }
+    // column parts of every off-diagonal tile of the strip
+#pragma unroll
+    for (int j = 0; j < JG; ++j) {
+        if (j < nj && J0 + j != I) {   // uniform across the workgroup
+            __syncthreads();
+            colred[wv][c0] = ca[j][0];
+            colred[wv][c0 + 1] = ca[j][1];
+            colred[wv][c1] = ca[j][2];
+            colred[wv][c1 + 1] = ca[j][3];
+            __syncthreads();
+            slab[((J0 + j) * nb + I) * ST + tid] = ((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid];
+        }
+    }
+}
+
+// out[a*T + r] = sum of the slab entries S[a][b] this rank produced, b ascending:
+//   row parts live at b = first tile of a strip (b % JG == 0, b <= a) when tile row a is ours,
+//   col parts at every b > a that is one of our tile rows.
+__global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, int64_t I0,
+                                                          int64_t I1, double *__restrict__ out,
+                                                          const int *__restrict__ done) {
+    if (done != nullptr && *done) return;
+    const int64_t a = blockIdx.x;
+    const double *p = slab + a * nb * ST + threadIdx.x;
+    double s = 0.0;
+    if (a >= I0 && a < I1)
+        for (int64_t b = 0; b <= a; b += JG) s += p[b * ST];
+    const int64_t bs = (a + 1 > I0) ? a + 1 : I0;
+    for (int64_t b = bs; b < I1; ++b) s += p[b * ST];
+    out[a * ST + threadIdx.x] = s;
+}
+
+static int64_t host_strips_before(int64_t I) {
+    const int64_t qq = I / JG, rr = I % JG;
+    return JG * qq * (qq + 1) / 2 + rr * (qq + 1);
+}
+
+int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
+                   int64_t ld, const double *w, double *slab, double *out, const int *done) {
+    const int64_t nstrips = host_strips_before(I1) - host_strips_before(I0);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
+    if (nstrips > 0) {
+        dim3 grid((unsigned)nstrips);
+        if (storage == BQ_F64) {
+            if (add_one)
+                symv_tiles_kernel<double, true><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
+            else
+                symv_tiles_kernel<double, false><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
+        } else {
+            if (add_one)
+                symv_tiles_kernel<float, true><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
+            else
+                symv_tiles_kernel<float, false><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
+        }
+    }
+    BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
+    symv_reduce_kernel<<<(unsigned)nb, 256, 0, ctx->stream>>>(slab, nb, I0, I1, out, done);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}

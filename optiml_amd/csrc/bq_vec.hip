@@ -93,6 +93,20 @@ __global__ void finish_kernel(int structure, int64_t n, int64_t N, double diag_a
     }
 }
 
+// p->s = P w on every rank, P the resident panel (elements optionally +1).  Row-block panels: local rows + all-gather;
+// symmetric tile panels: local lower-triangle tiles (both contributions) + all-reduce(sum).
+int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done) {
+    bq_ctx *ctx = p->ctx;
+    if (p->symmetric) {
+        BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->I0, p->I1, p->nb, p->ld, w, p->slab, p->s, done));
+        if (ctx->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_sum(ctx, p->s, p->nb * BQ_SYM_TILE));
+    } else {
+        BQ_TRY(bq_launch_gemv(ctx, p->panel, p->storage, add_one, p->r1 - p->r0, p->ld, w, p->s + p->r0, done));
+        if (ctx->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1));
+    }
+    return BQ_OK;
+}
+
 int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *done) {
     bq_ctx *ctx = p->ctx;
     const double *w = v;
@@ -100,8 +114,7 @@ int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *don
         prep_kernel<<<vec_grid(p->ld), BQ_VEC_BLOCK, 0, ctx->stream>>>(p->structure, p->n, v, p->sgn, p->w, done);
         w = p->w;
     }
-    BQ_TRY(bq_launch_gemv(ctx, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, w, p->s + p->r0, done));
-    if (ctx->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1));
+    BQ_TRY(bq_panel_product(p, p->add_one, w, done));
     finish_kernel<<<vec_grid(p->ldN), BQ_VEC_BLOCK, 0, ctx->stream>>>(p->structure, p->n, p->N, p->diag_add, p->s, v,
                                                                       p->sgn, out, done);
     BQ_HIP(hipGetLastError());

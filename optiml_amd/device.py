@@ -23,11 +23,13 @@ def device_count():
     return n.value
 
 
-def row_block(n, rank, world):
-    """Rows [begin, end) of an n-row panel owned by `rank` (blocks are 128-row aligned)."""
+def row_block(n, rank, world, symmetric=False):
+    """Rows [begin, end) of an n-row panel owned by `rank`: equal 128-aligned blocks for dense panels; with
+    symmetric=True the balanced triangular partition (256-aligned) of the kernel-built symmetric panels."""
     lib = _lib.load()
     b, e = C.c_int64(0), C.c_int64(0)
-    _lib.check(lib.bq_row_block(int(n), int(rank), int(world), C.byref(b), C.byref(e)))
+    fn = lib.bq_sym_row_block if symmetric else lib.bq_row_block
+    _lib.check(fn(int(n), int(rank), int(world), C.byref(b), C.byref(e)))
     return b.value, e.value
 
 
@@ -58,10 +60,13 @@ class Context:
         elif exchange == 'host':
             self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'host'
 
-            def _exchange(user, buf, n, r0, r1):
+            def _exchange(user, buf, n, r0, r1, op):
                 try:
                     view = np.ctypeslib.as_array(buf, shape=(n,))
-                    comm.allgather_rows(view, r0, r1)
+                    if op == 0:
+                        comm.allgather_rows(view, r0, r1)
+                    else:
+                        comm.allreduce_sum(view)
                     return 0
                 except Exception as exc:  # never let an exception cross the C boundary
                     import traceback

@@ -1,7 +1,7 @@
 """Host-side communicators used to bootstrap multi-GPU runs (rendezvous only — the data path is RCCL).
 
-A communicator provides: rank, world_size, broadcast_bytes(data, src), allgather_rows(buf, r0, r1), barrier(),
-max_float(x).  `TorchComm` rides on an initialised torch.distributed process group (gloo on the host; the
+A communicator provides: rank, world_size, broadcast_bytes(data, src), allgather_rows(buf, r0, r1),
+allreduce_sum(buf), barrier(), max_float(x).  `TorchComm` rides on an initialised torch.distributed process group (gloo on the host; the
 launcher `python -m torch.distributed.run` sets RANK/WORLD_SIZE/MASTER_*); `SocketComm` is a dependency-free
 TCP star for environments without torch.  torch is plumbing here, never on the compute path.
 """
@@ -65,6 +65,12 @@ class TorchComm(_Base):
             b, e = self.rows_of(n, r)
             if e > b:
                 buf[b:e] = part[:e - b].numpy()
+
+    def allreduce_sum(self, buf):
+        import torch
+        t = torch.from_numpy(np.array(buf, copy=True))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        buf[:] = t.numpy()
 
     def barrier(self):
         self._dist.barrier(group=self.group)
@@ -162,6 +168,15 @@ class SocketComm(_Base):
         for b, e, arr in parts:
             if e > b:
                 buf[b:e] = arr
+
+    def allreduce_sum(self, buf):
+        parts = self._gather(np.array(buf, copy=True))
+        total = None
+        if parts is not None:
+            total = parts[0].copy()
+            for p in parts[1:]:      # fixed rank order -> deterministic
+                total += p
+        buf[:] = self._bcast(total)
 
     def barrier(self):
         self._bcast(self._gather(None) and None)

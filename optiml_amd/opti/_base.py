@@ -209,15 +209,23 @@ class KernelQuadratic(Quadratic):
         return _DeviceProblem(ctx, h)
 
     def gram(self):
-        """The n x n Gram matrix K held by this rank's panel (all of it on a single-rank context)."""
-        return self.device_problem().panel_rows()
+        """The n x n Gram matrix K (single-rank contexts).  The device keeps only the 256 x 256 tiles on or below the
+        diagonal; the upper tiles are mirrored here."""
+        dev = self.device_problem()
+        if dev.ctx.world != 1:
+            raise RuntimeError('materialising K needs the whole panel: single-rank contexts only')
+        L = dev.panel_rows()
+        n = L.shape[0]
+        tile = np.arange(n) // 256
+        upper = tile[None, :] > tile[:, None]
+        return np.where(upper, L.T, L)
 
     @property
     def Q(self):
         dev = self.device_problem()
         if dev.ctx.world != 1:
             raise RuntimeError('materialising Q needs the whole panel: single-rank contexts only')
-        K = dev.panel_rows()
+        K = self.gram()
         n = K.shape[0]
         if self.structure == 'plain':
             Q = K

@@ -76,6 +76,16 @@ def gpu_mode(exchange, outdir):
     quad = KernelQuadratic(Xr, np.hstack((-yr, yr)) + 0.1, 'svr', PolyKernel(3, 'scale', 1.))
     opt = FrankWolfe(quad=quad, ub=np.ones(600), max_iter=40).minimize()
     res['fw_x'], res['fw_f'] = opt.x, opt.f_x
+    # dense Quadratic: row-block panel + all-gather -> bit-identical for any world size
+    from optiml_amd.opti import Quadratic
+    rs = np.random.RandomState(4)
+    G = rs.standard_normal((500, 520))
+    Qd = G @ G.T / 500
+    dq = Quadratic(Qd, rs.standard_normal(500))
+    res['dense_rows'] = np.array(dq.device_problem().dims()[2:])
+    res['dense_matvec'] = dq.device_problem().matvec(v[:500])
+    opt = ProjectedGradient(quad=dq, ub=np.ones(500), max_iter=40).minimize()
+    res['dense_pg_x'] = opt.x
     ms, cnt = ctx.profile_read(_lib.PROF_EXCH)
     comm.barrier()
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)

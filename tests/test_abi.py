@@ -51,6 +51,24 @@ def test_row_blocks_partition_the_panel(lib, n, world):
         assert c.rows_of(n) == (b, e)
 
 
+@pytest.mark.parametrize('n', [2, 255, 256, 257, 700, 100000, 250000])
+@pytest.mark.parametrize('world', [1, 2, 4, 8])
+def test_symmetric_row_blocks_balance_the_triangle(lib, n, world):
+    from optiml_amd.device import row_block
+    blocks = [row_block(n, r, world, symmetric=True) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n
+    for (b0, e0), (b1, e1) in zip(blocks, blocks[1:]):
+        assert e0 == b1 and b0 <= e0 and (b0 % 256 == 0 or b0 == n)
+    if n >= 100000:   # every rank streams about the same number of lower-triangle tiles
+        nb = -(-n // 256)
+        tiles = []
+        for b, e in blocks:
+            i0, i1 = b // 256, -(-e // 256)
+            tiles.append(i1 * (i1 + 1) // 2 - i0 * (i0 + 1) // 2)
+        assert sum(tiles) == nb * (nb + 1) // 2
+        assert max(tiles) <= 1.06 * (sum(tiles) / world)
+
+
 def test_bad_arguments_are_reported_not_crashed(lib):
     import ctypes as C
     from optiml_amd import _lib

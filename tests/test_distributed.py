@@ -62,15 +62,26 @@ def test_two_rank_row_block_exchange_cpu(tmp_path, kind):
 def test_two_ranks_reproduce_single_rank_bitwise(tmp_path):
     one = _launch('gpu-host', 1, tmp_path / 'w1')[0]
     two = _launch('gpu-host', 2, tmp_path / 'w2')
-    assert tuple(two[0]['rows']) == (0, 384) and tuple(two[1]['rows']) == (384, 700)
+    # kernel panels: symmetric tile storage, balanced triangular partition (700 rows = 3 tile rows -> 2 + 1)
+    assert tuple(two[0]['rows']) == (0, 512) and tuple(two[1]['rows']) == (512, 700)
+    # dense panels: equal 128-aligned row blocks
+    assert tuple(two[0]['dense_rows']) == (0, 256) and tuple(two[1]['dense_rows']) == (256, 500)
     for r in two:
-        for key in ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f'):
+        # row-block panels end in an all-gather: bit-identical for any rank count
+        for key in ('dense_matvec', 'dense_pg_x'):
             assert np.array_equal(r[key], one[key]), key
+        # symmetric tile panels end in an all-reduce(sum): same values up to the association of the rank sum
+        for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f'):
+            np.testing.assert_allclose(r[key], one[key], rtol=1e-12, atol=1e-12, err_msg=key)
+        for key in ('pg_x', 'fw_x'):
+            np.testing.assert_allclose(r[key], one[key], rtol=1e-9, atol=1e-11, err_msg=key)
+    for key in ('matvec', 'pg_x', 'fw_x', 'dense_pg_x'):     # and the ranks agree with each other exactly
+        assert np.array_equal(two[0][key], two[1][key]), key
 
 
 @pytest.mark.gpu
 def test_rccl_context_single_rank(tmp_path):
     ref = _launch('gpu-host', 1, tmp_path / 'ref')[0]
     got = _launch('gpu-rccl', 1, tmp_path / 'rccl')[0]
-    for key in ('matvec', 'pg_x', 'pg_hist', 'fw_x'):
+    for key in ('matvec', 'pg_x', 'pg_hist', 'fw_x', 'dense_matvec', 'dense_pg_x'):
         assert np.array_equal(got[key], ref[key]), key
