@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--storage', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--exchange', default='rccl', choices=['rccl', 'host'])
     ap.add_argument('--cpu-n', type=int, default=12000, help='sample size of the CPU baseline leg')
-    ap.add_argument('--cpu-steps', type=int, default=30)
+    ap.add_argument('--cpu-steps', type=int, default=150)
     ap.add_argument('--no-cpu', action='store_true')
     return ap.parse_args()
 
@@ -122,7 +122,24 @@ def main():
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
         from optiml_amd.dist import TorchComm
         comm = TorchComm()
-        ctx = device.init_distributed(comm, exchange=args.exchange)
+        # RCCL over xGMI is the data path.  If the communicator cannot be created on every rank (reported, never
+        # silent), the row-block exchange falls back to the host (gloo) transport so that the run still measures the
+        # sharded GPU path; `config.exchange` in the JSON line says which transport was used.
+        exchange, ctx, err = args.exchange, None, ''
+        if exchange == 'rccl':
+            try:
+                ctx = device.Context(comm=comm, exchange='rccl')
+            except Exception as exc:  # noqa: BLE001
+                err = repr(exc)
+            if comm.max_float(0.0 if ctx is not None else 1.0) > 0.0:
+                print(f'[bench] rank {rank}: RCCL context unavailable ({err or "failed on another rank"}); '
+                      'using the host exchange', file=sys.stderr, flush=True)
+                if ctx is not None:
+                    ctx.close()
+                ctx, exchange = None, 'host'
+        if ctx is None:
+            ctx = device.Context(comm=comm, exchange=exchange)
+        device.set_context(ctx)
     else:
         ctx = device.get_context()
 

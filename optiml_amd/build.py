@@ -43,7 +43,8 @@ def _stale(target, deps):
 
 
 def _compile(src, obj):
-    cmd = ['hipcc', '-x', 'hip', '-c', src, '-o', obj] + CXXFLAGS
+    extra = os.environ.get('BQ_EXTRA_CXXFLAGS', '').split()   # e.g. -DBQ_DIAG_STAMPS for a diagnostic build
+    cmd = ['hipcc', '-x', 'hip', '-c', src, '-o', obj] + CXXFLAGS + extra
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))

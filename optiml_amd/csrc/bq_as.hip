@@ -12,8 +12,8 @@
 //     no:    ratio step towards the candidate, f = evaluate, move variables that hit a bound into L / U (:195-220)
 // The restricted order |A| changes every iteration, so the host reads two small records per iteration (|A| and
 // {pivot info, feasible}); everything else stays on the stream.  When Q[A,A] is not positive definite the reference
-// silently switches to scipy's minres on the normal equations (:142-151); that branch is not built yet and fails
-// loudly with BQ_ERR_NOT_PD.
+// silently switches to scipy's minres on the normal equations (:142-151): here a persistent single-workgroup MINRES
+// kernel (bq_minres.hip) takes over for |A| <= 8192.
 #include <cmath>
 
 #include "bq_chol.h"
@@ -36,6 +36,7 @@ struct as_ws {
     double *x_eval = nullptr;  // x / g at the top of the current iteration (what a callback must see)
     double *g_eval = nullptr;
     int host_ints[8];
+    long long minres_calls = 0;
 };
 
 __device__ __forceinline__ double as_wmin(double v) {
@@ -327,10 +328,22 @@ int bq_as_iterate(bq_solver *s) {
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     if (info != 0) {
-        bq_set_error("restricted Hessian Q[A,A] (|A| = %lld) is not positive definite at pivot %d: the reference's "
-                     "minres fallback (active_set.py:142-151) is not available on the device",
-                     (long long)nA, info);
-        return BQ_ERR_NOT_PD;
+        // Q[A,A] is not positive definite: the reference's bare `except` switches to scipy's minres on the normal
+        // equations (active_set.py:142-151).  Rebuild the (destroyed) restricted Hessian with both triangles, solve,
+        // and redo the feasibility test on the minimum-residual candidate.
+        if (nA > 8192) {
+            bq_set_error("restricted Hessian Q[A,A] (|A| = %lld) is not positive definite at pivot %d and too large for "
+                         "the single-workgroup MINRES fallback (limit 8192)", (long long)nA, info);
+            return BQ_ERR_NOT_PD;
+        }
+        if (!ws->mr_vec) BQ_HIP(hipMalloc(&ws->mr_vec, sizeof(double) * 10 * ws->cap));
+        BQ_TRY(bq_chol_build_h(ws, s->p, w->idx, nA, nullptr, &np, true));
+        as_gather_rhs_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->p->q, w->Qz, ws->rhs, np);
+        BQ_TRY(bq_minres_normal(ws, w->ints, ws->cap, ws->mr_vec, w->ints + 7));
+        as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, ws->rhs, w->z, N, s->lb, s->ub, w->cand);
+        BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+        BQ_HIP(hipStreamSynchronize(st));
+        w->minres_calls += 1;
     }
     if (w->host_ints[2]) {
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);

@@ -12,8 +12,12 @@ struct bq_chol_ws {
     double *rhs = nullptr;    // right-hand side / solution (padded)
     double *tmp = nullptr;    // 128 scratch
     int *info = nullptr;      // 0 = ok, else 1 + index of the first non-positive pivot
+    double *mr_vec = nullptr; // 10 x cap scratch vectors of the MINRES fallback (allocated on first use)
 };
 
 int bq_chol_factor(bq_chol_ws *ws, int64_t np);
 int bq_chol_solve(bq_chol_ws *ws, int64_t np);
-int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out);
+int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out,
+                    bool full = false);
+// bq_minres.hip: x = argmin |H x - q'| via MINRES on H H^T x = H q' (H = ws->H full symmetric, q' = ws->rhs)
+int bq_minres_normal(bq_chol_ws *ws, const int *nA_dev, int64_t np, double *vec, int *iters_dev);

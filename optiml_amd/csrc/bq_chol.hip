@@ -18,63 +18,9 @@
 #include "bq_mfma_tile.h"
 
 constexpr int NB = 128;
-constexpr int TRI = NB * (NB + 1) / 2;  // packed lower triangle
-
-__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // j <= i
-
-// ---------------------------------------------------------------------------------------------
-// 1. diagonal block: factor + invert
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ H, int64_t ldh, int64_t k0,
-                                                         double *__restrict__ LinvT, int *__restrict__ info) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *Lp = smem;        // packed lower factor
-    double *Xp = smem + TRI;  // packed lower inverse
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        if (j <= i) Lp[tri(i, j)] = H[(k0 + i) * ldh + k0 + j];
-    }
-    __syncthreads();
-    bool ok = true;
-    for (int j = 0; j < NB; ++j) {
-        const double piv = Lp[tri(j, j)];
-        if (!(piv > 0.0)) {  // also catches NaN; identical in every thread -> uniform exit
-            if (tid == 0 && *info == 0) *info = (int)(k0 + j + 1);
-            ok = false;
-            break;
-        }
-        const double r = sqrt(piv);
-        __syncthreads();
-        for (int i = j + 1 + tid; i < NB; i += 256) Lp[tri(i, j)] /= r;
-        if (tid == 0) Lp[tri(j, j)] = r;
-        __syncthreads();
-        const int ti = tid >> 4, tk = tid & 15;
-        for (int i = j + 1 + ti; i < NB; i += 16) {
-            const double lij = Lp[tri(i, j)];
-            for (int k = j + 1 + tk; k <= i; k += 16) Lp[tri(i, k)] -= lij * Lp[tri(k, j)];
-        }
-        __syncthreads();
-    }
-    if (!ok) return;
-    // inverse of the lower-triangular factor, one column per thread (forward substitution on e_c)
-    if (tid < NB) {
-        const int c = tid;
-        for (int i = c; i < NB; ++i) {
-            double s = (i == c) ? 1.0 : 0.0;
-            for (int k = c; k < i; ++k) s -= Lp[tri(i, k)] * Xp[tri(k, c)];
-            Xp[tri(i, c)] = s / Lp[tri(i, i)];
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        if (j <= i) H[(k0 + i) * ldh + k0 + j] = Lp[tri(i, j)];
-        // image for the tile kernel: Bt[k][j] = Linv[j][k]  (zero above the diagonal of Linv)
-        const int k = i, jj = j;  // e enumerates (k, jj)
-        LinvT[k * NB + jj] = (k <= jj) ? Xp[tri(jj, k)] : 0.0;
-    }
-}
+// 1. diagonal block (factor + invert): bq_potrf_diag.hip
+int bq_potrf_diag_setup();
+void bq_launch_potrf_diag(hipStream_t st, double *H, int64_t ldh, int64_t k0, double *LinvT, int *info);
 
 // ---------------------------------------------------------------------------------------------
 // 2./3. block column: transpose to a k-major image, TRSM as GEMM, SYRK on the trailing triangle
@@ -155,22 +101,29 @@ __global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict
     if (tid == 0) tmp[r] = rhs[k0 + r] - (((red[0] + red[1]) + red[2]) + red[3]);
 }
 
-// out[i] = sum_j M[i][j] in[j] with M = Linv (transpose == 0) or Linv^T (transpose == 1); LinvT[k][j] = Linv[j][k]
-__global__ __launch_bounds__(128) void diag_mv_kernel(const double *__restrict__ LinvT, int transpose,
+// out[i] = sum_j M[i][j] in[j] with M = Linv (transpose == 0) or Linv^T (transpose == 1); LinvT[k][j] = Linv[j][k].
+// Two threads per output element split the 128-long sum; reads of LinvT are coalesced in the non-transposed case
+// (consecutive i) and row-contiguous per thread in the transposed one (L2-resident 128 KB).
+__global__ __launch_bounds__(256) void diag_mv_kernel(const double *__restrict__ LinvT, int transpose,
                                                       const double *__restrict__ in, double *__restrict__ out) {
     __shared__ double v[NB];
-    __shared__ double M[NB][NB + 1];
-    const int i = threadIdx.x;
-    v[i] = in[i];
-    for (int e = i; e < NB * NB; e += NB) M[e >> 7][e & 127] = LinvT[e];
+    __shared__ double half[2][NB];
+    const int i = threadIdx.x & 127, h = threadIdx.x >> 7;
+    if (threadIdx.x < NB) v[threadIdx.x] = in[threadIdx.x];
     __syncthreads();
     double s = 0.0;
     if (transpose) {
-        for (int j = i; j < NB; ++j) s = fma(M[i][j], v[j], s);  // Linv^T[i][j] = LinvT[i][j], upper triangular
+        // Linv^T[i][j] = LinvT[i][j], non-zero for j >= i
+        const int j0 = h ? 64 : 0, j1 = h ? NB : 64;
+        for (int j = (j0 > i ? j0 : i); j < j1; ++j) s = fma(LinvT[i * NB + j], v[j], s);
     } else {
-        for (int j = 0; j <= i; ++j) s = fma(M[j][i], v[j], s);  // Linv[i][j] = LinvT[j][i], lower triangular
+        // Linv[i][j] = LinvT[j][i], non-zero for j <= i
+        const int j0 = h ? 64 : 0, j1 = h ? NB : 64;
+        for (int j = j0; j < j1 && j <= i; ++j) s = fma(LinvT[j * NB + i], v[j], s);
     }
-    out[i] = s;
+    half[h][i] = s;
+    __syncthreads();
+    if (threadIdx.x < NB) out[i] = half[0][i] + half[1][i];
 }
 
 // rhs[c] -= sum_{r < 128} L[k0 + r][c] * x[r]  for c < k0
@@ -213,8 +166,7 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
     if (e == hipSuccess) e = hipMalloc(&ws->rhs, sizeof(double) * (ws->cap + NB));
     if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * NB);
     if (e == hipSuccess) e = hipMalloc(&ws->info, sizeof(int));
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 2 * TRI * (int)sizeof(double));
+    if (e == hipSuccess && bq_potrf_diag_setup() != BQ_OK) e = hipErrorUnknown;
     if (e != hipSuccess) {
         bq_set_error("factorisation workspace setup failed: %s", hipGetErrorString(e));
         bq_chol_ws_destroy(ws);
@@ -226,7 +178,8 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
 
 void bq_chol_ws_destroy(bq_chol_ws *ws) {
     if (!ws) return;
-    for (void *p : {(void *)ws->H, (void *)ws->Wt, (void *)ws->LinvT, (void *)ws->rhs, (void *)ws->tmp, (void *)ws->info})
+    for (void *p : {(void *)ws->H, (void *)ws->Wt, (void *)ws->LinvT, (void *)ws->rhs, (void *)ws->tmp, (void *)ws->info,
+                    (void *)ws->mr_vec})
         if (p) hipFree(p);
     delete ws;
 }
@@ -242,7 +195,7 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     const int64_t ldh = ws->ldh;
     for (int64_t k0 = 0; k0 < np; k0 += NB) {
         double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
-        potrf_diag_kernel<<<1, 256, 2 * TRI * sizeof(double), st>>>(ws->H, ldh, k0, LinvT, ws->info);
+        bq_launch_potrf_diag(st, ws->H, ldh, k0, LinvT, ws->info);
         const int64_t i0 = k0 + NB;
         if (i0 >= np) break;
         const int64_t T = (np - i0) / NB;
@@ -268,11 +221,11 @@ int bq_chol_solve(bq_chol_ws *ws, int64_t np) {
             fwd_panel_kernel<<<NB, 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp);
             src = ws->tmp;
         }
-        diag_mv_kernel<<<1, NB, 0, st>>>(LinvT, 0, src, ws->rhs + k0);
+        diag_mv_kernel<<<1, 256, 0, st>>>(LinvT, 0, src, ws->rhs + k0);
     }
     for (int64_t k0 = np - NB; k0 >= 0; k0 -= NB) {
         const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
-        diag_mv_kernel<<<1, NB, 0, st>>>(LinvT, 1, ws->rhs + k0, ws->rhs + k0);
+        diag_mv_kernel<<<1, 256, 0, st>>>(LinvT, 1, ws->rhs + k0, ws->rhs + k0);
         if (k0 > 0) bwd_update_kernel<<<(unsigned)((k0 / 2 + 255) / 256), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs + k0, ws->rhs);
     }
     BQ_HIP(hipGetLastError());
@@ -285,19 +238,24 @@ int bq_chol_solve(bq_chol_ws *ws, int64_t np) {
 template <typename T>
 __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64_t ldp, int64_t n,
                                const double *__restrict__ sgn, double diag_add, const int *__restrict__ idx, int64_t m,
-                               int64_t np, const double *__restrict__ hd, double *__restrict__ H, int64_t ldh) {
+                               int64_t np, const double *__restrict__ hd, double *__restrict__ H, int64_t ldh, int full) {
     const int64_t a0 = (int64_t)blockIdx.y * 32, b0 = (int64_t)blockIdx.x * 32;
-    if (b0 > a0 + 31) return;  // strictly-upper tile
+    if (!full && b0 > a0 + 31) return;  // strictly-upper tile
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int64_t b = b0 + tx;
     for (int j = ty; j < 32; j += 8) {
         const int64_t a = a0 + j;
-        if (a >= np || b > a) continue;
+        if (a >= np || (!full && b > a) || b >= np) continue;
         double v;
         if (a >= m) {
             v = (a == b) ? 1.0 : 0.0;
         } else {
-            const int64_t i = idx ? idx[a] : a, jj = idx ? idx[b] : b;
+            int64_t i = idx ? idx[a] : a, jj = idx ? idx[b] : b;
+            if (jj > i) {   // upper half of a full symmetric build: mirror (panels hold the lower tiles)
+                const int64_t t = i;
+                i = jj;
+                jj = t;
+            }
             // kernel-built panels keep only the tiles on/below the diagonal: always read (max, min)
             if (structure == BQ_PLAIN) {
                 v = (double)panel[i * ldp + jj];
@@ -318,17 +276,18 @@ __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64
     }
 }
 
-int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out) {
+int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out,
+                    bool full) {
     const int64_t np = bq_round_up(m > 0 ? m : 1, NB);
     BQ_ARG(np <= ws->cap, "H larger than the workspace");
     BQ_ARG(p->r0 == 0 && p->r1 == p->n, "the factorisation needs the whole panel on this rank");
     dim3 grid((unsigned)((np + 31) / 32), (unsigned)((np + 31) / 32));
     if (p->storage == BQ_F64)
         build_h_kernel<double><<<grid, 256, 0, ws->ctx->stream>>>(p->structure, (const double *)p->panel, p->ld, p->n, p->sgn,
-                                                                 p->diag_add, idx, m, np, hd, ws->H, ws->ldh);
+                                                                 p->diag_add, idx, m, np, hd, ws->H, ws->ldh, full ? 1 : 0);
     else
         build_h_kernel<float><<<grid, 256, 0, ws->ctx->stream>>>(p->structure, (const float *)p->panel, p->ld, p->n, p->sgn,
-                                                                p->diag_add, idx, m, np, hd, ws->H, ws->ldh);
+                                                                p->diag_add, idx, m, np, hd, ws->H, ws->ldh, full ? 1 : 0);
     BQ_HIP(hipGetLastError());
     *np_out = np;
     return BQ_OK;
