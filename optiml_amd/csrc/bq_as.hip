@@ -265,6 +265,7 @@ int bq_as_start(bq_solver *s) {
     as_ws *w = new as_ws();
     s->as_ws = w;
     BQ_HIP(hipMalloc(&w->idx, sizeof(int) * (s->N + 1)));
+    BQ_HIP(hipMemsetAsync(w->idx, 0, sizeof(int) * (s->N + 1), ctx->stream));
     BQ_HIP(hipMalloc(&w->ints, sizeof(int) * 8));
     BQ_HIP(hipMemsetAsync(w->ints, 0, sizeof(int) * 8, ctx->stream));
     for (double **v : {&w->cand, &w->z, &w->Qz, &w->x_eval, &w->g_eval}) {

@@ -247,7 +247,7 @@ __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64
         const int64_t a = a0 + j;
         if (a >= np || (!full && b > a) || b >= np) continue;
         double v;
-        if (a >= m) {
+        if (a >= m || b >= m) {   // pad rows AND pad columns (a full build visits b > a): never index idx[] there
             v = (a == b) ? 1.0 : 0.0;
         } else {
             int64_t i = idx ? idx[a] : a, jj = idx ? idx[b] : b;

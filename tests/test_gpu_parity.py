@@ -452,8 +452,8 @@ def test_fit_svc_as(amd, n):
 def test_active_set_singular_system_uses_minres(amd):
     """Linear kernel, n > d + 1: Q[A,A] is singular, the reference's Cholesky raises and it falls back to scipy's
     minres on the normal equations (active_set.py:142-151).  The device path takes the same branch (persistent MINRES
-    kernel).  minres stops at rtol 1e-5 and the branch is decided by rounding, so parity is loose: the first
-    iterations' objective values agree to 1e-3 and the method keeps descending inside the box."""
+    kernel).  minres stops at rtol 1e-5 and the branch is decided by rounding, so parity is loose: the objective
+    values of the first 12 iterations (not monotone in the reference either) agree to 1e-3."""
     from oracle import svm_oracle as so, bcqp_oracle as bo
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.ml.svm.kernels import linear
@@ -468,7 +468,6 @@ def test_active_set_singular_system_uses_minres(amd):
     cb._bq_needs_state = False
     opt = _solvers()['as'](quad=KernelQuadratic(X, q, 'svc', linear, y=y), ub=ub, max_iter=12, callback=cb).minimize()
     assert opt.status == 'stopped' and opt.iter == 12
-    np.testing.assert_allclose(hist[:6], ref['f_hist'][:6], rtol=1e-3, atol=1e-6)
-    np.testing.assert_allclose(hist[:6], g['linear_as_loss_hist'][:6], rtol=1e-3, atol=1e-6)
-    assert np.all(np.diff(hist) <= 1e-7 * np.maximum(1, np.abs(hist[:-1])))
+    np.testing.assert_allclose(hist, ref['f_hist'], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(hist, g['linear_as_loss_hist'][:13], rtol=1e-3, atol=1e-6)   # the reference itself
     assert np.all(opt.x >= -1e-9) and np.all(opt.x <= 1 + 1e-9)
