@@ -184,7 +184,7 @@ def main():
         T = 256
         i0, i1 = r0 // T, -(-r1 // T)
         tiles = i1 * (i1 + 1) // 2 - i0 * (i0 + 1) // 2
-        alg_bytes = tiles * (T * T * esz + 2 * T * 8) + 2 * n * 8
+        alg_bytes = tiles * (T * T * esz + T * 8) + (tiles // 8 + i1 - i0) * T * 8 + 2 * n * 8   # tiles + col parts + row parts
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         full_equiv = ((r1 - r0) * n * esz + 3 * n * 8) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         workload = f'svc_hinge_rbf_{args.solver}_dual_n{n}_d{d}'

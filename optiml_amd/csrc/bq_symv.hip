@@ -13,14 +13,15 @@
 //
 // Multi-GPU: rank r owns the tile rows [I_r, I_r+1) of a balanced triangular partition and therefore produces
 // partial sums for every output block; the partial vectors are combined by one all-reduce(sum) per product.
+#include <cstdlib>
+
 #include "bq_common.h"
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
 constexpr int ST = 256;   // tile edge (== BQ_SYM_TILE)
-constexpr int JG = 4;     // tiles per strip
-constexpr int SR = 4;     // rows per wave and step
+constexpr int JG_DEFAULT = 8;   // tiles per strip (8 x 2 KiB contiguous per row; best of the measured variants)
 
 template <typename T> struct ld2;
 template <> struct ld2<double> {
@@ -36,24 +37,25 @@ template <> struct ld2<float> {
 };
 
 // strips of tile row I: g = 0 .. I / JG ; linear index over tile rows [I0, I1)
-__device__ __forceinline__ int64_t strips_before(int64_t I) {  // sum_{i < I} (i / JG + 1)
+template <int JG>
+__device__ __host__ __forceinline__ int64_t strips_before(int64_t I) {  // sum_{i < I} (i / JG + 1)
     const int64_t qq = I / JG, rr = I % JG;
     return JG * qq * (qq + 1) / 2 + rr * (qq + 1);
 }
 
-template <typename T, bool ADD_ONE>
+template <typename T, bool ADD_ONE, int JG, int SR>
 __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict__ panel, int64_t ld, int64_t I0,
                                                             int64_t nb, const double *__restrict__ w,
                                                             double *__restrict__ slab, const int *__restrict__ done) {
     if (done != nullptr && *done) return;
     __shared__ double colred[4][ST];
     // decode (I, g) from the linear strip index
-    const int64_t t = (int64_t)blockIdx.x + strips_before(I0);
+    const int64_t t = (int64_t)blockIdx.x + strips_before<JG>(I0);
     int64_t I = (int64_t)sqrt(2.0 * (double)JG * (double)t);
     if (I >= nb) I = nb - 1;
-    while (I > 0 && strips_before(I) > t) --I;
-    while (strips_before(I + 1) <= t) ++I;
-    const int64_t g = t - strips_before(I);
+    while (I > 0 && strips_before<JG>(I) > t) --I;
+    while (strips_before<JG>(I + 1) <= t) ++I;
+    const int64_t g = t - strips_before<JG>(I);
     const int64_t J0 = g * JG;
     const int nj = (int)((J0 + JG <= I + 1) ? JG : (I + 1 - J0));  // tiles in this strip (J <= I)
 
@@ -108,24 +110,51 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
                 }
             }
         }
-        // halving butterfly: 4 row partials x 64 lanes -> one full row sum per 16-lane group
-        double u[2], s1;
+        // halving butterfly: SR row partials x 64 lanes -> one full row sum per (64 / SR)-lane group
+        double s1;
+        int rho;
+        if constexpr (SR == 8) {
+            const bool b3 = lane & 8;
+            double u[4], t2[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double send = b5 ? rp[i] : rp[i + 2];
-            const double keep = b5 ? rp[i + 2] : rp[i];
-            u[i] = keep + __shfl_xor(send, 32, 64);
+            for (int i = 0; i < 4; ++i) {
+                const double send = b5 ? rp[i] : rp[i + 4];
+                const double keep = b5 ? rp[i + 4] : rp[i];
+                u[i] = keep + __shfl_xor(send, 32, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double send = b4 ? u[i] : u[i + 2];
+                const double keep = b4 ? u[i + 2] : u[i];
+                t2[i] = keep + __shfl_xor(send, 16, 64);
+            }
+            {
+                const double send = b3 ? t2[0] : t2[1];
+                const double keep = b3 ? t2[1] : t2[0];
+                s1 = keep + __shfl_xor(send, 8, 64);
+            }
+            rho = (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
+        } else {
+            static_assert(SR == 4 || SR == 8, "SR");
+            double u[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double send = b5 ? rp[i] : rp[i + 2];
+                const double keep = b5 ? rp[i + 2] : rp[i];
+                u[i] = keep + __shfl_xor(send, 32, 64);
+            }
+            {
+                const double send = b4 ? u[0] : u[1];
+                const double keep = b4 ? u[1] : u[0];
+                s1 = keep + __shfl_xor(send, 16, 64);
+            }
+            s1 += __shfl_xor(s1, 8, 64);
+            rho = (b5 ? 2 : 0) + (b4 ? 1 : 0);
         }
-        {
-            const double send = b4 ? u[0] : u[1];
-            const double keep = b4 ? u[1] : u[0];
-            s1 = keep + __shfl_xor(send, 16, 64);
-        }
-        s1 += __shfl_xor(s1, 8, 64);
         s1 += __shfl_xor(s1, 4, 64);
         s1 += __shfl_xor(s1, 2, 64);
         s1 += __shfl_xor(s1, 1, 64);
-        if ((lane & 15) == 0) rowout[step * SR + (b5 ? 2 : 0) + (b4 ? 1 : 0)] = s1;
+        if ((lane & (64 / SR - 1)) == 0) rowout[step * SR + rho] = s1;
     }
     // column parts of every off-diagonal tile of the strip
 #pragma unroll
@@ -145,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
 // out[a*T + r] = sum of the slab entries S[a][b] this rank produced, b ascending:
 //   row parts live at b = first tile of a strip (b % JG == 0, b <= a) when tile row a is ours,
 //   col parts at every b > a that is one of our tile rows.
+template <int JG>
 __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, int64_t I0,
                                                           int64_t I1, double *__restrict__ out,
                                                           const int *__restrict__ done) {
@@ -159,32 +189,44 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restri
     out[a * ST + threadIdx.x] = s;
 }
 
-static int64_t host_strips_before(int64_t I) {
-    const int64_t qq = I / JG, rr = I % JG;
-    return JG * qq * (qq + 1) / 2 + rr * (qq + 1);
-}
-
-int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
-                   int64_t ld, const double *w, double *slab, double *out, const int *done) {
-    const int64_t nstrips = host_strips_before(I1) - host_strips_before(I0);
+template <int JG, int SR>
+static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
+                          int64_t ld, const double *w, double *slab, double *out, const int *done) {
+    const int64_t nstrips = strips_before<JG>(I1) - strips_before<JG>(I0);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
     if (nstrips > 0) {
         dim3 grid((unsigned)nstrips);
         if (storage == BQ_F64) {
             if (add_one)
-                symv_tiles_kernel<double, true><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<double, true, JG, SR><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
             else
-                symv_tiles_kernel<double, false><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<double, false, JG, SR><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
         } else {
             if (add_one)
-                symv_tiles_kernel<float, true><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<float, true, JG, SR><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
             else
-                symv_tiles_kernel<float, false><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<float, false, JG, SR><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
         }
     }
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
-    symv_reduce_kernel<<<(unsigned)nb, 256, 0, ctx->stream>>>(slab, nb, I0, I1, out, done);
+    symv_reduce_kernel<JG><<<(unsigned)nb, 256, 0, ctx->stream>>>(slab, nb, I0, I1, out, done);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
+}
+
+int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
+                   int64_t ld, const double *w, double *slab, double *out, const int *done) {
+    // BQ_SYMV_VARIANT=<tiles per strip><rows per step> selects a tuning variant (benchmarking only)
+    static const int variant = [] {
+        const char *e = getenv("BQ_SYMV_VARIANT");
+        return e ? atoi(e) : 84;
+    }();
+    switch (variant) {
+        case 44: return launch_variant<4, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+        case 48: return launch_variant<4, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+        case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+        case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+        default: return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+    }
 }
