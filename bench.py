@@ -6,14 +6,17 @@ Wolfe dual, n=100 000, d=128, fp64 (BASELINE.json `metric`), on N GPUs of one no
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one solver iteration (one row-block panel product Q d + the fused O(n) kernels + one all-gather
-for N > 1); the Gram panel is built once before the timed region and stays resident in HBM (its build time is
-reported separately).  N > 1: one process per GPU, rank r owns a row block of the panel, RCCL all-gather per
-product; total work is fixed as N grows ("strong" scaling).  torch.distributed (gloo) is used only for
-rendezvous / barrier / max-over-ranks — no torch tensor touches the compute path.
+A "step" is one solver iteration: one symmetric panel product Q d (this rank's lower-triangle tiles, streamed once)
++ the fused O(n) kernels + one all-reduce of the n-vector for N > 1.  The Gram panel is built once before the timed
+region and stays resident in HBM (its build time is reported separately).  N > 1: one process per GPU, rank r owns a
+balanced triangular share of the tile rows, RCCL all-reduce per product; total work is fixed as N grows ("strong"
+scaling).  torch.distributed (gloo) is used only for rendezvous / barrier / max-over-ranks — no torch tensor touches
+the compute path.
 
-Rank 0 prints ONE JSON line with `roofline` (HIP-event timing of the panel-product kernel on its own stream
-against 8 TB/s HBM) and `cpu_baseline` (the NumPy oracle in the reference formulation on a bounded sample).
+Rank 0 prints ONE JSON line with `roofline` (HIP-event timing of the panel-product kernel on its own stream against
+8 TB/s HBM, on the bytes that kernel has to move: its tiles + partial-product slab; `row_block_equivalent_GBs` restates
+the rate in SURVEY 8(d)'s n^2*s bytes) and `cpu_baseline` (the NumPy oracle in the reference formulation on a bounded
+sample).
 """
 import argparse
 import json
