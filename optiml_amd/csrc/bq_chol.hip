@@ -55,9 +55,11 @@ __global__ __launch_bounds__(256, 2) void trsm_gemm_kernel(double *__restrict__ 
     bq_tile_foreach(acc, [&](int r, int c, double v) { H[(arow + r) * ldh + k0 + c] = v; });
 }
 
-// A_ij -= X_i X_j^T over the lower-triangular tiles (ti >= tj) of the trailing matrix starting at i0
+// A_ij -= X_i X_j^T over the lower-triangular tiles (ti >= tj) of the trailing matrix starting at i0; X is the k-major
+// image Wt with kdim rows (128, or 256 when two factored block columns are applied in one pass: twice the flops per
+// byte of C-tile traffic)
 __global__ __launch_bounds__(256, 2) void syrk_kernel(double *__restrict__ H, int64_t ldh, int64_t i0,
-                                                      const double *__restrict__ Wt) {
+                                                      const double *__restrict__ Wt, int kdim) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     const int64_t b = blockIdx.x;
     int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
@@ -67,9 +69,24 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(double *__restrict__ H, in
     const int64_t arow = i0 + ti * NB, bcol = i0 + tj * NB;
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
-    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, bcol, NB, sm, acc);
+    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
     bq_tile_foreach(acc, [&](int r, int c, double v) {
         double *p = H + (arow + r) * ldh + bcol + c;
+        *p -= v;
+    });
+}
+
+// the same update restricted to the first block column of the trailing matrix (tiles (ti, 0)): makes the next block
+// column current so that it can be factored before the wide update runs
+__global__ __launch_bounds__(256, 2) void syrk_col_kernel(double *__restrict__ H, int64_t ldh, int64_t i0,
+                                                          const double *__restrict__ Wt) {
+    __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
+    const int64_t arow = i0 + (int64_t)blockIdx.x * NB;
+    bq_d4 acc[4][4];
+    bq_tile_zero(acc);
+    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, i0, NB, sm, acc);
+    bq_tile_foreach(acc, [&](int r, int c, double v) {
+        double *p = H + (arow + r) * ldh + i0 + c;
         *p -= v;
     });
 }
@@ -161,7 +178,7 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
         delete ws;
         return BQ_ERR_NOMEM;
     }
-    if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * NB * ws->ldh);
+    if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * 2 * NB * ws->ldh);
     if (e == hipSuccess) e = hipMalloc(&ws->LinvT, sizeof(double) * nblk * NB * NB);
     if (e == hipSuccess) e = hipMalloc(&ws->rhs, sizeof(double) * (ws->cap + NB));
     if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * NB);
@@ -193,17 +210,31 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_CHOL, &e0, &e1));
     BQ_HIP(hipMemsetAsync(ws->info, 0, sizeof(int), st));
     const int64_t ldh = ws->ldh;
-    for (int64_t k0 = 0; k0 < np; k0 += NB) {
-        double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
-        bq_launch_potrf_diag(st, ws->H, ldh, k0, LinvT, ws->info);
+    // Two block columns per pass: factor column A, bring column B up to date with a narrow update, factor column B, then
+    // apply both to the rest of the trailing matrix in ONE K = 256 update (half the C-tile traffic of two K = 128 passes).
+    double *WtA = ws->Wt, *WtB = ws->Wt + (int64_t)NB * ldh;
+    auto panel = [&](int64_t k0, double *Wimg) {   // diag(k0) done: TRSM the rows below and leave their image in Wimg
+        const int64_t i0 = k0 + NB;
+        const int64_t T = (np - i0) / NB;
+        const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
+        dim3 tg((unsigned)((np - i0 + 31) / 32), NB / 32);
+        panel_to_image_kernel<<<tg, 256, 0, st>>>(ws->H, ldh, k0, i0, np, Wimg);
+        trsm_gemm_kernel<<<(unsigned)T, 256, 0, st>>>(ws->H, ldh, k0, i0, Wimg, LinvT);
+        panel_to_image_kernel<<<tg, 256, 0, st>>>(ws->H, ldh, k0, i0, np, Wimg);
+    };
+    for (int64_t k0 = 0; k0 < np; k0 += 2 * NB) {
+        bq_launch_potrf_diag(st, ws->H, ldh, k0, ws->LinvT + (k0 / NB) * NB * NB, ws->info);
         const int64_t i0 = k0 + NB;
         if (i0 >= np) break;
-        const int64_t T = (np - i0) / NB;
-        dim3 tg((unsigned)((np - i0 + 31) / 32), NB / 32);
-        panel_to_image_kernel<<<tg, 256, 0, st>>>(ws->H, ldh, k0, i0, np, ws->Wt);
-        trsm_gemm_kernel<<<(unsigned)T, 256, 0, st>>>(ws->H, ldh, k0, i0, ws->Wt, LinvT);
-        panel_to_image_kernel<<<tg, 256, 0, st>>>(ws->H, ldh, k0, i0, np, ws->Wt);
-        syrk_kernel<<<(unsigned)(T * (T + 1) / 2), 256, 0, st>>>(ws->H, ldh, i0, ws->Wt);
+        panel(k0, WtA);
+        const int64_t TA = (np - i0) / NB;
+        syrk_col_kernel<<<(unsigned)TA, 256, 0, st>>>(ws->H, ldh, i0, WtA);
+        bq_launch_potrf_diag(st, ws->H, ldh, i0, ws->LinvT + (i0 / NB) * NB * NB, ws->info);
+        const int64_t j0 = i0 + NB;
+        if (j0 >= np) break;
+        panel(i0, WtB);
+        const int64_t T = (np - j0) / NB;
+        syrk_kernel<<<(unsigned)(T * (T + 1) / 2), 256, 0, st>>>(ws->H, ldh, j0, ws->Wt, 2 * NB);
     }
     BQ_HIP(hipGetLastError());
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_CHOL, e0, e1));
