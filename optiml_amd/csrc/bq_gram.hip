@@ -158,6 +158,7 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
 
 int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r0, int64_t r1, int kernel,
                    double gamma, double coef0, int degree, void *panel, int storage, int64_t ld, bool lower_tiles_only) {
+    if (r1 <= r0) return BQ_OK;   // a rank that owns no rows (more ranks than tile rows) has nothing to build
     gram_images img;
     // pad the image so that a tile starting at any r0 stays inside it
     int rc = make_image(ctx, X, n, d, &img);

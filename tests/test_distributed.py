@@ -85,3 +85,15 @@ def test_rccl_context_single_rank(tmp_path):
     got = _launch('gpu-rccl', 1, tmp_path / 'rccl')[0]
     for key in ('matvec', 'pg_x', 'pg_hist', 'fw_x', 'dense_matvec', 'dense_pg_x'):
         assert np.array_equal(got[key], ref[key]), key
+
+
+@pytest.mark.gpu
+def test_three_ranks_uneven_partitions(tmp_path):
+    """World size 3: uneven triangular / row-block partitions (700 rows -> tile rows 2 + 0 + 1; 500 rows -> 256+244+0)."""
+    one = _launch('gpu-host', 1, tmp_path / 'w1')[0]
+    three = _launch('gpu-host', 3, tmp_path / 'w3')
+    for r in three:
+        assert np.array_equal(r['dense_pg_x'], one['dense_pg_x'])
+        np.testing.assert_allclose(r['matvec'], one['matvec'], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(r['pg_x'], one['pg_x'], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['fw_x'], one['fw_x'], rtol=1e-9, atol=1e-11)

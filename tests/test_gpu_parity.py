@@ -471,3 +471,122 @@ def test_active_set_singular_system_uses_minres(amd):
     np.testing.assert_allclose(hist, ref['f_hist'], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(hist, g['linear_as_loss_hist'][:13], rtol=1e-3, atol=1e-6)   # the reference itself
     assert np.all(opt.x >= -1e-9) and np.all(opt.x <= 1 + 1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# API behaviour the reference's callers rely on
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,structure', [(1000, 'svc'), (2500, 'svc'), (4200, 'svc'), (1300, 'svr'), (3000, 'plain')])
+def test_symmetric_tile_product_against_oracle(amd, n, structure):
+    """Multi-tile-row / multi-strip shapes of the lower-triangle product (n not a multiple of the 256 tile)."""
+    from oracle import svm_oracle as so
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.kernels import gaussian
+    X, y = make_blobs(n, 9, seed=n)
+    K = so.gram('rbf', X)
+    rs = np.random.RandomState(n)
+    if structure == 'svc':
+        Q, q, _ = so.svc_dual(K, y, 1.0)
+        quad = KernelQuadratic(X, q, 'svc', gaussian, y=y)
+    elif structure == 'svr':
+        Q, q, _ = so.svr_dual(K, rs.standard_normal(n), 1.0, 0.1)
+        quad = KernelQuadratic(X, q, 'svr', gaussian)
+    else:
+        Q, q = K, rs.standard_normal(n)
+        quad = KernelQuadratic(X, q, 'plain', gaussian)
+    v = rs.standard_normal(len(q))
+    out = quad.device_problem().matvec(v)
+    np.testing.assert_allclose(out, Q @ v, rtol=1e-11, atol=1e-11 * np.abs(Q).sum(1).max())
+    f, g = quad.function_jacobian(v)
+    np.testing.assert_allclose(g, Q @ v + q, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(f, 0.5 * v @ Q @ v + q @ v, rtol=1e-11)
+    w = rs.standard_normal(n)
+    np.testing.assert_allclose(quad.device_problem().gram_matvec(w), K @ w, rtol=1e-11, atol=1e-10)
+    quad.release()
+
+
+def test_fp32_panel_storage_on_kernel_problem(amd):
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import InteriorPoint
+    from optiml_amd.ml.svm.kernels import gaussian
+    X, y = make_blobs(700, 10, seed=8)
+    ub = np.ones(700)
+    a = InteriorPoint(quad=KernelQuadratic(X, -ub, 'svc', gaussian, y=y), ub=ub).minimize()
+    b = InteriorPoint(quad=KernelQuadratic(X, -ub, 'svc', gaussian, y=y, storage='f32'), ub=ub).minimize()
+    assert a.status == b.status == 'optimal'
+    np.testing.assert_allclose(b.x, a.x, rtol=1e-4, atol=1e-5)     # SURVEY 8(d): fp32-storage tolerance
+    np.testing.assert_allclose(b.f_x, a.f_x, rtol=1e-6)
+    assert np.array_equal(a.x > 1e-6, b.x > 1e-6) or np.sum((a.x > 1e-6) != (b.x > 1e-6)) <= 2
+
+
+def test_callback_contract(amd):
+    """callback(opt, *callback_args) every iteration with the state of that iteration; StopIteration stops the run and
+    leaves status 'unknown' (optiml/opti/_base.py:119-127, projected_gradient.py:95-98)."""
+    from oracle import bcqp_oracle as bo
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import ProjectedGradient
+    g = load_golden('traj_svc_rbf_n256.npz')
+    seen = []
+
+    def cb(opt, tag, limit):
+        assert tag == 'hello'
+        seen.append((opt.iter, opt.f_x, opt.x.copy(), opt.g_x.copy()))
+        if opt.iter == limit:
+            raise StopIteration
+
+    opt = ProjectedGradient(quad=Quadratic(g['Q'], g['q']), ub=g['ub'], callback=cb, callback_args=('hello', 7)).minimize()
+    assert opt.status == 'unknown' and opt.iter == 7 and len(seen) == 8
+    ref = bo.projected_gradient(g['Q'], g['q'], g['ub'], max_iter=7, keep_x=range(8))
+    for k, (it, f, x, gx) in enumerate(seen):
+        assert it == k
+        np.testing.assert_allclose(f, ref['f_hist'][k], rtol=1e-10)
+        np.testing.assert_allclose(x, ref['x_at'][k], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gx, g['Q'] @ x + g['q'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(opt.x, ref['x_at'][7], rtol=1e-9, atol=1e-12)
+
+
+def test_small_problem_histories_and_verbose(amd, capsys):
+    """ndim <= 3: x0/x1/f_x histories are kept (optiml/opti/_base.py:78-82, 121-124); verbose prints the reference's
+    tab-separated lines (projected_gradient.py:79,93; interior_point.py:189,198)."""
+    import re
+    from optiml_amd.opti import Quadratic
+    g = load_golden('unit_problems.npz')
+    solvers = _solvers()
+    opt = solvers['pg'](quad=Quadratic(g['nd2_Q'], g['nd2_q']), ub=g['nd2_ub'], verbose=True).minimize()
+    out = capsys.readouterr().out
+    assert out.startswith('iter\t cost\t\t gnorm')
+    rows = [l for l in out.split('\n') if re.match(r'^\s*\d+\t', l)]
+    assert len(rows) == opt.iter + 1 == len(opt.f_x_history) == len(opt.x0_history) == len(opt.x1_history)
+    assert re.match(r'^ {3}0\t[ -]\d\.\d{4}e[+-]\d\d\t[ -]\d\.\d{4}e[+-]\d\d$', rows[0])
+    np.testing.assert_allclose(opt.f_x_history, g['nd2_pg_f_hist'], rtol=1e-9, atol=1e-12)
+    opt = solvers['ip'](quad=Quadratic(g['nd5_Q'], g['nd5_q']), ub=g['nd5_ub'], lb=g['nd5_lb'], verbose=5).minimize()
+    out = capsys.readouterr().out
+    assert out.startswith('iter\t cost\t\t p\t\t gap')
+    rows = [l for l in out.split('\n') if re.match(r'^\s*\d+\t', l)]
+    assert [int(r.split('\t')[0]) for r in rows] == list(range(0, opt.iter + 1, 5))   # verbose=5: every 5th iteration
+    for s in ('fw', 'as'):
+        solvers[s](quad=Quadratic(g['nd5_Q'], g['nd5_q']), ub=g['nd5_ub'], lb=g['nd5_lb'], verbose=True).minimize()
+        assert capsys.readouterr().out.startswith({'fw': 'iter\t cost\t\t lb\t\t gap', 'as': 'iter\t cost\t\t|B|'}[s])
+
+
+@pytest.mark.parametrize('s', ['pg', 'as', 'ip', 'fw'])
+def test_reference_integration_test_iris(amd, s):
+    """The reference's own integration test (optiml/ml/tests/test_svc.py:96-115): Iris, MinMax-scaled, 75/25 split
+    with seed 123456, one-vs-rest over SVC(hinge, gaussian, reg_intercept=True, dual=True, optimizer=...):
+    test accuracy >= 0.97."""
+    sk = pytest.importorskip('sklearn')
+    from sklearn.datasets import load_iris
+    from sklearn.model_selection import train_test_split
+    from sklearn.multiclass import OneVsRestClassifier as OVR
+    from sklearn.preprocessing import MinMaxScaler
+    from optiml_amd.ml.svm import SVC
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.ml.svm.losses import hinge
+    X, y = load_iris(return_X_y=True)
+    X_scaled = MinMaxScaler().fit_transform(X)
+    X_train, X_test, y_train, y_test = train_test_split(X_scaled, y, train_size=0.75, random_state=123456)
+    svc = OVR(SVC(loss=hinge, kernel=gaussian, reg_intercept=True, dual=True, optimizer=_solvers()[s]))
+    svc = svc.fit(X_train, y_train)
+    assert svc.score(X_test, y_test) >= 0.97
