@@ -46,7 +46,8 @@ typedef struct bq_problem bq_problem;
 typedef struct bq_solver bq_solver;
 
 enum { BQ_F64 = 0, BQ_F32 = 1 };                                    /* panel storage dtype */
-enum { BQ_KERNEL_LINEAR = 0, BQ_KERNEL_POLY = 1, BQ_KERNEL_RBF = 2 };
+/* linear, poly, rbf: kernels.py:40-129 (the named configs); sigmoid, laplacian: kernels.py:132-201 */
+enum { BQ_KERNEL_LINEAR = 0, BQ_KERNEL_POLY = 1, BQ_KERNEL_RBF = 2, BQ_KERNEL_SIGMOID = 3, BQ_KERNEL_LAPLACIAN = 4 };
 enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian structure */
 enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3 };                 /* solver kind */
 enum { BQ_STATUS_UNKNOWN = 0, BQ_STATUS_OPTIMAL = 1, BQ_STATUS_STOPPED = 2 };

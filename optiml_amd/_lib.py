@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libbcqp_hip.so')
 OK = 0
 ERR_HIP, ERR_RCCL, ERR_NOT_PD, ERR_NONFINITE, ERR_BADARG, ERR_NOMEM = -1, -2, -3, -4, -5, -6
 F64, F32 = 0, 1
-KERNEL_LINEAR, KERNEL_POLY, KERNEL_RBF = 0, 1, 2
+KERNEL_LINEAR, KERNEL_POLY, KERNEL_RBF, KERNEL_SIGMOID, KERNEL_LAPLACIAN = 0, 1, 2, 3, 4
 PLAIN, SVC, SVR = 0, 1, 2
 PG, FW, AS, IP = 0, 1, 2, 3
 STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}

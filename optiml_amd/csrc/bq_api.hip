@@ -332,7 +332,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     BQ_ARG(c && X && q && out, "NULL argument");
     BQ_ARG(structure == BQ_PLAIN || structure == BQ_SVC || structure == BQ_SVR, "structure");
     BQ_ARG(structure != BQ_SVC || y != nullptr, "labels required for BQ_SVC");
-    BQ_ARG(kernel == BQ_KERNEL_LINEAR || kernel == BQ_KERNEL_POLY || kernel == BQ_KERNEL_RBF, "kernel");
+    BQ_ARG(kernel >= BQ_KERNEL_LINEAR && kernel <= BQ_KERNEL_LAPLACIAN, "kernel");
     BQ_ARG(n >= 2 && d >= 1, "n/d");
     BQ_ARG(storage == BQ_F64 || storage == BQ_F32, "storage");
     BQ_ARG(kernel != BQ_KERNEL_POLY || degree > 0, "degree must be > 0");

@@ -87,11 +87,62 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
             kv = exp(-P.gamma * dist);
         } else if (P.kernel == BQ_KERNEL_POLY) {
             kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+        } else if (P.kernel == BQ_KERNEL_SIGMOID) {
+            kv = tanh(P.gamma * dot + P.coef0);
         } else {
             kv = dot;
         }
         store_elem<T>(out + (gi - P.arow0) * P.ld + gj, kv);
     });
+}
+
+// Laplacian kernel exp(-gamma * |x - y|_1) (kernels.py:159-163; sklearn's manhattan_distances sums |x_k - y_k| over
+// the features in order).  No GEMM form: a VALU kernel on the same k-major images, 64 x 64 outputs per workgroup,
+// 4 x 4 per thread, 32-deep k-chunks through LDS.
+constexpr int LT = 64, LK = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void gram_l1_kernel(gram_params P, T *__restrict__ out) {
+    __shared__ double As[LK][LT + 2], Bs[LK][LT + 2];
+    const int64_t tiles_n = (P.n + LT - 1) / LT;
+    const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int64_t arow = P.arow0 + tm * LT, bcol = tn * LT;
+    if (P.lower_only && (bcol / BQ_SYM_TILE) > (arow / BQ_SYM_TILE)) return;
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;   // 16 x 16 threads, 4 x 4 outputs each
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    for (int64_t kc = 0; kc < P.dp; kc += LK) {
+        __syncthreads();
+        for (int e = tid; e < LK * LT; e += 256) {
+            const int k = e / LT, r = e % LT;
+            const bool kin = kc + k < P.dp;
+            As[k][r] = (kin && arow + r < P.mp) ? P.At[(kc + k) * P.mp + arow + r] : 0.0;
+            Bs[k][r] = (kin && bcol + r < P.np) ? P.Bt[(kc + k) * P.np + bcol + r] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < LK; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = As[k][4 * tr + u];
+                b[u] = Bs[k][4 * tc + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += fabs(a[u] - b[v]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t gi = arow + 4 * tr + u, gj = bcol + 4 * tc + v;
+            if (gi < P.arow1 && gj < P.n) store_elem<T>(out + (gi - P.arow0) * P.ld + gj, exp(-P.gamma * acc[u][v]));
+        }
 }
 
 struct gram_images {
@@ -146,11 +197,21 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
     BQ_ARG(m_rows0 % GT == 0 || m_rows0 + tiles_m * GT <= A.mp, "row block must keep tiles inside the padded image");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_GRAM, &e0, &e1));
-    dim3 grid((unsigned)(tiles_m * tiles_n));
-    if (storage == BQ_F64)
-        gram_mfma_kernel<double><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));
-    else
-        gram_mfma_kernel<float><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
+    if (kernel == BQ_KERNEL_LAPLACIAN) {
+        const int64_t lm = (P.m + LT - 1) / LT, ln = (n + LT - 1) / LT;
+        BQ_ARG(lm * ln < (int64_t)2147483647, "Gram grid too large");
+        dim3 lgrid((unsigned)(lm * ln));
+        if (storage == BQ_F64)
+            gram_l1_kernel<double><<<lgrid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));
+        else
+            gram_l1_kernel<float><<<lgrid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
+    } else {
+        dim3 grid((unsigned)(tiles_m * tiles_n));
+        if (storage == BQ_F64)
+            gram_mfma_kernel<double><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));
+        else
+            gram_mfma_kernel<float><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
+    }
     BQ_HIP(hipGetLastError());
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_GRAM, e0, e1));
     return BQ_OK;

@@ -1,6 +1,6 @@
-"""Gram-matrix functors (linear, polynomial, Gaussian) evaluated on the device.
+"""Gram-matrix functors (linear, polynomial, Gaussian, Laplacian, sigmoid) evaluated on the device.
 
-Same classes, ctor arguments and validation as optiml/ml/svm/kernels.py:40-129.  `kernel(X, Y=None)` returns
+Same classes, ctor arguments and validation as optiml/ml/svm/kernels.py:40-208.  `kernel(X, Y=None)` returns
 the dense Gram matrix computed by the fp64-MFMA tile kernel; gamma='scale' is 1 / (n_features * X.var()) of
 the FIRST argument, 'auto' is 1 / n_features (kernels.py:93-94, :127-128).  The SVM estimators never call
 these on the training set: they hand the kernel *spec* to the device (`device_spec`) and keep K in HBM.
@@ -27,7 +27,8 @@ except ImportError:  # pragma: no cover
                 setattr(self, k, v)
             return self
 
-__all__ = ['Kernel', 'LinearKernel', 'PolyKernel', 'GaussianKernel', 'linear', 'poly', 'gaussian']
+__all__ = ['Kernel', 'LinearKernel', 'PolyKernel', 'GaussianKernel', 'LaplacianKernel', 'SigmoidKernel',
+           'linear', 'poly', 'gaussian', 'laplacian', 'sigmoid']
 
 
 def _resolve_gamma(gamma, X):
@@ -101,6 +102,39 @@ class GaussianKernel(Kernel):
         return _lib.KERNEL_RBF, _resolve_gamma(self.gamma, X), 0.0, 1
 
 
+class LaplacianKernel(Kernel):
+    """exp(-gamma |x - y|_1) — optiml/ml/svm/kernels.py:132-163 (L1 distance: VALU tile kernel, no GEMM form)."""
+
+    def __init__(self, gamma='scale'):
+        if isinstance(gamma, str):
+            if gamma not in ('scale', 'auto'):
+                raise ValueError(f'unknown gamma type {gamma}')
+        elif not gamma > 0:
+            raise ValueError('gamma must be > 0')
+        self.gamma = gamma
+
+    def device_spec(self, X):
+        return _lib.KERNEL_LAPLACIAN, _resolve_gamma(self.gamma, X), 0.0, 1
+
+
+class SigmoidKernel(Kernel):
+    """tanh(gamma <x, y> + coef0) — optiml/ml/svm/kernels.py:166-201 (MFMA Gram tile + tanh epilogue)."""
+
+    def __init__(self, gamma='scale', coef0=0.):
+        if isinstance(gamma, str):
+            if gamma not in ('scale', 'auto'):
+                raise ValueError(f'unknown gamma type {gamma}')
+        elif not gamma > 0:
+            raise ValueError('gamma must be > 0')
+        self.gamma = gamma
+        self.coef0 = coef0
+
+    def device_spec(self, X):
+        return _lib.KERNEL_SIGMOID, _resolve_gamma(self.gamma, X), float(self.coef0), 1
+
+
 linear = LinearKernel()
 poly = PolyKernel()
 gaussian = GaussianKernel()
+laplacian = LaplacianKernel()
+sigmoid = SigmoidKernel()

@@ -89,7 +89,8 @@ def test_python_surface_matches_reference_names():
         assert issubclass(getattr(con, name), con.BoxConstrainedQuadraticOptimizer)
     for name in ('SVM', 'SVC', 'SVR'):
         assert hasattr(svm, name)
-    for name in ('linear', 'poly', 'gaussian', 'LinearKernel', 'PolyKernel', 'GaussianKernel'):
+    for name in ('linear', 'poly', 'gaussian', 'laplacian', 'sigmoid', 'LinearKernel', 'PolyKernel', 'GaussianKernel',
+                 'LaplacianKernel', 'SigmoidKernel'):
         assert hasattr(kernels, name)
     for name in ('hinge', 'squared_hinge', 'epsilon_insensitive', 'squared_epsilon_insensitive'):
         assert hasattr(losses, name)

@@ -590,3 +590,22 @@ def test_reference_integration_test_iris(amd, s):
     svc = OVR(SVC(loss=hinge, kernel=gaussian, reg_intercept=True, dual=True, optimizer=_solvers()[s]))
     svc = svc.fit(X_train, y_train)
     assert svc.score(X_test, y_test) >= 0.97
+
+
+def test_laplacian_and_sigmoid_kernels(amd):
+    """the remaining kernel functors (optiml/ml/svm/kernels.py:132-201) against the reference fixture."""
+    from optiml_amd.ml.svm import SVC
+    from optiml_amd.ml.svm.kernels import laplacian, sigmoid, LaplacianKernel, SigmoidKernel
+    from optiml_amd.ml.svm.losses import hinge
+    g = load_golden('kernels_more.npz')
+    X, Y = g['X'], g['Y']
+    tol = dict(rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(laplacian(X), g['laplacian_scale_XX'], **tol)
+    np.testing.assert_allclose(laplacian(Y, X), g['laplacian_scale_YX'], **tol)
+    np.testing.assert_allclose(LaplacianKernel(0.2)(X), g['laplacian_g02_XX'], **tol)
+    np.testing.assert_allclose(sigmoid(X), g['sigmoid_scale_XX'], **tol)
+    np.testing.assert_allclose(SigmoidKernel('auto', 0.5)(Y, X), g['sigmoid_auto_c05_YX'], **tol)
+    assert np.all(np.diag(laplacian(X)) == 1.0)
+    est = SVC(loss=hinge, kernel=laplacian, C=1., reg_intercept=True, dual=True, optimizer=_solvers()['ip']).fit(
+        g['fit_X'], g['fit_y'])
+    _check_fit(est, g, 'laplacian_ip', g['fit_Xtest'], tol=1e-5)

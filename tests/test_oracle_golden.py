@@ -157,3 +157,18 @@ def test_pg_is_sensitive_to_rounding(golden):
     assert np.abs(a['x_at'][100] - b['x_at'][100]).max() < 1e-9
     assert np.abs(a['x_at'][500] - b['x_at'][500]).max() > 1e-6
     assert abs(a['f_x'] - b['f_x']) < 1e-5 * abs(a['f_x'])
+
+
+def test_kernels_laplacian_sigmoid(golden):
+    g = golden('kernels_more.npz')
+    X, Y = g['X'], g['Y']
+    tol = dict(rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(so.gram('laplacian', X), g['laplacian_scale_XX'], **tol)
+    np.testing.assert_allclose(so.gram('laplacian', Y, X), g['laplacian_scale_YX'], **tol)
+    np.testing.assert_allclose(so.gram('laplacian', X, None, 0.2), g['laplacian_g02_XX'], **tol)
+    np.testing.assert_allclose(so.gram('sigmoid', X), g['sigmoid_scale_XX'], **tol)
+    np.testing.assert_allclose(so.gram('sigmoid', Y, X, 'auto', 0.5), g['sigmoid_auto_c05_YX'], **tol)
+    res, post = so.fit_svc(g['fit_X'], g['fit_y'], 'ip', kind='laplacian')
+    assert res['iter'] == int(g['laplacian_ip_iter']) and res['status'] == str(g['laplacian_ip_status'])
+    np.testing.assert_allclose(res['x'], g['laplacian_ip_alphas'], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(so.decision('laplacian', post, g['fit_Xtest']), g['laplacian_ip_decision'], rtol=1e-8, atol=1e-10)

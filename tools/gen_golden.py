@@ -76,7 +76,7 @@ from optiml.opti.constrained import ProjectedGradient, FrankWolfe, ActiveSet, In
 from optiml.opti.utils import generate_box_constrained_quadratic  # noqa: E402
 from optiml.ml.svm import SVC, SVR  # noqa: E402
 from optiml.ml.svm.kernels import (LinearKernel, PolyKernel, GaussianKernel,  # noqa: E402
-                                   linear, gaussian)
+                                   LaplacianKernel, SigmoidKernel, linear, gaussian, laplacian, sigmoid)
 from optiml.ml.svm.losses import hinge, epsilon_insensitive  # noqa: E402
 
 from optiml_amd.datasets import make_blobs, make_regression  # noqa: E402
@@ -159,6 +159,25 @@ def gen_kernels(out):
     X32 = X.astype(np.float32)
     data['rbf_scale_XX_f32in'] = np.asarray(gaussian(X32), dtype=np.float64)
     np.savez_compressed(os.path.join(out, 'kernels.npz'), **data)
+
+
+def gen_kernels_more(out):
+    """the two remaining kernel functors (kernels.py:132-201) + one fit through each."""
+    rs = np.random.RandomState(0)
+    X = 1.7 * rs.standard_normal((64, 8)) + 0.3
+    Y = 0.9 * rs.standard_normal((16, 8)) - 0.2
+    data = {'X': X, 'Y': Y}
+    data['laplacian_scale_XX'] = laplacian(X)
+    data['laplacian_scale_YX'] = laplacian(Y, X)
+    data['laplacian_g02_XX'] = LaplacianKernel(gamma=0.2)(X)
+    data['sigmoid_scale_XX'] = sigmoid(X)
+    data['sigmoid_auto_c05_YX'] = SigmoidKernel(gamma='auto', coef0=0.5)(Y, X)
+    Xf, yf = make_blobs(300, 7, seed=77, sigma=6.0)
+    Xte, _ = make_blobs(32, 7, seed=78, sigma=6.0)
+    data.update(fit_X=Xf, fit_y=yf, fit_Xtest=Xte)
+    est = SVC(loss=hinge, kernel=laplacian, C=1., reg_intercept=True, dual=True, optimizer=InteriorPoint).fit(Xf, yf)
+    data.update(flat('laplacian_ip', _fit_record(est, Xte)))
+    np.savez_compressed(os.path.join(out, 'kernels_more.npz'), **data)
 
 
 def gen_trajectories(out):
@@ -273,9 +292,12 @@ def gen_cfg5(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
+    ap.add_argument('--only', default=None, help='run a single generator, e.g. gen_kernels_more')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    for fn in (gen_unit_problems, gen_kernels, gen_trajectories, gen_fits, gen_cfg5):
+    for fn in (gen_unit_problems, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5):
+        if args.only and fn.__name__ != args.only:
+            continue
         print(fn.__name__)
         fn(args.out)
     print('done ->', args.out)
