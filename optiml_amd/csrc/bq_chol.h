@@ -7,12 +7,17 @@ struct bq_chol_ws {
     int64_t cap = 0;   // largest padded order the workspace can hold (multiple of 128)
     int64_t ldh = 0;   // row pitch of H
     double *H = nullptr;      // cap x ldh, row-major; lower triangle = matrix, then its Cholesky factor
-    double *Wt = nullptr;     // 256 x ldh k-major images of the two block columns of the current pass
+    double *Wt = nullptr;     // 2 x (256 x ldh) k-major images of the two block columns of a pass (double-buffered)
     double *LinvT = nullptr;  // per diagonal block: 128 x 128 image of the inverse triangular factor
     double *rhs = nullptr;    // right-hand side / solution (padded)
     double *tmp = nullptr;    // 128 scratch
     int *info = nullptr;      // 0 = ok, else 1 + index of the first non-positive pivot
     double *mr_vec = nullptr; // 10 x cap scratch vectors of the MINRES fallback (allocated on first use)
+    // look-ahead: the narrow work of pass p+1 (diagonal blocks, TRSM, column update) runs on a side stream that owns
+    // a few reserved CUs while the wide trailing update of pass p runs on the rest of the chip
+    hipStream_t s_main = nullptr, s_side = nullptr;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool lookahead = false;
 };
 
 int bq_chol_factor(bq_chol_ws *ws, int64_t np);

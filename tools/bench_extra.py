@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--solver', default='pg')
     ap.add_argument('--max-iter', type=int, default=1000)
+    ap.add_argument('--progress', action='store_true', help='print one line per solver iteration (long runs)')
     a = ap.parse_args()
     from optiml_amd import _lib, device
     from optiml_amd.datasets import make_blobs
@@ -69,10 +70,12 @@ def main():
         from optiml_amd.ml.svm.losses import hinge
         from optiml_amd.opti.constrained import ProjectedGradient, FrankWolfe, InteriorPoint, ActiveSet
         cls = {'pg': ProjectedGradient, 'fw': FrankWolfe, 'ip': InteriorPoint, 'as': ActiveSet}[a.solver]
+        if a.progress:
+            cls.chunk = 1      # one device run per iteration so that verbose lines appear as the solve advances
         X, y = make_blobs(a.n, a.d, seed=0)
         t0 = time.perf_counter()
         est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls,
-                  max_iter=a.max_iter).fit(X, y)
+                  max_iter=a.max_iter, verbose=bool(a.progress)).fit(X, y)
         dt = time.perf_counter() - t0
         o = est.optimizer
         out.update(solver=a.solver, fit_s=dt, iters=o.iter, status=o.status, f=o.f_x, n_sv=int(len(est.support_)),
