@@ -564,7 +564,9 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
         return BQ_ERR_HIP;
     }
     if (kind == BQ_IP || kind == BQ_AS) {
-        rc = bq_chol_ws_create(c, s->N, &s->chol);
+        // InteriorPoint on the SVR structure factorises the reduced n x n system (bq_ip.hip)
+        rc = bq_chol_ws_create(c, (kind == BQ_IP && p->structure == BQ_SVR && bq_ip_svr_reduced()) ? p->n : s->N,
+                               &s->chol);
         if (rc != BQ_OK) {
             bq_solver_destroy(s);
             return rc;

@@ -22,7 +22,8 @@ struct bq_chol_ws {
 
 int bq_chol_factor(bq_chol_ws *ws, int64_t np);
 int bq_chol_solve(bq_chol_ws *ws, int64_t np);
+constexpr int BQ_H_KPLUS1 = 3;   // internal H-assembly mode: entries K_ij + 1 of the n x n panel
 int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out,
-                    bool full = false);
+                    bool full = false, int structure_override = -1);
 // bq_minres.hip: x = argmin |H x - q'| via MINRES on H H^T x = H q' (H = ws->H full symmetric, q' = ws->rhs)
 int bq_minres_normal(bq_chol_ws *ws, const int *nA_dev, int64_t np, double *vec, int *iters_dev);

@@ -374,6 +374,8 @@ __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64
                 v = (double)panel[i * ldp + jj];
             } else if (structure == BQ_SVC) {
                 v = sgn[i] * sgn[jj] * ((double)panel[i * ldp + jj] + 1.0);
+            } else if (structure == BQ_H_KPLUS1) {   // K + 1 of an n x n block (reduced SVR Newton system)
+                v = (double)panel[i * ldp + jj] + 1.0;
             } else {
                 const int64_t ii = i >= n ? i - n : i, jn = jj >= n ? jj - n : jj;
                 const int64_t hi = ii > jn ? ii : jn, lo = ii > jn ? jn : ii;
@@ -390,16 +392,17 @@ __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64
 }
 
 int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out,
-                    bool full) {
+                    bool full, int structure_override) {
+    const int structure = structure_override >= 0 ? structure_override : p->structure;
     const int64_t np = bq_round_up(m > 0 ? m : 1, NB);
     BQ_ARG(np <= ws->cap, "H larger than the workspace");
     BQ_ARG(p->r0 == 0 && p->r1 == p->n, "the factorisation needs the whole panel on this rank");
     dim3 grid((unsigned)((np + 31) / 32), (unsigned)((np + 31) / 32));
     if (p->storage == BQ_F64)
-        build_h_kernel<double><<<grid, 256, 0, ws->ctx->stream>>>(p->structure, (const double *)p->panel, p->ld, p->n, p->sgn,
+        build_h_kernel<double><<<grid, 256, 0, ws->ctx->stream>>>(structure, (const double *)p->panel, p->ld, p->n, p->sgn,
                                                                  p->diag_add, idx, m, np, hd, ws->H, ws->ldh, full ? 1 : 0);
     else
-        build_h_kernel<float><<<grid, 256, 0, ws->ctx->stream>>>(p->structure, (const float *)p->panel, p->ld, p->n, p->sgn,
+        build_h_kernel<float><<<grid, 256, 0, ws->ctx->stream>>>(structure, (const float *)p->panel, p->ld, p->n, p->sgn,
                                                                 p->diag_add, idx, m, np, hd, ws->H, ws->ldh, full ? 1 : 0);
     BQ_HIP(hipGetLastError());
     *np_out = np;
