@@ -142,3 +142,34 @@ def test_constructor_validation_mirrors_reference():
         SVC(loss=hinge, dual=True, reg_intercept=True, optimizer=ProjectedGradient).fit(X, np.arange(8))
     est = SVC(loss=hinge, dual=True, reg_intercept=True, optimizer=ProjectedGradient)
     assert est.get_params()['C'] == 1 and est.train_loss_history == []
+
+
+def _build_c_consumer(tmp_path):
+    import subprocess
+    from optiml_amd import build
+    lib = build.build()
+    exe = str(tmp_path / 'abi_smoke')
+    src = os.path.join(REPO, 'tests', 'c', 'abi_smoke.c')
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(REPO, 'include'), src, '-o', exe,
+           '-L', os.path.dirname(lib), '-lbcqp_hip', '-Wl,-rpath,' + os.path.dirname(lib), '-Wl,-rpath,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_consumer(tmp_path):
+    """include/bcqp.h is valid C99 and the library links and runs from a plain C program (host-only calls here)."""
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert 'c abi ok' in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_consumer_solves_on_gpu(tmp_path):
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    r = subprocess.run([exe, 'gpu'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert 'c abi gpu ok' in r.stdout
