@@ -253,7 +253,10 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
         rows = p->r1 - p->r0;
     }
     const size_t esz = p->storage == BQ_F64 ? 8 : 4;
-    const size_t bytes = (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld * esz;
+    // symmetric panels are stored packed: tile row I keeps (I+1)*256 columns
+    const size_t elems = p->symmetric ? (size_t)(bq_sym_off(p->I1) - bq_sym_off(p->I0))
+                                      : (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld;
+    const size_t bytes = (elems > 0 ? elems : 1) * esz;
     hipError_t e = hipMalloc(&p->panel, bytes);
     if (e != hipSuccess) {
         bq_set_error("cannot allocate the %lld x %lld panel (%.1f GB): %s", (long long)rows, (long long)p->ld,
@@ -434,6 +437,23 @@ extern "C" int bq_problem_panel_rows(bq_problem *p, int64_t row0, int64_t nrows,
     bq_ctx *c = p->ctx;
     BQ_HIP(hipSetDevice(c->device));
     if (nrows == 0) return BQ_OK;
+    if (p->symmetric) {
+        // packed layout: row i holds its (I+1)*256 leading columns; the rest of the output row (strictly-upper tiles) is 0
+        const size_t esz = p->storage == BQ_F64 ? 8 : 4;
+        std::vector<unsigned char> tmp((size_t)p->n * esz);
+        for (int64_t r = 0; r < nrows; ++r) {
+            const int64_t i = row0 + r;
+            const int64_t len = std::min(p->n, bq_sym_pitch(i / BQ_SYM_TILE));
+            BQ_HIP(hipMemcpyAsync(tmp.data(), (const unsigned char *)p->panel + (size_t)bq_sym_addr(i, 0, p->I0) * esz,
+                                  (size_t)len * esz, hipMemcpyDeviceToHost, c->stream));
+            BQ_HIP(hipStreamSynchronize(c->stream));
+            double *o = out + r * p->n;
+            for (int64_t j = 0; j < len; ++j)
+                o[j] = p->storage == BQ_F64 ? ((const double *)tmp.data())[j] : (double)((const float *)tmp.data())[j];
+            for (int64_t j = len; j < p->n; ++j) o[j] = 0.0;
+        }
+        return BQ_OK;
+    }
     const int64_t lr = row0 - p->r0;
     if (p->storage == BQ_F64) {
         BQ_HIP(hipMemcpy2DAsync(out, p->n * 8, (const double *)p->panel + lr * p->ld, p->ld * 8, p->n * 8, nrows,

@@ -349,7 +349,7 @@ int bq_chol_solve(bq_chol_ws *ws, int64_t np) {
 // H assembly: H[a][b] = Q[idx[a]][idx[b]] (+ hd[a] on the diagonal) for b <= a < m; identity on the pad
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64_t ldp, int64_t n,
+__global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64_t ldp, int packed, int64_t n,
                                const double *__restrict__ sgn, double diag_add, const int *__restrict__ idx, int64_t m,
                                int64_t np, const double *__restrict__ hd, double *__restrict__ H, int64_t ldh, int full) {
     const int64_t a0 = (int64_t)blockIdx.y * 32, b0 = (int64_t)blockIdx.x * 32;
@@ -371,15 +371,15 @@ __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64
             }
             // kernel-built panels keep only the tiles on/below the diagonal: always read (max, min)
             if (structure == BQ_PLAIN) {
-                v = (double)panel[i * ldp + jj];
+                v = (double)panel[packed ? bq_sym_addr(i, jj, 0) : i * ldp + jj];
             } else if (structure == BQ_SVC) {
-                v = sgn[i] * sgn[jj] * ((double)panel[i * ldp + jj] + 1.0);
+                v = sgn[i] * sgn[jj] * ((double)panel[bq_sym_addr(i, jj, 0)] + 1.0);
             } else if (structure == BQ_H_KPLUS1) {   // K + 1 of an n x n block (reduced SVR Newton system)
-                v = (double)panel[i * ldp + jj] + 1.0;
+                v = (double)panel[bq_sym_addr(i, jj, 0)] + 1.0;
             } else {
                 const int64_t ii = i >= n ? i - n : i, jn = jj >= n ? jj - n : jj;
                 const int64_t hi = ii > jn ? ii : jn, lo = ii > jn ? jn : ii;
-                const double pv = (double)panel[hi * ldp + lo] + 1.0;
+                const double pv = (double)panel[bq_sym_addr(hi, lo, 0)] + 1.0;
                 v = ((i >= n) == (jj >= n)) ? pv : -pv;
             }
             if (i == jj) {
@@ -399,10 +399,10 @@ int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, co
     BQ_ARG(p->r0 == 0 && p->r1 == p->n, "the factorisation needs the whole panel on this rank");
     dim3 grid((unsigned)((np + 31) / 32), (unsigned)((np + 31) / 32));
     if (p->storage == BQ_F64)
-        build_h_kernel<double><<<grid, 256, 0, ws->ctx->stream>>>(structure, (const double *)p->panel, p->ld, p->n, p->sgn,
+        build_h_kernel<double><<<grid, 256, 0, ws->ctx->stream>>>(structure, (const double *)p->panel, p->ld, p->symmetric ? 1 : 0, p->n, p->sgn,
                                                                  p->diag_add, idx, m, np, hd, ws->H, ws->ldh, full ? 1 : 0);
     else
-        build_h_kernel<float><<<grid, 256, 0, ws->ctx->stream>>>(structure, (const float *)p->panel, p->ld, p->n, p->sgn,
+        build_h_kernel<float><<<grid, 256, 0, ws->ctx->stream>>>(structure, (const float *)p->panel, p->ld, p->symmetric ? 1 : 0, p->n, p->sgn,
                                                                 p->diag_add, idx, m, np, hd, ws->H, ws->ldh, full ? 1 : 0);
     BQ_HIP(hipGetLastError());
     *np_out = np;

@@ -147,6 +147,15 @@ int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count);  // all-reduce(sum) 
 
 // bq_symv.hip: symmetric tile product over tile rows [I0, I1) -> out (nb*256 partial sums)
 constexpr int64_t BQ_SYM_TILE = 256;
+// Packed layout of a symmetric (kernel-built) panel: tile row I (256 rows) keeps only its columns [0, (I+1)*256), stored
+// row-major with pitch (I+1)*256; tile rows are concatenated.  Element (i, j), j's tile <= i's tile, of a panel whose
+// first stored tile row is I0:
+__host__ __device__ inline int64_t bq_sym_off(int64_t I) { return BQ_SYM_TILE * BQ_SYM_TILE * (I * (I + 1) / 2); }
+__host__ __device__ inline int64_t bq_sym_pitch(int64_t I) { return (I + 1) * BQ_SYM_TILE; }
+__host__ __device__ inline int64_t bq_sym_addr(int64_t i, int64_t j, int64_t I0) {
+    const int64_t I = i / BQ_SYM_TILE;
+    return bq_sym_off(I) - bq_sym_off(I0) + (i - I * BQ_SYM_TILE) * bq_sym_pitch(I) + j;
+}
 int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
                    int64_t ld, const double *w, double *slab, double *out, const int *done);
 int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done);  // -> p->s (complete on all ranks)
@@ -157,7 +166,7 @@ int bq_launch_gemv(bq_ctx *ctx, const void *panel, int storage, bool add_one, in
 
 // bq_gram.hip: panel rows [r0,r1) of kernel(X, X) (n x n), written in `storage` dtype with row pitch ld
 int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r0, int64_t r1, int kernel,
-                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld, bool lower_tiles_only);
+                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld, bool sym_packed);
 // rectangular cross-Gram fused with a coefficient contraction (decision function)
 int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                        const double *SV, const double *coef, double intercept, int64_t t, const double *Xt,

@@ -57,7 +57,7 @@ struct gram_params {
     int64_t mp, np, dp;
     int64_t arow0, arow1;    // global A rows [arow0, arow1) of this launch (arow0 tile-aligned)
     int same;                // A and B are the same matrix -> exact zero distance on the diagonal
-    int lower_only;          // skip tiles whose 256-tile lies strictly above the diagonal (symmetric panels)
+    int lower_only;          // symmetric panel: skip tiles strictly above the 256-tile diagonal, packed output layout
     int kernel, degree;
     double gamma, coef0;
     int64_t ld;              // output pitch (elements)
@@ -74,26 +74,42 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
     bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
-    bq_tile_foreach(acc, [&](int r, int c, double dot) {
-        const int64_t gi = arow + r, gj = bcol + c;
-        if (gi >= P.arow1 || gj >= P.n) return;
-        double kv;
-        if (P.kernel == BQ_KERNEL_RBF) {
-            double dist = -2.0 * dot;
-            dist += P.a2[gi];
-            dist += P.b2[gj];
-            dist = fmax(dist, 0.0);
-            if (P.same && gi == gj) dist = 0.0;
-            kv = exp(-P.gamma * dist);
-        } else if (P.kernel == BQ_KERNEL_POLY) {
-            kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
-        } else if (P.kernel == BQ_KERNEL_SIGMOID) {
-            kv = tanh(P.gamma * dot + P.coef0);
-        } else {
-            kv = dot;
+    // epilogue, row by row: one (packed or pitched) row base per accumulator row, then the kernel map per element
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
+    const int64_t I0 = P.arow0 / BQ_SYM_TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
+            if (gi >= P.arow1) continue;
+            T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
+            const double ai = P.a2[gi];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
+                if (gj >= P.n) continue;
+                const double dot = acc[i][j][v];
+                double kv;
+                if (P.kernel == BQ_KERNEL_RBF) {
+                    double dist = -2.0 * dot;
+                    dist += ai;
+                    dist += P.b2[gj];
+                    dist = fmax(dist, 0.0);
+                    if (P.same && gi == gj) dist = 0.0;
+                    kv = exp(-P.gamma * dist);
+                } else if (P.kernel == BQ_KERNEL_POLY) {
+                    kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                } else if (P.kernel == BQ_KERNEL_SIGMOID) {
+                    kv = tanh(P.gamma * dot + P.coef0);
+                } else {
+                    kv = dot;
+                }
+                store_elem<T>(rowp + gj, kv);
+            }
         }
-        store_elem<T>(out + (gi - P.arow0) * P.ld + gj, kv);
-    });
+    }
 }
 
 // Laplacian kernel exp(-gamma * |x - y|_1) (kernels.py:159-163; sklearn's manhattan_distances sums |x_k - y_k| over
@@ -141,7 +157,9 @@ __global__ __launch_bounds__(256) void gram_l1_kernel(gram_params P, T *__restri
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int64_t gi = arow + 4 * tr + u, gj = bcol + 4 * tc + v;
-            if (gi < P.arow1 && gj < P.n) store_elem<T>(out + (gi - P.arow0) * P.ld + gj, exp(-P.gamma * acc[u][v]));
+            if (gi < P.arow1 && gj < P.n)
+                store_elem<T>(out + (P.lower_only ? bq_sym_addr(gi, gj, P.arow0 / BQ_SYM_TILE) : (gi - P.arow0) * P.ld + gj),
+                              exp(-P.gamma * acc[u][v]));
         }
 }
 
@@ -218,7 +236,7 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
 }
 
 int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r0, int64_t r1, int kernel,
-                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld, bool lower_tiles_only) {
+                   double gamma, double coef0, int degree, void *panel, int storage, int64_t ld, bool sym_packed) {
     if (r1 <= r0) return BQ_OK;   // a rank that owns no rows (more ranks than tile rows) has nothing to build
     gram_images img;
     // pad the image so that a tile starting at any r0 stays inside it
@@ -233,7 +251,7 @@ int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r
         bq_set_error("row block start %lld is not a multiple of %d", (long long)r0, GT);
         return BQ_ERR_BADARG;
     }
-    rc = run_gram(ctx, img, img, r0, r1, n, true, kernel, gamma, coef0, degree, panel, storage, ld, lower_tiles_only);
+    rc = run_gram(ctx, img, img, r0, r1, n, true, kernel, gamma, coef0, degree, panel, storage, ld, sym_packed);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     free_image(&img);
     if (rc != BQ_OK) return rc;

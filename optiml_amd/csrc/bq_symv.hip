@@ -1,7 +1,8 @@
 // Symmetric panel product: out = K w reading only the tiles on or below the diagonal — half the HBM bytes of the
 // row-block product for the (symmetric) Gram panels of the SVM dual.
 //
-// The panel is cut into 256 x 256 tiles (I, J), J <= I.  A work item is a STRIP: up to JG consecutive tiles of one
+// The panel is cut into 256 x 256 tiles (I, J), J <= I, and stored PACKED: tile row I keeps only its (I+1)*256 leading
+// columns (row-major), so the lower triangle costs half the HBM of the square panel.  A work item is a STRIP: up to JG consecutive tiles of one
 // tile row, i.e. 256 rows x (JG * 2 KiB) contiguous bytes per row.  The workgroup streams the strip once (16-byte
 // non-temporal loads, lanes along the columns) and produces BOTH contributions the strip is responsible for:
 //   row part   S[I][J0][r]  = sum over the strip's columns of elem(K[I*T+r][c]) * w[c]        (to output block I)
@@ -60,7 +61,10 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
     const int nj = (int)((J0 + JG <= I + 1) ? JG : (I + 1 - J0));  // tiles in this strip (J <= I)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const T *rows = panel + ((I - I0) * ST + wv * 64) * ld + J0 * ST;  // panel row 0 is global row I0*ST
+    // packed symmetric layout: tile row I has pitch (I+1)*256 and starts at bq_sym_off(I) - bq_sym_off(I0)
+    const int64_t pitch = bq_sym_pitch(I);
+    const T *rows = panel + (bq_sym_off(I) - bq_sym_off(I0)) + (int64_t)(wv * 64) * pitch + J0 * ST;
+    (void)ld;
     const double *wI = w + I * ST + wv * 64;
     const int c0 = 2 * lane, c1 = 128 + 2 * lane;
     d2_t wj0[JG], wj1[JG];
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
                 d2_t a[SR], b[SR];
 #pragma unroll
                 for (int k = 0; k < SR; ++k) {
-                    const T *row = rows + (int64_t)(step * SR + k) * ld + j * ST;
+                    const T *row = rows + (int64_t)(step * SR + k) * pitch + j * ST;
                     a[k] = ld2<T>::get(row + c0);
                     b[k] = ld2<T>::get(row + c1);
                 }

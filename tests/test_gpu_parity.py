@@ -638,4 +638,6 @@ print(json.dumps({'iter': est.optimizer.iter, 'status': est.optimizer.status, 'f
     g = load_golden('fit_svr_n400.npz')
     assert res['status'] == 'optimal' and abs(res['iter'] - int(g['rbf_ip_iter'])) <= 6
     np.testing.assert_allclose(res['f'], float(g['rbf_ip_f_x']), rtol=1e-6)
-    np.testing.assert_allclose(res['alphas'], g['rbf_ip_alphas'], rtol=1e-3, atol=1e-4)
+    # the 2n x 2n SVR Hessian is singular: only a+ - a- is determined by the optimum
+    a, ref = np.asarray(res['alphas']), g['rbf_ip_alphas']
+    np.testing.assert_allclose(a[:400] - a[400:], ref[:400] - ref[400:], rtol=0, atol=5e-3)
