@@ -19,21 +19,30 @@
 #include "bq_common.h"
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
-typedef float f2_t __attribute__((ext_vector_type(2)));
 
 constexpr int ST = 256;   // tile edge (== BQ_SYM_TILE)
 constexpr int JG_DEFAULT = 8;   // tiles per strip (8 x 2 KiB contiguous per row; best of the measured variants)
 
-template <typename T> struct ld2;
-template <> struct ld2<double> {
-    static __device__ __forceinline__ d2_t get(const double *p) {
-        return __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+// One 16-byte non-temporal load per lane and row.  fp64: a lane owns columns {2l, 2l+1} and {128+2l, 128+2l+1} of a tile
+// (two loads); fp32: columns {4l .. 4l+3} (one float4 load).  c0 / c1 are the first columns of the two pairs.
+template <typename T> struct tile_ld;
+template <> struct tile_ld<double> {
+    static __device__ __forceinline__ int c0(int lane) { return 2 * lane; }
+    static __device__ __forceinline__ int c1(int lane) { return 128 + 2 * lane; }
+    static __device__ __forceinline__ void get(const double *row, int lane, d2_t &a, d2_t &b) {
+        a = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(row + 2 * lane));
+        b = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(row + 128 + 2 * lane));
     }
 };
-template <> struct ld2<float> {
-    static __device__ __forceinline__ d2_t get(const float *p) {
-        f2_t v = __builtin_nontemporal_load(reinterpret_cast<const f2_t *>(p));
-        return (d2_t){(double)v.x, (double)v.y};
+template <> struct tile_ld<float> {
+    static __device__ __forceinline__ int c0(int lane) { return 4 * lane; }
+    static __device__ __forceinline__ int c1(int lane) { return 4 * lane + 2; }
+    static __device__ __forceinline__ void get(const float *row, int lane, d2_t &a, d2_t &b) {
+        const f4_t v = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(row + 4 * lane));
+        a = (d2_t){(double)v.x, (double)v.y};
+        b = (d2_t){(double)v.z, (double)v.w};
     }
 };
 
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
     const T *rows = panel + (bq_sym_off(I) - bq_sym_off(I0)) + (int64_t)(wv * 64) * pitch + J0 * ST;
     (void)ld;
     const double *wI = w + I * ST + wv * 64;
-    const int c0 = 2 * lane, c1 = 128 + 2 * lane;
+    const int c0 = tile_ld<T>::c0(lane), c1 = tile_ld<T>::c1(lane);
     d2_t wj0[JG], wj1[JG];
     double ca[JG][4];
 #pragma unroll
@@ -95,8 +104,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
 #pragma unroll
                 for (int k = 0; k < SR; ++k) {
                     const T *row = rows + (int64_t)(step * SR + k) * pitch + j * ST;
-                    a[k] = ld2<T>::get(row + c0);
-                    b[k] = ld2<T>::get(row + c1);
+                    tile_ld<T>::get(row, lane, a[k], b[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < SR; ++k) {
@@ -231,6 +239,10 @@ int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, in
         case 48: return launch_variant<4, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
         case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
         case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
-        default: return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+        case 88: return launch_variant<8, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+        default:
+            // fp32 tiles are half as wide in bytes: 8 rows per step keep the same bytes in flight per lane
+            if (storage == BQ_F32) return launch_variant<8, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+            return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
     }
 }
