@@ -41,6 +41,8 @@ def parse():
     ap.add_argument('--samples', '--n', dest='n', type=int, default=100000)
     ap.add_argument('--features', '--d', dest='d', type=int, default=128)
     ap.add_argument('--solver', default='pg', choices=['pg', 'fw'])
+    ap.add_argument('--task', default='svc', choices=['svc', 'svr'], help='svr: eps-insensitive dual, dim 2n (config 4)')
+    ap.add_argument('--kernel', default='rbf', choices=['rbf', 'poly', 'linear'], help='poly: degree 3, coef0 1')
     ap.add_argument('--storage', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--exchange', default='rccl', choices=['rccl', 'host'])
     ap.add_argument('--cpu-n', type=int, default=12000, help='sample size of the CPU baseline leg')
@@ -82,10 +84,11 @@ def cpu_baseline(args):
     except Exception:
         threads = os.cpu_count() or 1
     ns = min(args.cpu_n, args.n)
-    X, y = make_blobs(ns, args.d, seed=0)
+    from optiml_amd.datasets import make_regression
+    X, y = make_blobs(ns, args.d, seed=0) if args.task == 'svc' else make_regression(ns, args.d, seed=0)
     t0 = time.perf_counter()
-    K = so.gram('rbf', X)
-    Q, q, ub = so.svc_dual(K, y, 1.0)
+    K = so.gram(args.kernel, X, None, 'scale', 1.0 if args.kernel == 'poly' else 0.0, 3)
+    Q, q, ub = so.svc_dual(K, y, 1.0) if args.task == 'svc' else so.svr_dual(K, y, 1.0, 0.1)
     del K
     t_build = time.perf_counter() - t0
     solve = bo.projected_gradient if args.solver == 'pg' else bo.frank_wolfe
@@ -151,8 +154,16 @@ def main():
             comm.barrier()
 
     n, d = args.n, args.d
-    X, y = make_blobs(n, d, seed=0)
-    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, storage=args.storage)
+    from optiml_amd.datasets import make_regression
+    from optiml_amd.ml.svm.kernels import PolyKernel, linear
+    kern = {'rbf': gaussian, 'poly': PolyKernel(3, 'scale', 1.0), 'linear': linear}[args.kernel]
+    if args.task == 'svc':
+        X, y = make_blobs(n, d, seed=0)
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage)
+    else:   # eps-insensitive SVR dual: 2n variables on one n x n panel (BASELINE config 4 shape)
+        X, y = make_regression(n, d, seed=0)
+        quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', kern, storage=args.storage)
+    N = quad.ndim
     ctx.profile(True)
     t0 = time.perf_counter()
     dev = quad.device_problem(ctx)
@@ -161,8 +172,8 @@ def main():
     _, _, r0, r1 = dev.dims()
 
     kind = _lib.PG if args.solver == 'pg' else _lib.FW
-    ub = np.ones(n)
-    solver = _DeviceSolver(dev, kind, np.zeros(n), ub, ub / 2, 1e-6, 10 ** 9)
+    ub = np.ones(N)
+    solver = _DeviceSolver(dev, kind, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
 
     rows, status = solver.run(max(args.warmup, 1))      # includes the start-up gradient product
     ctx.profile_read(_lib.PROF_MATVEC, reset=True)
@@ -190,14 +201,15 @@ def main():
         alg_bytes = tiles * (T * T * esz + T * 8) + (tiles // 8 + i1 - i0) * T * 8 + 2 * n * 8   # tiles + col parts + row parts
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         full_equiv = ((r1 - r0) * n * esz + 3 * n * 8) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        workload = f'svc_hinge_rbf_{args.solver}_dual_n{n}_d{d}'
+        workload = (f'svc_hinge_{args.kernel}_{args.solver}_dual_n{n}_d{d}' if args.task == 'svc' else
+                    f'svr_epsins_{args.kernel}_{args.solver}_dual_n{n}_d{d}')
         traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
         out = {
             'metric': 'dual_qp_iterations_per_sec', 'value': done / elapsed, 'unit': 'iter/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(done, 1),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64' if args.storage == 'f64' else 'f32-storage/f64-accumulate', 'data': 'synthetic',
-            'config': {'workload': workload, 'n': n, 'd': d, 'C': 1.0,
+            'config': {'workload': workload, 'n': n, 'd': d, 'dual_dim': N, 'C': 1.0,
                        'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange,
                        'rows_per_gpu': r1 - r0, 'device': ctx.name},
             'roofline': {'bound': 'hbm', 'kernel': 'symv_tiles_kernel (symmetric panel product Q*d)', 'achieved': achieved,

@@ -176,12 +176,9 @@ int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, i
                           const double *A, int64_t t, const double *B, double *out);
 
 // bq_vec.hip
-int bq_vec_prep(bq_problem *p, const double *v, const int *done_flag);                  // v (ldN) -> p->w (ld)
-int bq_vec_finish(bq_problem *p, const double *v, double *out, const int *done_flag);   // p->s (+v) -> out (ldN)
 int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *done_flag);  // out = Q v, all ranks
 int bq_vec_eval_f(bq_problem *p, const double *x, const double *Qx, double *g_out, double *f_dev);
 
-int bq_solver_alloc_common(bq_solver *s);
 int bq_pgfw_start(bq_solver *s);
 int bq_pgfw_iterate(bq_solver *s);
 int bq_ip_start(bq_solver *s);
