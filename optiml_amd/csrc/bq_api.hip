@@ -643,9 +643,17 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
         BQ_TRY(solver_first(s));
         s->initialised = true;
     }
-    // how often the host looks at the device `done` flag (kernels early-exit on it, so a late look is harmless;
-    // the factorising solvers are host-enqueued O(n^3) work per iteration, so they look every time)
-    const int64_t poll = (s->kind == BQ_IP || s->kind == BQ_AS || s->N >= 16384) ? 1 : 8;
+    // How often the host looks at the device `done` flag (a D2H copy + stream sync, ~30 us): kernels early-exit on the
+    // flag, so a late look only costs a few no-op launches.  The factorising solvers are host-enqueued O(n^3) work per
+    // iteration and look every time; PG/FW look about every 2 ms of estimated panel streaming time.
+    int64_t poll = 1;
+    if (s->kind == BQ_PG || s->kind == BQ_FW) {
+        const double esz = s->p->storage == BQ_F64 ? 8.0 : 4.0;
+        const double rows = (double)(s->p->r1 - s->p->r0);
+        const double iter_s = rows * (double)s->p->n * esz * (s->p->symmetric ? 0.5 : 1.0) / 5.0e12 + 30e-6;
+        poll = (int64_t)(2.0e-3 / iter_s);
+        poll = poll < 1 ? 1 : (poll > 64 ? 64 : poll);
+    }
     for (int64_t k = 0; k < max_steps; ++k) {
         BQ_TRY(solver_iterate(s));
         if ((k + 1) % poll == 0 && k + 1 < max_steps) {

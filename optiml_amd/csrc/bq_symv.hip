@@ -187,18 +187,37 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
 //   row parts live at b = first tile of a strip (b % JG == 0, b <= a) when tile row a is ours,
 //   col parts at every b > a that is one of our tile rows.
 template <int JG>
-__global__ __launch_bounds__(256) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, int64_t I0,
-                                                          int64_t I1, double *__restrict__ out,
-                                                          const int *__restrict__ done) {
+__global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, int64_t I0,
+                                                           int64_t I1, double *__restrict__ out,
+                                                           const int *__restrict__ done) {
     if (done != nullptr && *done) return;
+    // 1024 threads: thread (r, q) sums every 4th entry of the fixed entry list of output block a (two independent
+    // chains each for load-level parallelism); the four partial sums are combined in the fixed order q = 0..3
+    __shared__ double part[4][ST];
     const int64_t a = blockIdx.x;
-    const double *p = slab + a * nb * ST + threadIdx.x;
-    double s = 0.0;
-    if (a >= I0 && a < I1)
-        for (int64_t b = 0; b <= a; b += JG) s += p[b * ST];
+    const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
+    const double *p = slab + a * nb * ST + r;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t e = 0;   // running index over the entry list: row parts (b = 0, JG, 2JG, ... <= a) then col parts (b > a)
+    if (a >= I0 && a < I1) {
+        const int64_t nrow = a / JG + 1;
+        for (int64_t k = q; k < nrow; k += 8) {
+            s0 += p[(k * JG) * ST];
+            if (k + 4 < nrow) s1 += p[((k + 4) * JG) * ST];
+        }
+        e = nrow;
+    }
     const int64_t bs = (a + 1 > I0) ? a + 1 : I0;
-    for (int64_t b = bs; b < I1; ++b) s += p[b * ST];
-    out[a * ST + threadIdx.x] = s;
+    const int64_t ncol = I1 > bs ? I1 - bs : 0;
+    // keep the q-assignment a function of the position in the whole list (row parts first)
+    const int64_t shift = (4 - (e & 3)) & 3;
+    for (int64_t k = (q + shift) & 3; k < ncol; k += 8) {
+        s0 += p[(bs + k) * ST];
+        if (k + 4 < ncol) s1 += p[(bs + k + 4) * ST];
+    }
+    part[q][r] = s0 + s1;
+    __syncthreads();
+    if (q == 0) out[a * ST + r] = ((part[0][r] + part[1][r]) + part[2][r]) + part[3][r];
 }
 
 template <int JG, int SR>
@@ -222,7 +241,7 @@ static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_
         }
     }
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
-    symv_reduce_kernel<JG><<<(unsigned)nb, 256, 0, ctx->stream>>>(slab, nb, I0, I1, out, done);
+    symv_reduce_kernel<JG><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, I0, I1, out, done);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

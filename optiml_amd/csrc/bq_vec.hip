@@ -172,7 +172,7 @@ __global__ void grad_init_kernel(int64_t N, vecs V) {
 
 // apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and its reductions
 __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *__restrict__ part,
-                                      int64_t nblk) {
+                                      int64_t nblk, const double *__restrict__ sgn, double *__restrict__ w_out) {
     if (sc->done) return;
     __shared__ double sh[4];
     const double t = do_update ? sc->t : 0.0;
@@ -191,6 +191,7 @@ __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
             if (ubi - xi <= ACT_TOL && di > 0.0) di = 0.0;
             if (xi - lbi <= ACT_TOL && di < 0.0) di = 0.0;
             V.d[i] = di;
+            if (w_out != nullptr) w_out[i] = sgn[i] * di;   // fused panel-product input of the SVC structure
             sd2 += di * di;
             sgd += gi * di;
             sxg += xi * (gi + V.q[i]);
@@ -255,6 +256,32 @@ __global__ void den_partial_kernel(int64_t N, const double *__restrict__ d, cons
     if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
+// finish (gathered panel output -> Q d) fused with the partial sums of d'Qd
+__global__ void finish_den_kernel(int structure, int64_t n, int64_t N, double diag_add, const double *__restrict__ sv,
+                                  const double *__restrict__ d, const double *__restrict__ sgn,
+                                  double *__restrict__ Qd, const bq_scal *sc, double *__restrict__ part) {
+    if (sc->done) return;
+    __shared__ double sh[4];
+    double a = 0.0;
+    VEC_LOOP(i) {
+        double r = 0.0;
+        if (i < N) {
+            if (structure == BQ_PLAIN)
+                r = sv[i];
+            else if (structure == BQ_SVC)
+                r = sgn[i] * sv[i];
+            else
+                r = (i < n) ? sv[i] : -sv[i - n];
+            const double di = d[i];
+            if (diag_add != 0.0) r += diag_add * di;
+            a += di * r;
+        }
+        Qd[i] = r;
+    }
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
 // kind 0: PG  t = max_t if den <= 1e-16 else min(-g'd/den, max_t);  kind 1: FW  a = 1 if ... else min(-g'd/den, 1)
 __global__ void step_kernel(int kind, bq_scal *sc, const double *__restrict__ part, int64_t nblk, bq_iter_stat *stats) {
     if (sc->done) return;
@@ -278,7 +305,7 @@ __global__ void step_kernel(int kind, bq_scal *sc, const double *__restrict__ pa
 
 // FW: apply pending step, pick the vertex, form the (optionally trust-clipped) direction
 __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *__restrict__ part,
-                                      int64_t nblk) {
+                                      int64_t nblk, const double *__restrict__ sgn, double *__restrict__ w_out) {
     if (sc->done) return;
     __shared__ double sh[4];
     const double a = do_update ? sc->t : 0.0;
@@ -302,6 +329,7 @@ __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
             }
             const double di = yi - xi;
             V.d[i] = di;
+            if (w_out != nullptr) w_out[i] = sgn[i] * di;
             sgd += gi * di;
             sxg += xi * (gi + V.q[i]);
         }
@@ -377,16 +405,29 @@ int bq_pgfw_iterate(bq_solver *s) {
     const int *done = &s->sc->done;
     const int upd = s->started ? 1 : 0;
     vecs V = solver_vecs(s);
+    bq_problem *p = s->p;
+    // SVC structure: the update/eval kernel also writes the panel-product input w = y o d (saves the prep launch)
+    const bool fused_w = p->structure == BQ_SVC;
+    const double *sgn = fused_w ? p->sgn : nullptr;
+    double *w_out = fused_w ? p->w : nullptr;
     if (s->kind == BQ_PG) {
-        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk);
+        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
         pg_decide_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, s->partials, s->nblk, s->stats);
     } else {
-        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk);
+        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
         fw_decide_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, s->partials, s->nblk, s->stats);
     }
     s->started = true;
-    BQ_TRY(bq_problem_apply(s->p, s->d, s->Qd, done));
-    den_partial_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->d, s->Qd, s->sc, s->partials);
+    const double *w = s->d;   // BQ_PLAIN: the direction itself (same padded length as the panel width)
+    if (p->structure == BQ_SVC) {
+        w = p->w;
+    } else if (p->structure == BQ_SVR) {
+        prep_kernel<<<vec_grid(p->ld), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, s->d, p->sgn, p->w, done);
+        w = p->w;
+    }
+    BQ_TRY(bq_panel_product(p, p->add_one, w, done));
+    finish_den_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, p->N, p->diag_add, p->s, s->d, p->sgn,
+                                                                s->Qd, s->sc, s->partials);
     step_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->kind == BQ_PG ? 0 : 1, s->sc, s->partials, s->nblk, s->stats);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
