@@ -60,21 +60,20 @@ __global__ __launch_bounds__(256, 2) void trsm_gemm_kernel(double *__restrict__ 
 // image Wt with kdim rows (128, or 256 when two factored block columns are applied in one pass: twice the flops per
 // byte of C-tile traffic)
 __global__ __launch_bounds__(256, 2) void syrk_kernel(double *__restrict__ H, int64_t ldh, int64_t i0,
-                                                      const double *__restrict__ Wt, int kdim) {
+                                                      const double *__restrict__ Wt, int kdim, int64_t ntiles) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    const int64_t b = blockIdx.x;
+    const int64_t b = bq_xcd_remap(blockIdx.x, ntiles);
+    if (b >= ntiles) return;
     int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
     while (ti * (ti + 1) / 2 > b) --ti;
     const int64_t tj = b - ti * (ti + 1) / 2;
     const int64_t arow = i0 + ti * NB, bcol = i0 + tj * NB;
     bq_d4 acc[4][4];
-    bq_tile_zero(acc);
-    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
-    bq_tile_foreach(acc, [&](int r, int c, double v) {
-        double *p = H + (arow + r) * ldh + bcol + c;
-        *p -= v;
-    });
+    double *Ct = H + arow * ldh + bcol;
+    bq_tile_load(acc, Ct, ldh);   // acc = C, then acc -= X_i X_j^T, then plain stores
+    bq_mfma_tile_128<true>(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
+    bq_tile_store(acc, Ct, ldh);
 }
 
 // the same update restricted to the first block column of the trailing matrix (tiles (ti, 0)): makes the next block
@@ -84,12 +83,10 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(double *__restrict__ H
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     const int64_t arow = i0 + (int64_t)blockIdx.x * NB;
     bq_d4 acc[4][4];
-    bq_tile_zero(acc);
-    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, i0, NB, sm, acc);
-    bq_tile_foreach(acc, [&](int r, int c, double v) {
-        double *p = H + (arow + r) * ldh + i0 + c;
-        *p -= v;
-    });
+    double *Ct = H + arow * ldh + i0;
+    bq_tile_load(acc, Ct, ldh);   // acc = C, then acc -= X_i X_j^T, then plain stores
+    bq_mfma_tile_128<true>(Wt, ldh, arow, Wt, ldh, i0, NB, sm, acc);
+    bq_tile_store(acc, Ct, ldh);
 }
 
 // the K = 256 update restricted to the first TWO block columns of the trailing matrix starting at r0 (tiles (ti, 0) and
@@ -101,12 +98,10 @@ __global__ __launch_bounds__(256, 2) void syrk_head2_kernel(double *__restrict__
     const int64_t ti = b < T ? b : b - T + 1, tj = b < T ? 0 : 1;
     const int64_t arow = r0 + ti * NB, bcol = r0 + tj * NB;
     bq_d4 acc[4][4];
-    bq_tile_zero(acc);
-    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
-    bq_tile_foreach(acc, [&](int r, int c, double v) {
-        double *p = H + (arow + r) * ldh + bcol + c;
-        *p -= v;
-    });
+    double *Ct = H + arow * ldh + bcol;
+    bq_tile_load(acc, Ct, ldh);   // acc = C, then acc -= X_i X_j^T, then plain stores
+    bq_mfma_tile_128<true>(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
+    bq_tile_store(acc, Ct, ldh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,7 +286,7 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
         const int64_t r0 = 2 * p * NB + 4 * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
-        syrk_kernel<<<(unsigned)(T * (T + 1) / 2), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB);
+        syrk_kernel<<<bq_xcd_grid(T * (T + 1) / 2), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T * (T + 1) / 2);
     };
     const int64_t npass = (np + 2 * NB - 1) / (2 * NB);
     if (!ws->lookahead || np < 16 * NB) {

@@ -61,16 +61,32 @@ struct gram_params {
     int kernel, degree;
     double gamma, coef0;
     int64_t ld;              // output pitch (elements)
+    int64_t ntiles;          // tiles of this launch (XCD-aware remap bound)
 };
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     // tiles of the same A-row block are adjacent in blockIdx -> they share the A slice in L2
-    const int64_t tiles_n = (P.n + GT - 1) / GT;
-    const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
-    const int64_t arow = P.arow0 + tm * GT, bcol = tn * GT;
-    if (P.lower_only && (bcol / BQ_SYM_TILE) > (arow / BQ_SYM_TILE)) return;
+    const int64_t bid = bq_xcd_remap(blockIdx.x, P.ntiles);
+    if (bid >= P.ntiles) return;
+    int64_t arow, bcol;
+    if (P.lower_only) {
+        // symmetric panel: enumerate only the 256-tiles (I, J <= I) of this rank's tile rows, 4 sub-tiles of 128 each
+        const int64_t I0 = P.arow0 / BQ_SYM_TILE;
+        const int64_t t = bid / 4 + I0 * (I0 + 1) / 2, sub = bid % 4;
+        int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        while (I * (I + 1) / 2 > t) --I;
+        const int64_t J = t - I * (I + 1) / 2;
+        arow = I * BQ_SYM_TILE + (sub >> 1) * GT;
+        bcol = J * BQ_SYM_TILE + (sub & 1) * GT;
+        if (arow >= P.arow1 || bcol >= P.n) return;
+    } else {
+        const int64_t tiles_n = (P.n + GT - 1) / GT;
+        arow = P.arow0 + (bid / tiles_n) * GT;
+        bcol = (bid % tiles_n) * GT;
+    }
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
     bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
@@ -224,7 +240,13 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
         else
             gram_l1_kernel<float><<<lgrid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
     } else {
-        dim3 grid((unsigned)(tiles_m * tiles_n));
+        if (lower_only) {
+            const int64_t I0 = m_rows0 / BQ_SYM_TILE, I1 = (m_rows1 + BQ_SYM_TILE - 1) / BQ_SYM_TILE;
+            P.ntiles = 4 * (I1 * (I1 + 1) / 2 - I0 * (I0 + 1) / 2);
+        } else {
+            P.ntiles = tiles_m * tiles_n;
+        }
+        dim3 grid(bq_xcd_grid(P.ntiles));
         if (storage == BQ_F64)
             gram_mfma_kernel<double><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));
         else

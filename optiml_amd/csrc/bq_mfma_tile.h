@@ -27,6 +27,9 @@ struct bq_tile_smem {
 };
 
 // kdim must be a multiple of 16; arow/bcol multiples of 2 with arow+127 < lda, bcol+127 < ldb.
+// NEG_A: accumulate -A*B^T (the A slice is negated while it is staged), so that a kernel can start from acc = C and
+// finish with plain stores instead of a serialised read-modify-write epilogue.
+template <bool NEG_A = false>
 __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, int64_t lda, int64_t arow,
                                                  const double *__restrict__ Bt, int64_t ldb, int64_t bcol,
                                                  int64_t kdim, bq_tile_smem &sm, bq_d4 (&acc)[4][4]) {
@@ -47,7 +50,7 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
         for (int u = 0; u < 4; ++u) {
             const int j = tid + 256 * u;
             const int k = j >> 6, c2 = j & 63;
-            *reinterpret_cast<bq_d2 *>(&sm.A[buf][k][2 * c2]) = ra[u];
+            *reinterpret_cast<bq_d2 *>(&sm.A[buf][k][2 * c2]) = NEG_A ? -ra[u] : ra[u];
             *reinterpret_cast<bq_d2 *>(&sm.B[buf][k][2 * c2]) = rb[u];
         }
     };
@@ -80,6 +83,31 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
     }
 }
 
+// Load / store a whole accumulator tile from / to a row-major matrix (pitch ld): 64 independent 8-byte accesses per lane,
+// issued back to back (no read-after-write chain between them).
+__device__ __forceinline__ void bq_tile_load(bq_d4 (&acc)[4][4], const double *__restrict__ C, int64_t ld) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc[i][j][v] = C[(int64_t)(wr * 64 + i * 16 + crow + 4 * v) * ld + wc * 64 + j * 16 + ccol];
+}
+__device__ __forceinline__ void bq_tile_store(const bq_d4 (&acc)[4][4], double *__restrict__ C, int64_t ld) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                C[(int64_t)(wr * 64 + i * 16 + crow + 4 * v) * ld + wc * 64 + j * 16 + ccol] = acc[i][j][v];
+}
+
 // Visit every accumulator element of this lane: f(row_in_tile, col_in_tile, value)
 template <typename F>
 __device__ __forceinline__ void bq_tile_foreach(bq_d4 (&acc)[4][4], F &&f) {
@@ -93,6 +121,16 @@ __device__ __forceinline__ void bq_tile_foreach(bq_d4 (&acc)[4][4], F &&f) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) f(wr * 64 + i * 16 + crow + 4 * v, wc * 64 + j * 16 + ccol, acc[i][j][v]);
 }
+
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so neighbouring
+// linear tile indices — which share an operand slice — land on different L2s.  Remap so that every XCD walks a
+// CONTIGUOUS chunk of the tile list: launch 8 * ceil(total / 8) blocks and let block `bid` take tile
+// (bid % 8) * chunk + bid / 8 (blocks past the end exit).  Speed only; any placement is correct.
+__device__ __forceinline__ int64_t bq_xcd_remap(int64_t bid, int64_t total) {
+    const int64_t chunk = (total + 7) / 8;
+    return (bid % 8) * chunk + bid / 8;
+}
+static inline unsigned bq_xcd_grid(int64_t total) { return (unsigned)(((total + 7) / 8) * 8); }
 
 __device__ __forceinline__ void bq_tile_zero(bq_d4 (&acc)[4][4]) {
 #pragma unroll
