@@ -206,18 +206,27 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
     // at n = 16 384 did not finish within its 300 s limit (cause not yet established), so the default is the
     // single-stream order.  Any failure to create the masked streams also falls back to it.
     const char *la = getenv("BQ_CHOL_LOOKAHEAD");
-    if (la != nullptr && atoi(la) != 0 && ctx->num_cu >= 64) {
-        const int words = (ctx->num_cu + 31) / 32;
-        std::vector<uint32_t> side(words, 0u), mainm(words, 0u);
-        const int reserved = 16;
-        for (int cu = 0; cu < ctx->num_cu; ++cu) {
-            if (cu < reserved)
-                side[cu / 32] |= 1u << (cu % 32);
-            else
-                mainm[cu / 32] |= 1u << (cu % 32);
+    const int la_mode = la != nullptr ? atoi(la) : 0;   // 1: CU-masked streams, 2: priority streams (narrow work high)
+    if (la_mode != 0 && ctx->num_cu >= 64) {
+        bool ok;
+        if (la_mode == 2) {
+            int lo = 0, hi = 0;
+            ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+                 hipStreamCreateWithPriority(&ws->s_main, hipStreamNonBlocking, lo) == hipSuccess &&
+                 hipStreamCreateWithPriority(&ws->s_side, hipStreamNonBlocking, hi) == hipSuccess;
+        } else {
+            const int words = (ctx->num_cu + 31) / 32;
+            std::vector<uint32_t> side(words, 0u), mainm(words, 0u);
+            const int reserved = 16;
+            for (int cu = 0; cu < ctx->num_cu; ++cu) {
+                if (cu < reserved)
+                    side[cu / 32] |= 1u << (cu % 32);
+                else
+                    mainm[cu / 32] |= 1u << (cu % 32);
+            }
+            ok = hipExtStreamCreateWithCUMask(&ws->s_main, (uint32_t)words, mainm.data()) == hipSuccess &&
+                 hipExtStreamCreateWithCUMask(&ws->s_side, (uint32_t)words, side.data()) == hipSuccess;
         }
-        bool ok = hipExtStreamCreateWithCUMask(&ws->s_main, (uint32_t)words, mainm.data()) == hipSuccess &&
-                  hipExtStreamCreateWithCUMask(&ws->s_side, (uint32_t)words, side.data()) == hipSuccess;
         for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ws->ev[i], hipEventDisableTiming) == hipSuccess;
         ws->lookahead = ok;
         if (!ok) (void)hipGetLastError();

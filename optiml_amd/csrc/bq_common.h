@@ -183,7 +183,7 @@ int bq_pgfw_start(bq_solver *s);
 int bq_pgfw_iterate(bq_solver *s);
 int bq_ip_start(bq_solver *s);
 int bq_ip_iterate(bq_solver *s);
-bool bq_ip_svr_reduced();   // opt-in n x n Schur reduction of the SVR Newton system (BQ_IP_SVR_REDUCED=1)
+bool bq_ip_svr_reduced();   // n x n Schur reduction of the SVR Newton system (default; BQ_IP_SVR_REDUCED=0 disables)
 int bq_as_start(bq_solver *s);
 int bq_as_iterate(bq_solver *s);
 void bq_as_free(bq_solver *s);

@@ -220,30 +220,33 @@ __global__ void ip_copy_kernel(int64_t n, const double *__restrict__ src, double
     if (i < npad) dst[i] = (i < n) ? src[i] : 0.0;
 }
 
-// SVR: the 2n x 2n Newton matrix [[P + D1, -P], [-P, P + D2]] (P = K + 1, D = diag part hd) reduces to an n x n SPD
-// system by eliminating the second block row:  (P + C) u = w1 + P t,  C = D1 D2 / (D1 + D2),  t = (w1 + w2) / D2,
-// dx1 = u D2 / (D1 + D2),  dx2 = (w1 + w2 - D1 dx1) / D2  — an 8x cheaper factorisation than the reference's
-// 2n x 2n one ("SVR 2n structure + IP"), same solution.
+// SVR: the 2n x 2n Newton system [[P + D1, -P], [-P, P + D2]] [dx1; dx2] = [w1; w2] (P = K + 1, D = diag part hd)
+// reduces to an n x n SPD system in u = dx1 - dx2.  Adding the two block rows gives D1 dx1 + D2 dx2 = w1 + w2, hence
+//   (P + C) u = (D2 w1 - D1 w2) / (D1 + D2),   C = D1 D2 / (D1 + D2),
+//   dx1 = (w1 + w2 + D2 u) / (D1 + D2),   dx2 = (w1 + w2 - D1 u) / (D1 + D2).
+// Every division is by D1 + D2 (never by one of the two alone), so the elimination is symmetric in the two halves and
+// does not lose digits when one of them is tiny.  An 8x cheaper factorisation than the reference's 2n x 2n one
+// ("SVR 2n structure + IP"), same solution.
 __global__ void ip_svr_reduce_kernel(int64_t n, const double *__restrict__ hd, const double *__restrict__ w,
                                      double *__restrict__ cdiag, double *__restrict__ t, const bq_scal *sc) {
     if (sc->done) return;
     VEC_LOOP(i) {
         double c = 0.0, tv = 0.0;
         if (i < n) {
-            const double d1 = hd[i], d2 = hd[n + i];
-            c = d1 * d2 / (d1 + d2);
-            tv = (w[i] + w[n + i]) / d2;
+            const double d1 = hd[i], d2 = hd[n + i], inv = 1.0 / (d1 + d2);
+            c = d1 * d2 * inv;
+            tv = (d2 * w[i] - d1 * w[n + i]) * inv;
         }
         cdiag[i] = c;   // both arrays are padded: the pad stays 0
         t[i] = tv;
     }
 }
 
-__global__ void ip_svr_rhs_kernel(int64_t n, int64_t np, const double *__restrict__ w, const double *__restrict__ Pt,
-                                  double *__restrict__ rhs, const bq_scal *sc) {
+__global__ void ip_svr_rhs_kernel(int64_t n, int64_t np, const double *__restrict__ t, double *__restrict__ rhs,
+                                  const bq_scal *sc) {
     if (sc->done) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np) rhs[i] = (i < n) ? w[i] + Pt[i] : 0.0;
+    if (i < np) rhs[i] = (i < n) ? t[i] : 0.0;
 }
 
 // in place: w (2n) -> dx (2n)
@@ -252,22 +255,21 @@ __global__ void ip_svr_expand_kernel(int64_t n, const double *__restrict__ hd, c
     if (sc->done) return;
     VEC_LOOP(i) {
         if (i < n) {
-            const double d1 = hd[i], d2 = hd[n + i];
-            const double w1 = w[i], w2 = w[n + i];
-            const double dx1 = u[i] * d2 / (d1 + d2);
-            w[i] = dx1;
-            w[n + i] = (w1 + w2 - d1 * dx1) / d2;
+            const double d1 = hd[i], d2 = hd[n + i], inv = 1.0 / (d1 + d2);
+            const double sum = w[i] + w[n + i], ui = u[i];
+            w[i] = (sum + d2 * ui) * inv;
+            w[n + i] = (sum - d1 * ui) * inv;
         }
     }
 }
 
-// The reduction changes the rounding of the (very ill-conditioned) late Newton systems enough to shift the iteration
-// count by a few (73 -> 71 on the SVR fixture), so the DEFAULT is the reference's own 2n x 2n factorisation (exact
-// trajectory parity) and the reduction is opt-in: BQ_IP_SVR_REDUCED=1.
+// Default ON: on the reference's SVR fixtures the reduced system reproduces the 2n x 2n trajectory (same iteration
+// count, objective to 1e-14, alpha+ - alpha- to 1e-11).  BQ_IP_SVR_REDUCED=0 selects the reference's own 2n x 2n
+// factorisation instead.
 bool bq_ip_svr_reduced() {
     static const bool on = [] {
         const char *e = getenv("BQ_IP_SVR_REDUCED");
-        return e != nullptr && atoi(e) != 0;
+        return e == nullptr || atoi(e) != 0;
     }();
     return on;
 }
@@ -318,9 +320,8 @@ int bq_ip_iterate(bq_solver *s) {
         const int64_t n = p->n;
         double *cdiag = s->dlp;   // scratch until ip_ratio_kernel rewrites dlp
         ip_svr_reduce_kernel<<<vgrid(p->ld), BQ_VEC_BLOCK, 0, st>>>(n, s->hd, s->rhs, cdiag, p->w, s->sc);
-        BQ_TRY(bq_panel_product(p, true, p->w, done));   // p->s = (K + 1) t
         BQ_TRY(bq_chol_build_h(ws, p, nullptr, n, cdiag, &np, false, BQ_H_KPLUS1));
-        ip_svr_rhs_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(n, np, s->rhs, p->s, ws->rhs, s->sc);
+        ip_svr_rhs_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(n, np, p->w, ws->rhs, s->sc);
         BQ_TRY(bq_chol_factor(ws, np));
         BQ_TRY(bq_chol_solve(ws, np));
         ip_svr_expand_kernel<<<vgrid(p->ld), BQ_VEC_BLOCK, 0, st>>>(n, s->hd, ws->rhs, s->rhs, s->sc);

@@ -9,13 +9,14 @@
 // Algorithm (32-wide sub-blocks, 8 waves).  The code is kept COMPACT (runtime loops, small unroll factors): this
 // kernel runs every phase once per launch, so a fully unrolled body is bound by instruction fetch, not by math
 // (measured: 240 us unrolled).
-//   for each sub-block column: (1) wave 0 factors the 32 x 32 diagonal block and inverts its factor, wave-synchronously
-//   in LDS (no workgroup barriers: LDS operations of one wave are ordered); (2) the rows below get
+//   for each sub-block column: (1) wave 0 factors the 32 x 32 diagonal block and inverts its factor with rows held in
+//   registers and cross-row operands fetched by v_readlane (no LDS round trip on the sequential chain); (2) the rows below get
 //   L_ik = A_ik X_kk^T; (3) the trailing lower triangle gets A_ij -= L_ik L_jk^T in 4 x 4 register micro-tiles.
 //   Then the off-diagonal blocks of X by block forward substitution along the block sub-diagonals:
 //   X_ic = -X_ii (sum_j L_ij X_jc).
 // A non-positive (or NaN) pivot is reported through *info (1-based global index), like LAPACK's potrf.
 #include "bq_common.h"
+#include <type_traits>
 
 constexpr int PB = 128;        // block order
 constexpr int PS = 32;         // sub-block
@@ -29,6 +30,13 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// v_readlane of a double (lane index uniform)
+__device__ __forceinline__ double rdlane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ H, int64_t ldh, int64_t k0,
@@ -64,52 +72,73 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
         double *D = M + o * PL + o;   // the 32 x 32 diagonal block, D[i * PL + j]
         // ---- (1) diagonal block: factor, then invert the factor; wave 0 only, wave-synchronous ---------------------
         if (wv == 0) {
-            const int i = lane & 31, hh = lane >> 5;   // row i; the two half-waves split the column range
+            // Lane i (both half-waves compute the same thing; only lanes < 32 store) owns ROW i of the block.
+            // Factor: left-looking over panels of 8 columns held in registers; every cross-row operand is another
+            // lane's register, fetched with v_readlane (uniform lane index), so the sequential chain has no LDS round
+            // trips.  Rows above the diagonal carry harmless finite garbage and are never stored.
+            const int i = lane & 31;
             int bad = 0;
+            double myri = 1.0;   // 1 / L[i][i]
 #pragma unroll 1
-            for (int j = 0; j < PS; ++j) {
-                double d = D[j * PL + j];
-                if (!(d > 0.0)) {   // uniform
-                    if (bad == 0) bad = o + j + 1;
-                    d = 1.0;
+            for (int pb = 0; pb < PS / 8; ++pb) {
+                const int c0 = 8 * pb;
+                double a[8];
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) a[cc] = D[i * PL + c0 + cc];
+#pragma unroll 2
+                for (int k = 0; k < c0; ++k) {
+                    const double lik = D[i * PL + k];   // L[c0 + cc][k] is lane (c0 + cc)'s lik
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) a[cc] = fma(-lik, rdlane(lik, c0 + cc), a[cc]);
                 }
-                double ri = rsqrt(d);
-                ri = ri * fma(-0.5 * d * ri, ri, 1.5);   // Newton step: 1/sqrt(d) to full fp64 accuracy
-                const double lij = D[i * PL + j] * ri;    // meaningful for i > j
-                wave_lds_fence();
-                if (hh == 0) {
-                    if (i > j) D[i * PL + j] = lij;
-                    if (i == j) {
-                        D[j * PL + j] = d * ri;
-                        dinv[o + j] = ri;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = c0 + jj;
+                    double d = rdlane(a[jj], j);
+                    if (!(d > 0.0)) {   // uniform
+                        if (bad == 0) bad = o + j + 1;
+                        d = 1.0;
                     }
+                    double ri = rsqrt(d);
+                    ri = ri * fma(-0.5 * d * ri, ri, 1.5);   // Newton step: 1/sqrt(d) to full fp64 accuracy
+                    const double l = (i == j) ? d * ri : a[jj] * ri;
+                    a[jj] = l;
+                    if (i == j) myri = ri;
+#pragma unroll
+                    for (int cc = jj + 1; cc < 8; ++cc) a[cc] = fma(-l, rdlane(l, c0 + cc), a[cc]);
                 }
-                wave_lds_fence();
-                // row i of the trailing block: D[i][k] -= L[i][j] * L[k][j], k = j+1 .. i  (k split by parity)
-                if (i > j) {
-#pragma unroll 4
-                    for (int k = j + 1 + hh; k <= i; k += 2) D[i * PL + k] = fma(-lij, D[k * PL + j], D[i * PL + k]);
+                if (lane < 32) {
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc)
+                        if (i >= c0 + cc) D[i * PL + c0 + cc] = a[cc];
                 }
                 wave_lds_fence();
             }
-            // inverse of the 32 x 32 factor: lane c builds column c of X by forward substitution; x is kept in the
-            // scratch column W[.][c] while it is needed, then stored transposed into the upper triangle of D
-            if (hh == 0) {
-                const int c = i;
-                double *xc = W + c;   // W[k * PW + c]
+            if (lane < 32) dinv[o + i] = myri;
+            // Inverse of the factor, X = L^-1: lane i owns row i of Y with X[i][:] = myri * Y[i][:] and
+            // Y[i][:] = e_i - sum_{k < i} L[i][k] myri_k Y[k][:]; step j subtracts row j (final by then) from the rows
+            // below it.  Y[j][c] = 0 for c > j bounds the column range of each group of 8 steps.
+            double y[PS];
+#pragma unroll
+            for (int c = 0; c < PS; ++c) y[c] = (c == i) ? 1.0 : 0.0;
+            auto steps = [&](auto tag) {
+                constexpr int J0 = decltype(tag)::value;
 #pragma unroll 1
-                for (int ii = c; ii < PS; ++ii) {
-                    double s0 = (ii == c) ? 1.0 : 0.0, s1 = 0.0;
-                    int k = c;
-#pragma unroll 2
-                    for (; k + 1 < ii; k += 2) {
-                        s0 = fma(-D[ii * PL + k], xc[k * PW], s0);
-                        s1 = fma(-D[ii * PL + k + 1], xc[(k + 1) * PW], s1);
-                    }
-                    if (k < ii) s0 = fma(-D[ii * PL + k], xc[k * PW], s0);
-                    xc[ii * PW] = (s0 + s1) * dinv[o + ii];
+                for (int j = J0; j < J0 + 8; ++j) {
+                    const double m = (i > j) ? D[i * PL + j] * rdlane(myri, j) : 0.0;
+#pragma unroll
+                    for (int c = 0; c < J0 + 8; ++c) y[c] = fma(-m, rdlane(y[c], j), y[c]);
                 }
-                for (int ii = c + 1; ii < PS; ++ii) D[c * PL + ii] = xc[ii * PW];   // X[ii][c] -> row c (upper)
+            };
+            steps(std::integral_constant<int, 0>{});
+            steps(std::integral_constant<int, 8>{});
+            steps(std::integral_constant<int, 16>{});
+            steps(std::integral_constant<int, 24>{});
+            wave_lds_fence();
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < PS - 1; ++c)
+                    if (c < i) D[c * PL + i] = y[c] * myri;   // X[i][c] at its transposed home (row c, upper)
             }
             if (bad != 0 && lane == 0) *flag = bad;
         }

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--d', type=int, default=128)
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--solver', default='pg')
+    ap.add_argument('--task', choices=['svc', 'svr'], default='svc')
     ap.add_argument('--max-iter', type=int, default=1000)
     ap.add_argument('--progress', action='store_true', help='print one line per solver iteration (long runs)')
     a = ap.parse_args()
@@ -72,14 +73,24 @@ def main():
         cls = {'pg': ProjectedGradient, 'fw': FrankWolfe, 'ip': InteriorPoint, 'as': ActiveSet}[a.solver]
         if a.progress:
             cls.chunk = 1      # one device run per iteration so that verbose lines appear as the solve advances
-        X, y = make_blobs(a.n, a.d, seed=0)
+        if a.task == 'svr':
+            from optiml_amd.ml.svm import SVR
+            from optiml_amd.ml.svm.losses import epsilon_insensitive
+            from optiml_amd.datasets import make_regression
+            X, y = make_regression(a.n, a.d, seed=0)
+            y = (y - y.mean()) / y.std()
+            est = SVR(loss=epsilon_insensitive, epsilon=0.1, kernel=gaussian, C=1., reg_intercept=True, dual=True,
+                      optimizer=cls, max_iter=a.max_iter, verbose=bool(a.progress))
+        else:
+            X, y = make_blobs(a.n, a.d, seed=0)
+            est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls,
+                      max_iter=a.max_iter, verbose=bool(a.progress))
         t0 = time.perf_counter()
-        est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls,
-                  max_iter=a.max_iter, verbose=bool(a.progress)).fit(X, y)
+        est.fit(X, y)
         dt = time.perf_counter() - t0
         o = est.optimizer
-        out.update(solver=a.solver, fit_s=dt, iters=o.iter, status=o.status, f=o.f_x, n_sv=int(len(est.support_)),
-                   iter_per_s=o.iter / dt, train_acc=float(est.score(X[:5000], y[:5000])))
+        out.update(task=a.task, solver=a.solver, fit_s=dt, iters=o.iter, status=o.status, f=o.f_x,
+                   n_sv=int(len(est.support_)), iter_per_s=o.iter / dt, score=float(est.score(X[:5000], y[:5000])))
     print(json.dumps(out), flush=True)
 
 
