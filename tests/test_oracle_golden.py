@@ -172,3 +172,82 @@ def test_kernels_laplacian_sigmoid(golden):
     assert res['iter'] == int(g['laplacian_ip_iter']) and res['status'] == str(g['laplacian_ip_status'])
     np.testing.assert_allclose(res['x'], g['laplacian_ip_alphas'], rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(so.decision('laplacian', post, g['fit_Xtest']), g['laplacian_ip_decision'], rtol=1e-8, atol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# augmented-Lagrangian dual + stochastic update rules (oracle/al_oracle.py)
+# ---------------------------------------------------------------------------------------------------------------
+from oracle import al_oracle as ao  # noqa: E402
+
+AL_RULES = {  # fixture name -> (rule, kwargs): mirrors AL_RULES of tools/gen_golden.py
+    'sgd': ('sgd', dict(step_size=0.004)),
+    'sgd_polyak': ('sgd', dict(step_size=0.0003, momentum_type='polyak', momentum=0.9)),
+    'sgd_nesterov': ('sgd', dict(step_size=0.0005, momentum_type='nesterov', momentum=0.8)),
+    'adam': ('adam', dict(step_size=0.002)),
+    'adam_nesterov': ('adam', dict(step_size=0.002, momentum_type='nesterov', momentum=0.5)),
+    'amsgrad': ('amsgrad', dict(step_size=0.002)),
+    'amsgrad_polyak': ('amsgrad', dict(step_size=0.002, momentum_type='polyak', momentum=0.5)),
+    'adamax': ('adamax', dict(step_size=0.002, beta1=0.8, beta2=0.99)),
+    'adagrad': ('adagrad', dict(step_size=1.)),
+    'adadelta': ('adadelta', dict(step_size=1., decay=0.9)),
+    'rmsprop': ('rmsprop', dict(step_size=0.01)),
+    'rmsprop_nesterov': ('rmsprop', dict(step_size=0.01, momentum_type='nesterov', momentum=0.5, decay=0.95)),
+}
+AL_NOB = ('sgd', 'adagrad', 'adadelta', 'rmsprop', 'rmsprop_nesterov')
+
+
+def _al_rules_problem(g, with_intercept):
+    X, y = g['rules_X'], g['rules_y']
+    Q = so.gram('rbf', X) * np.outer(y, y)
+    n = len(y)
+    if with_intercept:
+        return Q + np.outer(y, y), -np.ones(n), None, 0.05 * np.ones(n), np.ones(n), 2.5
+    return Q, -np.ones(n), y, np.zeros(n), np.ones(n), 1.
+
+
+def _cmp_al(res, g, prefix, rtol=1e-9, atol=1e-11):
+    assert res['status'] == str(g[prefix + '_status'])
+    assert res['iter'] == int(g[prefix + '_iter'])
+    np.testing.assert_allclose(res['f_hist'], g[prefix + '_f_hist'], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(res['pf_hist'], g[prefix + '_pf_hist'], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(res['x'], g[prefix + '_x'], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(res['g_x'], g[prefix + '_g_x'], rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(res['dual_x'], g[prefix + '_dual_x'], rtol=rtol, atol=atol)
+    for k, xk in zip(g[prefix + '_x_iters'], g[prefix + '_x_at']):
+        np.testing.assert_allclose(res['x_at'][int(k)], xk, rtol=rtol, atol=atol)
+
+
+def test_al_reference_unit_problem(golden):
+    # optiml/opti/constrained/tests/test_lagrangian_quadratic.py:18-22
+    g = golden('al_dual.npz')
+    al = ao.AugLag(g['nd2_Q'], g['nd2_q'], a=g['nd2_a'], lb=np.zeros(2), ub=g['nd2_ub'], rho=1.)
+    res = ao.minimize(al, g['nd2_x0'], 'adagrad', epochs=15000, step_size=1, keep=(1, 2, 10, 100, 1000))
+    _cmp_al(res, g, 'nd2_adagrad')
+
+
+@pytest.mark.parametrize('name', AL_NOB)
+def test_al_rules_equality_constrained(golden, name):
+    g = golden('al_dual.npz')
+    Q, q, a, lb, ub, rho = _al_rules_problem(g, False)
+    rule, kw = AL_RULES[name]
+    res = ao.minimize(ao.AugLag(Q, q, a=a, lb=lb, ub=ub, rho=rho), g['rules_x0'], rule, epochs=300, tol=1e-10,
+                      keep=(1, 2, 10, 100, 299), **kw)
+    _cmp_al(res, g, 'rules_' + name)
+
+
+@pytest.mark.parametrize('name', sorted(AL_RULES))
+def test_al_rules_box_only(golden, name):
+    g = golden('al_dual.npz')
+    Q, q, a, lb, ub, rho = _al_rules_problem(g, True)
+    rule, kw = AL_RULES[name]
+    res = ao.minimize(ao.AugLag(Q, q, a=a, lb=lb, ub=ub, rho=rho), g['rules_x0'], rule, epochs=300, tol=1e-10,
+                      keep=(1, 2, 10, 100, 299), **kw)
+    _cmp_al(res, g, 'rulesb_' + name)
+
+
+def test_al_tolerance_stop(golden):
+    g = golden('al_dual.npz')
+    Q, q, a, lb, ub, rho = _al_rules_problem(g, False)
+    res = ao.minimize(ao.AugLag(Q, q, a=a, lb=lb, ub=ub, rho=rho), g['rules_x0'], 'adagrad', epochs=20000, tol=2e-3,
+                      step_size=1., keep=(1, 10))
+    _cmp_al(res, g, 'tol_adagrad')
