@@ -49,13 +49,18 @@ enum { BQ_F64 = 0, BQ_F32 = 1 };                                    /* panel sto
 /* linear, poly, rbf: kernels.py:40-129 (the named configs); sigmoid, laplacian: kernels.py:132-201 */
 enum { BQ_KERNEL_LINEAR = 0, BQ_KERNEL_POLY = 1, BQ_KERNEL_RBF = 2, BQ_KERNEL_SIGMOID = 3, BQ_KERNEL_LAPLACIAN = 4 };
 enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian structure */
+/* OR-ed into the structure: leave out the rank-one term yy' / ee' of the regularised intercept, i.e. the
+ * reg_intercept=False duals Q = K*yy' and Q = [[K,-K],[-K,K]] (svm/_base.py:552-559, 1096-1099).  Products only:
+ * InteriorPoint / ActiveSet refuse such a problem (the reference has no box solver for it either, :621-624). */
+#define BQ_NO_RANK_ONE 16
 enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3 };                 /* solver kind */
 enum { BQ_STATUS_UNKNOWN = 0, BQ_STATUS_OPTIMAL = 1, BQ_STATUS_STOPPED = 2 };
 /* BQ_GET_X / BQ_GET_G: the point (and gradient) the LAST ITERATION RECORD was evaluated at — what the
  * reference's callback sees at the top of that iteration.  BQ_GET_X_NOW / BQ_GET_G_NOW: the current iterate
  * (differs only for ActiveSet, whose loop body moves x after the record: active_set.py:156-160, 208). */
 enum { BQ_GET_X = 0, BQ_GET_G = 1, BQ_GET_LP = 2, BQ_GET_LM = 3, BQ_GET_D = 4,
-       BQ_GET_MASK_L = 5, BQ_GET_MASK_U = 6, BQ_GET_X_NOW = 7, BQ_GET_G_NOW = 8 };
+       BQ_GET_MASK_L = 5, BQ_GET_MASK_U = 6, BQ_GET_X_NOW = 7, BQ_GET_G_NOW = 8,
+       BQ_GET_DUAL = 9 /* augmented Lagrangian: [mu (if a_eq); lambda_lb (if lb); lambda_ub (if ub)] */ };
 
 /* One row per evaluation at the top of a solver iteration (what the reference's callback/verbose
  * line sees).  r1/r2/r3 by solver:  PG: |proj grad|_2, step t, max_t;  FW: best lower bound, gap,
@@ -135,6 +140,34 @@ int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stats, int64_t 
                   int64_t *n_stats, int *status);
 int bq_solver_state(const bq_solver *s, int64_t *iter, int *status, double *f_x);
 int bq_solver_get(bq_solver *s, int what, double *out);
+
+/* ---- augmented-Lagrangian dual + first-order update rules ------------------------------------
+ * min 1/2 x'Qx + q'x  s.t.  a_eq'x = 0 (optional), lb <= x <= ub (each optional), relaxed into
+ *   L(x) = f(x) + dual'c(x) + rho/2 |[c_eq; max(c_in, 0)]|^2,  c = [a_eq'x; lb - x; x - ub]
+ * (AugmentedLagrangianQuadratic, optiml/opti/constrained/_base.py:224-410) and minimised by one of the reference's
+ * full-batch "stochastic" rules (optiml/opti/unconstrained/stochastic/, the seven rule files) with the multiplier update and stop tests
+ * of optiml/opti/_base.py:129-146.  This is the SVC/SVR dual branch for unconstrained optimizers
+ * (optiml/ml/svm/_base.py:638-723, :1188-1270), including reg_intercept=False (equality row y / [1;-1]).
+ * Records: f = L(x), r1 = primal value f(x), r2 = |c(x_new)|_2, r3 = |d dual|_2 + |d x|_2 (the two stop-test values).
+ * With no constraint at all (a_eq = lb = ub = NULL) it is the plain rule on the quadratic: runs `epochs` iterations. */
+enum { BQ_RULE_SGD = 0, BQ_RULE_ADAM = 1, BQ_RULE_AMSGRAD = 2, BQ_RULE_ADAMAX = 3, BQ_RULE_ADAGRAD = 4,
+       BQ_RULE_ADADELTA = 5, BQ_RULE_RMSPROP = 6 };
+enum { BQ_MOM_NONE = 0, BQ_MOM_POLYAK = 1, BQ_MOM_NESTEROV = 2 };
+typedef struct bq_al_params {
+    int32_t rule, momentum_type;   /* AdaGrad and AdaDelta have no momentum (the reference classes take none) */
+    double step_size, momentum;    /* scalars only (the reference also accepts schedules: host-side feature, not built) */
+    double beta1, beta2;           /* Adam, AMSGrad, AdaMax */
+    double decay;                  /* AdaDelta, RMSProp */
+    double offset;
+    double rho, tol;               /* penalty (> 0); tolerance of the two stop tests */
+    int64_t epochs;                /* full batch: one epoch per iteration; 'stopped' when reached */
+} bq_al_params;
+/* x0 is required (the reference draws it uniform(0,1): optiml/opti/_base.py:36-57 — host side); dual0 (layout of
+ * BQ_GET_DUAL) may be NULL = zeros.  The returned solver is driven by bq_solver_run / _state / _get / _destroy. */
+int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const double *a_eq, const double *lb,
+                        const double *ub, const double *x0, const double *dual0, bq_solver **out);
+/* number of multipliers (length of BQ_GET_DUAL) */
+int bq_al_solver_dual_size(const bq_solver *s, int64_t *n_dual);
 
 /* ---- prediction (optiml/ml/svm/_base.py:284-287) ------------------------------- */
 /* out[t] = sum_m coef[m] * kernel(SV[m], Xt[t]) + intercept   (SV: m x d, Xt: t x d, row-major fp64) */

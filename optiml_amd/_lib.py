@@ -17,13 +17,22 @@ KERNEL_LINEAR, KERNEL_POLY, KERNEL_RBF, KERNEL_SIGMOID, KERNEL_LAPLACIAN = 0, 1,
 PLAIN, SVC, SVR = 0, 1, 2
 PG, FW, AS, IP = 0, 1, 2, 3
 STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
-GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW = range(9)
+GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW, GET_DUAL = range(10)
+NO_RANK_ONE = 16
+RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
+MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
 ABI_VERSION = 1
 
 
 class IterStat(C.Structure):
     _fields_ = [('iter', C.c_int64), ('f', C.c_double), ('r1', C.c_double), ('r2', C.c_double), ('r3', C.c_double)]
+
+
+class AlParams(C.Structure):
+    _fields_ = [('rule', C.c_int32), ('momentum_type', C.c_int32), ('step_size', C.c_double), ('momentum', C.c_double),
+                ('beta1', C.c_double), ('beta2', C.c_double), ('decay', C.c_double), ('offset', C.c_double),
+                ('rho', C.c_double), ('tol', C.c_double), ('epochs', C.c_int64)]
 
 
 STAT_DTYPE = np.dtype([('iter', np.int64), ('f', np.float64), ('r1', np.float64), ('r2', np.float64),
@@ -65,6 +74,8 @@ PROTOTYPES = {
     'bq_solver_run': (C.c_int, [_vp, _i64, C.POINTER(IterStat), _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
     'bq_solver_state': (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), _dp]),
     'bq_solver_get': (C.c_int, [_vp, C.c_int, _dp]),
+    'bq_al_solver_create': (C.c_int, [_vp, C.POINTER(AlParams), _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
+    'bq_al_solver_dual_size': (C.c_int, [_vp, C.POINTER(_i64)]),
     'bq_decision_function': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _dp,
                                        C.c_double, _i64, _dp, _dp]),
     'bq_gram_matrix': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _i64, _dp, _dp]),

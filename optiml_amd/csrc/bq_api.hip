@@ -3,7 +3,7 @@
 #include <cstdarg>
 #include <cstdlib>
 
-#include "bq_common.h"
+#include "bq_al.h"
 
 static thread_local std::string g_last_error;
 
@@ -333,6 +333,8 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
                                         const double *y, int kernel, double gamma, double coef0, int degree,
                                         double diag_add, const double *q, int storage, bq_problem **out) {
     BQ_ARG(c && X && q && out, "NULL argument");
+    const bool no_rank_one = (structure & BQ_NO_RANK_ONE) != 0;
+    structure &= ~BQ_NO_RANK_ONE;
     BQ_ARG(structure == BQ_PLAIN || structure == BQ_SVC || structure == BQ_SVR, "structure");
     BQ_ARG(structure != BQ_SVC || y != nullptr, "labels required for BQ_SVC");
     BQ_ARG(kernel >= BQ_KERNEL_LINEAR && kernel <= BQ_KERNEL_LAPLACIAN, "kernel");
@@ -345,7 +347,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     p->structure = structure;
     p->storage = storage;
     p->kernel = kernel;
-    p->add_one = structure != BQ_PLAIN;
+    p->add_one = structure != BQ_PLAIN && !no_rank_one;
     p->gamma = gamma;
     p->coef0 = coef0;
     p->degree = degree;
@@ -519,6 +521,12 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
         if (ptr) hipFree(ptr);
     if (s->chol) bq_chol_ws_destroy(s->chol);
     bq_as_free(s);
+    if (s->al) {
+        bq_al_vecs &V = s->al->V;   // x, g, step (= s->d) and Qx (= s->Qd) are owned by the common slots above
+        for (void *ptr : {(void *)V.xe, (void *)V.s1, (void *)V.s2, (void *)V.s3, (void *)V.a, (void *)V.llb, (void *)V.lub})
+            if (ptr) hipFree(ptr);
+        delete s->al;
+    }
     delete s;
     return BQ_OK;
 }
@@ -531,6 +539,10 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
     BQ_ARG(fw_t >= 0.0 && fw_t < 1.0, "t has to lie in [0, 1)");  // frank_wolfe.py:84-85
     if ((kind == BQ_IP || kind == BQ_AS) && p->ctx->world > 1) {
         bq_set_error("InteriorPoint/ActiveSet factorise the whole Hessian: use a single-rank context (replicas only)");
+        return BQ_ERR_BADARG;
+    }
+    if ((kind == BQ_IP || kind == BQ_AS) && p->structure != BQ_PLAIN && !p->add_one) {
+        bq_set_error("InteriorPoint/ActiveSet are not built for the BQ_NO_RANK_ONE duals (svm/_base.py:621-624)");
         return BQ_ERR_BADARG;
     }
     bq_ctx *c = p->ctx;
@@ -596,7 +608,109 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
     return BQ_OK;
 }
 
+extern "C" int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const double *a_eq, const double *lb,
+                                   const double *ub, const double *x0, const double *dual0, bq_solver **out) {
+    BQ_ARG(p && prm && x0 && out, "NULL argument");
+    BQ_ARG(prm->rule >= BQ_RULE_SGD && prm->rule <= BQ_RULE_RMSPROP, "update rule");
+    BQ_ARG(prm->momentum_type >= BQ_MOM_NONE && prm->momentum_type <= BQ_MOM_NESTEROV, "unknown momentum type");
+    BQ_ARG(prm->momentum_type == BQ_MOM_NONE || (prm->rule != BQ_RULE_ADAGRAD && prm->rule != BQ_RULE_ADADELTA),
+           "AdaGrad / AdaDelta take no momentum");
+    BQ_ARG(prm->step_size > 0.0, "step_size must be > 0");                       // stochastic/_base.py:86-87
+    BQ_ARG(prm->momentum >= 0.0 && prm->momentum < 1.0, "momentum must be between 0 and 1");   // :240-241
+    BQ_ARG(prm->epochs > 0, "max_iter must be > 0");                             // optiml/opti/_base.py:73-74
+    BQ_ARG(prm->rho > 0.0, "rho must be must > 0");                              // constrained/_base.py:276-277
+    BQ_ARG(prm->offset > 0.0 || prm->rule == BQ_RULE_SGD, "offset must be > 0");
+    BQ_ARG(prm->beta1 >= 0.0 && prm->beta1 < 1.0, "beta1 has to lie in [0, 1)");
+    BQ_ARG(prm->beta2 >= 0.0 && prm->beta2 < 1.0, "beta2 has to lie in [0, 1)");
+    BQ_ARG(prm->decay >= 0.0 && prm->decay < 1.0, "decay has to lie in [0, 1)");
+    bq_ctx *c = p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    bq_solver *s = new bq_solver();
+    s->p = p;
+    s->kind = BQ_AL;
+    s->N = p->N;
+    s->ldN = p->ldN;
+    s->nblk = p->ldN / BQ_VEC_TILE;
+    s->al = new bq_al_state();
+    s->al->prm = *prm;
+    bq_al_vecs &V = s->al->V;
+    memset(&V, 0, sizeof(V));
+    int rc = BQ_OK;
+    for (double **v : {&s->x, &s->g, &s->d, &s->Qd, &V.xe, &V.s1})
+        if (rc == BQ_OK) rc = alloc_vec(s, v);
+    const bool two = prm->rule == BQ_RULE_ADAM || prm->rule == BQ_RULE_AMSGRAD || prm->rule == BQ_RULE_ADAMAX ||
+                     prm->rule == BQ_RULE_ADADELTA;
+    if (rc == BQ_OK && two) rc = alloc_vec(s, &V.s2);
+    if (rc == BQ_OK && prm->rule == BQ_RULE_AMSGRAD) rc = alloc_vec(s, &V.s3);
+    if (rc == BQ_OK && a_eq) rc = alloc_vec(s, &V.a);
+    if (rc == BQ_OK && lb) rc = alloc_vec(s, &s->lb);
+    if (rc == BQ_OK && lb) rc = alloc_vec(s, &V.llb);
+    if (rc == BQ_OK && ub) rc = alloc_vec(s, &s->ub);
+    if (rc == BQ_OK && ub) rc = alloc_vec(s, &V.lub);
+    if (rc != BQ_OK) {
+        bq_solver_destroy(s);
+        return rc;
+    }
+    V.x = s->x;
+    V.g = s->g;
+    V.step = s->d;
+    V.Qx = s->Qd;
+    V.q = p->q;
+    V.lb = lb ? s->lb : nullptr;
+    V.ub = ub ? s->ub : nullptr;
+    auto up = [&](double *dev, const double *src) {
+        return hipMemcpyAsync(dev, src, sizeof(double) * s->N, hipMemcpyHostToDevice, c->stream);
+    };
+    hipError_t e = up(s->x, x0);
+    if (e == hipSuccess) e = up(V.xe, x0);
+    if (e == hipSuccess && a_eq) e = up(V.a, a_eq);
+    if (e == hipSuccess && lb) e = up(s->lb, lb);
+    if (e == hipSuccess && ub) e = up(s->ub, ub);
+    std::vector<double> ones;
+    if (e == hipSuccess && prm->rule == BQ_RULE_RMSPROP) {   // rmsprop.py: moving_mean_squared starts at ones
+        ones.assign((size_t)s->N, 1.0);
+        e = up(V.s1, ones.data());
+    }
+    memset(&s->host, 0, sizeof(bq_scal));
+    if (dual0) {
+        const double *d0 = dual0;
+        if (a_eq) s->host.al_mu = *d0++;
+        if (e == hipSuccess && lb) {
+            e = up(V.llb, d0);
+            d0 += s->N;
+        }
+        if (e == hipSuccess && ub) e = up(V.lub, d0);
+    }
+    if (e == hipSuccess) e = hipMalloc(&s->partials, sizeof(double) * BQ_MAX_PARTIAL_Q * s->nblk);
+    if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_scal));
+    if (e == hipSuccess) {
+        s->host.max_iter = prm->epochs;
+        s->host.eps = prm->tol;
+        s->host.status = BQ_STATUS_UNKNOWN;
+        s->host.f = NAN;
+        s->host.al_pf = NAN;
+        e = hipMemcpyAsync(s->sc, &s->host, sizeof(bq_scal), hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        bq_set_error("solver setup failed: %s", hipGetErrorString(e));
+        bq_solver_destroy(s);
+        return BQ_ERR_HIP;
+    }
+    *out = s;
+    return BQ_OK;
+}
+
+extern "C" int bq_al_solver_dual_size(const bq_solver *s, int64_t *n_dual) {
+    BQ_ARG(s && n_dual, "NULL argument");
+    BQ_ARG(s->al != nullptr, "not an augmented-Lagrangian solver");
+    const bq_al_vecs &V = s->al->V;
+    *n_dual = (V.a ? 1 : 0) + (V.llb ? s->N : 0) + (V.lub ? s->N : 0);
+    return BQ_OK;
+}
+
 static int solver_first(bq_solver *s) {
+    if (s->kind == BQ_AL) return BQ_OK;   // nothing to prepare: every iteration evaluates Q x afresh
     switch (s->kind) {
         case BQ_PG:
         case BQ_FW:
@@ -609,6 +723,7 @@ static int solver_first(bq_solver *s) {
 }
 
 static int solver_iterate(bq_solver *s) {
+    if (s->kind == BQ_AL) return bq_al_iterate(s);
     switch (s->kind) {
         case BQ_PG:
         case BQ_FW:
@@ -647,7 +762,7 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
     // flag, so a late look only costs a few no-op launches.  The factorising solvers are host-enqueued O(n^3) work per
     // iteration and look every time; PG/FW look about every 2 ms of estimated panel streaming time.
     int64_t poll = 1;
-    if (s->kind == BQ_PG || s->kind == BQ_FW) {
+    if (s->kind == BQ_PG || s->kind == BQ_FW || s->kind == BQ_AL) {
         const double esz = s->p->storage == BQ_F64 ? 8.0 : 4.0;
         const double rows = (double)(s->p->r1 - s->p->r0);
         const double iter_s = rows * (double)s->p->n * esz * (s->p->symmetric ? 0.5 : 1.0) / 5.0e12 + 30e-6;
@@ -694,8 +809,21 @@ extern "C" int bq_solver_get(bq_solver *s, int what, double *out) {
     bq_ctx *c = s->p->ctx;
     BQ_HIP(hipSetDevice(c->device));
     const double *src = nullptr;
+    if (what == BQ_GET_DUAL) {
+        BQ_ARG(s->al != nullptr, "multipliers exist for the augmented-Lagrangian solver only");
+        const bq_al_vecs &V = s->al->V;
+        double *o = out;
+        if (V.a) *o++ = s->host.al_mu;
+        for (const double *v : {(const double *)V.llb, (const double *)V.lub})
+            if (v) {
+                BQ_HIP(hipMemcpyAsync(o, v, sizeof(double) * s->N, hipMemcpyDeviceToHost, c->stream));
+                o += s->N;
+            }
+        BQ_HIP(hipStreamSynchronize(c->stream));
+        return BQ_OK;
+    }
     switch (what) {
-        case BQ_GET_X: src = s->kind == BQ_AS ? bq_as_view(s, BQ_GET_X) : s->x; break;
+        case BQ_GET_X: src = s->kind == BQ_AS ? bq_as_view(s, BQ_GET_X) : (s->al ? s->al->V.xe : s->x); break;
         case BQ_GET_G: src = s->kind == BQ_AS ? bq_as_view(s, BQ_GET_G) : s->g; break;
         case BQ_GET_X_NOW: src = s->x; break;
         case BQ_GET_G_NOW: src = s->g; break;

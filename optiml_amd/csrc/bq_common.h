@@ -113,10 +113,23 @@ struct bq_scal {
     double f, ng, gd, max_t, den, t;          // PG / FW
     double low, best_lb, gap;                  // FW
     double p, mu, xr, step;                    // IP
+    double al_mu, al_ax, al_pf;                // augmented Lagrangian: multiplier of the equality row, a'x, primal value
+    long long al_epoch;
+    long long al_last;                         // the epoch test fired: the gradient of the last record is still due
     double aux[8];
 };
 
 struct bq_chol_ws;
+
+// augmented-Lagrangian driver (bq_al.hip): device vectors (null pointer = that constraint family is absent)
+struct bq_al_vecs {
+    double *x, *xe, *g, *Qx, *q, *step, *s1, *s2, *s3;
+    double *a, *lb, *ub, *llb, *lub;   // equality row; bounds; their multipliers
+};
+struct bq_al_state {
+    bq_al_params prm;
+    bq_al_vecs V;
+};
 
 struct bq_solver {
     bq_problem *p = nullptr;
@@ -134,6 +147,7 @@ struct bq_solver {
     bool started = false;      // an evaluation has run, so a pending step may exist
     bq_chol_ws *chol = nullptr;
     void *as_ws = nullptr;
+    bq_al_state *al = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -187,6 +201,7 @@ bool bq_ip_svr_reduced();   // n x n Schur reduction of the SVR Newton system (d
 int bq_as_start(bq_solver *s);
 int bq_as_iterate(bq_solver *s);
 void bq_as_free(bq_solver *s);
+int bq_al_iterate(bq_solver *s);   // bq_al.hip
 const double *bq_as_view(bq_solver *s, int what);
 
 // bq_chol.hip

@@ -85,7 +85,6 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
                 double a[8];
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc) a[cc] = D[i * PL + c0 + cc];
-#pragma unroll 2
                 for (int k = 0; k < c0; ++k) {
                     const double lik = D[i * PL + k];   // L[c0 + cc][k] is lane (c0 + cc)'s lik
 #pragma unroll

@@ -1,12 +1,15 @@
 """sklearn-compatible SVC / SVR restricted to the box-constrained dual path, device-resident.
 
 Constructor arguments, validation and fitted attributes follow optiml/ml/svm/_base.py (SVM :187-282,
-SVC :366-419, SVR :907-963).  Only the branch
+SVC :366-419, SVR :907-963).  Two dual branches are implemented:
 
     dual=True, reg_intercept=True, optimizer in {ProjectedGradient, FrankWolfe, ActiveSet, InteriorPoint}
+        (SVC.fit :547-559, :619-636, :725, :867-880; SVR.fit :1091-1104, :1169-1186, :1277, :1423-1437)
+    dual=True, optimizer in {StochasticGradientDescent, Adam, AMSGrad, AdaMax, AdaGrad, AdaDelta, RMSProp}
+        on the augmented Lagrangian of the dual, reg_intercept True or False, all four losses
+        (SVC.fit :638-723, :776-860; SVR.fit :1188-1270, :1330-1415) — SURVEY 8(f).3
 
-is implemented (SVC.fit :547-559, :619-636, :725, :867-880; SVR.fit :1091-1104, :1169-1186, :1277,
-:1423-1437): the Gram panel is built and kept in HBM, the Wolfe dual never exists as an n x n host matrix
+In both the Gram panel is built and kept in HBM, the Wolfe dual never exists as an n x n host matrix
 (`self.obj` is a lazy `KernelQuadratic`), and the support-vector / intercept post-processing uses one masked
 panel product instead of the reference's Python loop.  Every other configuration raises NotImplementedError
 (as the reference does for reg_intercept=False and for the squared losses with these optimizers).
@@ -18,7 +21,8 @@ import numpy as np
 from ... import _lib
 from ...device import get_context
 from ...opti import Optimizer, KernelQuadratic
-from ...opti.constrained import BoxConstrainedQuadraticOptimizer, ProjectedGradient
+from ...opti.constrained import BoxConstrainedQuadraticOptimizer, ProjectedGradient, AugmentedLagrangianQuadratic
+from ...opti.unconstrained.stochastic import StochasticOptimizer, StochasticMomentumOptimizer
 from .kernels import Kernel, LinearKernel, gaussian, BaseEstimator
 from .losses import (Hinge, SquaredHinge, EpsilonInsensitive, SquaredEpsilonInsensitive,
                      squared_hinge, squared_epsilon_insensitive)
@@ -39,7 +43,14 @@ except ImportError:  # pragma: no cover
 __all__ = ['SVM', 'SVC', 'SVR']
 
 _OUT_OF_SCOPE = ('only dual=True with a box-constrained optimizer (ProjectedGradient, FrankWolfe, ActiveSet, '
-                 'InteriorPoint) is implemented by optiml_amd')
+                 'InteriorPoint) or a stochastic optimizer on the augmented-Lagrangian dual is implemented by '
+                 'optiml_amd')
+
+try:
+    from sklearn.exceptions import ConvergenceWarning
+except ImportError:  # pragma: no cover
+    class ConvergenceWarning(UserWarning):
+        pass
 
 
 class SVM(BaseEstimator, ABC):
@@ -124,9 +135,15 @@ class SVM(BaseEstimator, ABC):
         return np.dot(X, self.coef_) + self.intercept_
 
     def _store_train_info(self, opt):
-        self.train_loss_history.append(opt.f_x)
+        if opt.is_lagrangian_dual():
+            self.train_loss_history.append(opt.primal_f_x)
+        else:
+            self.train_loss_history.append(opt.f_x)
 
     _store_train_info._bq_needs_state = False  # reads opt.f_x only: replayed from the device iteration records
+
+    def _is_stochastic(self):
+        return self.dual and isinstance(self.optimizer, type) and issubclass(self.optimizer, StochasticOptimizer)
 
     def _check_bcqp(self):
         if not self.dual or isinstance(self.optimizer, str) or not (
@@ -141,6 +158,23 @@ class SVM(BaseEstimator, ABC):
         self.obj = obj
         self.optimizer = self.optimizer(quad=obj, ub=ub, tol=self.tol, max_iter=self.max_iter,
                                         callback=hook, verbose=self.verbose).minimize()
+        self.alphas_ = self.optimizer.x
+
+    def _run_lagrangian(self, primal, a, ub):
+        """svm/_base.py:674-723 (SVC) / :1188-1270 (SVR): augmented Lagrangian of the dual + a stochastic optimizer."""
+        import warnings
+        if isinstance(self.learning_rate, str) or not self.learning_rate > 0:
+            raise ValueError('the dual needs a numeric learning_rate > 0')
+        n = primal.ndim
+        self.obj = AugmentedLagrangianQuadratic(primal=primal, A=a, b=None if a is None else np.zeros(1),
+                                                lb=np.zeros(n), ub=ub, rho=self.rho)
+        kw = dict(f=self.obj, tol=self.tol, step_size=self.learning_rate, epochs=self.max_iter,
+                  random_state=self.random_state, callback=self._store_train_info, verbose=self.verbose)
+        if issubclass(self.optimizer, StochasticMomentumOptimizer):
+            kw.update(momentum_type=self.momentum_type, momentum=self.momentum)
+        self.optimizer = self.optimizer(**kw).minimize()
+        if self.optimizer.status == 'stopped':
+            warnings.warn('max_iter reached but the optimization has not converged yet', ConvergenceWarning)
         self.alphas_ = self.optimizer.x
 
     def _intercept_sum(self, obj, sv, dual_coef, sv_y):
@@ -177,16 +211,24 @@ class SVC(ClassifierMixin, SVM):
                              'to train a model over more than two labels')
         # LabelBinarizer(neg_label=-1): the larger class label maps to +1 (svm/_base.py:419, 436-440)
         y = np.where(y == self.classes_[-1], 1., -1.)
-        self._check_bcqp()
-        if self.loss == SquaredHinge:
-            # bcqp optimizer with 0 <= x <= +inf is not available (svm/_base.py:771-774)
-            raise NotImplementedError('squared hinge is not available with box-constrained optimizers')
-        if self.loss != Hinge:
-            raise TypeError(f'{self.loss} is not an allowed loss')
         X = np.ascontiguousarray(X, dtype=float)
         n = len(y)
-        obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage)
-        self._run(obj, np.ones(n) * self.C)
+        if self._is_stochastic():
+            if self.loss not in (Hinge, SquaredHinge):
+                raise TypeError(f'{self.loss} is not an allowed loss')
+            sq = self.loss == SquaredHinge   # Q += I/(2C), no upper bound (svm/_base.py:727-730, :778-794)
+            obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage,
+                                  diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept)
+            self._run_lagrangian(obj, None if self.reg_intercept else y, None if sq else np.ones(n) * self.C)
+        else:
+            self._check_bcqp()
+            if self.loss == SquaredHinge:
+                # bcqp optimizer with 0 <= x <= +inf is not available (svm/_base.py:771-774)
+                raise NotImplementedError('squared hinge is not available with box-constrained optimizers')
+            if self.loss != Hinge:
+                raise TypeError(f'{self.loss} is not an allowed loss')
+            obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage)
+            self._run(obj, np.ones(n) * self.C)
 
         sv = self.alphas_ > 1e-6
         self.support_ = np.arange(len(self.alphas_))[sv]
@@ -230,17 +272,27 @@ class SVR(RegressorMixin, SVM):
         if targets > 1:
             raise ValueError('use sklearn.multioutput.MultiOutputRegressor '
                              'to train a model over more than one target')
-        self._check_bcqp()
-        if self.loss == SquaredEpsilonInsensitive:
-            # bcqp optimizer with 0 <= x <= +inf is not available (svm/_base.py:1325-1328)
-            raise NotImplementedError('squared epsilon-insensitive is not available with box-constrained optimizers')
-        if self.loss != EpsilonInsensitive:
-            raise TypeError(f'{self.loss} is not an allowed loss')
         X = np.ascontiguousarray(X, dtype=float)
         n = len(y)
         q = np.hstack((-y, y)) + self.epsilon
-        obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage)
-        self._run(obj, np.ones(2 * n) * self.C)
+        if self._is_stochastic():
+            if self.loss not in (EpsilonInsensitive, SquaredEpsilonInsensitive):
+                raise TypeError(f'{self.loss} is not an allowed loss')
+            sq = self.loss == SquaredEpsilonInsensitive   # Q += I/(2C), no upper bound (svm/_base.py:1279-1283, :1332-1348)
+            obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage,
+                                  diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept)
+            e = np.hstack((np.ones(n), -np.ones(n)))   # equality row
+            self._run_lagrangian(obj, None if self.reg_intercept else e, None if sq else np.ones(2 * n) * self.C)
+        else:
+            self._check_bcqp()
+            if self.loss == SquaredEpsilonInsensitive:
+                # bcqp optimizer with 0 <= x <= +inf is not available (svm/_base.py:1325-1328)
+                raise NotImplementedError('squared epsilon-insensitive is not available with box-constrained '
+                                          'optimizers')
+            if self.loss != EpsilonInsensitive:
+                raise TypeError(f'{self.loss} is not an allowed loss')
+            obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage)
+            self._run(obj, np.ones(2 * n) * self.C)
 
         alphas_p, alphas_n = np.split(self.alphas_, 2)
         sv = np.logical_or(alphas_p > 1e-6, alphas_n > 1e-6)

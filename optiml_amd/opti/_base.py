@@ -172,12 +172,14 @@ class KernelQuadratic(Quadratic):
     structure 'svc': Q = K*yy' + yy' (+ diag*I), n variables      (optiml/ml/svm/_base.py:552-555, 628)
     structure 'svr': Q = [[K,-K],[-K,K]] + ee', 2n variables      (optiml/ml/svm/_base.py:1096-1099, 1178)
     structure 'plain': Q = K (+ diag*I)
+    `rank_one=False` leaves out the yy' / ee' term of the regularised intercept: the reg_intercept=False duals
+    Q = K*yy' and [[K,-K],[-K,K]] (:552-555, :1096-1099) that the augmented-Lagrangian path solves with an equality row.
     `.Q` materialises the dense matrix from the device panel on demand (inspection / small problems only).
     """
 
     _STRUCT = {'plain': _lib.PLAIN, 'svc': _lib.SVC, 'svr': _lib.SVR}
 
-    def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64'):
+    def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64', rank_one=True):
         X = np.ascontiguousarray(X, dtype=float)
         if structure not in self._STRUCT:
             raise ValueError(f'unknown structure {structure}')
@@ -194,6 +196,7 @@ class KernelQuadratic(Quadratic):
         self.X, self.q, self.structure, self.kernel = X, q, structure, kernel
         self.y = None if y is None else np.ascontiguousarray(y, dtype=float)
         self.diag = float(diag)
+        self.rank_one = bool(rank_one)
         self.storage = storage
         self.kind, self.gamma, self.coef0, self.degree = kernel.device_spec(X)
         self._dev = None
@@ -203,7 +206,7 @@ class KernelQuadratic(Quadratic):
         h = C.c_void_p()
         n, d = self.X.shape
         _lib.check(lib.bq_problem_create_kernel(
-            ctx.handle, self._STRUCT[self.structure], n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
+            ctx.handle, self._STRUCT[self.structure] | (0 if self.rank_one else _lib.NO_RANK_ONE), n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
             self.gamma, self.coef0, self.degree, self.diag, _lib.ptr(self.q),
             _lib.F32 if self.storage == 'f32' else _lib.F64, C.byref(h)))
         return _DeviceProblem(ctx, h)
@@ -230,9 +233,9 @@ class KernelQuadratic(Quadratic):
         if self.structure == 'plain':
             Q = K
         elif self.structure == 'svc':
-            Q = (K + 1.0) * np.outer(self.y, self.y)
+            Q = (K + (1.0 if self.rank_one else 0.0)) * np.outer(self.y, self.y)
         else:
-            P = K + 1.0
+            P = K + (1.0 if self.rank_one else 0.0)
             Q = np.vstack((np.hstack((P, -P)), np.hstack((-P, P))))
         if self.diag:
             Q = Q + self.diag * np.eye(Q.shape[0])
@@ -240,7 +243,8 @@ class KernelQuadratic(Quadratic):
 
 
 class Optimizer(ABC):
-    """State and callback contract of optiml/opti/_base.py:9-181 (the part a plain Quadratic exercises)."""
+    """State and callback contract of optiml/opti/_base.py:9-181, including the (augmented-)Lagrangian bookkeeping
+    of the callback (:96-117): primal value, duality gap, past_x."""
 
     def __init__(self, f, x=None, eps=1e-6, tol=1e-8, max_iter=1000, callback=None, callback_args=(),
                  random_state=None, verbose=False):
@@ -248,12 +252,17 @@ class Optimizer(ABC):
             raise TypeError(f'{f} is not an allowed optimization function')
         self.f = f
         if x is None:
+            # optiml/opti/_base.py:36-57: uniform(0, 1) start (the multipliers of an augmented Lagrangian live in f)
             x = np.random.uniform if random_state is None else np.random.RandomState(random_state).uniform
         if callable(x):
             self.x = x(size=f.ndim)
         else:
             self.x = np.asarray(x, dtype=float)
         self.f_x = np.nan
+        if self.is_lagrangian_dual():
+            self.past_x = self.x.copy()
+            self.primal_f_x = np.nan
+            self.dgap = np.nan
         self.g_x = np.zeros(0)
         self.eps = eps
         self.tol = tol
@@ -262,7 +271,7 @@ class Optimizer(ABC):
         self.max_iter = max_iter
         self.iter = 0
         self.status = 'unknown'
-        if self.f.ndim <= 3:
+        if self.f.ndim <= 3 or (hasattr(self.f, 'primal') and self.f.primal.ndim <= 3):
             self.x0_history = []
             self.x1_history = []
             self.f_x_history = []
@@ -272,18 +281,32 @@ class Optimizer(ABC):
         self.verbose = verbose
 
     def is_lagrangian_dual(self):
-        return False
+        return hasattr(self.f, 'primal')
 
     def is_augmented_lagrangian_dual(self):
-        return False
+        return self.is_lagrangian_dual() and hasattr(self.f, 'rho')
 
     def callback(self, args=()):
-        if self.f.ndim <= 3:
-            self.x0_history.append(self.x[0])
-            self.x1_history.append(self.x[1])
-            self.f_x_history.append(self.f_x)
-        if callable(self._callback):
-            self._callback(self, *args, *self.callback_args)
+        if self.is_lagrangian_dual():
+            # primal_f_x is set from the device iteration record by the driver (one product per iteration, not three)
+            self.dgap = abs((self.primal_f_x - self.f_x) / max(abs(self.primal_f_x), 1))
+            if self.is_verbose():
+                print('\tpcost: {: 1.4e}'.format(self.primal_f_x), end='')
+                print('\tdgap: {: 1.4e}'.format(self.dgap), end='')
+            if self.f.primal.ndim == 2:
+                self.x0_history.append(self.x[0])
+                self.x1_history.append(self.x[1])
+                self.f_x_history.append(self.primal_f_x)
+            if callable(self._callback):
+                self._callback(self, *args, *self.callback_args)
+            self.past_x = self.x.copy()
+        else:
+            if self.f.ndim <= 3:
+                self.x0_history.append(self.x[0])
+                self.x1_history.append(self.x[1])
+                self.f_x_history.append(self.f_x)
+            if callable(self._callback):
+                self._callback(self, *args, *self.callback_args)
 
     def is_verbose(self):
         return self.verbose and not self.iter % self.verbose

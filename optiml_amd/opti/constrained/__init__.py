@@ -1,6 +1,7 @@
-__all__ = ['BoxConstrainedQuadraticOptimizer', 'ProjectedGradient', 'ActiveSet', 'FrankWolfe', 'InteriorPoint']
+__all__ = ['BoxConstrainedQuadraticOptimizer', 'AugmentedLagrangianQuadratic', 'ProjectedGradient', 'ActiveSet',
+           'FrankWolfe', 'InteriorPoint']
 
-from ._base import BoxConstrainedQuadraticOptimizer
+from ._base import BoxConstrainedQuadraticOptimizer, AugmentedLagrangianQuadratic
 from .projected_gradient import ProjectedGradient
 from .active_set import ActiveSet
 from .frank_wolfe import FrankWolfe

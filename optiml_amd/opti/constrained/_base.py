@@ -15,9 +15,9 @@ from abc import ABC
 import numpy as np
 
 from ... import _lib
-from .._base import Optimizer, Quadratic
+from .._base import Optimizer, OptimizationFunction, Quadratic
 
-__all__ = ['BoxConstrainedQuadraticOptimizer']
+__all__ = ['BoxConstrainedQuadraticOptimizer', 'AugmentedLagrangianQuadratic']
 
 
 class _DeviceSolver:
@@ -150,3 +150,127 @@ class BoxConstrainedQuadraticOptimizer(Optimizer, ABC):
 
     def _finalize(self, solver):
         pass
+
+
+class AugmentedLagrangianQuadratic(Quadratic):
+    r"""Augmented-Lagrangian relaxation of   min 1/2 x'Qx + q'x : A x = b, lb <= x <= ub   (SURVEY 8(f).3).
+
+    Interface of optiml/opti/constrained/_base.py:224-410 (ctor arguments, checks, `primal`, `rho`, `n_eq`, `dual_x`,
+    `past_dual_x`, `constraints/function/jacobian/function_jacobian`).  The stacked matrix [A; -I; I] is never
+    formed: the rows are the single equality row and the coordinates.  What the device path covers is what the
+    SVC/SVR duals need (optiml/ml/svm/_base.py:680-694, :1192-1207): ONE equality row with b = 0, bounds lb / ub, no
+    general G x <= h rows — anything else raises NotImplementedError.  The multipliers are ordered as in the
+    reference: [mu; lambda_lb; lambda_ub].
+    """
+
+    def __init__(self, primal, A=None, b=None, G=None, h=None, lb=None, ub=None, rho=1):
+        if not isinstance(primal, Quadratic):
+            raise TypeError(f'{primal} is not an allowed quadratic function')
+        OptimizationFunction.__init__(self, primal.ndim)
+        self.primal = primal
+        if G is None and h is not None:
+            raise ValueError('incomplete inequality constraint (missing G)')
+        if G is not None and h is None:
+            raise ValueError('incomplete inequality constraint (missing h)')
+        if A is None and b is not None:
+            raise ValueError('incomplete equality constraint (missing A)')
+        if A is not None and b is None:
+            raise ValueError('incomplete equality constraint (missing b)')
+        if G is not None:
+            raise NotImplementedError('general inequality rows G x <= h are not built: use lb / ub')
+        if not rho > 0:
+            raise ValueError('rho must be must > 0')
+        self.A = np.atleast_2d(A).astype(float) if A is not None else None
+        self.b = None if b is None else np.atleast_1d(np.asarray(b, dtype=float))
+        if self.A is not None:
+            if self.A.shape != (1, self.ndim):
+                raise NotImplementedError('a single equality row of length ndim is built')
+            if self.b.size != 1 or self.b[0] != 0:
+                raise NotImplementedError('the equality row is built for b = 0')
+        self.lb = np.asarray(lb, dtype=float) if lb is not None else None
+        self.ub = np.asarray(ub, dtype=float) if ub is not None else None
+        for v, name in ((self.lb, 'lb'), (self.ub, 'ub')):
+            if v is not None and v.shape != (self.ndim,):
+                raise ValueError(f'{name} size does not match with Q')
+        self.rho = rho
+        self.n_eq = 0 if self.A is None else 1
+        self.dual_x = np.zeros(self.n_eq + (self.ndim if self.lb is not None else 0) +
+                               (self.ndim if self.ub is not None else 0))   # mu_lmbda
+        self.past_dual_x = self.dual_x.copy()
+
+    # the Hessian / linear term are the primal's (lazy for KernelQuadratic)
+    @property
+    def Q(self):
+        return self.primal.Q
+
+    @property
+    def q(self):
+        return self.primal.q
+
+    def device_problem(self, ctx=None):
+        return self.primal.device_problem(ctx)
+
+    def release(self):
+        self.primal.release()
+
+    @property
+    def AG(self):
+        """[A; -I; I] as a dense matrix (inspection / small problems only)."""
+        rows = [] if self.A is None else [self.A]
+        if self.lb is not None:
+            rows.append(-np.eye(self.ndim))
+        if self.ub is not None:
+            rows.append(np.eye(self.ndim))
+        return np.concatenate(rows) if rows else np.zeros((0, self.ndim))
+
+    @property
+    def bh(self):
+        parts = [] if self.A is None else [self.b]
+        if self.lb is not None:
+            parts.append(-self.lb)
+        if self.ub is not None:
+            parts.append(self.ub)
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def constraints(self, x):
+        x = np.asarray(x, dtype=float)
+        parts = [] if self.A is None else [self.A @ x - self.b]
+        if self.lb is not None:
+            parts.append(self.lb - x)
+        if self.ub is not None:
+            parts.append(x - self.ub)
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def _clipped(self, c):
+        cc = c.copy()
+        cc[self.n_eq:] = np.clip(c[self.n_eq:], a_min=0, a_max=None)
+        return cc
+
+    def function(self, x):
+        return self.function_jacobian(x)[0]
+
+    def jacobian(self, x):
+        return self.function_jacobian(x)[1]
+
+    def function_jacobian(self, x):
+        """constrained/_base.py:393-404 with one device product (value and gradient of the primal together)."""
+        x = np.asarray(x, dtype=float)
+        pf, pg = self.primal.function_jacobian(x)
+        c = self.constraints(x)
+        cc = self._clipped(c)
+        fun = pf + self.dual_x @ c + 0.5 * self.rho * np.linalg.norm(cc) ** 2
+        jac = pg.copy()
+        k = 0
+        if self.A is not None:
+            jac += (self.dual_x[0] + self.rho * cc[0]) * self.A[0]
+            k = 1
+        n = self.ndim
+        if self.lb is not None:
+            jac -= self.dual_x[k:k + n] + self.rho * cc[k:k + n]
+            k += n
+        if self.ub is not None:
+            jac += self.dual_x[k:k + n] + self.rho * cc[k:k + n]
+        return fun, jac
+
+    def hessian(self, x):
+        raise NotImplementedError('the Hessian of the augmented Lagrangian is not built')

@@ -173,3 +173,70 @@ def test_c_consumer_solves_on_gpu(tmp_path):
     r = subprocess.run([exe, 'gpu'], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert 'c abi gpu ok' in r.stdout
+
+
+def test_lagrangian_surface_and_validation_mirror_reference():
+    """SURVEY 8(f).3 host side: class names, ctor checks and defaults of optiml/opti/constrained/_base.py:242-277 and
+    optiml/opti/unconstrained/stochastic/*.py (no device call is made)."""
+    import warnings
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import AugmentedLagrangianQuadratic
+    from optiml_amd.opti.unconstrained import stochastic as st
+    quad = Quadratic(np.eye(4) * 2, -np.ones(4))
+    with pytest.raises(TypeError):
+        AugmentedLagrangianQuadratic(primal=object())
+    with pytest.raises(ValueError):
+        AugmentedLagrangianQuadratic(primal=quad, A=np.ones(4))                 # missing b
+    with pytest.raises(ValueError):
+        AugmentedLagrangianQuadratic(primal=quad, b=np.zeros(1))                # missing A
+    with pytest.raises(ValueError):
+        AugmentedLagrangianQuadratic(primal=quad, h=np.zeros(1))                # missing G
+    with pytest.raises(ValueError):
+        AugmentedLagrangianQuadratic(primal=quad, lb=np.zeros(4), rho=0)
+    with pytest.raises(NotImplementedError):
+        AugmentedLagrangianQuadratic(primal=quad, G=np.eye(4), h=np.ones(4))    # general G rows: not built
+    with pytest.raises(NotImplementedError):
+        AugmentedLagrangianQuadratic(primal=quad, A=np.ones((2, 4)), b=np.zeros(2))
+    al = AugmentedLagrangianQuadratic(primal=quad, A=[1, -1, 1, -1], b=np.zeros(1), lb=np.zeros(4), ub=np.ones(4), rho=2)
+    assert al.ndim == 4 and al.n_eq == 1 and al.rho == 2 and al.primal is quad
+    assert al.dual_x.shape == (9,) and not al.dual_x.any() and al.AG.shape == (9, 4) and al.bh.shape == (9,)
+    x = np.array([1.5, -0.5, 0.25, 0.5])
+    np.testing.assert_allclose(al.constraints(x), al.AG @ x - al.bh)
+    for cls in (st.StochasticGradientDescent, st.Adam, st.AMSGrad, st.AdaMax, st.AdaGrad, st.AdaDelta, st.RMSProp):
+        assert issubclass(cls, st.StochasticOptimizer)
+        opt = cls(f=al, random_state=3)
+        assert opt.is_lagrangian_dual() and opt.is_augmented_lagrangian_dual()
+        np.testing.assert_array_equal(opt.x, np.random.RandomState(3).uniform(size=4))   # opti/_base.py:36-57
+        np.testing.assert_array_equal(opt.past_x, opt.x)
+        assert opt.epochs == 1000 and opt.epoch == 0 and opt.iter == 0 and opt.status == 'unknown'
+        assert np.isnan(opt.f_x) and np.isnan(opt.primal_f_x) and np.isnan(opt.dgap)
+        with pytest.raises(ValueError):
+            cls(f=al, step_size=0)
+        with pytest.raises(ValueError):
+            cls(f=al, epochs=0)
+        with pytest.raises(TypeError):
+            cls(f=object())
+    assert (st.StochasticGradientDescent(f=al).step_size, st.Adam(f=al).step_size, st.AdaMax(f=al).step_size,
+            st.AdaGrad(f=al).step_size, st.AdaDelta(f=al).step_size, st.RMSProp(f=al).step_size) == \
+        (0.01, 0.001, 0.002, 1., 1., 0.001)
+    assert st.AdaDelta(f=al).offset == 1e-6 and st.AdaGrad(f=al).offset == 1e-8 and st.RMSProp(f=al).decay == 0.9
+    for cls in (st.StochasticGradientDescent, st.Adam, st.AMSGrad, st.AdaMax, st.RMSProp):
+        assert issubclass(cls, st.StochasticMomentumOptimizer)
+        with pytest.raises(ValueError):
+            cls(f=al, momentum_type='heavy')
+        with pytest.raises(ValueError):
+            cls(f=al, momentum=1.0)
+    with pytest.raises(ValueError):
+        st.Adam(f=al, beta1=1.0)
+    with pytest.raises(ValueError):
+        st.AdaDelta(f=al, decay=1.0)
+    with pytest.raises(ValueError):
+        st.AdaGrad(f=al, offset=0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        st.Adam(f=al, beta1=0.99, beta2=0.9)                                     # adam.py: convergence-analysis warning
+        assert len(w) == 1
+    with pytest.raises(NotImplementedError):
+        st.AdaGrad(f=al, batch_size=2)                                           # no samples to batch
+    with pytest.raises(NotImplementedError):
+        st.AdaGrad(f=al, step_size=iter([1., .5]))                               # schedules: not built
