@@ -40,7 +40,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--samples', '--n', dest='n', type=int, default=100000)
     ap.add_argument('--features', '--d', dest='d', type=int, default=128)
-    ap.add_argument('--solver', default='pg', choices=['pg', 'fw'])
+    ap.add_argument('--solver', default='pg', choices=['pg', 'fw', 'adagrad'],
+                    help='adagrad: AdaGrad on the augmented Lagrangian of the reg_intercept=False dual (SURVEY 8f.3)')
     ap.add_argument('--task', default='svc', choices=['svc', 'svr'], help='svr: eps-insensitive dual, dim 2n (config 4)')
     ap.add_argument('--kernel', default='rbf', choices=['rbf', 'poly', 'linear'], help='poly: degree 3, coef0 1')
     ap.add_argument('--storage', default='f64', choices=['f64', 'f32'])
@@ -91,6 +92,8 @@ def cpu_baseline(args):
     Q, q, ub = so.svc_dual(K, y, 1.0) if args.task == 'svc' else so.svr_dual(K, y, 1.0, 0.1)
     del K
     t_build = time.perf_counter() - t0
+    if args.solver == 'adagrad':
+        return cpu_baseline_al(args, threads)
     solve = bo.projected_gradient if args.solver == 'pg' else bo.frank_wolfe
     solve(Q, q, ub, max_iter=2)  # warm
     t0 = time.perf_counter()
@@ -103,6 +106,33 @@ def cpu_baseline(args):
             'sample': f'oracle {args.solver.upper()} (dense fp64 Q on host, 3 products/iter), n={ns} d={args.d}, '
                       f'{its} iterations in {dt:.2f}s = {rate:.3f} iter/s measured; value scaled by (n_s/n)^2 to '
                       f'n={args.n}; Gram+Q assembly {t_build:.2f}s excluded',
+            'measured_iter_per_s_at_sample': rate, 'sample_n': ns}
+
+
+def cpu_baseline_al(args, threads):
+    """Oracle AdaGrad on the augmented Lagrangian in the reference formulation: dense Q and the dense stacked
+    constraint matrix [a; -I; I] ((2N+1) x N), three products with Q per iteration."""
+    from oracle import al_oracle as ao, svm_oracle as so
+    from optiml_amd.datasets import make_blobs, make_regression
+    ns = min(args.cpu_n, args.n, 4000)
+    X, y = make_blobs(ns, args.d, seed=0) if args.task == 'svc' else make_regression(ns, args.d, seed=0)
+    K = so.gram(args.kernel, X, None, 'scale', 1.0 if args.kernel == 'poly' else 0.0, 3)
+    if args.task == 'svc':
+        Q, q, a = K * np.outer(y, y), -np.ones(ns), y
+    else:
+        Q, q = np.vstack((np.hstack((K, -K)), np.hstack((-K, K)))), np.hstack((-y, y)) + 0.1
+        a = np.hstack((np.ones(ns), -np.ones(ns)))
+    N = len(q)
+    al = ao.AugLag(Q, q, a=a, lb=np.zeros(N), ub=np.ones(N), rho=1.)
+    steps = max(10, args.cpu_steps // 5)
+    t0 = time.perf_counter()
+    res = ao.minimize(al, np.random.RandomState(0).uniform(size=N), 'adagrad', epochs=steps + 1, step_size=1.)
+    dt = time.perf_counter() - t0
+    rate = res['iter'] / dt
+    return {'value': rate * (ns / args.n) ** 2, 'unit': 'iter/s', 'cores': int(threads), 'kind': 'port',
+            'sample': f'oracle AdaGrad on the augmented Lagrangian (dense fp64 Q and dense [a;-I;I] on host), n={ns} '
+                      f'd={args.d}, {res["iter"]} iterations in {dt:.2f}s = {rate:.3f} iter/s measured; value scaled '
+                      f'by (n_s/n)^2 to n={args.n}',
             'measured_iter_per_s_at_sample': rate, 'sample_n': ns}
 
 
@@ -157,12 +187,15 @@ def main():
     from optiml_amd.datasets import make_regression
     from optiml_amd.ml.svm.kernels import PolyKernel, linear
     kern = {'rbf': gaussian, 'poly': PolyKernel(3, 'scale', 1.0), 'linear': linear}[args.kernel]
+    al = args.solver == 'adagrad'   # reg_intercept=False dual: no rank-one term, equality row handled by the multiplier
     if args.task == 'svc':
         X, y = make_blobs(n, d, seed=0)
-        quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage)
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage, rank_one=not al)
+        a_eq = y
     else:   # eps-insensitive SVR dual: 2n variables on one n x n panel (BASELINE config 4 shape)
         X, y = make_regression(n, d, seed=0)
-        quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', kern, storage=args.storage)
+        quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', kern, storage=args.storage, rank_one=not al)
+        a_eq = np.hstack((np.ones(n), -np.ones(n)))
     N = quad.ndim
     ctx.profile(os.environ.get('BQ_BENCH_NOPROF', '0') != '1')   # HIP-event timing of the dominant kernel (roofline)
     t0 = time.perf_counter()
@@ -171,9 +204,15 @@ def main():
     gram_ms, _ = ctx.profile_read(_lib.PROF_GRAM, reset=True)
     _, _, r0, r1 = dev.dims()
 
-    kind = _lib.PG if args.solver == 'pg' else _lib.FW
     ub = np.ones(N)
-    solver = _DeviceSolver(dev, kind, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
+    if al:
+        from optiml_amd.opti.unconstrained.stochastic._base import _AlDeviceSolver
+        prm = _lib.AlParams(rule=_lib.RULE_ADAGRAD, momentum_type=0, step_size=1., momentum=0., beta1=0., beta2=0.,
+                            decay=0., offset=1e-8, rho=1., tol=1e-12, epochs=10 ** 9)
+        solver = _AlDeviceSolver(dev, prm, a_eq, np.zeros(N), ub, np.random.RandomState(0).uniform(size=N), None)
+    else:
+        kind = _lib.PG if args.solver == 'pg' else _lib.FW
+        solver = _DeviceSolver(dev, kind, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
 
     rows, status = solver.run(max(args.warmup, 1))      # includes the start-up gradient product
     ctx.profile_read(_lib.PROF_MATVEC, reset=True)

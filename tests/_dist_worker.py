@@ -86,6 +86,17 @@ def gpu_mode(exchange, outdir):
     res['dense_matvec'] = dq.device_problem().matvec(v[:500])
     opt = ProjectedGradient(quad=dq, ub=np.ones(500), max_iter=40).minimize()
     res['dense_pg_x'] = opt.x
+    # augmented-Lagrangian dual: same sharded product, everything else replicated
+    from optiml_amd.opti.constrained import AugmentedLagrangianQuadratic
+    from optiml_amd.opti.unconstrained.stochastic import AdaGrad, Adam
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, rank_one=False)
+    al = AugmentedLagrangianQuadratic(primal=quad, A=y, b=np.zeros(1), lb=np.zeros(n), ub=np.ones(n))
+    opt = AdaGrad(f=al, x=np.random.RandomState(3).uniform(size=n), step_size=1., epochs=80).minimize()
+    res['al_x'], res['al_dual'], res['al_f'] = opt.x, al.dual_x, opt.f_x
+    al = AugmentedLagrangianQuadratic(primal=dq, lb=np.zeros(500), ub=np.ones(500), rho=2.)
+    opt = Adam(f=al, x=np.random.RandomState(3).uniform(size=500), step_size=0.01, epochs=60,
+               momentum_type='nesterov', momentum=0.5).minimize()
+    res['dense_al_x'] = opt.x
     ms, cnt = ctx.profile_read(_lib.PROF_EXCH)
     comm.barrier()
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)

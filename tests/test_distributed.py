@@ -68,14 +68,14 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path):
     assert tuple(two[0]['dense_rows']) == (0, 256) and tuple(two[1]['dense_rows']) == (256, 500)
     for r in two:
         # row-block panels end in an all-gather: bit-identical for any rank count
-        for key in ('dense_matvec', 'dense_pg_x'):
+        for key in ('dense_matvec', 'dense_pg_x', 'dense_al_x'):
             assert np.array_equal(r[key], one[key]), key
         # symmetric tile panels end in an all-reduce(sum): same values up to the association of the rank sum
-        for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f'):
+        for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f'):
             np.testing.assert_allclose(r[key], one[key], rtol=1e-12, atol=1e-12, err_msg=key)
-        for key in ('pg_x', 'fw_x'):
+        for key in ('pg_x', 'fw_x', 'al_x', 'al_dual'):
             np.testing.assert_allclose(r[key], one[key], rtol=1e-9, atol=1e-11, err_msg=key)
-    for key in ('matvec', 'pg_x', 'fw_x', 'dense_pg_x'):     # and the ranks agree with each other exactly
+    for key in ('matvec', 'pg_x', 'fw_x', 'dense_pg_x', 'al_x', 'dense_al_x'):     # and the ranks agree with each other exactly
         assert np.array_equal(two[0][key], two[1][key]), key
 
 
@@ -83,7 +83,7 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path):
 def test_rccl_context_single_rank(tmp_path):
     ref = _launch('gpu-host', 1, tmp_path / 'ref')[0]
     got = _launch('gpu-rccl', 1, tmp_path / 'rccl')[0]
-    for key in ('matvec', 'pg_x', 'pg_hist', 'fw_x', 'dense_matvec', 'dense_pg_x'):
+    for key in ('matvec', 'pg_x', 'pg_hist', 'fw_x', 'dense_matvec', 'dense_pg_x', 'al_x', 'dense_al_x'):
         assert np.array_equal(got[key], ref[key]), key
 
 
@@ -97,3 +97,5 @@ def test_three_ranks_uneven_partitions(tmp_path):
         np.testing.assert_allclose(r['matvec'], one['matvec'], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(r['pg_x'], one['pg_x'], rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(r['fw_x'], one['fw_x'], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r['al_x'], one['al_x'], rtol=1e-9, atol=1e-11)
+        assert np.array_equal(r['dense_al_x'], one['dense_al_x'])
