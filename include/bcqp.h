@@ -169,6 +169,22 @@ int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const double *a_
 /* number of multipliers (length of BQ_GET_DUAL) */
 int bq_al_solver_dual_size(const bq_solver *s, int64_t *n_dual);
 
+/* ---- SMO on the resident Gram panel (optiml/ml/svm/smo.py) -----------------------------------------
+ * SMOClassifier (:99-357) / SMORegression (:386-797): the reg_intercept=False duals through SVC/SVR(optimizer='smo')
+ * (optiml/ml/svm/_base.py:560-573, :1106-1120).  `p` is a kernel-built problem of n samples (only its Gram panel K is
+ * used; single-rank contexts); y: labels in {+1,-1} (BQ_SVC) or targets (BQ_SVR).  One call of bq_smo_run advances
+ * by at most max_outer outer iterations (one sweep over the samples each, smo.py:327-351) and reports the total
+ * number done and whether the loop has terminated.  Ties between free samples with bit-identical cached errors are
+ * resolved towards the smaller index (the reference: CPython set order) — see oracle/smo_oracle.py. */
+typedef struct bq_smo bq_smo;
+enum { BQ_SMO_ALPHAS = 0,   /* n (BQ_SVC) or [alpha+; alpha-] 2n (BQ_SVR) */
+       BQ_SMO_ERRORS = 1,   /* n: the error cache */
+       BQ_SMO_SCALARS = 2   /* 6: b_up, b_low, b_up_idx, b_low_idx, successful pair steps, intercept b */ };
+int bq_smo_create(bq_problem *p, int task, const double *y, double C, double epsilon, double tol, bq_smo **out);
+int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, int *finished);
+int bq_smo_get(bq_smo *s, int what, double *out);
+int bq_smo_destroy(bq_smo *s);
+
 /* ---- prediction (optiml/ml/svm/_base.py:284-287) ------------------------------- */
 /* out[t] = sum_m coef[m] * kernel(SV[m], Xt[t]) + intercept   (SV: m x d, Xt: t x d, row-major fp64) */
 int bq_decision_function(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m,

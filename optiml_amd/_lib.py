@@ -19,6 +19,7 @@ PG, FW, AS, IP = 0, 1, 2, 3
 STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
 GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW, GET_DUAL = range(10)
 NO_RANK_ONE = 16
+SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS = range(3)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
@@ -76,6 +77,10 @@ PROTOTYPES = {
     'bq_solver_get': (C.c_int, [_vp, C.c_int, _dp]),
     'bq_al_solver_create': (C.c_int, [_vp, C.POINTER(AlParams), _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     'bq_al_solver_dual_size': (C.c_int, [_vp, C.POINTER(_i64)]),
+    'bq_smo_create': (C.c_int, [_vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.POINTER(_vp)]),
+    'bq_smo_run': (C.c_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    'bq_smo_get': (C.c_int, [_vp, C.c_int, _dp]),
+    'bq_smo_destroy': (C.c_int, [_vp]),
     'bq_decision_function': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _dp,
                                        C.c_double, _i64, _dp, _dp]),
     'bq_gram_matrix': (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_int, _i64, _i64, _dp, _i64, _dp, _dp]),

@@ -1,0 +1,690 @@
+// SMO on the resident Gram panel — SURVEY 8(f).4.
+//
+// Restates on the device the reference's sequential minimal optimisation for the reg_intercept=False duals
+// (optiml/ml/svm/smo.py): classification (:99-357, Platt's SMO with the two-threshold rule of Keerthi et al.) and
+// regression (:386-797, Shevade et al.).  The algorithm is a sequential sweep over the samples with data-dependent
+// control flow, so it is latency-bound, not bandwidth-bound: ONE persistent 1024-thread workgroup runs a whole outer
+// iteration per launch.  Thread 0 carries the scalar pair logic; all threads share the three vector jobs of an examine:
+//   (1) E_i = sum_j coef_j K[i][j] for a sample whose error is not cached — only rows j with a non-zero multiplier are
+//       fetched from the panel (the dense dot of the reference touches all n entries of K[i]);
+//   (2) the error-cache update of the free set after a successful pair step (two panel rows);
+//   (3) the re-computation of the two thresholds over the free set.
+// The index sets I0..I4 of the reference are functions of (alpha, y) and are not stored.
+// TIE RULE: where the reference's `for i in self.I0` loop (CPython set order) decides between two free samples with
+// bit-identical cached errors, this kernel takes the smaller index (oracle/smo_oracle.py, tie='index').
+// K[i][j] comes from the packed lower-triangular tile-row panel (bq_sym_addr): the row part is contiguous, the
+// part right of the diagonal tile is read down the column of the later tile rows.
+#include <cfloat>
+#include <cmath>
+
+#include "bq_common.h"
+
+constexpr int SMO_T = 1024;
+
+struct bq_smo_scal {
+    double b_up, b_low;
+    long long i_up, i_low;
+    long long outer, steps, changed;
+    int sweep_all, finished, err_flag, pad;
+};
+
+struct bq_smo {
+    bq_problem *p = nullptr;
+    int task = BQ_SVC;
+    int64_t n = 0;
+    double C = 1.0, eps = 0.0, tol = 1e-3;
+    double *y = nullptr, *a = nullptr, *am = nullptr, *err = nullptr;   // a: alpha (SVC) / alpha+ (SVR); am: alpha-
+    bq_smo_scal *sc = nullptr;
+    bq_smo_scal host;
+};
+
+template <typename T>
+struct KView {
+    const T *panel;
+    __device__ __forceinline__ double at(int64_t i, int64_t j) const {
+        const int64_t ti = i / BQ_SYM_TILE, tj = j / BQ_SYM_TILE;
+        return (double)(tj <= ti ? panel[bq_sym_addr(i, j, 0)] : panel[bq_sym_addr(j, i, 0)]);
+    }
+};
+
+// block-wide deterministic reductions (fixed tree: lane shuffles, then the 16 wave results in order).  The order is part
+// of the contract: oracle/smo_oracle.py (dot='tree') reproduces it bit for bit — thread t adds its elements j = t,
+// t + 1024, ... in ascending order with separately rounded products, the 64 lanes of a wave fold by halves, the 16 wave
+// sums are added in wave order.
+__device__ __forceinline__ double smo_bsum(double v, double *sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < SMO_T / 64; ++w) r += sh[w];
+    return r;
+}
+
+struct ValIdx {
+    double v;
+    long long i;
+};
+// maximum with the smaller index on ties (sign = +1) / minimum with the smaller index on ties (sign = -1)
+__device__ __forceinline__ ValIdx better(ValIdx a, ValIdx b, int sign) {
+    const bool b_wins = sign > 0 ? (b.v > a.v || (b.v == a.v && b.i < a.i && b.i >= 0))
+                                 : (b.v < a.v || (b.v == a.v && b.i < a.i && b.i >= 0));
+    if (a.i < 0) return b.i >= 0 ? b : a;
+    if (b.i < 0) return a;
+    return b_wins ? b : a;
+}
+__device__ __forceinline__ ValIdx smo_bbest(ValIdx x, int sign, double *shv, long long *shi) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ValIdx o;
+        o.v = __shfl_down(x.v, off, 64);
+        o.i = __shfl_down(x.i, off, 64);
+        x = better(x, o, sign);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        shv[threadIdx.x >> 6] = x.v;
+        shi[threadIdx.x >> 6] = x.i;
+    }
+    __syncthreads();
+    ValIdx r{shv[0], shi[0]};
+#pragma unroll
+    for (int w = 1; w < SMO_T / 64; ++w) r = better(r, ValIdx{shv[w], shi[w]}, sign);
+    return r;
+}
+
+struct SmoShared {
+    double red[SMO_T / 64];
+    double bv[SMO_T / 64];
+    long long bi[SMO_T / 64];
+    // scalar state, owned by thread 0 between barriers
+    double b_up, b_low;
+    long long i_up, i_low;
+    // broadcast slots of the current examine
+    double E2, c1, c2;
+    long long i1;
+    int go, took, fail;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// classification (smo.py:130-319)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
+                                                        double *a, double *err, double C, double tol,
+                                                        bq_smo_scal *sc) {
+    __shared__ SmoShared S;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        S.b_up = sc->b_up;
+        S.b_low = sc->b_low;
+        S.i_up = sc->i_up;
+        S.i_low = sc->i_low;
+        S.fail = 0;
+    }
+    __syncthreads();
+    if (sc->finished) return;
+    const bool sweep_all = sc->sweep_all != 0;
+    long long changed = 0, steps = 0;
+    for (int64_t i2 = 0; i2 < n; ++i2) {
+        const double a2 = a[i2], y2 = y[i2];
+        const bool free2 = a2 > 0.0 && a2 < C;
+        if (!sweep_all && !free2) continue;                      // uniform
+        __syncthreads();   // every thread has read a[i2] before thread 0 may overwrite it below
+        const bool up2 = (y2 == 1.0 && a2 == 0.0) || (y2 == -1.0 && a2 == C);     // I1 or I2
+        const bool low2 = (y2 == 1.0 && a2 == C) || (y2 == -1.0 && a2 == 0.0);    // I3 or I4
+        // ---- E2 (smo.py:279-291) ----------------------------------------------------------------------------
+        if (!free2) {
+            double part = 0.0;
+            for (int64_t j = tid; j < n; j += SMO_T) {
+                const double aj = a[j];
+                if (aj != 0.0) part = part + __dmul_rn(__dmul_rn(aj, y[j]), K.at(i2, j));   // no fma: see smo_bsum
+            }
+            const double dot = smo_bsum(part, S.red);
+            if (tid == 0) {
+                const double E2 = dot - y2;
+                err[i2] = E2;
+                S.E2 = E2;
+                if (up2 && E2 < S.b_up) {
+                    S.b_up = E2;
+                    S.i_up = i2;
+                } else if (low2 && E2 > S.b_low) {
+                    S.b_low = E2;
+                    S.i_low = i2;
+                }
+            }
+        } else if (tid == 0) {
+            S.E2 = err[i2];
+        }
+        // ---- choose i1 and solve the pair (smo.py:293-319, :130-196) — thread 0 --------------------------------
+        if (tid == 0) {
+            const double E2 = S.E2;
+            long long i1 = -1;
+            if ((free2 || up2) && S.b_low - E2 > 2 * tol) i1 = S.i_low;
+            if ((free2 || low2) && E2 - S.b_up > 2 * tol) i1 = S.i_up;
+            if (i1 >= 0 && free2) i1 = (S.b_low - E2 > E2 - S.b_up) ? S.i_low : S.i_up;
+            int go = 0;
+            if (i1 >= 0 && i1 != i2) {
+                const double a1 = a[i1], y1 = y[i1], E1 = err[i1];
+                double L, H;
+                if (y1 != y2) {
+                    L = fmax(0.0, a2 - a1);
+                    H = fmin(C, C + a2 - a1);
+                } else {
+                    L = fmax(0.0, a2 + a1 - C);
+                    H = fmin(C, a2 + a1);
+                }
+                if (L != H) {
+                    const double k11 = K.at(i1, i1), k22 = K.at(i2, i2), k12 = K.at(i1, i2);
+                    const double eta = k11 + k22 - 2 * k12;
+                    double n2;
+                    if (eta > 0.0) {
+                        n2 = fmax(L, fmin(a2 + __dmul_rn(y2, E1 - E2) / eta, H));
+                    } else {
+                        const double lo = __dmul_rn(__dmul_rn(y2, E1 - E2), L), hi = __dmul_rn(__dmul_rn(y2, E1 - E2), H);
+                        n2 = lo > hi + 1e-12 ? L : (lo < hi - 1e-12 ? H : a2);
+                    }
+                    if (!(fabs(n2 - a2) < __dmul_rn(1e-12, n2 + a2 + 1e-12))) {
+                        double n1 = a1 + __dmul_rn(__dmul_rn(y1, y2), a2 - n2);
+                        const double c1 = __dmul_rn(y1, n1 - a1), c2 = __dmul_rn(y2, n2 - a2);
+                        // own entries of the error cache, with the old multipliers (smo.py:203-204)
+                        err[i1] = E1 + (__dmul_rn(c1, k11) + __dmul_rn(c2, k12));
+                        err[i2] = E2 + (__dmul_rn(c1, k12) + __dmul_rn(c2, k22));
+                        n2 = n2 > C - __dmul_rn(1e-8, C) ? C : (n2 <= __dmul_rn(1e-8, C) ? 0.0 : n2);
+                        n1 = n1 > C - __dmul_rn(1e-8, C) ? C : (n1 <= __dmul_rn(1e-8, C) ? 0.0 : n1);
+                        a[i1] = n1;
+                        a[i2] = n2;
+                        S.c1 = c1;
+                        S.c2 = c2;
+                        S.i1 = i1;
+                        go = 1;
+                    }
+                }
+            }
+            S.go = go;
+        }
+        __syncthreads();
+        if (S.go) {
+            // ---- error cache of the free set + thresholds over the free set (smo.py:199-201, :241-252) -----------
+            const long long i1 = S.i1;
+            const double c1 = S.c1, c2 = S.c2;
+            ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
+            for (int64_t j = tid; j < n; j += SMO_T) {
+                const double aj = a[j];
+                if (aj > 0.0 && aj < C) {
+                    double e = err[j];
+                    if (j != i1 && j != i2) {
+                        e += __dmul_rn(c1, K.at(i1, j)) + __dmul_rn(c2, K.at(i2, j));
+                        err[j] = e;
+                    }
+                    if (e > hi.v) hi = ValIdx{e, (long long)j};     // ascending j: first maximum / minimum kept
+                    if (e < lo.v) lo = ValIdx{e, (long long)j};
+                }
+            }
+            hi = smo_bbest(hi, +1, S.bv, S.bi);
+            lo = smo_bbest(lo, -1, S.bv, S.bi);
+            if (tid == 0) {
+                S.b_up = DBL_MAX;
+                S.b_low = -DBL_MAX;
+                S.i_up = -1;
+                S.i_low = -1;
+                if (hi.i >= 0 && hi.v > S.b_low) {
+                    S.b_low = hi.v;
+                    S.i_low = hi.i;
+                }
+                if (lo.i >= 0 && lo.v < S.b_up) {
+                    S.b_up = lo.v;
+                    S.i_up = lo.i;
+                }
+                const long long pair[2] = {i1, (long long)i2};
+                for (int k = 0; k < 2; ++k) {   // the two touched samples when they left the free set (smo.py:253-268)
+                    const long long i = pair[k];
+                    const double ai = a[i], yi = y[i], ei = err[i];
+                    if (ai > 0.0 && ai < C) continue;
+                    const bool low_i = (yi == 1.0 && ai == C) || (yi == -1.0 && ai == 0.0);
+                    if (low_i) {
+                        if (ei > S.b_low) {
+                            S.b_low = ei;
+                            S.i_low = i;
+                        }
+                    } else if (ei < S.b_up) {
+                        S.b_up = ei;
+                        S.i_up = i;
+                    }
+                }
+                if (S.i_low < 0 || S.i_up < 0) S.fail = 1;   // 'unexpected status'
+            }
+            ++changed;
+            ++steps;
+        }
+        __syncthreads();
+        if (S.fail) break;
+        if (!sweep_all && S.b_up > S.b_low - 2 * tol) {   // optimality on the free set (smo.py:339-342)
+            changed = 0;
+            break;
+        }
+    }
+    if (tid == 0) {
+        sc->b_up = S.b_up;
+        sc->b_low = S.b_low;
+        sc->i_up = S.i_up;
+        sc->i_low = S.i_low;
+        sc->steps += steps;
+        sc->changed = changed;
+        sc->err_flag = S.fail;
+        int next_all = sweep_all ? 0 : (changed == 0 ? 1 : 0);
+        sc->sweep_all = next_all;
+        sc->outer += 1;
+        sc->finished = (S.fail || !(changed > 0 || next_all)) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// regression (smo.py:447-758)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int svr_kind(double p, double m, double C) {
+    if ((p > 0.0 && p < C) || (m > 0.0 && m < C)) return 0;
+    if (p == 0.0 && m == 0.0) return 1;
+    if (p == 0.0 && m == C) return 2;
+    if (p == C && m == 0.0) return 3;
+    return -1;
+}
+__device__ __forceinline__ double svr_clip(double v, double C) {
+    return v > C - __dmul_rn(1e-10, C) ? C : (v <= __dmul_rn(1e-10, C) ? 0.0 : v);
+}
+// minimiser of the pair sub-problem on [L, H]: Newton step when eta > 0, else the better end point
+__device__ __forceinline__ double svr_solve(double L, double H, double base, double num, double lin, double eta) {
+    if (eta > 0.0) return fmax(L, fmin(base + num / eta, H));
+    return __dmul_rn(L, lin) > __dmul_rn(H, lin) ? L : H;
+}
+__device__ __forceinline__ long long svr_pick(const SmoShared &S, double vlow, double vup, double tol) {
+    if (S.b_low - vlow > 2 * tol) return (vlow - S.b_up > S.b_low - vlow) ? S.i_up : S.i_low;
+    if (vup - S.b_up > 2 * tol) return (S.b_low - vup > vup - S.b_up) ? S.i_low : S.i_up;
+    return -1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
+                                                        double *ap, double *an, double *err, double C,
+                                                        double eps, double tol, bq_smo_scal *sc) {
+    __shared__ SmoShared S;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        S.b_up = sc->b_up;
+        S.b_low = sc->b_low;
+        S.i_up = sc->i_up;
+        S.i_low = sc->i_low;
+        S.fail = 0;
+    }
+    __syncthreads();
+    if (sc->finished) return;
+    const bool sweep_all = sc->sweep_all != 0;
+    long long changed = 0, steps = 0;
+    for (int64_t i2 = 0; i2 < n; ++i2) {
+        const double p2 = ap[i2], m2 = an[i2];
+        const int k2 = svr_kind(p2, m2, C);
+        if (!sweep_all && k2 != 0) continue;   // uniform
+        __syncthreads();   // every thread has read ap/an[i2] before thread 0 may overwrite them below
+        if (k2 != 0) {
+            double part = 0.0;
+            for (int64_t j = tid; j < n; j += SMO_T) {
+                const double cj = ap[j] - an[j];
+                if (cj != 0.0) part = part + __dmul_rn(cj, K.at(i2, j));
+            }
+            const double dot = smo_bsum(part, S.red);
+            if (tid == 0) {
+                const double E2 = y[i2] - dot;
+                err[i2] = E2;
+                S.E2 = E2;
+                if (k2 == 1) {
+                    if (E2 + eps < S.b_up) {
+                        S.b_up = E2 + eps;
+                        S.i_up = i2;
+                    } else if (E2 - eps > S.b_low) {
+                        S.b_low = E2 - eps;
+                        S.i_low = i2;
+                    }
+                } else if (k2 == 2 && E2 + eps > S.b_low) {
+                    S.b_low = E2 + eps;
+                    S.i_low = i2;
+                } else if (k2 == 3 && E2 - eps < S.b_up) {
+                    S.b_up = E2 - eps;
+                    S.i_up = i2;
+                }
+            }
+        } else if (tid == 0) {
+            S.E2 = err[i2];
+        }
+        if (tid == 0) {
+            const double E2 = S.E2;
+            long long i1 = -1;
+            if (k2 == 0) {
+                if (p2 > 0.0 && p2 < C)
+                    i1 = svr_pick(S, E2 - eps, E2 - eps, tol);
+                else if (m2 > 0.0 && m2 < C)
+                    i1 = svr_pick(S, E2 + eps, E2 + eps, tol);
+            } else if (k2 == 1) {
+                i1 = svr_pick(S, E2 + eps, E2 - eps, tol);
+            } else if (k2 == 2) {
+                if ((E2 + eps) - S.b_up > 2 * tol) i1 = S.i_up;
+            } else if (k2 == 3) {
+                if (S.b_low - (E2 - eps) > 2 * tol) i1 = S.i_low;
+            } else {
+                S.fail = 1;   // 'the index could not be found'
+            }
+            int go = 0;
+            if (i1 >= 0 && i1 != i2 && !S.fail) {
+                const double p1o = ap[i1], m1o = an[i1];
+                double p1 = p1o, m1 = m1o, q2 = p2, r2 = m2;   // q2 / r2: working copies of alpha2+ / alpha2-
+                const double k11 = K.at(i1, i1), k22 = K.at(i2, i2), k12 = K.at(i1, i2);
+                const double eta = fmax(k11 + k22 - 2 * k12, 0.0);
+                const double gamma = p1 - m1 + q2 - r2;
+                double dE = err[i1] - E2;
+                bool tried[4] = {false, false, false, false};
+                bool moved = false, done = false;
+                while (!done) {   // at most three rounds (smo.py:471)
+                    if (!tried[0] && (p1 > 0 || (m1 == 0 && dE > 0)) && (q2 > 0 || (r2 == 0 && dE < 0))) {
+                        const double L = fmax(0.0, gamma - C), H = fmin(C, gamma);
+                        if (L < H) {
+                            const double v2 = svr_solve(L, H, q2, -dE, -dE, eta), v1 = p1 - (v2 - q2);
+                            if (fabs(v1 - p1) > 1e-12 || fabs(v2 - q2) > 1e-12) {
+                                p1 = v1;
+                                q2 = v2;
+                                moved = true;
+                            }
+                        } else {
+                            done = true;
+                        }
+                        tried[0] = true;
+                    } else if (!tried[1] && (p1 > 0 || (m1 == 0 && dE > 2 * eps)) &&
+                               (r2 > 0 || (q2 == 0 && dE > 2 * eps))) {
+                        const double L = fmax(0.0, -gamma), H = fmin(C, -gamma + C);
+                        if (L < H) {
+                            const double v2 = svr_solve(L, H, r2, dE - 2 * eps, -2 * eps + dE, eta), v1 = p1 + (v2 - r2);
+                            if (fabs(v1 - p1) > 1e-12 || fabs(v2 - r2) > 1e-12) {
+                                p1 = v1;
+                                r2 = v2;
+                                moved = true;
+                            }
+                        } else {
+                            done = true;
+                        }
+                        tried[1] = true;
+                    } else if (!tried[2] && (m1 > 0 || (p1 == 0 && dE < -2 * eps)) &&
+                               (q2 > 0 || (r2 == 0 && dE < -2 * eps))) {
+                        const double L = fmax(0.0, gamma), H = fmin(C, C + gamma);
+                        if (L < H) {
+                            const double v2 = svr_solve(L, H, q2, -(dE + 2 * eps), -(2 * eps + dE), eta);
+                            const double v1 = m1 + (v2 - q2);
+                            if (fabs(v1 - m1) > 1e-12 || fabs(v2 - q2) > 1e-12) {
+                                m1 = v1;
+                                q2 = v2;
+                                moved = true;
+                            }
+                        } else {
+                            done = true;
+                        }
+                        tried[2] = true;
+                    } else if (!tried[3] && (m1 > 0 || (p1 == 0 && dE < 0)) && (r2 > 0 || (q2 == 0 && dE > 0))) {
+                        const double L = fmax(0.0, -gamma - C), H = fmin(C, -gamma);
+                        if (L < H) {
+                            const double v2 = svr_solve(L, H, r2, dE, dE, eta), v1 = m1 - (v2 - r2);
+                            if (fabs(v1 - m1) > 1e-12 || fabs(v2 - r2) > 1e-12) {
+                                m1 = v1;
+                                r2 = v2;
+                                moved = true;
+                            }
+                        } else {
+                            done = true;
+                        }
+                        tried[3] = true;
+                    } else {
+                        done = true;
+                    }
+                    dE += __dmul_rn(eta, (q2 - r2) - (p2 - m2));
+                }
+                if (moved) {
+                    const double c1 = (p1o - m1o) - (p1 - m1), c2 = (p2 - m2) - (q2 - r2);
+                    err[i1] = err[i1] + (__dmul_rn(c1, k11) + __dmul_rn(c2, k12));
+                    err[i2] = E2 + (__dmul_rn(c1, k12) + __dmul_rn(c2, k22));
+                    ap[i1] = svr_clip(p1, C);
+                    an[i1] = svr_clip(m1, C);
+                    ap[i2] = svr_clip(q2, C);
+                    an[i2] = svr_clip(r2, C);
+                    S.c1 = c1;
+                    S.c2 = c2;
+                    S.i1 = i1;
+                    go = 1;
+                }
+            }
+            S.go = go;
+        }
+        __syncthreads();
+        if (S.go) {
+            const long long i1 = S.i1;
+            const double c1 = S.c1, c2 = S.c2;
+            ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
+            for (int64_t j = tid; j < n; j += SMO_T) {
+                const double pj = ap[j], mj = an[j];
+                const bool pin = pj > 0.0 && pj < C, nin = mj > 0.0 && mj < C;
+                if (pin || nin) {
+                    double e = err[j];
+                    if (j != i1 && j != i2) {
+                        e += __dmul_rn(c1, K.at(i1, j)) + __dmul_rn(c2, K.at(i2, j));
+                        err[j] = e;
+                    }
+                    // smo.py:641-653: alpha+ inside is tried first, alpha- inside only when that test fails
+                    if (pin && e - eps > hi.v)
+                        hi = ValIdx{e - eps, (long long)j};
+                    else if (nin && e + eps > hi.v)
+                        hi = ValIdx{e + eps, (long long)j};
+                    if (pin && e - eps < lo.v)
+                        lo = ValIdx{e - eps, (long long)j};
+                    else if (nin && e + eps < lo.v)
+                        lo = ValIdx{e + eps, (long long)j};
+                }
+            }
+            hi = smo_bbest(hi, +1, S.bv, S.bi);
+            lo = smo_bbest(lo, -1, S.bv, S.bi);
+            if (tid == 0) {
+                S.b_up = DBL_MAX;
+                S.b_low = -DBL_MAX;
+                S.i_up = -1;
+                S.i_low = -1;
+                if (hi.i >= 0 && hi.v > S.b_low) {
+                    S.b_low = hi.v;
+                    S.i_low = hi.i;
+                }
+                if (lo.i >= 0 && lo.v < S.b_up) {
+                    S.b_up = lo.v;
+                    S.i_up = lo.i;
+                }
+                const long long pair[2] = {i1, (long long)i2};
+                for (int k = 0; k < 2; ++k) {   // smo.py:654-668
+                    const long long i = pair[k];
+                    const int ki = svr_kind(ap[i], an[i], C);
+                    const double ei = err[i];
+                    if (ki == 0) continue;
+                    if (ki == 2 && ei + eps > S.b_low) {
+                        S.b_low = ei + eps;
+                        S.i_low = i;
+                    } else if (ki == 1 && ei - eps > S.b_low) {
+                        S.b_low = ei - eps;
+                        S.i_low = i;
+                    }
+                    if (ki == 3 && ei - eps < S.b_up) {
+                        S.b_up = ei - eps;
+                        S.i_up = i;
+                    } else if (ki == 1 && ei + eps < S.b_up) {
+                        S.b_up = ei + eps;
+                        S.i_up = i;
+                    }
+                }
+                if (S.i_low < 0 || S.i_up < 0) S.fail = 1;
+            }
+            ++changed;
+            ++steps;
+        }
+        __syncthreads();
+        if (S.fail) break;
+        if (!sweep_all && S.b_up > S.b_low - 2 * tol) {
+            changed = 0;
+            break;
+        }
+    }
+    if (tid == 0) {
+        sc->b_up = S.b_up;
+        sc->b_low = S.b_low;
+        sc->i_up = S.i_up;
+        sc->i_low = S.i_low;
+        sc->steps += steps;
+        sc->changed = changed;
+        sc->err_flag = S.fail;
+        int next_all = sweep_all ? 0 : (changed == 0 ? 1 : 0);
+        sc->sweep_all = next_all;
+        sc->outer += 1;
+        sc->finished = (S.fail || !(changed > 0 || next_all)) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int bq_smo_destroy(bq_smo *s) {
+    if (s == nullptr) return BQ_OK;
+    hipSetDevice(s->p->ctx->device);
+    hipStreamSynchronize(s->p->ctx->stream);
+    for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->sc})
+        if (ptr) hipFree(ptr);
+    delete s;
+    return BQ_OK;
+}
+
+extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C, double epsilon, double tol,
+                             bq_smo **out) {
+    BQ_ARG(p && y && out, "NULL argument");
+    BQ_ARG(task == BQ_SVC || task == BQ_SVR, "task must be BQ_SVC or BQ_SVR");
+    BQ_ARG(p->kernel >= 0 && p->symmetric, "SMO needs a kernel-built problem (its Gram panel)");
+    BQ_ARG(C > 0.0, "C must be > 0");
+    BQ_ARG(epsilon >= 0.0, "epsilon must be >= 0");
+    BQ_ARG(tol > 0.0, "tol must be > 0");
+    if (p->ctx->world > 1) {
+        bq_set_error("SMO walks the samples sequentially over the whole panel: use a single-rank context (replicas only)");
+        return BQ_ERR_BADARG;
+    }
+    bq_ctx *c = p->ctx;
+    const int64_t n = p->n;
+    int64_t first_pos = -1, first_neg = -1;
+    if (task == BQ_SVC) {
+        for (int64_t i = 0; i < n; ++i) {
+            BQ_ARG(y[i] == 1.0 || y[i] == -1.0, "labels must be +1 / -1");
+            if (y[i] == 1.0 && first_pos < 0) first_pos = i;
+            if (y[i] == -1.0 && first_neg < 0) first_neg = i;
+        }
+        BQ_ARG(first_pos >= 0 && first_neg >= 0, "both classes are needed");
+    }
+    BQ_HIP(hipSetDevice(c->device));
+    bq_smo *s = new bq_smo();
+    s->p = p;
+    s->task = task;
+    s->n = n;
+    s->C = C;
+    s->eps = epsilon;
+    s->tol = tol;
+    hipError_t e = hipSuccess;
+    for (double **v : {&s->y, &s->a, &s->am, &s->err}) {
+        if (e == hipSuccess) e = hipMalloc(v, sizeof(double) * n);
+        if (e == hipSuccess) e = hipMemsetAsync(*v, 0, sizeof(double) * n, c->stream);
+    }
+    if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_smo_scal));
+    if (e == hipSuccess) e = hipMemcpyAsync(s->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
+    memset(&s->host, 0, sizeof(s->host));
+    s->host.sweep_all = 1;
+    if (task == BQ_SVC) {   // smo.py:119-128
+        s->host.b_up = -1.0;
+        s->host.b_low = 1.0;
+        s->host.i_up = first_pos;
+        s->host.i_low = first_neg;
+        const double m1 = -1.0, p1 = 1.0;
+        if (e == hipSuccess) e = hipMemcpyAsync(s->err + first_pos, &m1, sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->err + first_neg, &p1, sizeof(double), hipMemcpyHostToDevice, c->stream);
+    } else {                // smo.py:442-445
+        s->host.b_up = y[0] + epsilon;
+        s->host.b_low = y[0] - epsilon;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(s->sc, &s->host, sizeof(bq_smo_scal), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        bq_set_error("SMO setup failed: %s", hipGetErrorString(e));
+        bq_smo_destroy(s);
+        return BQ_ERR_HIP;
+    }
+    *out = s;
+    return BQ_OK;
+}
+
+extern "C" int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, int *finished) {
+    BQ_ARG(s && outer_iters && finished, "NULL argument");
+    BQ_ARG(max_outer > 0, "max_outer must be > 0");
+    bq_problem *p = s->p;
+    bq_ctx *c = p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    for (int64_t k = 0; k < max_outer && !s->host.finished; ++k) {
+        if (s->task == BQ_SVC) {
+            if (p->storage == BQ_F64)
+                smo_svc_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
+                                                                    s->a, s->err, s->C, s->tol, s->sc);
+            else
+                smo_svc_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
+                                                                  s->a, s->err, s->C, s->tol, s->sc);
+        } else {
+            if (p->storage == BQ_F64)
+                smo_svr_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
+                                                                    s->a, s->am, s->err, s->C, s->eps, s->tol, s->sc);
+            else
+                smo_svr_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
+                                                                  s->a, s->am, s->err, s->C, s->eps, s->tol, s->sc);
+        }
+        BQ_HIP(hipGetLastError());
+        BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_smo_scal), hipMemcpyDeviceToHost, c->stream));
+        BQ_HIP(hipStreamSynchronize(c->stream));
+        if (s->host.err_flag) {
+            bq_set_error("SMO reached an unexpected status (no threshold index)");   // smo.py:270-271, :756
+            return BQ_ERR_NONFINITE;
+        }
+    }
+    *outer_iters = s->host.outer;
+    *finished = s->host.finished;
+    return BQ_OK;
+}
+
+extern "C" int bq_smo_get(bq_smo *s, int what, double *out) {
+    BQ_ARG(s && out, "NULL argument");
+    bq_ctx *c = s->p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    switch (what) {
+        case BQ_SMO_ALPHAS:
+            BQ_HIP(hipMemcpyAsync(out, s->a, sizeof(double) * s->n, hipMemcpyDeviceToHost, c->stream));
+            if (s->task == BQ_SVR)
+                BQ_HIP(hipMemcpyAsync(out + s->n, s->am, sizeof(double) * s->n, hipMemcpyDeviceToHost, c->stream));
+            break;
+        case BQ_SMO_ERRORS:
+            BQ_HIP(hipMemcpyAsync(out, s->err, sizeof(double) * s->n, hipMemcpyDeviceToHost, c->stream));
+            break;
+        case BQ_SMO_SCALARS:
+            out[0] = s->host.b_up;
+            out[1] = s->host.b_low;
+            out[2] = (double)s->host.i_up;
+            out[3] = (double)s->host.i_low;
+            out[4] = (double)s->host.steps;
+            out[5] = s->task == BQ_SVC ? -(s->host.b_low + s->host.b_up) / 2 : (s->host.b_low + s->host.b_up) / 2;
+            break;
+        default:
+            bq_set_error("bad argument: what");
+            return BQ_ERR_BADARG;
+    }
+    BQ_HIP(hipStreamSynchronize(c->stream));
+    return BQ_OK;
+}

@@ -8,6 +8,8 @@ SVC :366-419, SVR :907-963).  Two dual branches are implemented:
     dual=True, optimizer in {StochasticGradientDescent, Adam, AMSGrad, AdaMax, AdaGrad, AdaDelta, RMSProp}
         on the augmented Lagrangian of the dual, reg_intercept True or False, all four losses
         (SVC.fit :638-723, :776-860; SVR.fit :1188-1270, :1330-1415) — SURVEY 8(f).3
+    dual=True, reg_intercept=False, optimizer='smo' (or SMO): SMOClassifier / SMORegression on the resident panel
+        (SVC.fit :560-573, SVR.fit :1106-1120) — SURVEY 8(f).4
 
 In both the Gram panel is built and kept in HBM, the Wolfe dual never exists as an n x n host matrix
 (`self.obj` is a lazy `KernelQuadratic`), and the support-vector / intercept post-processing uses one masked
@@ -24,6 +26,7 @@ from ...opti import Optimizer, KernelQuadratic
 from ...opti.constrained import BoxConstrainedQuadraticOptimizer, ProjectedGradient, AugmentedLagrangianQuadratic
 from ...opti.unconstrained.stochastic import StochasticOptimizer, StochasticMomentumOptimizer
 from .kernels import Kernel, LinearKernel, gaussian, BaseEstimator
+from .smo import SMO, SMOClassifier, SMORegression
 from .losses import (Hinge, SquaredHinge, EpsilonInsensitive, SquaredEpsilonInsensitive,
                      squared_hinge, squared_epsilon_insensitive)
 
@@ -83,7 +86,8 @@ class SVM(BaseEstimator, ABC):
         if not isinstance(dual, bool):
             raise ValueError('dual must be a boolean value')
         self.dual = dual
-        if not (isinstance(optimizer, str) or (isinstance(optimizer, type) and issubclass(optimizer, Optimizer))):
+        if not (isinstance(optimizer, str) or (isinstance(optimizer, type) and
+                                               (issubclass(optimizer, Optimizer) or issubclass(optimizer, SMO)))):
             raise TypeError(f'{optimizer} is not an allowed optimization method')
         self.optimizer = optimizer
         self.master_solver = master_solver
@@ -141,6 +145,9 @@ class SVM(BaseEstimator, ABC):
             self.train_loss_history.append(opt.f_x)
 
     _store_train_info._bq_needs_state = False  # reads opt.f_x only: replayed from the device iteration records
+
+    def _is_smo(self):
+        return self.dual and (self.optimizer == 'smo' or self.optimizer is SMO)
 
     def _is_stochastic(self):
         return self.dual and isinstance(self.optimizer, type) and issubclass(self.optimizer, StochasticOptimizer)
@@ -213,7 +220,14 @@ class SVC(ClassifierMixin, SVM):
         y = np.where(y == self.classes_[-1], 1., -1.)
         X = np.ascontiguousarray(X, dtype=float)
         n = len(y)
-        if self._is_stochastic():
+        if self._is_smo():
+            if self.loss != Hinge or self.reg_intercept:
+                raise NotImplementedError('SMO solves the hinge dual with an unregularised intercept')   # :571-573
+            obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage, rank_one=False)
+            self.obj = obj
+            self.optimizer = SMOClassifier(obj, X, y, None, self.kernel, self.C, self.tol, self.verbose).minimize()
+            self.alphas_ = self.optimizer.alphas
+        elif self._is_stochastic():
             if self.loss not in (Hinge, SquaredHinge):
                 raise TypeError(f'{self.loss} is not an allowed loss')
             sq = self.loss == SquaredHinge   # Q += I/(2C), no upper bound (svm/_base.py:727-730, :778-794)
@@ -234,6 +248,11 @@ class SVC(ClassifierMixin, SVM):
         self.support_ = np.arange(len(self.alphas_))[sv]
         self.support_vectors_, sv_y, alphas = X[sv], y[sv], self.alphas_[sv]
         self.dual_coef_ = alphas * sv_y
+        if isinstance(self.optimizer, SMOClassifier):   # svm/_base.py:569-571, :872
+            if isinstance(self.kernel, LinearKernel):
+                self.coef_ = self.optimizer.w
+            self.intercept_ = self.optimizer.b
+            return self
         if isinstance(self.kernel, LinearKernel):
             self.coef_ = np.dot(self.dual_coef_, self.support_vectors_)
         self.intercept_ += self._intercept_sum(obj, sv, self.dual_coef_, sv_y)
@@ -275,7 +294,15 @@ class SVR(RegressorMixin, SVM):
         X = np.ascontiguousarray(X, dtype=float)
         n = len(y)
         q = np.hstack((-y, y)) + self.epsilon
-        if self._is_stochastic():
+        if self._is_smo():
+            if self.loss != EpsilonInsensitive or self.reg_intercept:
+                raise NotImplementedError('SMO solves the epsilon-insensitive dual with an unregularised intercept')
+            obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage, rank_one=False)
+            self.obj = obj
+            self.optimizer = SMORegression(obj, X, y, None, self.kernel, self.C, self.epsilon, self.tol,
+                                           self.verbose).minimize()
+            self.alphas_ = np.concatenate((self.optimizer.alphas_p, self.optimizer.alphas_n))
+        elif self._is_stochastic():
             if self.loss not in (EpsilonInsensitive, SquaredEpsilonInsensitive):
                 raise TypeError(f'{self.loss} is not an allowed loss')
             sq = self.loss == SquaredEpsilonInsensitive   # Q += I/(2C), no upper bound (svm/_base.py:1279-1283, :1332-1348)
@@ -299,6 +326,11 @@ class SVR(RegressorMixin, SVM):
         self.support_ = np.arange(len(alphas_p))[sv]
         self.support_vectors_, sv_y, alphas_p, alphas_n = X[sv], y[sv], alphas_p[sv], alphas_n[sv]
         self.dual_coef_ = alphas_p - alphas_n
+        if isinstance(self.optimizer, SMORegression):   # svm/_base.py:1116-1118, :1428
+            if isinstance(self.kernel, LinearKernel):
+                self.coef_ = self.optimizer.w
+            self.intercept_ = self.optimizer.b
+            return self
         if isinstance(self.kernel, LinearKernel):
             self.coef_ = np.dot(self.dual_coef_, self.support_vectors_)
         self.intercept_ += self._intercept_sum(obj, sv, self.dual_coef_, sv_y)

@@ -251,3 +251,59 @@ def test_al_tolerance_stop(golden):
     res = ao.minimize(ao.AugLag(Q, q, a=a, lb=lb, ub=ub, rho=rho), g['rules_x0'], 'adagrad', epochs=20000, tol=2e-3,
                       step_size=1., keep=(1, 10))
     _cmp_al(res, g, 'tol_adagrad')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SMO (oracle/smo_oracle.py)
+# ---------------------------------------------------------------------------------------------------------------
+from oracle import smo_oracle as smo  # noqa: E402
+
+SMO_SVC = [(n, k, t) for n in (200, 600) for k in ('rbf', 'linear') for t in ('0.001', '0.0001')]
+SMO_SVR = [(n, k, t) for n in (150, 400) for k in ('rbf', 'linear') for t in ('0.001', '0.0001')
+           if not (n == 400 and k == 'linear' and t == '0.0001')]   # 11 572 sweeps in Python: kept for the GPU test
+
+
+class _Snap:
+    def __init__(self, keys):
+        self.keys, self.rows, self.up, self.low = keys, [], [], []
+
+    def __call__(self, it, s):
+        if it < 40:
+            self.rows.append(np.concatenate([getattr(s, k) for k in self.keys]))
+            self.up.append(s.b_up)
+            self.low.append(s.b_low)
+
+
+def _cmp_smo(res, snap, g, p, keys):
+    assert res['iter'] == int(g[p + '_iter']) and res['finished']
+    for k in keys:
+        np.testing.assert_allclose(res[k], g[p + '_' + k], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res['b'], float(g[p + '_b']), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose([res['b_up'], res['b_low']], [float(g[p + '_b_up']), float(g[p + '_b_low'])], rtol=1e-9)
+    np.testing.assert_allclose(res['errors'], g[p + '_errors'], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(np.stack(snap.rows), g[p + '_outer_alphas'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(snap.up, g[p + '_outer_b_up'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(snap.low, g[p + '_outer_b_low'], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('n,kname,tol', SMO_SVC + [(200, 'rbf', 'C10')])
+def test_smo_classifier(golden, n, kname, tol):
+    g = golden('smo.npz')
+    X, y = g[f'svc{n}_X'], g[f'svc{n}_y']
+    yb = np.where(y == np.unique(y)[-1], 1., -1.)
+    K = so.gram(kname, X)
+    snap = _Snap(('a',))
+    if tol == 'C10':
+        res, p = smo.smo_svc(K, yb, C=10., tol=1e-3, spy=snap), f'svc{n}_{kname}_C10'
+    else:
+        res, p = smo.smo_svc(K, yb, C=1., tol=float(tol), spy=snap), f'svc{n}_{kname}_tol{tol}'
+    _cmp_smo(res, snap, g, p, ('alphas',))
+
+
+@pytest.mark.parametrize('n,kname,tol', SMO_SVR)
+def test_smo_regression(golden, n, kname, tol):
+    g = golden('smo.npz')
+    X, y = g[f'svr{n}_X'], g[f'svr{n}_y']
+    snap = _Snap(('ap', 'an'))
+    res = smo.smo_svr(so.gram(kname, X), y, C=1., epsilon=0.1, tol=float(tol), spy=snap)
+    _cmp_smo(res, snap, g, f'svr{n}_{kname}_tol{tol}', ('alphas_p', 'alphas_n'))

@@ -417,13 +417,116 @@ def gen_lagrangian(out):
     np.savez_compressed(os.path.join(out, 'fit_al_svr_n150.npz'), **data)
 
 
+def gen_smo(out):
+    """SMO (optiml/ml/svm/smo.py) through SVC.fit / SVR.fit(dual=True, optimizer='smo').  The state
+    after every outer iteration is captured through the objective the reference evaluates for its verbose line."""
+    import io
+    from optiml.ml.svm import smo as ref_smo
+    KEEP = 40   # outer iterations whose state is stored (the final state is always stored)
+
+    class Spy:
+        """records (alphas, b_up, b_low, errors) whenever SMO evaluates its cost line (once per outer iteration)"""
+
+        def __init__(self):
+            self.opt = None
+            self.alphas, self.b_up, self.b_low = [], [], []
+
+        def function(self, x):
+            self.alphas.append(np.array(x, dtype=float, copy=True))
+            self.b_up.append(float(self.opt.b_up))
+            self.b_low.append(float(self.opt.b_low))
+            return 0.
+
+    def run_svc(X, y, kern, C, tol):
+        yb = np.where(y == np.unique(y)[-1], 1., -1.)
+        K = kern(X)
+        spy = Spy()
+        opt = ref_smo.SMOClassifier(spy, X, yb, K, kern, C, tol, verbose=1)
+        spy.opt = opt
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt.minimize()
+        rec = {'alphas': opt.alphas.copy(), 'b': float(opt.b), 'iter': int(opt.iter), 'b_up': float(opt.b_up),
+               'b_low': float(opt.b_low), 'errors': opt.errors.copy(), 'outer_alphas': np.stack(spy.alphas[:KEEP]),
+               'outer_b_up': np.array(spy.b_up[:KEEP]), 'outer_b_low': np.array(spy.b_low[:KEEP])}
+        if isinstance(kern, LinearKernel):
+            rec['w'] = np.asarray(opt.w, dtype=float)
+        return rec
+
+    def run_svr(X, y, kern, C, eps, tol):
+        K = kern(X)
+        spy = Spy()
+        opt = ref_smo.SMORegression(spy, X, y, K, kern, C, eps, tol, verbose=1)
+        spy.opt = opt
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt.minimize()
+        rec = {'alphas_p': opt.alphas_p.copy(), 'alphas_n': opt.alphas_n.copy(), 'b': float(opt.b),
+               'iter': int(opt.iter), 'b_up': float(opt.b_up), 'b_low': float(opt.b_low), 'errors': opt.errors.copy(),
+               'outer_alphas': np.stack(spy.alphas[:KEEP]), 'outer_b_up': np.array(spy.b_up[:KEEP]),
+               'outer_b_low': np.array(spy.b_low[:KEEP])}
+        if isinstance(kern, LinearKernel):
+            rec['w'] = np.asarray(opt.w, dtype=float)
+        return rec
+
+    data = {}
+    for n, d in ((200, 6), (600, 10)):
+        X, y = make_blobs(n, d, seed=400 + n, sigma=6.0)
+        data.update({f'svc{n}_X': X, f'svc{n}_y': y})
+        for kname, kern in (('rbf', gaussian), ('linear', linear)):
+            for tol in (1e-3, 1e-4):
+                r = run_svc(X, y, kern, 1.0, tol)
+                tag = f'svc{n}_{kname}_tol{tol:g}'
+                data.update(flat(tag, r))
+                print(f"  {tag}: outer={r['iter']} nsv={(r['alphas'] > 1e-6).sum()} b={r['b']:.8f}")
+    r = run_svc(data['svc200_X'], data['svc200_y'], gaussian, 10.0, 1e-3)
+    data.update(flat('svc200_rbf_C10', r))
+    print(f"  svc200_rbf_C10: outer={r['iter']} b={r['b']:.8f}")
+    for n, d in ((150, 5), (400, 8)):
+        X, y = make_regression(n, d, seed=500 + n)
+        data.update({f'svr{n}_X': X, f'svr{n}_y': y})
+        for kname, kern in (('rbf', gaussian), ('linear', linear)):
+            for tol in (1e-3, 1e-4):
+                r = run_svr(X, y, kern, 1.0, 0.1, tol)
+                tag = f'svr{n}_{kname}_tol{tol:g}'
+                data.update(flat(tag, r))
+                print(f"  {tag}: outer={r['iter']} nsv={((r['alphas_p'] > 1e-6) | (r['alphas_n'] > 1e-6)).sum()} "
+                      f"b={r['b']:.8f}")
+    np.savez_compressed(os.path.join(out, 'smo.npz'), **data)
+
+    # end to end through SVC.fit / SVR.fit (optiml/ml/tests/test_svc.py:71-79, test_svr.py:86-94)
+    X, y = make_blobs(300, 6, seed=450, sigma=6.0)
+    Xte, _ = make_blobs(32, 6, seed=1250, sigma=6.0)
+    data = {'X': X, 'y': y, 'Xtest': Xte}
+    for kname, kern in (('rbf', gaussian), ('linear', linear)):
+        est = SVC(loss=hinge, kernel=kern, C=1., dual=True, optimizer='smo').fit(X, y)
+        rec = {'alphas': est.alphas_, 'support': est.support_, 'dual_coef': est.dual_coef_,
+               'intercept': float(est.intercept_), 'iter': int(est.optimizer.iter),
+               'decision': est.decision_function(Xte)}
+        if kname == 'linear':
+            rec['coef'] = np.asarray(est.coef_, dtype=float)
+        data.update(flat('svc_' + kname, rec))
+        print(f"  fit svc {kname}: outer={rec['iter']} nsv={len(est.support_)} b={rec['intercept']:.8f}")
+    Xr, yr = make_regression(250, 5, seed=550)
+    Xrt, _ = make_regression(32, 5, seed=1350)
+    data.update(Xr=Xr, yr=yr, Xrtest=Xrt)
+    for kname, kern in (('rbf', gaussian), ('linear', linear)):
+        est = SVR(loss=epsilon_insensitive, epsilon=0.1, kernel=kern, C=1., dual=True, optimizer='smo').fit(Xr, yr)
+        rec = {'alphas': est.alphas_, 'support': est.support_, 'dual_coef': est.dual_coef_,
+               'intercept': float(est.intercept_), 'iter': int(est.optimizer.iter),
+               'decision': est.decision_function(Xrt)}
+        if kname == 'linear':
+            rec['coef'] = np.asarray(est.coef_, dtype=float)
+        data.update(flat('svr_' + kname, rec))
+        print(f"  fit svr {kname}: outer={rec['iter']} nsv={len(est.support_)} b={rec['intercept']:.8f}")
+    np.savez_compressed(os.path.join(out, 'fit_smo.npz'), **data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(REPO, 'tests', 'golden'))
     ap.add_argument('--only', default=None, help='run a single generator, e.g. gen_kernels_more')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    for fn in (gen_unit_problems, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5, gen_lagrangian):
+    for fn in (gen_unit_problems, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5, gen_lagrangian, gen_smo):
         if args.only and fn.__name__ != args.only:
             continue
         print(fn.__name__)
