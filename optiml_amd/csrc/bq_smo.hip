@@ -5,8 +5,9 @@
 // regression (:386-797, Shevade et al.).  The algorithm is a sequential sweep over the samples with data-dependent
 // control flow, so it is latency-bound, not bandwidth-bound: ONE persistent 1024-thread workgroup runs a whole outer
 // iteration per launch.  Thread 0 carries the scalar pair logic; all threads share the three vector jobs of an examine:
-//   (1) E_i = sum_j coef_j K[i][j] for a sample whose error is not cached — only rows j with a non-zero multiplier are
-//       fetched from the panel (the dense dot of the reference touches all n entries of K[i]);
+//   (1) E_i = sum_j coef_j K[i][j] for a sample whose error is not cached — over a compact, ascending list of the
+//       samples with a non-zero coefficient (rebuilt by a block-wide compaction whenever a pair step changes it), so an
+//       examine costs O(n_sv / 1024) loads per thread instead of the reference's dense O(n) dot;
 //   (2) the error-cache update of the free set after a successful pair step (two panel rows);
 //   (3) the re-computation of the two thresholds over the free set.
 // The index sets I0..I4 of the reference are functions of (alpha, y) and are not stored.
@@ -34,6 +35,7 @@ struct bq_smo {
     int64_t n = 0;
     double C = 1.0, eps = 0.0, tol = 1e-3;
     double *y = nullptr, *a = nullptr, *am = nullptr, *err = nullptr;   // a: alpha (SVC) / alpha+ (SVR); am: alpha-
+    int *nz = nullptr;                                                   // n: support list (ascending indices)
     bq_smo_scal *sc = nullptr;
     bq_smo_scal host;
 };
@@ -104,17 +106,70 @@ struct SmoShared {
     long long i_up, i_low;
     // broadcast slots of the current examine
     double E2, c1, c2;
-    long long i1;
-    int go, took, fail;
+    long long i1, next;
+    int go, rebuild, fail;
+    int nnz;                      // length of the support list
+    int scan[SMO_T / 64];
 };
+
+// exclusive prefix sum of one int per thread (wave scan, then the 16 wave totals); *total gets the block sum
+__device__ __forceinline__ int smo_bscan(int v, int *sh, int *total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SMO_T / 64; ++w) {
+        if (w < wv) base += sh[w];
+        tot += sh[w];
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// ascending list of the samples whose coefficient is non-zero (thread t compacts the contiguous chunk t)
+template <typename Pred>
+__device__ __forceinline__ void smo_rebuild(int64_t n, int *__restrict__ nz, SmoShared &S, Pred nonzero) {
+    const int64_t chunk = (n + SMO_T - 1) / SMO_T;
+    const int64_t lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int cnt = 0;
+#pragma unroll 4
+    for (int64_t j = lo; j < hi; ++j) cnt += nonzero(j) ? 1 : 0;
+    int total;
+    int pos = smo_bscan(cnt, S.scan, &total);
+    for (int64_t j = lo; j < hi; ++j)
+        if (nonzero(j)) nz[pos++] = (int)j;
+    if (threadIdx.x == 0) S.nnz = total;
+    __syncthreads();
+}
+
+// smallest index >= from that satisfies pred, or n (all threads get the same answer)
+template <typename Pred>
+__device__ __forceinline__ int64_t smo_next(int64_t from, int64_t n, SmoShared &S, Pred pred) {
+    for (int64_t base = from; base < n; base += SMO_T) {
+        const int64_t j = base + threadIdx.x;
+        ValIdx c{0.0, (j < n && pred(j)) ? (long long)j : -1};
+        // all values equal: the reduction returns the smallest valid index
+        c = smo_bbest(c, -1, S.bv, S.bi);
+        if (c.i >= 0) return c.i;
+    }
+    return n;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // classification (smo.py:130-319)
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
-                                                        double *a, double *err, double C, double tol,
-                                                        bq_smo_scal *sc) {
+                                                        double *a, double *err, int *nz, double C,
+                                                        double tol, bq_smo_scal *sc) {
     __shared__ SmoShared S;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -128,19 +183,23 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
     if (sc->finished) return;
     const bool sweep_all = sc->sweep_all != 0;
     long long changed = 0, steps = 0;
-    for (int64_t i2 = 0; i2 < n; ++i2) {
+    auto nonzero = [&](int64_t j) { return a[j] != 0.0; };
+    auto isfree = [&](int64_t j) { const double v = a[j]; return v > 0.0 && v < C; };
+    smo_rebuild(n, nz, S, nonzero);
+    // all samples in turn, or only the free ones (re-evaluated as the sweep goes, smo.py:336-338)
+    int64_t i2 = sweep_all ? 0 : smo_next(0, n, S, isfree);
+    while (i2 < n) {
         const double a2 = a[i2], y2 = y[i2];
         const bool free2 = a2 > 0.0 && a2 < C;
-        if (!sweep_all && !free2) continue;                      // uniform
         __syncthreads();   // every thread has read a[i2] before thread 0 may overwrite it below
         const bool up2 = (y2 == 1.0 && a2 == 0.0) || (y2 == -1.0 && a2 == C);     // I1 or I2
         const bool low2 = (y2 == 1.0 && a2 == C) || (y2 == -1.0 && a2 == 0.0);    // I3 or I4
         // ---- E2 (smo.py:279-291) ----------------------------------------------------------------------------
         if (!free2) {
             double part = 0.0;
-            for (int64_t j = tid; j < n; j += SMO_T) {
-                const double aj = a[j];
-                if (aj != 0.0) part = part + __dmul_rn(__dmul_rn(aj, y[j]), K.at(i2, j));   // no fma: see smo_bsum
+            for (int q = tid; q < S.nnz; q += SMO_T) {
+                const int64_t j = nz[q];
+                part = part + __dmul_rn(__dmul_rn(a[j], y[j]), K.at(i2, j));   // no fma: see smo_bsum
             }
             const double dot = smo_bsum(part, S.red);
             if (tid == 0) {
@@ -196,6 +255,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                         n1 = n1 > C - __dmul_rn(1e-8, C) ? C : (n1 <= __dmul_rn(1e-8, C) ? 0.0 : n1);
                         a[i1] = n1;
                         a[i2] = n2;
+                        S.rebuild = ((a1 == 0.0) != (n1 == 0.0)) || ((a2 == 0.0) != (n2 == 0.0));
                         S.c1 = c1;
                         S.c2 = c2;
                         S.i1 = i1;
@@ -208,10 +268,12 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
         __syncthreads();
         if (S.go) {
             // ---- error cache of the free set + thresholds over the free set (smo.py:199-201, :241-252) -----------
+            if (S.rebuild) smo_rebuild(n, nz, S, nonzero);   // uniform; the list now reflects the new multipliers
             const long long i1 = S.i1;
             const double c1 = S.c1, c2 = S.c2;
             ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
-            for (int64_t j = tid; j < n; j += SMO_T) {
+            for (int q = tid; q < S.nnz; q += SMO_T) {   // the free set is a subset of the support list
+                const int64_t j = nz[q];
                 const double aj = a[j];
                 if (aj > 0.0 && aj < C) {
                     double e = err[j];
@@ -265,6 +327,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
             changed = 0;
             break;
         }
+        i2 = sweep_all ? i2 + 1 : smo_next(i2 + 1, n, S, isfree);
     }
     if (tid == 0) {
         sc->b_up = S.b_up;
@@ -307,8 +370,8 @@ __device__ __forceinline__ long long svr_pick(const SmoShared &S, double vlow, d
 
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
-                                                        double *ap, double *an, double *err, double C,
-                                                        double eps, double tol, bq_smo_scal *sc) {
+                                                        double *ap, double *an, double *err, int *nz,
+                                                        double C, double eps, double tol, bq_smo_scal *sc) {
     __shared__ SmoShared S;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -322,16 +385,19 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
     if (sc->finished) return;
     const bool sweep_all = sc->sweep_all != 0;
     long long changed = 0, steps = 0;
-    for (int64_t i2 = 0; i2 < n; ++i2) {
+    auto nonzero = [&](int64_t j) { return ap[j] != 0.0 || an[j] != 0.0; };   // a superset of the free set
+    auto isfree = [&](int64_t j) { return svr_kind(ap[j], an[j], C) == 0; };
+    smo_rebuild(n, nz, S, nonzero);
+    int64_t i2 = sweep_all ? 0 : smo_next(0, n, S, isfree);
+    while (i2 < n) {
         const double p2 = ap[i2], m2 = an[i2];
         const int k2 = svr_kind(p2, m2, C);
-        if (!sweep_all && k2 != 0) continue;   // uniform
         __syncthreads();   // every thread has read ap/an[i2] before thread 0 may overwrite them below
         if (k2 != 0) {
             double part = 0.0;
-            for (int64_t j = tid; j < n; j += SMO_T) {
-                const double cj = ap[j] - an[j];
-                if (cj != 0.0) part = part + __dmul_rn(cj, K.at(i2, j));
+            for (int q = tid; q < S.nnz; q += SMO_T) {
+                const int64_t j = nz[q];
+                part = part + __dmul_rn(ap[j] - an[j], K.at(i2, j));
             }
             const double dot = smo_bsum(part, S.red);
             if (tid == 0) {
@@ -449,10 +515,13 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
                     const double c1 = (p1o - m1o) - (p1 - m1), c2 = (p2 - m2) - (q2 - r2);
                     err[i1] = err[i1] + (__dmul_rn(c1, k11) + __dmul_rn(c2, k12));
                     err[i2] = E2 + (__dmul_rn(c1, k12) + __dmul_rn(c2, k22));
-                    ap[i1] = svr_clip(p1, C);
-                    an[i1] = svr_clip(m1, C);
-                    ap[i2] = svr_clip(q2, C);
-                    an[i2] = svr_clip(r2, C);
+                    const double np1 = svr_clip(p1, C), nm1 = svr_clip(m1, C), np2 = svr_clip(q2, C), nm2 = svr_clip(r2, C);
+                    ap[i1] = np1;
+                    an[i1] = nm1;
+                    ap[i2] = np2;
+                    an[i2] = nm2;
+                    S.rebuild = ((p1o != 0.0 || m1o != 0.0) != (np1 != 0.0 || nm1 != 0.0)) ||
+                                ((p2 != 0.0 || m2 != 0.0) != (np2 != 0.0 || nm2 != 0.0));
                     S.c1 = c1;
                     S.c2 = c2;
                     S.i1 = i1;
@@ -463,10 +532,12 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
         }
         __syncthreads();
         if (S.go) {
+            if (S.rebuild) smo_rebuild(n, nz, S, nonzero);   // uniform
             const long long i1 = S.i1;
             const double c1 = S.c1, c2 = S.c2;
             ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
-            for (int64_t j = tid; j < n; j += SMO_T) {
+            for (int q = tid; q < S.nnz; q += SMO_T) {
+                const int64_t j = nz[q];
                 const double pj = ap[j], mj = an[j];
                 const bool pin = pj > 0.0 && pj < C, nin = mj > 0.0 && mj < C;
                 if (pin || nin) {
@@ -533,6 +604,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
             changed = 0;
             break;
         }
+        i2 = sweep_all ? i2 + 1 : smo_next(i2 + 1, n, S, isfree);
     }
     if (tid == 0) {
         sc->b_up = S.b_up;
@@ -556,7 +628,7 @@ extern "C" int bq_smo_destroy(bq_smo *s) {
     if (s == nullptr) return BQ_OK;
     hipSetDevice(s->p->ctx->device);
     hipStreamSynchronize(s->p->ctx->stream);
-    for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->sc})
+    for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->nz, (void *)s->sc})
         if (ptr) hipFree(ptr);
     delete s;
     return BQ_OK;
@@ -598,6 +670,7 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
         if (e == hipSuccess) e = hipMalloc(v, sizeof(double) * n);
         if (e == hipSuccess) e = hipMemsetAsync(*v, 0, sizeof(double) * n, c->stream);
     }
+    if (e == hipSuccess) e = hipMalloc(&s->nz, sizeof(int) * n);
     if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_smo_scal));
     if (e == hipSuccess) e = hipMemcpyAsync(s->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
     memset(&s->host, 0, sizeof(s->host));
@@ -635,17 +708,17 @@ extern "C" int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, in
         if (s->task == BQ_SVC) {
             if (p->storage == BQ_F64)
                 smo_svc_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
-                                                                    s->a, s->err, s->C, s->tol, s->sc);
+                                                                    s->a, s->err, s->nz, s->C, s->tol, s->sc);
             else
                 smo_svc_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
-                                                                  s->a, s->err, s->C, s->tol, s->sc);
+                                                                  s->a, s->err, s->nz, s->C, s->tol, s->sc);
         } else {
             if (p->storage == BQ_F64)
                 smo_svr_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
-                                                                    s->a, s->am, s->err, s->C, s->eps, s->tol, s->sc);
+                                                                    s->a, s->am, s->err, s->nz, s->C, s->eps, s->tol, s->sc);
             else
                 smo_svr_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
-                                                                  s->a, s->am, s->err, s->C, s->eps, s->tol, s->sc);
+                                                                  s->a, s->am, s->err, s->nz, s->C, s->eps, s->tol, s->sc);
         }
         BQ_HIP(hipGetLastError());
         BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_smo_scal), hipMemcpyDeviceToHost, c->stream));
