@@ -59,15 +59,24 @@ __global__ __launch_bounds__(256, 2) void trsm_gemm_kernel(double *__restrict__ 
 // A_ij -= X_i X_j^T over the lower-triangular tiles (ti >= tj) of the trailing matrix starting at i0; X is the k-major
 // image Wt with kdim rows (128, or 256 when two factored block columns are applied in one pass: twice the flops per
 // byte of C-tile traffic)
+// Tile order: the 128 x 128 tiles are grouped into 8 x 8 super-tiles and every super-tile is dealt to ONE XCD (workgroups
+// go round-robin over the 8 XCDs by block id).  An XCD runs 64 workgroups at a time (32 CUs x 2), i.e. one super-tile:
+// its 8 row slices + 8 column slices of the image (16 x 256 KiB at K = 256) fit the XCD's 4 MiB L2 and are each reused
+// 8 times, instead of every tile streaming its own column slice from HBM/MALL (row-major order: 64 different column
+// slices in flight per XCD).  Blocks of a diagonal super-tile that fall above the diagonal exit at once.
 __global__ __launch_bounds__(256, 2) void syrk_kernel(double *__restrict__ H, int64_t ldh, int64_t i0,
-                                                      const double *__restrict__ Wt, int kdim, int64_t ntiles) {
+                                                      const double *__restrict__ Wt, int kdim, int64_t T, int64_t nsuper) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    const int64_t b = bq_xcd_remap(blockIdx.x, ntiles);
-    if (b >= ntiles) return;
-    int64_t ti = (int64_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-    while (ti * (ti + 1) / 2 > b) --ti;
-    const int64_t tj = b - ti * (ti + 1) / 2;
+    const int64_t bid = blockIdx.x, slot = bid / 8;
+    const int64_t sidx = (slot / 64) * 8 + bid % 8;
+    if (sidx >= nsuper) return;
+    int64_t si = (int64_t)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);
+    while ((si + 1) * (si + 2) / 2 <= sidx) ++si;
+    while (si * (si + 1) / 2 > sidx) --si;
+    const int64_t sj = sidx - si * (si + 1) / 2;
+    const int local = (int)(slot % 64);
+    const int64_t ti = 8 * si + local / 8, tj = 8 * sj + local % 8;
+    if (ti >= T || tj > ti) return;
     const int64_t arow = i0 + ti * NB, bcol = i0 + tj * NB;
     bq_d4 acc[4][4];
     double *Ct = H + arow * ldh + bcol;
@@ -202,11 +211,13 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
         bq_chol_ws_destroy(ws);
         return BQ_ERR_HIP;
     }
-    // look-ahead streams: OPT-IN (BQ_CHOL_LOOKAHEAD=1).  Measured +9 % at n = 32 768, nothing at n = 50 000, and one run
-    // at n = 16 384 did not finish within its 300 s limit (cause not yet established), so the default is the
-    // single-stream order.  Any failure to create the masked streams also falls back to it.
+    // Look-ahead: the narrow work of pass p+1 is issued on a high-priority stream beside the wide update of pass p
+    // (BQ_CHOL_LOOKAHEAD=2, the default; =0 issues everything in order on one stream; =1 uses CU-masked streams and is
+    // experimental: one run with it at n = 16 384 did not finish within its limit).  Measured +5 % at n = 50 000: the
+    // diagonal-block kernel needs a whole free CU (136 KB of LDS, 8 waves) and the wide update keeps every CU's
+    // register file full, so the priority stream mostly gets its turn in the tail of the wide kernel.
     const char *la = getenv("BQ_CHOL_LOOKAHEAD");
-    const int la_mode = la != nullptr ? atoi(la) : 0;   // 1: CU-masked streams, 2: priority streams (narrow work high)
+    const int la_mode = la != nullptr ? atoi(la) : 2;   // 0: off, 1: CU-masked streams, 2: priority streams (default)
     if (la_mode != 0 && ctx->num_cu >= 64) {
         bool ok;
         if (la_mode == 2) {
@@ -295,7 +306,8 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
         const int64_t r0 = 2 * p * NB + 4 * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
-        syrk_kernel<<<bq_xcd_grid(T * (T + 1) / 2), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T * (T + 1) / 2);
+        const int64_t S = (T + 7) / 8, nsuper = S * (S + 1) / 2;
+        syrk_kernel<<<(unsigned)(((nsuper + 7) / 8) * 8 * 64), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T, nsuper);
     };
     const int64_t npass = (np + 2 * NB - 1) / (2 * NB);
     if (!ws->lookahead || np < 16 * NB) {
