@@ -230,6 +230,12 @@ def main():
     ex_ms, ex_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
 
     esz = 8 if args.storage == 'f64' else 4
+    probe = (0.0, 0.0)
+    if rank == 0:
+        try:   # outside the timed region: what a plain streaming read / copy reaches on this GPU (8 GiB scratch)
+            probe = ctx.probe_bandwidth(4 << 30, 5)
+        except Exception as exc:  # noqa: BLE001  (e.g. not enough free HBM beside a very large panel)
+            print(f'[bench] bandwidth probe skipped: {exc!r}', file=sys.stderr, flush=True)
     if rank == 0:
         avg_ms = mv_ms / max(mv_cnt, 1)
         # the dominant kernel is the symmetric tile product: this rank streams the 256 x 256 tiles on/below the
@@ -256,7 +262,9 @@ def main():
                          'traffic': traffic['hbm_bytes'] if traffic else None,
                          'traffic_source': traffic['source'] if traffic else None, 'avg_launch_ms': avg_ms, 'launches': mv_cnt,
                          'algorithmic_bytes_per_launch': alg_bytes, 'tiles_per_launch': tiles,
-                         'row_block_equivalent_GBs': full_equiv},
+                         'row_block_equivalent_GBs': full_equiv, 'measured_stream_read_GBs': probe[0],
+                         'measured_copy_GBs': probe[1],
+                         'frac_of_measured_stream_read': (achieved / probe[0]) if probe[0] else None},
             'steps_done': done, 'solver_status': status,
             'f_last': float(rows['f'][-1]) if done else None,
             'kkt_resid_last': float(rows['r1'][-1]) if done and args.solver == 'pg' else None,

@@ -94,6 +94,9 @@ int bq_ctx_info(const bq_ctx *ctx, int *device, int *rank, int *world, char *nam
  * product, 1 = Gram build, 2 = Cholesky factorisation, 3 = row-block exchange. */
 int bq_ctx_profile(bq_ctx *ctx, int enable);
 int bq_ctx_profile_read(bq_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
+/* measured HBM ceilings of this GPU on a scratch buffer of `bytes`: a read-only streaming sweep and a
+ * device-to-device copy (read + written bytes), in GB/s — the yardstick beside the nominal 8 TB/s */
+int bq_ctx_probe_bandwidth(bq_ctx *ctx, int64_t bytes, int reps, double *read_gbs, double *copy_gbs);
 /* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic): equal 128-aligned
  * blocks for dense panels; bq_sym_row_block: the balanced triangular partition (256-aligned) of the symmetric
  * kernel panels, whose ranks stream only the tiles on/below the diagonal */

@@ -503,6 +503,67 @@ extern "C" int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// HBM streaming probe: what a plain read-only sweep and a device-to-device copy reach on this GPU, so that a roofline
+// fraction can be quoted against the measured ceiling as well as the nominal 8 TB/s
+// ---------------------------------------------------------------------------------------------
+typedef double probe_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void probe_read_kernel(const probe_d2 *__restrict__ src, int64_t n2,
+                                                         double *__restrict__ sink) {
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const probe_d2 v = __builtin_nontemporal_load(src + i);
+        acc += v.x + v.y;
+    }
+    if (acc == 12345.678) *sink = acc;   // keeps the loads alive, practically never true
+}
+
+extern "C" int bq_ctx_probe_bandwidth(bq_ctx *c, int64_t bytes, int reps, double *read_gbs, double *copy_gbs) {
+    BQ_ARG(c && read_gbs && copy_gbs, "NULL argument");
+    BQ_ARG(bytes >= (1 << 20) && reps >= 1, "bytes >= 1 MiB, reps >= 1");
+    BQ_HIP(hipSetDevice(c->device));
+    bytes &= ~(int64_t)4095;
+    double *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&a, (size_t)bytes);
+    if (e == hipSuccess) e = hipMalloc(&b, (size_t)bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0, (size_t)bytes, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, (size_t)bytes, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms_read = 0.f, ms_copy = 0.f;
+    if (e == hipSuccess) {
+        const int64_t n2 = bytes / 16;
+        const unsigned grid = (unsigned)(c->num_cu * 16);
+        probe_read_kernel<<<grid, 256, 0, c->stream>>>((const probe_d2 *)a, n2, b);   // warm
+        hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps; ++r) probe_read_kernel<<<grid, 256, 0, c->stream>>>((const probe_d2 *)a, n2, b);
+        hipEventRecord(e1, c->stream);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_read, e0, e1);
+    }
+    if (e == hipSuccess) {
+        hipMemcpyAsync(b, a, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream);   // warm
+        hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps; ++r) hipMemcpyAsync(b, a, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream);
+        hipEventRecord(e1, c->stream);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_copy, e0, e1);
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    if (e != hipSuccess) {
+        bq_set_error("bandwidth probe failed: %s", hipGetErrorString(e));
+        return BQ_ERR_HIP;
+    }
+    *read_gbs = (double)bytes * reps / (ms_read * 1e-3) / 1e9;
+    *copy_gbs = 2.0 * (double)bytes * reps / (ms_copy * 1e-3) / 1e9;   // bytes read + bytes written
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // solvers
 // ---------------------------------------------------------------------------------------------
 static int alloc_vec(bq_solver *s, double **v) {

@@ -99,6 +99,12 @@ class Context:
         _lib.check(self._lib.bq_ctx_profile_read(self.handle, which, C.byref(ms), C.byref(cnt), 1 if reset else 0))
         return ms.value, cnt.value
 
+    def probe_bandwidth(self, nbytes=4 << 30, reps=5):
+        """(read_GBs, copy_GBs): measured streaming-read and device-copy bandwidth of this GPU."""
+        r, c = C.c_double(0), C.c_double(0)
+        _lib.check(self._lib.bq_ctx_probe_bandwidth(self.handle, int(nbytes), int(reps), C.byref(r), C.byref(c)))
+        return r.value, c.value
+
     def close(self):
         if self._h:
             self._lib.bq_ctx_destroy(self._h)
