@@ -24,36 +24,22 @@ int bq_potrf_diag_setup();
 void bq_launch_potrf_diag(hipStream_t st, double *H, int64_t ldh, int64_t k0, double *LinvT, int *info);
 
 // ---------------------------------------------------------------------------------------------
-// 2./3. block column: transpose to a k-major image, TRSM as GEMM, SYRK on the trailing triangle
+// 2./3. block column: TRSM as GEMM (which also leaves the k-major image of its result), SYRK on the trailing triangle
 // ---------------------------------------------------------------------------------------------
-// Wt[kk][i] = H[i][k0 + kk] for i in [i0, np), kk < 128
-__global__ void panel_to_image_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0, int64_t i0, int64_t np,
-                                      double *__restrict__ Wt) {
-    __shared__ double tile[32][33];
-    const int64_t r0 = i0 + (int64_t)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8) {
-        const int64_t r = r0 + j;
-        tile[j][tx] = (r < np) ? H[r * ldh + k0 + c0 + tx] : 0.0;
-    }
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
-        const int64_t r = r0 + tx;
-        if (r < np) Wt[(int64_t)(c0 + j) * ldh + r] = tile[tx][j];
-    }
-}
-
-// X = A_ik * Linv_kk^T for the row tiles below the diagonal block; written back in place
+// X = A_ik * Linv_kk^T for the row tiles below the diagonal block.  A is read straight from H (row-major operand of the
+// tile kernel: no transposing pre-pass); X is written back in place AND as the k-major image Wt[c][row] that the trailing
+// updates consume (no transposing post-pass either).
 __global__ __launch_bounds__(256, 2) void trsm_gemm_kernel(double *__restrict__ H, int64_t ldh, int64_t k0, int64_t i0,
-                                                           const double *__restrict__ Wt,
-                                                           const double *__restrict__ LinvT) {
+                                                           double *__restrict__ Wt, const double *__restrict__ LinvT) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     const int64_t arow = i0 + (int64_t)blockIdx.x * NB;
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
-    bq_mfma_tile_128(Wt, ldh, arow, LinvT, NB, 0, NB, sm, acc);
-    bq_tile_foreach(acc, [&](int r, int c, double v) { H[(arow + r) * ldh + k0 + c] = v; });
+    bq_mfma_tile_128<false, true>(H + k0, ldh, arow, LinvT, NB, 0, NB, sm, acc);
+    bq_tile_foreach(acc, [&](int r, int c, double v) {
+        H[(arow + r) * ldh + k0 + c] = v;
+        Wt[(int64_t)c * ldh + arow + r] = v;
+    });
 }
 
 // A_ij -= X_i X_j^T over the lower-triangular tiles (ti >= tj) of the trailing matrix starting at i0; X is the k-major
@@ -68,15 +54,25 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(double *__restrict__ H, in
                                                       const double *__restrict__ Wt, int kdim, int64_t T, int64_t nsuper) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     const int64_t bid = blockIdx.x, slot = bid / 8;
-    const int64_t sidx = (slot / 64) * 8 + bid % 8;
-    if (sidx >= nsuper) return;
-    int64_t si = (int64_t)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);
-    while ((si + 1) * (si + 2) / 2 <= sidx) ++si;
-    while (si * (si + 1) / 2 > sidx) --si;
-    const int64_t sj = sidx - si * (si + 1) / 2;
-    const int local = (int)(slot % 64);
-    const int64_t ti = 8 * si + local / 8, tj = 8 * sj + local % 8;
-    if (ti >= T || tj > ti) return;
+    int64_t ti, tj;
+    if (nsuper == 0) {   // small grids (a few rounds at most): plain row-major triangle, every XCD equally loaded
+        if (bid >= T * (T + 1) / 2) return;
+        ti = (int64_t)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+        while (ti * (ti + 1) / 2 > bid) --ti;
+        tj = bid - ti * (ti + 1) / 2;
+    } else {
+        const int64_t sidx = (slot / 64) * 8 + bid % 8;
+        if (sidx >= nsuper) return;
+        int64_t si = (int64_t)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);
+        while ((si + 1) * (si + 2) / 2 <= sidx) ++si;
+        while (si * (si + 1) / 2 > sidx) --si;
+        const int64_t sj = sidx - si * (si + 1) / 2;
+        const int local = (int)(slot % 64);
+        ti = 8 * si + local / 8;
+        tj = 8 * sj + local % 8;
+        if (ti >= T || tj > ti) return;
+    }
     const int64_t arow = i0 + ti * NB, bcol = i0 + tj * NB;
     bq_d4 acc[4][4];
     double *Ct = H + arow * ldh + bcol;
@@ -282,10 +278,7 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
             const int64_t i0 = k0 + NB;
             const int64_t T = (np - i0) / NB;
             const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
-            dim3 tg((unsigned)((np - i0 + 31) / 32), NB / 32);
-            panel_to_image_kernel<<<tg, 256, 0, s>>>(ws->H, ldh, k0, i0, np, Wimg);
             trsm_gemm_kernel<<<(unsigned)T, 256, 0, s>>>(ws->H, ldh, k0, i0, Wimg, LinvT);
-            panel_to_image_kernel<<<tg, 256, 0, s>>>(ws->H, ldh, k0, i0, np, Wimg);
         };
         bq_launch_potrf_diag(s, ws->H, ldh, a0, ws->LinvT + (a0 / NB) * NB * NB, ws->info);
         const int64_t b0 = a0 + NB;
@@ -306,8 +299,11 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
         const int64_t r0 = 2 * p * NB + 4 * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
-        const int64_t S = (T + 7) / 8, nsuper = S * (S + 1) / 2;
-        syrk_kernel<<<(unsigned)(((nsuper + 7) / 8) * 8 * 64), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T, nsuper);
+        const int64_t S = (T + 7) / 8, ntiles = T * (T + 1) / 2;
+        // super-tiles pay off once an XCD has many of them; below ~8 rounds of the chip the even split wins
+        const int64_t nsuper = ntiles >= 8 * 512 ? S * (S + 1) / 2 : 0;
+        const unsigned grid = nsuper ? (unsigned)(((nsuper + 7) / 8) * 8 * 64) : (unsigned)ntiles;
+        syrk_kernel<<<grid, 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T, nsuper);
     };
     const int64_t npass = (np + 2 * NB - 1) / (2 * NB);
     if (!ws->lookahead || np < 16 * NB) {

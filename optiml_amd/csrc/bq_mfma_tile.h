@@ -29,7 +29,10 @@ struct bq_tile_smem {
 // kdim must be a multiple of 16; arow/bcol multiples of 2 with arow+127 < lda, bcol+127 < ldb.
 // NEG_A: accumulate -A*B^T (the A slice is negated while it is staged), so that a kernel can start from acc = C and
 // finish with plain stores instead of a serialised read-modify-write epilogue.
-template <bool NEG_A = false>
+// A_ROWS: the A operand is NOT an image but the row-major matrix itself, element (arow + r, k) at At[(arow + r) * lda + k]
+// (16 contiguous doubles per row and chunk); it is transposed on its way into LDS.  Saves the transposing pre-pass for
+// operands that are consumed once (the TRSM input).
+template <bool NEG_A = false, bool A_ROWS = false>
 __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, int64_t lda, int64_t arow,
                                                  const double *__restrict__ Bt, int64_t ldb, int64_t bcol,
                                                  int64_t kdim, bq_tile_smem &sm, bq_d4 (&acc)[4][4]) {
@@ -41,7 +44,10 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
         for (int u = 0; u < 4; ++u) {
             const int j = tid + 256 * u;
             const int k = j >> 6, c2 = j & 63;
-            ra[u] = *reinterpret_cast<const bq_d2 *>(At + (kc + k) * lda + arow + 2 * c2);
+            if (A_ROWS)
+                ra[u] = *reinterpret_cast<const bq_d2 *>(At + (arow + (j >> 3)) * lda + kc + 2 * (j & 7));
+            else
+                ra[u] = *reinterpret_cast<const bq_d2 *>(At + (kc + k) * lda + arow + 2 * c2);
             rb[u] = *reinterpret_cast<const bq_d2 *>(Bt + (kc + k) * ldb + bcol + 2 * c2);
         }
     };
@@ -50,7 +56,13 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
         for (int u = 0; u < 4; ++u) {
             const int j = tid + 256 * u;
             const int k = j >> 6, c2 = j & 63;
-            *reinterpret_cast<bq_d2 *>(&sm.A[buf][k][2 * c2]) = NEG_A ? -ra[u] : ra[u];
+            const bq_d2 va = NEG_A ? -ra[u] : ra[u];
+            if (A_ROWS) {
+                sm.A[buf][2 * (j & 7)][j >> 3] = va.x;
+                sm.A[buf][2 * (j & 7) + 1][j >> 3] = va.y;
+            } else {
+                *reinterpret_cast<bq_d2 *>(&sm.A[buf][k][2 * c2]) = va;
+            }
             *reinterpret_cast<bq_d2 *>(&sm.B[buf][k][2 * c2]) = rb[u];
         }
     };
