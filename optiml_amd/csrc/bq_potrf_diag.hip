@@ -9,11 +9,12 @@
 // Algorithm (32-wide sub-blocks, 8 waves).  The code is kept COMPACT (runtime loops, small unroll factors): this
 // kernel runs every phase once per launch, so a fully unrolled body is bound by instruction fetch, not by math
 // (measured: 240 us unrolled).
-//   for each sub-block column: (1) wave 0 factors the 32 x 32 diagonal block and inverts its factor with rows held in
-//   registers and cross-row operands fetched by v_readlane (no LDS round trip on the sequential chain); (2) the rows below get
-//   L_ik = A_ik X_kk^T; (3) the trailing lower triangle gets A_ij -= L_ik L_jk^T in 4 x 4 register micro-tiles.
-//   Then the off-diagonal blocks of X by block forward substitution along the block sub-diagonals:
-//   X_ic = -X_ii (sum_j L_ij X_jc).
+//   for each sub-block column: (1) wave 0 factors the 32 x 32 diagonal block with rows held in registers and
+//   cross-row operands fetched by v_readlane (no LDS round trip on the sequential chain); (2) the rows below solve
+//   x L_kk^T = a in place by forward substitution, one thread per row; (3) the trailing lower triangle gets
+//   A_ij -= L_ik L_jk^T in 4 x 4 register micro-tiles.  Only then are the four 32 x 32 factors inverted — by four waves
+//   concurrently, off the factorisation's critical path — and the off-diagonal blocks of X follow by block forward
+//   substitution along the block sub-diagonals: X_ic = -X_ii (sum_j L_ij X_jc).
 // A non-positive (or NaN) pivot is reported through *info (1-based global index), like LAPACK's potrf.
 #include "bq_common.h"
 #include <type_traits>
@@ -37,6 +38,29 @@ __device__ __forceinline__ double rdlane(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
+}
+
+typedef double pd_d4 __attribute__((ext_vector_type(4)));
+
+// v of the lane (lane ^ 1) / (lane ^ 2) of the same quad, as DPP quad permutes (a few cycles; __shfl_xor goes through the
+// LDS crossbar).  CTRL: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E.
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave: 16 x 16 tile  acc = sum_{k < K} A(r, k) * B(k, c)  on v_mfma_f64_16x16x4_f64.  Operand lane map: this lane
+// supplies A(lane & 15, 4 s + (lane >> 4)) and B(4 s + (lane >> 4), lane & 15) at step s; result element v of the lane
+// is (row (lane >> 4) + 4 v, col lane & 15).  A and B are functors over LDS (any layout, incl. the triangular ones).
+template <typename FA, typename FB>
+__device__ __forceinline__ pd_d4 wave_tile16(int K, FA A, FB B) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+    pd_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A(fr, k0 + fk), B(k0 + fk, fr), acc, 0, 0, 0);
+    return acc;
 }
 
 __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ H, int64_t ldh, int64_t k0,
@@ -79,16 +103,18 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
             const int i = lane & 31;
             int bad = 0;
             double myri = 1.0;   // 1 / L[i][i]
-#pragma unroll 1
-            for (int pb = 0; pb < PS / 8; ++pb) {
-                const int c0 = 8 * pb;
+            auto panel = [&](auto tag) {
+                constexpr int c0 = decltype(tag)::value;
                 double a[8];
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc) a[cc] = D[i * PL + c0 + cc];
-                for (int k = 0; k < c0; ++k) {
-                    const double lik = D[i * PL + k];   // L[c0 + cc][k] is lane (c0 + cc)'s lik
+                double lk[c0 > 0 ? c0 : 1];   // this row's entries of the columns already factored, loaded up front
 #pragma unroll
-                    for (int cc = 0; cc < 8; ++cc) a[cc] = fma(-lik, rdlane(lik, c0 + cc), a[cc]);
+                for (int k = 0; k < c0; ++k) lk[k] = D[i * PL + k];
+#pragma unroll
+                for (int k = 0; k < c0; ++k) {   // L[c0 + cc][k] is lane (c0 + cc)'s lk[k]
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) a[cc] = fma(-lk[k], rdlane(lk[k], c0 + cc), a[cc]);
                 }
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
@@ -112,33 +138,12 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
                         if (i >= c0 + cc) D[i * PL + c0 + cc] = a[cc];
                 }
                 wave_lds_fence();
-            }
-            if (lane < 32) dinv[o + i] = myri;
-            // Inverse of the factor, X = L^-1: lane i owns row i of Y with X[i][:] = myri * Y[i][:] and
-            // Y[i][:] = e_i - sum_{k < i} L[i][k] myri_k Y[k][:]; step j subtracts row j (final by then) from the rows
-            // below it.  Y[j][c] = 0 for c > j bounds the column range of each group of 8 steps.
-            double y[PS];
-#pragma unroll
-            for (int c = 0; c < PS; ++c) y[c] = (c == i) ? 1.0 : 0.0;
-            auto steps = [&](auto tag) {
-                constexpr int J0 = decltype(tag)::value;
-#pragma unroll 1
-                for (int j = J0; j < J0 + 8; ++j) {
-                    const double m = (i > j) ? D[i * PL + j] * rdlane(myri, j) : 0.0;
-#pragma unroll
-                    for (int c = 0; c < J0 + 8; ++c) y[c] = fma(-m, rdlane(y[c], j), y[c]);
-                }
             };
-            steps(std::integral_constant<int, 0>{});
-            steps(std::integral_constant<int, 8>{});
-            steps(std::integral_constant<int, 16>{});
-            steps(std::integral_constant<int, 24>{});
-            wave_lds_fence();
-            if (lane < 32) {
-#pragma unroll
-                for (int c = 0; c < PS - 1; ++c)
-                    if (c < i) D[c * PL + i] = y[c] * myri;   // X[i][c] at its transposed home (row c, upper)
-            }
+            panel(std::integral_constant<int, 0>{});
+            panel(std::integral_constant<int, 8>{});
+            panel(std::integral_constant<int, 16>{});
+            panel(std::integral_constant<int, 24>{});
+            if (lane < 32) dinv[o + i] = myri;
             if (bad != 0 && lane == 0) *flag = bad;
         }
         __syncthreads();
@@ -147,67 +152,61 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
         const int R0 = o + PS;   // first row below the diagonal block
         const int m = PB - R0;   // rows below
         if (m == 0) break;
-        // ---- (2) panel: L[r][o + j] = sum_{t <= j} A[r][o + t] * X[o + j][o + t], X(j, t) at D[t][j] / dinv -------
+        // ---- (2) panel: the rows below solve x L_kk^T = a by forward substitution, entirely in registers.  Four lanes
+        // of one wave share a row; lane h keeps x_t for t = h (mod 4) and sums its terms of sum_{t<j} x_t L[j][t] (the
+        // factor's entries are LDS reads that do not depend on x, so they are issued ahead), two quad shuffles combine
+        // the four partial sums, every lane of the group then knows x_j.  Not-yet-computed x_t are zero, so no masking
+        // is needed.  No inverse of the sub-block is needed on the critical path. --------------------------------------
         {
-            const int r = tid >> 2, h = tid & 3;    // four threads per row, 8 outputs each, staged through W
+            const int r = tid >> 2, h = tid & 3;
             if (r < m) {
-                const double *arow = M + (R0 + r) * PL + o;
-                double acc[PS / 4];
+                double *row = M + (R0 + r) * PL + o;
+                double a[PS], x[PS / 4];
 #pragma unroll
-                for (int jj = 0; jj < PS / 4; ++jj) acc[jj] = 0.0;
-                const int jbase = h * (PS / 4);
-#pragma unroll 2
-                for (int t = 0; t < jbase + PS / 4; ++t) {
-                    const double at = arow[t];
-                    const double dt = dinv[o + t];
+                for (int j = 0; j < PS; ++j) a[j] = row[j];
 #pragma unroll
-                    for (int jj = 0; jj < PS / 4; ++jj) {
-                        const int j = jbase + jj;
-                        const double xv = (t == j) ? dt : D[t * PL + j];
-                        if (t <= j) acc[jj] = fma(at, xv, acc[jj]);
+                for (int q = 0; q < PS / 4; ++q) x[q] = 0.0;
+#pragma unroll
+                for (int j = 0; j < PS; ++j) {
+                    const double *Lj = D + j * PL + h;   // L[j][h + 4 q]
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int q = 0; 4 * q < j; ++q) {
+                        if (q & 1)
+                            s1 = fma(-x[q], Lj[4 * q], s1);
+                        else
+                            s0 = fma(-x[q], Lj[4 * q], s0);
                     }
+                    double sum = s0 + s1;
+                    sum += quad_swap<0xB1>(sum);
+                    sum += quad_swap<0x4E>(sum);
+                    const double xj = (a[j] + sum) * dinv[o + j];
+                    if (h == (j & 3)) x[j >> 2] = xj;
                 }
 #pragma unroll
-                for (int jj = 0; jj < PS / 4; ++jj) W[r * PW + jbase + jj] = acc[jj];
+                for (int q = 0; q < PS / 4; ++q) row[h + 4 * q] = x[q];
             }
-            __syncthreads();
-            for (int e = tid; e < m * PS; e += PT) M[(R0 + e / PS) * PL + o + (e % PS)] = W[(e / PS) * PW + (e % PS)];
         }
         __syncthreads();
         STAMP();
-        // ---- (3) trailing update in 4 x 4 micro-tiles of the lower triangle ---------------------------------------
+        // ---- (3) trailing update A_ij -= L_ik L_jk^T on the MFMA: one wave per 16 x 16 tile of the lower triangle ----
         {
-            const int mt = m / 4;
+            const int mt = m / 16;
             const int ntiles = mt * (mt + 1) / 2;
-            for (int idx = tid; idx < ntiles; idx += PT) {
+            const int fr = lane & 15, fk = lane >> 4;
+            for (int idx = wv; idx < ntiles; idx += PT / 64) {
                 int tr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
                 while ((tr + 1) * (tr + 2) / 2 <= idx) ++tr;
                 while (tr * (tr + 1) / 2 > idx) --tr;
                 const int tc = idx - tr * (tr + 1) / 2;
-                const int rr = R0 + 4 * tr, cc = R0 + 4 * tc;
-                double acc[4][4];
+                const double *Ar = M + (R0 + 16 * tr) * PL + o, *Bc = M + (R0 + 16 * tc) * PL + o;
+                const pd_d4 acc = wave_tile16(PS, [&](int r, int k) { return Ar[r * PL + k]; },
+                                              [&](int k, int c) { return Bc[c * PL + k]; });
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-#pragma unroll 4
-                for (int t = 0; t < PS; ++t) {
-                    double ar[4], bc[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        ar[u] = M[(rr + u) * PL + o + t];
-                        bc[u] = M[(cc + u) * PL + o + t];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[u][v] = fma(ar[u], bc[v], acc[u][v]);
+                for (int v = 0; v < 4; ++v) {
+                    const int row = R0 + 16 * tr + fk + 4 * v, col = R0 + 16 * tc + fr;
+                    if (col <= row) M[row * PL + col] -= acc[v];
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (cc + v <= rr + u) M[(rr + u) * PL + cc + v] -= acc[u][v];
             }
         }
         __syncthreads();
@@ -220,47 +219,100 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
         return;
     }
 
-    // ---- off-diagonal blocks of X = L^-1 along the block sub-diagonals ------------------------------------------------
-    // X(p, q) for p > q is M[q][p]; X(p, p) = dinv[p]; X(p, q) = 0 for p < q.
-    for (int dd = 1; dd < PB / PS; ++dd) {
-        const int nblk = PB / PS - dd;   // targets (i = c + dd, c), c = 0 .. nblk-1
-        // stage A: W_b = sum_{j = c}^{i-1} L_ij X_jc
-        for (int idx = tid; idx < nblk * PS * PS; idx += PT) {
-            const int b = idx / (PS * PS), u = (idx / PS) % PS, v = idx % PS;
-            const int c = b, i = b + dd;
-            double s0 = 0.0, s1 = 0.0;
-            for (int j = c; j < i; ++j) {
-                const double *Lrow = M + (PS * i + u) * PL + PS * j;
-                const double *Xcol = M + (PS * c + v) * PL + PS * j;   // X[32 j + t][32 c + v], t = 0..31
-                if (j == c) {
-                    // diagonal block of X: lower triangular, rows t >= v
-                    s0 = fma(Lrow[v], dinv[PS * c + v], s0);
-#pragma unroll 2
-                    for (int t = v + 1; t < PS; ++t) s1 = fma(Lrow[t], Xcol[t], s1);
-                } else {
-#pragma unroll 4
-                    for (int t = 0; t < PS; t += 2) {
-                        s0 = fma(Lrow[t], Xcol[t], s0);
-                        s1 = fma(Lrow[t + 1], Xcol[t + 1], s1);
-                    }
-                }
+    // ---- inverses of the four 32 x 32 diagonal factors, two waves each, all eight concurrently ---------------------------
+    // X = L^-1: lane i owns row i of Y with X[i][:] = ri_i * Y[i][:] and Y[i][:] = e_i - sum_{k < i} L[i][k] ri_k Y[k][:];
+    // step j subtracts row j (final by then) from the rows below it.  Y[j][c] = 0 for c > j, so the columns of the
+    // 8-column group g only change in steps j >= 8 g: a wave takes groups {0, 3} or {1, 2} — 320 column-steps either way.
+    // Cross-row operands are other lanes' registers (v_readlane).
+    {
+        const int o = (wv >> 1) * PS;
+        double *D = M + o * PL + o;
+        const int i = lane & 31;
+        const int gA = (wv & 1) ? 1 : 0, gB = (wv & 1) ? 2 : 3;   // column groups of this wave, gA < gB
+        const double myri = dinv[o + i];
+        double ya[8], yb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ya[c] = (8 * gA + c == i) ? 1.0 : 0.0;
+            yb[c] = (8 * gB + c == i) ? 1.0 : 0.0;
+        }
+#pragma unroll 1
+        for (int j = 8 * gA; j < 8 * gB; ++j) {
+            const double m = (i > j) ? D[i * PL + j] * rdlane(myri, j) : 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ya[c] = fma(-m, rdlane(ya[c], j), ya[c]);
+        }
+#pragma unroll 1
+        for (int j = 8 * gB; j < PS; ++j) {
+            const double m = (i > j) ? D[i * PL + j] * rdlane(myri, j) : 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                ya[c] = fma(-m, rdlane(ya[c], j), ya[c]);
+                yb[c] = fma(-m, rdlane(yb[c], j), yb[c]);
             }
-            W[b * PS * PW + u * PW + v] = s0 + s1;
         }
-        __syncthreads();
-        // stage B: X_ic = -X_ii W_b   (X_ii lower triangular: t <= u)
-        for (int idx = tid; idx < nblk * PS * PS; idx += PT) {
-            const int b = idx / (PS * PS), u = (idx / PS) % PS, v = idx % PS;
-            const int c = b, i = b + dd;
-            const double *Wb = W + b * PS * PW + v;
-            const double *Xii = M + PS * i * PL + PS * i + u;   // X_ii[u][t] (t < u) at M[32 i + t][32 i + u]
-            double s0 = dinv[PS * i + u] * Wb[u * PW], s1 = 0.0;
-#pragma unroll 2
-            for (int t = 0; t < u; ++t) s1 = fma(Xii[t * PL], Wb[t * PW], s1);
-            M[(PS * c + v) * PL + PS * i + u] = -(s0 + s1);   // X[32 i + u][32 c + v] at its transposed home
+        if (lane < 32) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {   // X[i][col] at its transposed home (row col, upper)
+                if (8 * gA + c < i) D[(8 * gA + c) * PL + i] = ya[c] * myri;
+                if (8 * gB + c < i) D[(8 * gB + c) * PL + i] = yb[c] * myri;
+            }
         }
-        __syncthreads();
-        STAMP();
+    }
+    __syncthreads();
+    STAMP();
+
+    // ---- off-diagonal blocks of X = L^-1 along the block sub-diagonals, on the MFMA ------------------------------------
+    // X(p, q) for p > q is M[q][p]; X(p, p) = dinv[p]; X(p, q) = 0 for p < q.  A job is one 16 x 16 quadrant of one
+    // 32 x 32 target block; the eight waves share the jobs of a stage.
+    {
+        const int fr = lane & 15, fk = lane >> 4;
+        for (int dd = 1; dd < PB / PS; ++dd) {
+            const int njobs = (PB / PS - dd) * 4;   // targets (i = c + dd, c), c = 0 .. nblk-1, four quadrants each
+            // stage A: W_b = sum_{j = c}^{i-1} L_ij X_jc
+            for (int job = wv; job < njobs; job += PT / 64) {
+                const int b = job >> 2, tr = (job >> 1) & 1, tc = job & 1;
+                const int c = b, i = b + dd;
+                pd_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int j = c; j < i; ++j) {
+                    const double *Lij = M + (PS * i + 16 * tr) * PL + PS * j;        // L_ij[16 tr + r][k]
+                    const double *Xjc = M + (PS * c + 16 * tc) * PL + PS * j;        // X_jc[k][16 tc + cc] at M[32 c + col][32 j + k]
+                    pd_d4 part;
+                    if (j == c) {   // diagonal block of X: lower triangular with dinv on the diagonal
+                        part = wave_tile16(PS, [&](int r, int k) { return Lij[r * PL + k]; },
+                                           [&](int k, int cc) {
+                                               const int col = 16 * tc + cc;
+                                               return k > col ? Xjc[cc * PL + k] : (k == col ? dinv[PS * c + col] : 0.0);
+                                           });
+                    } else {
+                        part = wave_tile16(PS, [&](int r, int k) { return Lij[r * PL + k]; },
+                                           [&](int k, int cc) { return Xjc[cc * PL + k]; });
+                    }
+                    acc += part;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) W[b * PS * PW + (16 * tr + fk + 4 * v) * PW + 16 * tc + fr] = acc[v];
+            }
+            __syncthreads();
+            // stage B: X_ic = -X_ii W_b   (X_ii lower triangular, strictly lower part at its transposed home)
+            for (int job = wv; job < njobs; job += PT / 64) {
+                const int b = job >> 2, tr = (job >> 1) & 1, tc = job & 1;
+                const int c = b, i = b + dd;
+                const double *Xii = M + PS * i * PL + PS * i;   // X_ii[u][t] (t < u) at Xii[t * PL + u]
+                const double *Wb = W + b * PS * PW + 16 * tc;
+                const pd_d4 acc = wave_tile16(PS,
+                                              [&](int r, int k) {
+                                                  const int u = 16 * tr + r;
+                                                  return k < u ? Xii[k * PL + u] : (k == u ? dinv[PS * i + u] : 0.0);
+                                              },
+                                              [&](int k, int cc) { return Wb[k * PW + cc]; });
+#pragma unroll
+                for (int v = 0; v < 4; ++v)   // X[32 i + u][32 c + col] at its transposed home
+                    M[(PS * c + 16 * tc + fr) * PL + PS * i + 16 * tr + fk + 4 * v] = -acc[v];
+            }
+            __syncthreads();
+            STAMP();
+        }
     }
 
     for (int e = tid; e < PB * PB; e += PT) {
