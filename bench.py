@@ -44,7 +44,8 @@ def parse():
                     help='adagrad: AdaGrad on the augmented Lagrangian of the reg_intercept=False dual (SURVEY 8f.3)')
     ap.add_argument('--task', default='svc', choices=['svc', 'svr'], help='svr: eps-insensitive dual, dim 2n (config 4)')
     ap.add_argument('--kernel', default='rbf', choices=['rbf', 'poly', 'linear'], help='poly: degree 3, coef0 1')
-    ap.add_argument('--storage', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--storage', default='f64', choices=['f64', 'f32', 'stream'],
+                    help='stream: no resident panel, Gram tiles recomputed on the MFMA inside every product')
     ap.add_argument('--exchange', default='rccl', choices=['rccl', 'host'])
     ap.add_argument('--cpu-n', type=int, default=12000, help='sample size of the CPU baseline leg')
     ap.add_argument('--cpu-steps', type=int, default=150)
@@ -253,7 +254,7 @@ def main():
             'metric': 'dual_qp_iterations_per_sec', 'value': done / elapsed, 'unit': 'iter/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(done, 1),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f64' if args.storage == 'f64' else 'f32-storage/f64-accumulate', 'data': 'synthetic',
+            'dtype': 'f64' if args.storage in ('f64', 'stream') else 'f32-storage/f64-accumulate', 'data': 'synthetic',
             'config': {'workload': workload, 'n': n, 'd': d, 'dual_dim': N, 'C': 1.0,
                        'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange,
                        'rows_per_gpu': r1 - r0, 'device': ctx.name},
@@ -271,6 +272,12 @@ def main():
             'gram_build_s': gram_ms * 1e-3, 'problem_setup_s': t_gram_total,
             'exchange_ms_per_step': (ex_ms / max(ex_cnt, 1)) if ex_cnt else 0.0,
         }
+        if args.storage == 'stream':   # no panel: the product is the fused Gram-tile x vector kernel, MFMA-bound
+            flops = 2.0 * (-(-(r1 - r0) // 128) * 128) * (-(-n // 128) * 128) * (-(-d // 16) * 16)
+            tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gram_stream_kernel (Gram tiles recomputed, fused with the product)',
+                               'achieved': tf, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': tf / 78.6, 'traffic': None,
+                               'avg_launch_ms': avg_ms, 'launches': mv_cnt, 'flops_per_launch': flops}
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(args)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

@@ -45,7 +45,10 @@ typedef struct bq_ctx bq_ctx;
 typedef struct bq_problem bq_problem;
 typedef struct bq_solver bq_solver;
 
-enum { BQ_F64 = 0, BQ_F32 = 1 };                                    /* panel storage dtype */
+/* panel storage: fp64, fp32 (fp64 accumulation), or none at all — BQ_STREAM recomputes the Gram tiles on the MFMA inside
+ * every product (kernel problems with an inner-product kernel; PG / FW / augmented-Lagrangian solvers only): the
+ * fallback for n^2 s > HBM */
+enum { BQ_F64 = 0, BQ_F32 = 1, BQ_STREAM = 2 };
 /* linear, poly, rbf: kernels.py:40-129 (the named configs); sigmoid, laplacian: kernels.py:132-201 */
 enum { BQ_KERNEL_LINEAR = 0, BQ_KERNEL_POLY = 1, BQ_KERNEL_RBF = 2, BQ_KERNEL_SIGMOID = 3, BQ_KERNEL_LAPLACIAN = 4 };
 enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian structure */

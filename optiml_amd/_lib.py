@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libbcqp_hip.so')
 
 OK = 0
 ERR_HIP, ERR_RCCL, ERR_NOT_PD, ERR_NONFINITE, ERR_BADARG, ERR_NOMEM = -1, -2, -3, -4, -5, -6
-F64, F32 = 0, 1
+F64, F32, STREAM = 0, 1, 2
+STORAGE = {'f64': 0, 'f32': 1, 'stream': 2}
 KERNEL_LINEAR, KERNEL_POLY, KERNEL_RBF, KERNEL_SIGMOID, KERNEL_LAPLACIAN = 0, 1, 2, 3, 4
 PLAIN, SVC, SVR = 0, 1, 2
 PG, FW, AS, IP = 0, 1, 2, 3

@@ -252,6 +252,7 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
         BQ_TRY(bq_row_block(n, c->rank, c->world, &p->r0, &p->r1));
         rows = p->r1 - p->r0;
     }
+    if (p->streamed) return BQ_OK;   // no resident panel
     const size_t esz = p->storage == BQ_F64 ? 8 : 4;
     // symmetric panels are stored packed: tile row I keeps (I+1)*256 columns
     const size_t elems = p->symmetric ? (size_t)(bq_sym_off(p->I1) - bq_sym_off(p->I0))
@@ -274,6 +275,7 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
     for (void *ptr : {(void *)p->panel, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
                       (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab})
         if (ptr) hipFree(ptr);
+    bq_stream_free(p->stream_img);
     delete p;
     return BQ_OK;
 }
@@ -339,7 +341,8 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     BQ_ARG(structure != BQ_SVC || y != nullptr, "labels required for BQ_SVC");
     BQ_ARG(kernel >= BQ_KERNEL_LINEAR && kernel <= BQ_KERNEL_LAPLACIAN, "kernel");
     BQ_ARG(n >= 2 && d >= 1, "n/d");
-    BQ_ARG(storage == BQ_F64 || storage == BQ_F32, "storage");
+    BQ_ARG(storage == BQ_F64 || storage == BQ_F32 || storage == BQ_STREAM, "storage");
+    BQ_ARG(storage != BQ_STREAM || kernel != BQ_KERNEL_LAPLACIAN, "the streamed mode is built for the inner-product kernels");
     BQ_ARG(kernel != BQ_KERNEL_POLY || degree > 0, "degree must be > 0");
     BQ_HIP(hipSetDevice(c->device));
     bq_problem *p = new bq_problem();
@@ -353,7 +356,8 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     p->degree = degree;
     p->diag_add = diag_add;
     p->d = d;
-    p->symmetric = true;  // Gram panels are symmetric: store and stream only the tiles on/below the diagonal
+    p->streamed = storage == BQ_STREAM;
+    p->symmetric = !p->streamed;  // Gram panels are symmetric: store and stream only the tiles on/below the diagonal
     int rc = problem_layout(p, n, structure == BQ_SVR ? 2 * n : n);
     if (rc == BQ_OK) rc = problem_alloc_common(p, q);
     if (rc != BQ_OK) {
@@ -373,7 +377,10 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
         if ((e = hipMemsetAsync(p->sgn, 0, sizeof(double) * p->ld, c->stream)) != hipSuccess) return fail(e);
         if ((e = hipMemcpyAsync(p->sgn, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e);
     }
-    rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld, true);
+    if (p->streamed)
+        rc = bq_stream_prepare(c, p->X, n, d, p->r0, p->r1, &p->stream_img);
+    else
+        rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld, true);
     if (rc != BQ_OK) {
         bq_problem_destroy(p);
         return rc;
@@ -436,6 +443,7 @@ extern "C" int bq_problem_gram_matvec(bq_problem *p, const double *w, double *ou
 extern "C" int bq_problem_panel_rows(bq_problem *p, int64_t row0, int64_t nrows, double *out) {
     BQ_ARG(p && out, "NULL argument");
     BQ_ARG(row0 >= p->r0 && row0 + nrows <= p->r1 && nrows >= 0, "rows outside this rank's block");
+    BQ_ARG(!p->streamed, "a streamed problem keeps no panel");
     bq_ctx *c = p->ctx;
     BQ_HIP(hipSetDevice(c->device));
     if (nrows == 0) return BQ_OK;
@@ -481,6 +489,9 @@ extern "C" int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms) 
     const bool prof = c->profiling;
     c->profiling = false;
     auto local = [&]() {
+        if (p->streamed)
+            return bq_stream_product(c, p->stream_img, p->n, p->r0, p->r1, p->kernel, p->gamma, p->coef0, p->degree,
+                                     p->add_one, p->w, p->s + p->r0, nullptr);
         return p->symmetric ? bq_launch_symv(c, p->panel, p->storage, p->add_one, p->I0, p->I1, p->nb, p->ld, p->w,
                                              p->slab, p->s, nullptr)
                             : bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w,
@@ -600,6 +611,10 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
     BQ_ARG(fw_t >= 0.0 && fw_t < 1.0, "t has to lie in [0, 1)");  // frank_wolfe.py:84-85
     if ((kind == BQ_IP || kind == BQ_AS) && p->ctx->world > 1) {
         bq_set_error("InteriorPoint/ActiveSet factorise the whole Hessian: use a single-rank context (replicas only)");
+        return BQ_ERR_BADARG;
+    }
+    if ((kind == BQ_IP || kind == BQ_AS) && p->streamed) {
+        bq_set_error("InteriorPoint/ActiveSet assemble their systems from the resident panel: not available in the streamed mode");
         return BQ_ERR_BADARG;
     }
     if ((kind == BQ_IP || kind == BQ_AS) && p->structure != BQ_PLAIN && !p->add_one) {

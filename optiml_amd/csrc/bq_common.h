@@ -88,6 +88,8 @@ struct bq_problem {
     // symmetric mode (kernel-built panels): only tiles on/below the diagonal are stored and streamed; this rank owns
     // the 256-row tile rows [I0, I1) of nb, panel row 0 is global row I0*256
     bool symmetric = false;
+    bool streamed = false;     // BQ_STREAM: no panel, Gram tiles recomputed inside every product (stream_img)
+    void *stream_img = nullptr;
     int64_t I0 = 0, I1 = 0, nb = 0;
     double *slab = nullptr;   // nb x nb x 256 partial products
     double *part = nullptr;   // nb*256: this rank's partial K w (all-reduced across ranks)
@@ -185,6 +187,12 @@ int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r
 int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                        const double *SV, const double *coef, double intercept, int64_t t, const double *Xt,
                        double *out);
+
+// streamed mode (bq_gram.hip): persistent k-major image of X + the fused Gram-tile x vector product
+int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int64_t r0, int64_t r1, void **out);
+void bq_stream_free(void *h);
+int bq_stream_product(bq_ctx *ctx, void *h, int64_t n, int64_t r0, int64_t r1, int kernel, double gamma, double coef0,
+                      int degree, bool add_one, const double *w, double *out_rows, const int *done);
 
 int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                           const double *A, int64_t t, const double *B, double *out);

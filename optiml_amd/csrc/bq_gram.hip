@@ -377,3 +377,191 @@ int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, i
     }
     return BQ_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streamed mode (BQ_STREAM): no resident panel — every product recomputes the Gram tiles on the MFMA and contracts them
+// with the input vector inside the same kernel (the fallback when n^2 s does not fit in HBM).
+// One workgroup owns a 128-row tile of this rank's row block and a chunk of column tiles: per column tile the shared
+// tile kernel yields the 128 x 128 dot products, the kernel map turns them into K (or K + 1) and each lane folds its 64
+// values into 16 per-row sums.  At the end the 16 lanes that share a row are combined with shuffles, the two waves that
+// share a row block through LDS, and the chunk's 128 row sums go to S[chunk][row]; stream_reduce_kernel adds the chunks
+// in order.  No symmetry credit (each tile is computed where it is used): 2 n^2 d flop per product.
+// ---------------------------------------------------------------------------------------------------------------
+struct bq_stream_images {
+    gram_images img;
+    double *S = nullptr;       // nchunk x rows_pad partial products
+    int64_t rows_pad = 0;
+    int nchunk = 1;
+};
+
+__global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, const double *__restrict__ w, int add_one,
+                                                             int64_t tiles_per_chunk, double *__restrict__ S,
+                                                             int64_t rows_pad, const int *done) {
+    if (done != nullptr && *done) return;
+    __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
+    __shared__ double rowbuf[2][64];
+    const int64_t tiles_n = (P.n + GT - 1) / GT;
+    const int64_t tm = blockIdx.x, chunk = blockIdx.y;
+    const int64_t arow = P.arow0 + tm * GT;
+    const int64_t j0 = chunk * tiles_per_chunk, j1 = (j0 + tiles_per_chunk < tiles_n) ? j0 + tiles_per_chunk : tiles_n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
+    double rs[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) rs[i][v] = 0.0;
+    for (int64_t J = j0; J < j1; ++J) {
+        const int64_t bcol = J * GT;
+        bq_d4 acc[4][4];
+        bq_tile_zero(acc);
+        bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
+        double wj[4], bj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
+            wj[j] = gj < P.n ? w[gj] : 0.0;
+            bj[j] = P.b2[gj];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
+                const double ai = P.a2[gi];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
+                    const double dot = acc[i][j][v];
+                    double kv;
+                    if (P.kernel == BQ_KERNEL_RBF) {
+                        double dist = -2.0 * dot;
+                        dist += ai;
+                        dist += bj[j];
+                        dist = fmax(dist, 0.0);
+                        if (gi == gj) dist = 0.0;
+                        kv = exp(-P.gamma * dist);
+                    } else if (P.kernel == BQ_KERNEL_POLY) {
+                        kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                    } else if (P.kernel == BQ_KERNEL_SIGMOID) {
+                        kv = tanh(P.gamma * dot + P.coef0);
+                    } else {
+                        kv = dot;
+                    }
+                    if (add_one) kv += 1.0;
+                    rs[i][v] = fma(kv, wj[j], rs[i][v]);
+                }
+            }
+        }
+        __syncthreads();   // the next tile's prologue refills the LDS buffers
+    }
+    // the 16 lanes with the same (lane >> 4) hold the same rows: fold them, then the two column waves
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double x = rs[i][v];
+            x += __shfl_xor(x, 1, 64);
+            x += __shfl_xor(x, 2, 64);
+            x += __shfl_xor(x, 4, 64);
+            x += __shfl_xor(x, 8, 64);
+            rs[i][v] = x;
+        }
+    if (wc == 1 && ccol == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rowbuf[wr][i * 16 + crow + 4 * v] = rs[i][v];
+    }
+    __syncthreads();
+    if (wc == 0 && ccol == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = i * 16 + crow + 4 * v;
+                const int64_t gi = arow + wr * 64 + r;
+                S[chunk * rows_pad + (gi - P.arow0)] = gi < P.arow1 ? rs[i][v] + rowbuf[wr][r] : 0.0;
+            }
+    }
+}
+
+__global__ void stream_reduce_kernel(const double *__restrict__ S, int64_t rows, int64_t rows_pad, int nchunk,
+                                     double *__restrict__ out, const int *done) {
+    if (done != nullptr && *done) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    double a = 0.0;
+    for (int c = 0; c < nchunk; ++c) a += S[(int64_t)c * rows_pad + i];
+    out[i] = a;
+}
+
+int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int64_t r0, int64_t r1, void **out) {
+    bq_stream_images *st = new bq_stream_images();
+    int rc = make_image(ctx, Xdev, n, d, &st->img);
+    if (rc != BQ_OK) {
+        delete st;
+        return rc;
+    }
+    const int64_t tiles_m = (r1 - r0 + GT - 1) / GT, tiles_n = (n + GT - 1) / GT;
+    st->rows_pad = (tiles_m > 0 ? tiles_m : 1) * GT;
+    // enough workgroups to fill the chip a few times over, but never more chunks than column tiles
+    int nchunk = (int)((4 * (int64_t)ctx->num_cu * 2 + tiles_m - 1) / (tiles_m > 0 ? tiles_m : 1));
+    nchunk = nchunk < 1 ? 1 : (nchunk > 16 ? 16 : nchunk);
+    if (nchunk > tiles_n) nchunk = (int)tiles_n;
+    st->nchunk = nchunk;
+    if (hipMalloc(&st->S, sizeof(double) * st->rows_pad * nchunk) != hipSuccess) {
+        bq_set_error("cannot allocate the streamed-product scratch");
+        free_image(&st->img);
+        delete st;
+        return BQ_ERR_NOMEM;
+    }
+    *out = st;
+    return BQ_OK;
+}
+
+void bq_stream_free(void *h) {
+    if (!h) return;
+    bq_stream_images *st = (bq_stream_images *)h;
+    free_image(&st->img);
+    if (st->S) hipFree(st->S);
+    delete st;
+}
+
+// out_rows[0 : r1 - r0) = (K or K + 1)[r0:r1, :] w
+int bq_stream_product(bq_ctx *ctx, void *h, int64_t n, int64_t r0, int64_t r1, int kernel, double gamma, double coef0,
+                      int degree, bool add_one, const double *w, double *out_rows, const int *done) {
+    if (r1 <= r0) return BQ_OK;
+    bq_stream_images *st = (bq_stream_images *)h;
+    BQ_ARG(kernel != BQ_KERNEL_LAPLACIAN, "the streamed mode is built for the inner-product kernels (linear, poly, rbf, sigmoid)");
+    gram_params P;
+    P.lower_only = 0;
+    P.At = P.Bt = st->img.At;
+    P.a2 = P.b2 = st->img.a2;
+    P.m = r1 - r0;
+    P.n = n;
+    P.mp = P.np = st->img.mp;
+    P.dp = st->img.dp;
+    P.arow0 = r0;
+    P.arow1 = r1;
+    P.same = 1;
+    P.kernel = kernel;
+    P.degree = degree;
+    P.gamma = gamma;
+    P.coef0 = coef0;
+    P.ld = 0;
+    P.ntiles = 0;
+    const int64_t tiles_m = (P.m + GT - 1) / GT, tiles_n = (n + GT - 1) / GT;
+    BQ_ARG(r0 % GT == 0, "row block must be tile aligned");
+    const int64_t per = (tiles_n + st->nchunk - 1) / st->nchunk;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
+    dim3 grid((unsigned)tiles_m, (unsigned)st->nchunk);
+    gram_stream_kernel<<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
+    stream_reduce_kernel<<<(unsigned)((P.m + 255) / 256), 256, 0, ctx->stream>>>(st->S, P.m, st->rows_pad, st->nchunk,
+                                                                                 out_rows, done);
+    BQ_HIP(hipGetLastError());
+    BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
+    return BQ_OK;
+}

@@ -97,6 +97,11 @@ __global__ void finish_kernel(int structure, int64_t n, int64_t N, double diag_a
 // symmetric tile panels: local lower-triangle tiles (both contributions) + all-reduce(sum).
 int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done) {
     bq_ctx *ctx = p->ctx;
+    if (p->streamed) {   // no panel: Gram tiles recomputed inside the product (bq_gram.hip), row blocks + all-gather
+        BQ_TRY(bq_stream_product(ctx, p->stream_img, p->n, p->r0, p->r1, p->kernel, p->gamma, p->coef0, p->degree, add_one,
+                                 w, p->s + p->r0, done));
+        return bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1);
+    }
     if (p->symmetric) {
         BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->I0, p->I1, p->nb, p->ld, w, p->slab, p->s, done));
         if (ctx->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_sum(ctx, p->s, p->nb * BQ_SYM_TILE));

@@ -175,6 +175,8 @@ class KernelQuadratic(Quadratic):
     `rank_one=False` leaves out the yy' / ee' term of the regularised intercept: the reg_intercept=False duals
     Q = K*yy' and [[K,-K],[-K,K]] (:552-555, :1096-1099) that the augmented-Lagrangian path solves with an equality row.
     `.Q` materialises the dense matrix from the device panel on demand (inspection / small problems only).
+    `storage='stream'` keeps NO panel: every product recomputes the Gram tiles on the MFMA (for n^2 beyond HBM; first-order
+    solvers only, no `.Q`).
     """
 
     _STRUCT = {'plain': _lib.PLAIN, 'svc': _lib.SVC, 'svr': _lib.SVR}
@@ -193,6 +195,8 @@ class KernelQuadratic(Quadratic):
             raise ValueError('q size does not match with Q')
         if structure == 'svc' and (y is None or len(y) != n):
             raise ValueError('labels are required for the svc structure')
+        if storage not in _lib.STORAGE:
+            raise ValueError(f'unknown storage {storage}')
         self.X, self.q, self.structure, self.kernel = X, q, structure, kernel
         self.y = None if y is None else np.ascontiguousarray(y, dtype=float)
         self.diag = float(diag)
@@ -208,7 +212,7 @@ class KernelQuadratic(Quadratic):
         _lib.check(lib.bq_problem_create_kernel(
             ctx.handle, self._STRUCT[self.structure] | (0 if self.rank_one else _lib.NO_RANK_ONE), n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
             self.gamma, self.coef0, self.degree, self.diag, _lib.ptr(self.q),
-            _lib.F32 if self.storage == 'f32' else _lib.F64, C.byref(h)))
+            _lib.STORAGE[self.storage], C.byref(h)))
         return _DeviceProblem(ctx, h)
 
     def gram(self):

@@ -641,3 +641,48 @@ print(json.dumps({'iter': est.optimizer.iter, 'status': est.optimizer.status, 'f
     # the 2n x 2n SVR Hessian is singular: only a+ - a- is determined by the optimum
     a, ref = np.asarray(res['alphas']), g['rbf_ip_alphas']
     np.testing.assert_allclose(a[:400] - a[400:], ref[:400] - ref[400:], rtol=0, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# streamed mode (BQ_STREAM): no resident panel, Gram tiles recomputed inside every product (SURVEY 8(d) fallback)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('structure,kname', [('svc', 'rbf'), ('svr', 'poly'), ('svc', 'linear'), ('plain', 'sigmoid')])
+@pytest.mark.parametrize('n', [300, 1300])
+def test_streamed_product_matches_the_resident_panel(amd, structure, kname, n):
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm import kernels as kk
+    from optiml_amd.datasets import make_blobs
+    kern = {'rbf': kk.gaussian, 'poly': kk.PolyKernel(3, 'scale', 1.), 'linear': kk.linear, 'sigmoid': kk.sigmoid}[kname]
+    X, y = make_blobs(n, 9, seed=n)
+    N = 2 * n if structure == 'svr' else n
+    q = np.random.RandomState(1).standard_normal(N)
+    args = dict(y=y if structure == 'svc' else None)
+    a = KernelQuadratic(X, q, structure, kern, **args)
+    b = KernelQuadratic(X, q, structure, kern, storage='stream', **args)
+    v = np.random.RandomState(2).standard_normal(N)
+    np.testing.assert_allclose(b.device_problem().matvec(v), a.device_problem().matvec(v), rtol=1e-11, atol=1e-11)
+    fa, ga = a.function_jacobian(v)
+    fb, gb = b.function_jacobian(v)
+    np.testing.assert_allclose(fb, fa, rtol=1e-11)
+    np.testing.assert_allclose(gb, ga, rtol=1e-11, atol=1e-11)
+    w = np.random.RandomState(3).standard_normal(n)
+    np.testing.assert_allclose(b.device_problem().gram_matvec(w), a.device_problem().gram_matvec(w), rtol=1e-11, atol=1e-11)
+    with pytest.raises(Exception):
+        b.gram()          # nothing is resident
+
+
+def test_streamed_fit_follows_the_reference(amd):
+    """SVC.fit with storage='stream': FrankWolfe trajectory of the fixture (stable solver) to the usual tolerance; the
+    factorising solvers refuse the mode."""
+    from optiml_amd import _lib
+    from optiml_amd.ml.svm import SVC
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.ml.svm.losses import hinge
+    from optiml_amd.opti.constrained import FrankWolfe, InteriorPoint
+    g = load_golden('fit_svc_n600.npz')
+    est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=FrankWolfe, max_iter=1000,
+              storage='stream').fit(g['X'], g['y'])
+    _check_fit(est, g, 'rbf_fw', g['Xtest'])
+    with pytest.raises(_lib.BcqpError):
+        SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=InteriorPoint,
+            storage='stream').fit(g['X'], g['y'])
