@@ -395,95 +395,76 @@ struct bq_stream_images {
     int nchunk = 1;
 };
 
+template <int KIND>
 __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, const double *__restrict__ w, int add_one,
                                                              int64_t tiles_per_chunk, double *__restrict__ S,
                                                              int64_t rows_pad, const int *done) {
     if (done != nullptr && *done) return;
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    __shared__ double rowbuf[2][64];
+    __shared__ double rowsum[4][64];   // per wave: running sums of its 64 rows over its 64 columns of every tile so far
+    __shared__ double rowsq[4][64];    // per wave: squared norms of its 64 rows (kept out of the registers on purpose: as
+                                       // loop invariants they would stay live across the MFMA loop and force spills)
     const int64_t tiles_n = (P.n + GT - 1) / GT;
     const int64_t tm = blockIdx.x, chunk = blockIdx.y;
     const int64_t arow = P.arow0 + tm * GT;
     const int64_t j0 = chunk * tiles_per_chunk, j1 = (j0 + tiles_per_chunk < tiles_n) ? j0 + tiles_per_chunk : tiles_n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
-    double rs[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) rs[i][v] = 0.0;
+    rowsum[wv][lane] = 0.0;
+    rowsq[wv][lane] = P.a2[arow + (wv >> 1) * 64 + lane];
     for (int64_t J = j0; J < j1; ++J) {
         const int64_t bcol = J * GT;
         bq_d4 acc[4][4];
         bq_tile_zero(acc);
         bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
-        double wj[4], bj[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
-            wj[j] = gj < P.n ? w[gj] : 0.0;
-            bj[j] = P.b2[gj];
-        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's loads (w, norms) below the MFMA loop: hoisted above it
+                                             // they stay live across it and spill
+        // epilogue: kernel map, contraction with this tile's slice of w, fold over the 16 lanes that share a row; the
+        // running row sums live in LDS so that no accumulator stays in registers across the MFMA loop
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
-                const double ai = P.a2[gi];
+                const double ai = KIND == BQ_KERNEL_RBF ? rowsq[wv][i * 16 + crow + 4 * v] : 0.0;
+                double part = 0.0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
                     const double dot = acc[i][j][v];
                     double kv;
-                    if (P.kernel == BQ_KERNEL_RBF) {
+                    if (KIND == BQ_KERNEL_RBF) {
                         double dist = -2.0 * dot;
                         dist += ai;
-                        dist += bj[j];
+                        dist += P.b2[gj];
                         dist = fmax(dist, 0.0);
                         if (gi == gj) dist = 0.0;
                         kv = exp(-P.gamma * dist);
-                    } else if (P.kernel == BQ_KERNEL_POLY) {
+                    } else if (KIND == BQ_KERNEL_POLY) {
                         kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
-                    } else if (P.kernel == BQ_KERNEL_SIGMOID) {
+                    } else if (KIND == BQ_KERNEL_SIGMOID) {
                         kv = tanh(P.gamma * dot + P.coef0);
                     } else {
                         kv = dot;
                     }
                     if (add_one) kv += 1.0;
-                    rs[i][v] = fma(kv, wj[j], rs[i][v]);
+                    part = fma(kv, w[gj], part);   // w is zero beyond n (padded to the panel pitch)
+                    if (KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY)
+                        __builtin_amdgcn_sched_barrier(0);   // one exp / pow chain at a time (register pressure)
                 }
+                part += __shfl_xor(part, 1, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64);
+                part += __shfl_xor(part, 8, 64);
+                if (ccol == 0) rowsum[wv][i * 16 + crow + 4 * v] += part;
             }
         }
         __syncthreads();   // the next tile's prologue refills the LDS buffers
     }
-    // the 16 lanes with the same (lane >> 4) hold the same rows: fold them, then the two column waves
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            double x = rs[i][v];
-            x += __shfl_xor(x, 1, 64);
-            x += __shfl_xor(x, 2, 64);
-            x += __shfl_xor(x, 4, 64);
-            x += __shfl_xor(x, 8, 64);
-            rs[i][v] = x;
-        }
-    if (wc == 1 && ccol == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) rowbuf[wr][i * 16 + crow + 4 * v] = rs[i][v];
-    }
     __syncthreads();
-    if (wc == 0 && ccol == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = i * 16 + crow + 4 * v;
-                const int64_t gi = arow + wr * 64 + r;
-                S[chunk * rows_pad + (gi - P.arow0)] = gi < P.arow1 ? rs[i][v] + rowbuf[wr][r] : 0.0;
-            }
+    if (wc == 0) {   // the two waves of a row block (column halves) are combined in a fixed order
+        const int64_t gi = arow + wr * 64 + lane;
+        S[chunk * rows_pad + (gi - P.arow0)] = gi < P.arow1 ? rowsum[wv][lane] + rowsum[wv + 1][lane] : 0.0;
     }
 }
 
@@ -558,7 +539,21 @@ int bq_stream_product(bq_ctx *ctx, void *h, int64_t n, int64_t r0, int64_t r1, i
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
     dim3 grid((unsigned)tiles_m, (unsigned)st->nchunk);
-    gram_stream_kernel<<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
+    // one instantiation per kernel map: with all of exp / pow / tanh inlined in the 64-element epilogue the kernel spilled
+    switch (kernel) {
+        case BQ_KERNEL_RBF:
+            gram_stream_kernel<BQ_KERNEL_RBF><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
+            break;
+        case BQ_KERNEL_POLY:
+            gram_stream_kernel<BQ_KERNEL_POLY><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
+            break;
+        case BQ_KERNEL_SIGMOID:
+            gram_stream_kernel<BQ_KERNEL_SIGMOID><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
+            break;
+        default:
+            gram_stream_kernel<BQ_KERNEL_LINEAR><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
+            break;
+    }
     stream_reduce_kernel<<<(unsigned)((P.m + 255) / 256), 256, 0, ctx->stream>>>(st->S, P.m, st->rows_pad, st->nchunk,
                                                                                  out_rows, done);
     BQ_HIP(hipGetLastError());
