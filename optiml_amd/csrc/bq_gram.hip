@@ -47,8 +47,8 @@ __global__ void row_norms_kernel(const double *__restrict__ X, int64_t n, int64_
 }
 
 template <typename T> __device__ __forceinline__ void store_elem(T *p, double v);
-template <> __device__ __forceinline__ void store_elem<double>(double *p, double v) { *p = v; }
-template <> __device__ __forceinline__ void store_elem<float>(float *p, double v) { *p = (float)v; }
+template <> __device__ __forceinline__ void store_elem<double>(double *p, double v) { __builtin_nontemporal_store(v, p); }
+template <> __device__ __forceinline__ void store_elem<float>(float *p, double v) { __builtin_nontemporal_store((float)v, p); }
 
 struct gram_params {
     const double *At, *Bt;   // k-major padded images: At[dp][mp], Bt[dp][np]
@@ -64,67 +64,64 @@ struct gram_params {
     int64_t ntiles;          // tiles of this launch (XCD-aware remap bound)
 };
 
+// One workgroup owns a 128-row tile row and a strip of GRAM_STRIP consecutive 128-column tiles (blockIdx.y): looping over
+// the strip keeps the row slice of the image hot and amortises the workgroup start over several tiles (one tile per
+// workgroup ran at 36 % MFMA-pipe utilisation: `profiles/r01/pmc_mfma_ip_n50000.txt`).
+constexpr int GRAM_STRIP = 8;
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    // tiles of the same A-row block are adjacent in blockIdx -> they share the A slice in L2
-    const int64_t bid = bq_xcd_remap(blockIdx.x, P.ntiles);
-    if (bid >= P.ntiles) return;
-    int64_t arow, bcol;
-    if (P.lower_only) {
-        // symmetric panel: enumerate only the 256-tiles (I, J <= I) of this rank's tile rows, 4 sub-tiles of 128 each
-        const int64_t I0 = P.arow0 / BQ_SYM_TILE;
-        const int64_t t = bid / 4 + I0 * (I0 + 1) / 2, sub = bid % 4;
-        int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        while (I * (I + 1) / 2 > t) --I;
-        const int64_t J = t - I * (I + 1) / 2;
-        arow = I * BQ_SYM_TILE + (sub >> 1) * GT;
-        bcol = J * BQ_SYM_TILE + (sub & 1) * GT;
-        if (arow >= P.arow1 || bcol >= P.n) return;
-    } else {
-        const int64_t tiles_n = (P.n + GT - 1) / GT;
-        arow = P.arow0 + (bid / tiles_n) * GT;
-        bcol = (bid % tiles_n) * GT;
+    const int64_t arow = P.arow0 + (int64_t)blockIdx.x * GT;
+    int64_t tiles_n = (P.n + GT - 1) / GT;
+    if (P.lower_only) {   // symmetric panel: columns up to the end of this row's 256-tile on the diagonal
+        const int64_t lim = ((arow / BQ_SYM_TILE) + 1) * (BQ_SYM_TILE / GT);
+        tiles_n = lim < tiles_n ? lim : tiles_n;
     }
-    bq_d4 acc[4][4];
-    bq_tile_zero(acc);
-    bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
-    // epilogue, row by row: one (packed or pitched) row base per accumulator row, then the kernel map per element
+    const int64_t j0 = (int64_t)blockIdx.y * GRAM_STRIP;
+    const int64_t j1 = j0 + GRAM_STRIP < tiles_n ? j0 + GRAM_STRIP : tiles_n;
+    if (j0 >= j1) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
     const int64_t I0 = P.arow0 / BQ_SYM_TILE;
+    for (int64_t J = j0; J < j1; ++J) {
+        const int64_t bcol = J * GT;
+        bq_d4 acc[4][4];
+        bq_tile_zero(acc);
+        bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
+        // epilogue, row by row: one (packed or pitched) row base per accumulator row, then the kernel map per element
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
-            if (gi >= P.arow1) continue;
-            T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
-            const double ai = P.a2[gi];
+            for (int v = 0; v < 4; ++v) {
+                const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
+                if (gi >= P.arow1) continue;
+                T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
+                const double ai = P.a2[gi];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
-                if (gj >= P.n) continue;
-                const double dot = acc[i][j][v];
-                double kv;
-                if (P.kernel == BQ_KERNEL_RBF) {
-                    double dist = -2.0 * dot;
-                    dist += ai;
-                    dist += P.b2[gj];
-                    dist = fmax(dist, 0.0);
-                    if (P.same && gi == gj) dist = 0.0;
-                    kv = exp(-P.gamma * dist);
-                } else if (P.kernel == BQ_KERNEL_POLY) {
-                    kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
-                } else if (P.kernel == BQ_KERNEL_SIGMOID) {
-                    kv = tanh(P.gamma * dot + P.coef0);
-                } else {
-                    kv = dot;
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
+                    if (gj >= P.n) continue;
+                    const double dot = acc[i][j][v];
+                    double kv;
+                    if (P.kernel == BQ_KERNEL_RBF) {
+                        double dist = -2.0 * dot;
+                        dist += ai;
+                        dist += P.b2[gj];
+                        dist = fmax(dist, 0.0);
+                        if (P.same && gi == gj) dist = 0.0;
+                        kv = exp(-P.gamma * dist);
+                    } else if (P.kernel == BQ_KERNEL_POLY) {
+                        kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                    } else if (P.kernel == BQ_KERNEL_SIGMOID) {
+                        kv = tanh(P.gamma * dot + P.coef0);
+                    } else {
+                        kv = dot;
+                    }
+                    store_elem<T>(rowp + gj, kv);
                 }
-                store_elem<T>(rowp + gj, kv);
             }
         }
+        __syncthreads();   // the next tile's prologue refills the LDS buffers
     }
 }
 
@@ -240,13 +237,8 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
         else
             gram_l1_kernel<float><<<lgrid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
     } else {
-        if (lower_only) {
-            const int64_t I0 = m_rows0 / BQ_SYM_TILE, I1 = (m_rows1 + BQ_SYM_TILE - 1) / BQ_SYM_TILE;
-            P.ntiles = 4 * (I1 * (I1 + 1) / 2 - I0 * (I0 + 1) / 2);
-        } else {
-            P.ntiles = tiles_m * tiles_n;
-        }
-        dim3 grid(bq_xcd_grid(P.ntiles));
+        P.ntiles = tiles_m * tiles_n;
+        dim3 grid((unsigned)tiles_m, (unsigned)((tiles_n + GRAM_STRIP - 1) / GRAM_STRIP));
         if (storage == BQ_F64)
             gram_mfma_kernel<double><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));
         else

@@ -134,16 +134,6 @@ __device__ __forceinline__ void bq_tile_foreach(bq_d4 (&acc)[4][4], F &&f) {
             for (int j = 0; j < 4; ++j) f(wr * 64 + i * 16 + crow + 4 * v, wc * 64 + j * 16 + ccol, acc[i][j][v]);
 }
 
-// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so neighbouring
-// linear tile indices — which share an operand slice — land on different L2s.  Remap so that every XCD walks a
-// CONTIGUOUS chunk of the tile list: launch 8 * ceil(total / 8) blocks and let block `bid` take tile
-// (bid % 8) * chunk + bid / 8 (blocks past the end exit).  Speed only; any placement is correct.
-__device__ __forceinline__ int64_t bq_xcd_remap(int64_t bid, int64_t total) {
-    const int64_t chunk = (total + 7) / 8;
-    return (bid % 8) * chunk + bid / 8;
-}
-static inline unsigned bq_xcd_grid(int64_t total) { return (unsigned)(((total + 7) / 8) * 8); }
-
 __device__ __forceinline__ void bq_tile_zero(bq_d4 (&acc)[4][4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
