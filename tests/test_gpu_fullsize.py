@@ -104,3 +104,71 @@ def test_config2_shape_against_the_oracle():
     np.testing.assert_allclose(hist, ref['f_hist'], rtol=1e-9)
     np.testing.assert_allclose(opt.x, ref['x_at'][30], rtol=1e-6, atol=1e-9)
     quad.release()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the other dual branches and the streamed mode at the headline size
+# ---------------------------------------------------------------------------------------------------------------
+def test_streamed_product_equals_the_resident_panel_at_full_size(headline):
+    """storage='stream' (Gram tiles recomputed inside the product) against the resident triangular panel."""
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    n, X, y, quad = headline
+    v = np.random.RandomState(7).standard_normal(n)
+    ref = quad.device_problem().matvec(v)
+    st = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, storage='stream')
+    try:
+        np.testing.assert_allclose(st.device_problem().matvec(v), ref, rtol=1e-10, atol=1e-7)
+    finally:
+        st.release()
+
+
+def test_smo_reaches_the_kkt_conditions_at_full_size(headline):
+    """SVC.fit(optimizer='smo') at n = 100 000: the optimality conditions of Keerthi et al. recomputed from the returned
+    multipliers with ONE independent device product (F = K (alpha*y) - y), the equality constraint, the box."""
+    from optiml_amd.ml.svm import SVC
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.ml.svm.losses import hinge
+    n, X, y, quad = headline
+    tol = 1e-3
+    est = SVC(loss=hinge, kernel=gaussian, C=1., dual=True, optimizer='smo', tol=tol).fit(X, y)
+    a = est.alphas_
+    assert a.min() >= 0 and a.max() <= 1
+    assert abs(a @ y) <= 1e-8 * max(1.0, a.sum())            # y'alpha = 0 is maintained by every pair step
+    F = quad.device_problem().gram_matvec(a * y) - y           # resident panel of the fixture: an independent product
+    free = (a > 0) & (a < 1)
+    up = free | ((y == 1) & (a == 0)) | ((y == -1) & (a == 1))
+    low = free | ((y == 1) & (a == 1)) | ((y == -1) & (a == 0))
+    b_up, b_low = F[up].min(), F[low].max()
+    assert b_low <= b_up + 2 * tol + 1e-9
+    assert b_low - tol - 1e-9 <= -est.intercept_ <= b_up + tol + 1e-9
+    assert 100 < len(est.support_) < 5000 and est.score(X[:2000], y[:2000]) > 0.99
+    est.obj.release()
+
+
+def test_augmented_lagrangian_records_are_consistent_at_full_size(headline):
+    """AdaGrad on the augmented Lagrangian of the reg_intercept=False dual, 12 iterations at n = 100 000: the recorded
+    primal values equal an independent evaluation at the recorded point, multipliers stay feasible, the value decreases."""
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import AugmentedLagrangianQuadratic
+    from optiml_amd.opti.unconstrained.stochastic import AdaGrad
+    n, X, y, quad = headline
+    primal = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, rank_one=False)
+    al = AugmentedLagrangianQuadratic(primal=primal, A=y, b=np.zeros(1), lb=np.zeros(n), ub=np.ones(n), rho=1.)
+    seen = []
+
+    def cb(opt):     # full state: forces one host round trip per iteration
+        seen.append((opt.iter, opt.f_x, opt.primal_f_x, opt.x.copy()))
+    try:
+        opt = AdaGrad(f=al, x=np.random.RandomState(0).uniform(size=n), step_size=1., epochs=12, callback=cb).minimize()
+        assert opt.status == 'stopped' and opt.iter == 11 and len(seen) == 12
+        for it, f, pf, x in (seen[0], seen[5], seen[11]):
+            np.testing.assert_allclose(pf, primal.function(x), rtol=1e-10)
+        fs = [s[1] for s in seen]
+        assert fs[-1] < fs[0]
+        assert np.all(al.dual_x[1:] >= 0) and np.isfinite(al.dual_x).all()
+        # the multiplier of the equality row after the last update: rho * sum_k y'x_k over the updates
+        assert np.isfinite(opt.g_x).all() and opt.g_x.shape == (n,)
+    finally:
+        primal.release()
