@@ -97,6 +97,12 @@ def gpu_mode(exchange, outdir):
     opt = Adam(f=al, x=np.random.RandomState(3).uniform(size=500), step_size=0.01, epochs=60,
                momentum_type='nesterov', momentum=0.5).minimize()
     res['dense_al_x'] = opt.x
+    # streamed mode: row blocks of recomputed Gram tiles + all-gather
+    sq = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, storage='stream')
+    res['stream_rows'] = np.array(sq.device_problem().dims()[2:])
+    res['stream_matvec'] = sq.device_problem().matvec(v)
+    opt = FrankWolfe(quad=sq, ub=np.ones(n), max_iter=30).minimize()
+    res['stream_fw_x'] = opt.x
     ms, cnt = ctx.profile_read(_lib.PROF_EXCH)
     comm.barrier()
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)

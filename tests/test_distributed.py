@@ -66,9 +66,12 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path):
     assert tuple(two[0]['rows']) == (0, 512) and tuple(two[1]['rows']) == (512, 700)
     # dense panels: equal 128-aligned row blocks
     assert tuple(two[0]['dense_rows']) == (0, 256) and tuple(two[1]['dense_rows']) == (256, 500)
+    # streamed kernel problems: the same equal 128-aligned row blocks (700 rows -> 384 + 316), all-gather
+    assert tuple(two[0]['stream_rows']) == (0, 384) and tuple(two[1]['stream_rows']) == (384, 700)
+    np.testing.assert_allclose(one['stream_matvec'], one['matvec'], rtol=1e-11, atol=1e-11)
     for r in two:
         # row-block panels end in an all-gather: bit-identical for any rank count
-        for key in ('dense_matvec', 'dense_pg_x', 'dense_al_x'):
+        for key in ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'stream_matvec', 'stream_fw_x'):
             assert np.array_equal(r[key], one[key]), key
         # symmetric tile panels end in an all-reduce(sum): same values up to the association of the rank sum
         for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f'):
