@@ -117,6 +117,7 @@ struct bq_scal {
     double p, mu, xr, step;                    // IP
     double al_mu, al_ax, al_pf;                // augmented Lagrangian: multiplier of the equality row, a'x, primal value
     long long al_epoch;
+    unsigned int ticket[2], pad1[2];           // last-block tickets of the fused reduce-and-decide kernels (PG / FW)
     long long al_last;                         // the epoch test fired: the gradient of the last record is still due
     double aux[8];
 };

@@ -175,9 +175,28 @@ __global__ void grad_init_kernel(int64_t N, vecs V) {
     }
 }
 
-// apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and its reductions
-__global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *__restrict__ part,
-                                      int64_t nblk, const double *__restrict__ sgn, double *__restrict__ w_out) {
+// The block that takes the last ticket of a launch finishes the reduction over the per-block partial sums and takes the
+// iteration's scalar decisions in the same kernel (one launch and one dependent-kernel gap less per reduction; the
+// fixed-order final sum is the same code as before, so results do not depend on which block is last).
+__device__ __forceinline__ bool last_block(unsigned int *ticket) {
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        __threadfence();   // this block's partial sums are visible device-wide before the ticket is taken
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (last) __threadfence();   // and the other blocks' partial sums are visible to this one
+    return last != 0;
+}
+
+__device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
+__device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
+__device__ __forceinline__ void step_body(int kind, bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
+
+// apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and its reductions; the last
+// block finalises them: objective, |d|, record, stop tests (projected_gradient.py:81-110)
+__global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
+                                      const double *__restrict__ sgn, double *__restrict__ w_out, bq_iter_stat *stats) {
     if (sc->done) return;
     __shared__ double sh[4];
     const double t = do_update ? sc->t : 0.0;
@@ -214,10 +233,13 @@ __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
         part[2 * nblk + blockIdx.x] = sxg;
         part[3 * nblk + blockIdx.x] = rmin;
     }
+    if (last_block(&sc->ticket[0])) {
+        pg_decide_body(sc, part, nblk, stats);
+        if (threadIdx.x == 0) sc->ticket[0] = 0;
+    }
 }
 
-__global__ void pg_decide_kernel(bq_scal *sc, const double *__restrict__ part, int64_t nblk, bq_iter_stat *stats) {
-    if (sc->done) return;
+__device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
     __shared__ double sh[4];
     const double sd2 = final_sum(part + 0 * nblk, nblk, sh);
     const double sgd = final_sum(part + 1 * nblk, nblk, sh);
@@ -249,22 +271,11 @@ __global__ void pg_decide_kernel(bq_scal *sc, const double *__restrict__ part, i
     }
 }
 
-__global__ void den_partial_kernel(int64_t N, const double *__restrict__ d, const double *__restrict__ Qd,
-                                   const bq_scal *sc, double *__restrict__ part) {
-    if (sc->done) return;
-    __shared__ double sh[4];
-    double a = 0.0;
-    VEC_LOOP(i) {
-        if (i < N) a += d[i] * Qd[i];
-    }
-    a = block_sum(a, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = a;
-}
-
 // finish (gathered panel output -> Q d) fused with the partial sums of d'Qd
 __global__ void finish_den_kernel(int structure, int64_t n, int64_t N, double diag_add, const double *__restrict__ sv,
                                   const double *__restrict__ d, const double *__restrict__ sgn,
-                                  double *__restrict__ Qd, const bq_scal *sc, double *__restrict__ part) {
+                                  double *__restrict__ Qd, bq_scal *sc, double *part, int64_t nblk, int kind,
+                                  bq_iter_stat *stats) {
     if (sc->done) return;
     __shared__ double sh[4];
     double a = 0.0;
@@ -285,11 +296,14 @@ __global__ void finish_den_kernel(int structure, int64_t n, int64_t N, double di
     }
     a = block_sum(a, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = a;
+    if (last_block(&sc->ticket[1])) {   // the last block turns d'Qd into the step length (and closes the iteration)
+        step_body(kind, sc, part, nblk, stats);
+        if (threadIdx.x == 0) sc->ticket[1] = 0;
+    }
 }
 
 // kind 0: PG  t = max_t if den <= 1e-16 else min(-g'd/den, max_t);  kind 1: FW  a = 1 if ... else min(-g'd/den, 1)
-__global__ void step_kernel(int kind, bq_scal *sc, const double *__restrict__ part, int64_t nblk, bq_iter_stat *stats) {
-    if (sc->done) return;
+__device__ __forceinline__ void step_body(int kind, bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
     __shared__ double sh[4];
     const double den = final_sum(part, nblk, sh);
     if (threadIdx.x == 0) {
@@ -309,8 +323,8 @@ __global__ void step_kernel(int kind, bq_scal *sc, const double *__restrict__ pa
 }
 
 // FW: apply pending step, pick the vertex, form the (optionally trust-clipped) direction
-__global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *__restrict__ part,
-                                      int64_t nblk, const double *__restrict__ sgn, double *__restrict__ w_out) {
+__global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
+                                      const double *__restrict__ sgn, double *__restrict__ w_out, bq_iter_stat *stats) {
     if (sc->done) return;
     __shared__ double sh[4];
     const double a = do_update ? sc->t : 0.0;
@@ -347,10 +361,13 @@ __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
         part[1 * nblk + blockIdx.x] = sgd;
         part[2 * nblk + blockIdx.x] = sxg;
     }
+    if (last_block(&sc->ticket[0])) {
+        fw_decide_body(sc, part, nblk, stats);
+        if (threadIdx.x == 0) sc->ticket[0] = 0;
+    }
 }
 
-__global__ void fw_decide_kernel(bq_scal *sc, const double *__restrict__ part, int64_t nblk, bq_iter_stat *stats) {
-    if (sc->done) return;
+__device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
     __shared__ double sh[4];
     const double sgy = final_sum(part + 0 * nblk, nblk, sh);
     const double sgd = final_sum(part + 1 * nblk, nblk, sh);
@@ -416,11 +433,11 @@ int bq_pgfw_iterate(bq_solver *s) {
     const double *sgn = fused_w ? p->sgn : nullptr;
     double *w_out = fused_w ? p->w : nullptr;
     if (s->kind == BQ_PG) {
-        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
-        pg_decide_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, s->partials, s->nblk, s->stats);
+        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out,
+                                                                         s->stats);
     } else {
-        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
-        fw_decide_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, s->partials, s->nblk, s->stats);
+        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out,
+                                                                         s->stats);
     }
     s->started = true;
     const double *w = s->d;   // BQ_PLAIN: the direction itself (same padded length as the panel width)
@@ -432,8 +449,8 @@ int bq_pgfw_iterate(bq_solver *s) {
     }
     BQ_TRY(bq_panel_product(p, p->add_one, w, done));
     finish_den_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, p->N, p->diag_add, p->s, s->d, p->sgn,
-                                                                s->Qd, s->sc, s->partials);
-    step_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->kind == BQ_PG ? 0 : 1, s->sc, s->partials, s->nblk, s->stats);
+                                                                s->Qd, s->sc, s->partials, s->nblk, s->kind == BQ_PG ? 0 : 1,
+                                                                s->stats);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
