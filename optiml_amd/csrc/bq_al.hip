@@ -43,6 +43,24 @@ __device__ __forceinline__ double al_fsum(const double *part, int64_t nblk, doub
     return al_bsum(a, sh);
 }
 
+// the block that takes the last ticket of a launch finishes the reduction and takes the scalar decisions in the same
+// kernel (same fixed-order final sums as a separate one-block kernel: results do not depend on which block is last)
+__device__ __forceinline__ bool al_last_block(unsigned int *ticket) {
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (last) __threadfence();
+    return last != 0;
+}
+
+__device__ __forceinline__ void al_record_body(bq_scal *sc, const bq_al_params &prm, int has_eq, const double *part,
+                                               int64_t nblk, bq_iter_stat *stats);
+__device__ __forceinline__ void al_check_body(bq_scal *sc, const bq_al_params &prm, int has_eq, int has_rows,
+                                              const double *part, int64_t nblk, bq_iter_stat *stats);
+
 // nesterov: x += momentum * previous step, before the gradient is taken (gradient_descent.py:78-81 and the like)
 __global__ void al_jump_kernel(int64_t N, bq_al_vecs V, double mom, const bq_scal *sc) {
     if (sc->done) return;
@@ -52,7 +70,8 @@ __global__ void al_jump_kernel(int64_t N, bq_al_vecs V, double mom, const bq_sca
 }
 
 // partial sums of everything the value needs at x (Qx already computed)
-__global__ void al_eval_kernel(int64_t N, bq_al_vecs V, const bq_scal *sc, double *__restrict__ part, int64_t nblk) {
+__global__ void al_eval_kernel(int64_t N, bq_al_vecs V, bq_scal *sc, double *part, int64_t nblk, bq_al_params prm,
+                               int has_eq, bq_iter_stat *stats) {
     if (sc->done) return;
     __shared__ double sh[4];
     double xqx = 0.0, qx = 0.0, ax = 0.0, dc = 0.0, cl = 0.0;
@@ -86,12 +105,15 @@ __global__ void al_eval_kernel(int64_t N, bq_al_vecs V, const bq_scal *sc, doubl
         part[3 * nblk + blockIdx.x] = dc;
         part[4 * nblk + blockIdx.x] = cl;
     }
+    if (al_last_block(&sc->ticket[0])) {
+        al_record_body(sc, prm, has_eq, part, nblk, stats);
+        if (threadIdx.x == 0) sc->ticket[0] = 0;
+    }
 }
 
-// one block: value, primal value, iteration record, epoch test     (adagrad.py:85-101 and the like)
-__global__ void al_record_kernel(bq_scal *sc, bq_al_params prm, int has_eq, const double *__restrict__ part,
-                                 int64_t nblk, bq_iter_stat *stats) {
-    if (sc->done) return;
+// last block of al_eval_kernel: value, primal value, iteration record, epoch test     (adagrad.py:85-101 and the like)
+__device__ __forceinline__ void al_record_body(bq_scal *sc, const bq_al_params &prm, int has_eq, const double *part,
+                                               int64_t nblk, bq_iter_stat *stats) {
     __shared__ double sh[4];
     const double xqx = al_fsum(part + 0 * nblk, nblk, sh);
     const double qx = al_fsum(part + 1 * nblk, nblk, sh);
@@ -127,9 +149,9 @@ __global__ void al_record_kernel(bq_scal *sc, bq_al_params prm, int has_eq, cons
 }
 
 // gradient, rule step, momentum, x update, multiplier update of the coordinate rows, and the partial sums the stop
-// test needs at the new point
-__global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, const bq_scal *sc,
-                                 double *__restrict__ part, int64_t nblk) {
+// test needs at the new point; the last block then updates the equality multiplier and runs the stop tests
+__global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_scal *sc, double *part, int64_t nblk,
+                                 int has_eq, int has_rows, bq_iter_stat *stats) {
     const bool last = sc->al_last != 0;   // 'stopped' at this evaluation: write its gradient, take no step
     if (sc->done && !last) return;
     __shared__ double sh[4];
@@ -253,7 +275,13 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, cons
             dx += (xn - x) * (xn - x);
         }
     }
-    if (last) return;   // uniform
+    if (last) {   // uniform: no step after the last evaluation; the flag is consumed by the block that finishes last
+        if (al_last_block(&sc->ticket[1]) && threadIdx.x == 0) {
+            sc->al_last = 0;
+            sc->ticket[1] = 0;
+        }
+        return;
+    }
     axn = al_bsum(axn, sh);
     cn = al_bsum(cn, sh);
     dl = al_bsum(dl, sh);
@@ -264,15 +292,16 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, cons
         part[2 * nblk + blockIdx.x] = dl;
         part[3 * nblk + blockIdx.x] = dx;
     }
+    if (al_last_block(&sc->ticket[1])) {
+        al_check_body(sc, prm, has_eq, has_rows, part, nblk, stats);
+        if (threadIdx.x == 0) sc->ticket[1] = 0;
+    }
 }
 
-// one block: multiplier of the equality row, the two stop tests, iter += 1     (optiml/opti/_base.py:129-146)
-__global__ void al_check_kernel(bq_scal *sc, bq_al_params prm, int has_eq, int has_rows, const double *__restrict__ part,
-                                int64_t nblk, bq_iter_stat *stats) {
-    if (sc->done) {
-        if (threadIdx.x == 0) sc->al_last = 0;
-        return;
-    }
+// last block of al_update_kernel: multiplier of the equality row, the two stop tests, iter += 1
+// (optiml/opti/_base.py:129-146)
+__device__ __forceinline__ void al_check_body(bq_scal *sc, const bq_al_params &prm, int has_eq, int has_rows,
+                                              const double *part, int64_t nblk, bq_iter_stat *stats) {
     __shared__ double sh[4];
     const double axn = al_fsum(part + 0 * nblk, nblk, sh);
     double cn = al_fsum(part + 1 * nblk, nblk, sh);
@@ -310,10 +339,9 @@ int bq_al_iterate(bq_solver *s) {
     if (prm.momentum_type == BQ_MOM_NESTEROV)
         al_jump_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, prm.momentum, s->sc);
     BQ_TRY(bq_problem_apply(p, al->V.x, al->V.Qx, done));
-    al_eval_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, s->sc, s->partials, s->nblk);
-    al_record_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, prm, has_eq, s->partials, s->nblk, s->stats);
-    al_update_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, prm, s->sc, s->partials, s->nblk);
-    al_check_kernel<<<1, BQ_VEC_BLOCK, 0, st>>>(s->sc, prm, has_eq, has_rows, s->partials, s->nblk, s->stats);
+    al_eval_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, s->sc, s->partials, s->nblk, prm, has_eq, s->stats);
+    al_update_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, prm, s->sc, s->partials, s->nblk, has_eq,
+                                                             has_rows, s->stats);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
