@@ -6,8 +6,9 @@
 // control flow, so it is latency-bound, not bandwidth-bound: ONE persistent 1024-thread workgroup runs a whole outer
 // iteration per launch.  Thread 0 carries the scalar pair logic; all threads share the three vector jobs of an examine:
 //   (1) E_i = sum_j coef_j K[i][j] for a sample whose error is not cached — over a compact, ascending list of the
-//       samples with a non-zero coefficient (rebuilt by a block-wide compaction whenever a pair step changes it), so an
-//       examine costs O(n_sv / 1024) loads per thread instead of the reference's dense O(n) dot;
+//       samples with a non-zero coefficient (mirrored in LDS, kept current by in-place insert / erase / update after
+//       every pair step), so an examine costs O(n_sv / 1024) panel reads per thread instead of the reference's dense
+//       O(n) dot;
 //   (2) the error-cache update of the free set after a successful pair step (two panel rows);
 //   (3) the re-computation of the two thresholds over the free set.
 // The index sets I0..I4 of the reference are functions of (alpha, y) and are not stored.
@@ -36,6 +37,7 @@ struct bq_smo {
     double C = 1.0, eps = 0.0, tol = 1e-3;
     double *y = nullptr, *a = nullptr, *am = nullptr, *err = nullptr;   // a: alpha (SVC) / alpha+ (SVR); am: alpha-
     int *nz = nullptr;                                                   // n: support list (ascending indices)
+    double *cf = nullptr;                                                // n: and its coefficients
     bq_smo_scal *sc = nullptr;
     bq_smo_scal host;
 };
@@ -107,7 +109,10 @@ struct SmoShared {
     // broadcast slots of the current examine
     double E2, c1, c2;
     long long i1, next;
-    int go, rebuild, fail;
+    int go, fail;
+    int pos, found;               // sup_apply
+    int mem1, mem2;               // new list membership of the two touched samples
+    double cf1, cf2;              // and their new coefficients
     int nnz;                      // length of the support list
     int scan[SMO_T / 64];
 };
@@ -163,14 +168,108 @@ __device__ __forceinline__ int64_t smo_next(int64_t from, int64_t n, SmoShared &
     return n;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Support list: the samples with a non-zero multiplier, ascending, with their coefficients c_j (alpha_j y_j, or
+// alpha+_j - alpha-_j).  Global arrays hold the whole list; its first SMO_CAP entries are mirrored in LDS so that an
+// error evaluation costs one level of global latency (the panel entry) instead of three (index, multiplier, entry).
+// A pair step changes at most two entries: they are inserted / erased / updated in place (binary search + a parallel
+// shift), not by rebuilding the list.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SMO_CAP = 4096;
+struct SupList {
+    int nz[SMO_CAP];
+    double cf[SMO_CAP];
+};
+struct SupGlobal {
+    int *nz;
+    double *cf;
+};
+__device__ __forceinline__ int sup_idx(const SupList &L, const SupGlobal &G, int q) { return q < SMO_CAP ? L.nz[q] : G.nz[q]; }
+__device__ __forceinline__ double sup_cf(const SupList &L, const SupGlobal &G, int q) { return q < SMO_CAP ? L.cf[q] : G.cf[q]; }
+__device__ __forceinline__ void sup_put(SupList &L, const SupGlobal &G, int q, int idx, double c) {
+    G.nz[q] = idx;
+    G.cf[q] = c;
+    if (q < SMO_CAP) {
+        L.nz[q] = idx;
+        L.cf[q] = c;
+    }
+}
+
+// after smo_rebuild filled G.nz: coefficients + LDS mirror
+template <typename Coef>
+__device__ __forceinline__ void sup_fill(SupList &L, const SupGlobal &G, SmoShared &S, Coef coef) {
+    for (int q = threadIdx.x; q < S.nnz; q += SMO_T) {
+        const int j = G.nz[q];
+        sup_put(L, G, q, j, coef(j));
+    }
+    __syncthreads();
+}
+
+// make the list reflect sample idx: member = its multiplier(s) are non-zero now, c = its coefficient.  All threads call
+// this with the same arguments.
+__device__ __forceinline__ void sup_apply(SupList &L, const SupGlobal &G, SmoShared &S, int idx, bool member, double c) {
+    if (threadIdx.x == 0) {   // lower bound of idx
+        int lo = 0, hi = S.nnz;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sup_idx(L, G, mid) < idx)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        S.pos = lo;
+        S.found = (lo < S.nnz && sup_idx(L, G, lo) == idx) ? 1 : 0;
+    }
+    __syncthreads();
+    const int pos = S.pos, nnz = S.nnz;
+    const bool found = S.found != 0;
+    if (member && found) {
+        if (threadIdx.x == 0) sup_put(L, G, pos, idx, c);
+    } else if (member) {   // insert: shift [pos, nnz) one to the right, highest chunk first
+        for (int top = nnz - 1; top >= pos; top -= SMO_T) {
+            const int q = top - (int)threadIdx.x;
+            int vi = 0;
+            double vc = 0.0;
+            if (q >= pos) {
+                vi = sup_idx(L, G, q);
+                vc = sup_cf(L, G, q);
+            }
+            __syncthreads();
+            if (q >= pos) sup_put(L, G, q + 1, vi, vc);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            sup_put(L, G, pos, idx, c);
+            S.nnz = nnz + 1;
+        }
+    } else if (found) {    // erase: shift (pos, nnz) one to the left, lowest chunk first
+        for (int bot = pos + 1; bot < nnz; bot += SMO_T) {
+            const int q = bot + (int)threadIdx.x;
+            int vi = 0;
+            double vc = 0.0;
+            if (q < nnz) {
+                vi = sup_idx(L, G, q);
+                vc = sup_cf(L, G, q);
+            }
+            __syncthreads();
+            if (q < nnz) sup_put(L, G, q - 1, vi, vc);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) S.nnz = nnz - 1;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // classification (smo.py:130-319)
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
-                                                        double *a, double *err, int *nz, double C,
+                                                        double *a, double *err, SupGlobal G, double C,
                                                         double tol, bq_smo_scal *sc) {
     __shared__ SmoShared S;
+    __shared__ SupList L;
     const int tid = threadIdx.x;
     if (tid == 0) {
         S.b_up = sc->b_up;
@@ -185,7 +284,8 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
     long long changed = 0, steps = 0;
     auto nonzero = [&](int64_t j) { return a[j] != 0.0; };
     auto isfree = [&](int64_t j) { const double v = a[j]; return v > 0.0 && v < C; };
-    smo_rebuild(n, nz, S, nonzero);
+    smo_rebuild(n, G.nz, S, nonzero);
+    sup_fill(L, G, S, [&](int j) { return __dmul_rn(a[j], y[j]); });
     // all samples in turn, or only the free ones (re-evaluated as the sweep goes, smo.py:336-338)
     int64_t i2 = sweep_all ? 0 : smo_next(0, n, S, isfree);
     while (i2 < n) {
@@ -197,10 +297,8 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
         // ---- E2 (smo.py:279-291) ----------------------------------------------------------------------------
         if (!free2) {
             double part = 0.0;
-            for (int q = tid; q < S.nnz; q += SMO_T) {
-                const int64_t j = nz[q];
-                part = part + __dmul_rn(__dmul_rn(a[j], y[j]), K.at(i2, j));   // no fma: see smo_bsum
-            }
+            for (int q = tid; q < S.nnz; q += SMO_T)   // c_j = alpha_j y_j, rounded once; no fma: see smo_bsum
+                part = part + __dmul_rn(sup_cf(L, G, q), K.at(i2, sup_idx(L, G, q)));
             const double dot = smo_bsum(part, S.red);
             if (tid == 0) {
                 const double E2 = dot - y2;
@@ -255,7 +353,10 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                         n1 = n1 > C - __dmul_rn(1e-8, C) ? C : (n1 <= __dmul_rn(1e-8, C) ? 0.0 : n1);
                         a[i1] = n1;
                         a[i2] = n2;
-                        S.rebuild = ((a1 == 0.0) != (n1 == 0.0)) || ((a2 == 0.0) != (n2 == 0.0));
+                        S.mem1 = n1 != 0.0;
+                        S.mem2 = n2 != 0.0;
+                        S.cf1 = __dmul_rn(n1, y1);
+                        S.cf2 = __dmul_rn(n2, y2);
                         S.c1 = c1;
                         S.c2 = c2;
                         S.i1 = i1;
@@ -268,12 +369,13 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
         __syncthreads();
         if (S.go) {
             // ---- error cache of the free set + thresholds over the free set (smo.py:199-201, :241-252) -----------
-            if (S.rebuild) smo_rebuild(n, nz, S, nonzero);   // uniform; the list now reflects the new multipliers
             const long long i1 = S.i1;
+            sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);   // the list now reflects the new multipliers
+            sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
             const double c1 = S.c1, c2 = S.c2;
             ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
             for (int q = tid; q < S.nnz; q += SMO_T) {   // the free set is a subset of the support list
-                const int64_t j = nz[q];
+                const int64_t j = sup_idx(L, G, q);
                 const double aj = a[j];
                 if (aj > 0.0 && aj < C) {
                     double e = err[j];
@@ -370,9 +472,10 @@ __device__ __forceinline__ long long svr_pick(const SmoShared &S, double vlow, d
 
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
-                                                        double *ap, double *an, double *err, int *nz,
+                                                        double *ap, double *an, double *err, SupGlobal G,
                                                         double C, double eps, double tol, bq_smo_scal *sc) {
     __shared__ SmoShared S;
+    __shared__ SupList L;
     const int tid = threadIdx.x;
     if (tid == 0) {
         S.b_up = sc->b_up;
@@ -387,7 +490,8 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
     long long changed = 0, steps = 0;
     auto nonzero = [&](int64_t j) { return ap[j] != 0.0 || an[j] != 0.0; };   // a superset of the free set
     auto isfree = [&](int64_t j) { return svr_kind(ap[j], an[j], C) == 0; };
-    smo_rebuild(n, nz, S, nonzero);
+    smo_rebuild(n, G.nz, S, nonzero);
+    sup_fill(L, G, S, [&](int j) { return ap[j] - an[j]; });
     int64_t i2 = sweep_all ? 0 : smo_next(0, n, S, isfree);
     while (i2 < n) {
         const double p2 = ap[i2], m2 = an[i2];
@@ -395,10 +499,8 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
         __syncthreads();   // every thread has read ap/an[i2] before thread 0 may overwrite them below
         if (k2 != 0) {
             double part = 0.0;
-            for (int q = tid; q < S.nnz; q += SMO_T) {
-                const int64_t j = nz[q];
-                part = part + __dmul_rn(ap[j] - an[j], K.at(i2, j));
-            }
+            for (int q = tid; q < S.nnz; q += SMO_T)
+                part = part + __dmul_rn(sup_cf(L, G, q), K.at(i2, sup_idx(L, G, q)));
             const double dot = smo_bsum(part, S.red);
             if (tid == 0) {
                 const double E2 = y[i2] - dot;
@@ -520,8 +622,10 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
                     an[i1] = nm1;
                     ap[i2] = np2;
                     an[i2] = nm2;
-                    S.rebuild = ((p1o != 0.0 || m1o != 0.0) != (np1 != 0.0 || nm1 != 0.0)) ||
-                                ((p2 != 0.0 || m2 != 0.0) != (np2 != 0.0 || nm2 != 0.0));
+                    S.mem1 = np1 != 0.0 || nm1 != 0.0;
+                    S.mem2 = np2 != 0.0 || nm2 != 0.0;
+                    S.cf1 = np1 - nm1;
+                    S.cf2 = np2 - nm2;
                     S.c1 = c1;
                     S.c2 = c2;
                     S.i1 = i1;
@@ -532,12 +636,13 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
         }
         __syncthreads();
         if (S.go) {
-            if (S.rebuild) smo_rebuild(n, nz, S, nonzero);   // uniform
             const long long i1 = S.i1;
+            sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);
+            sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
             const double c1 = S.c1, c2 = S.c2;
             ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
             for (int q = tid; q < S.nnz; q += SMO_T) {
-                const int64_t j = nz[q];
+                const int64_t j = sup_idx(L, G, q);
                 const double pj = ap[j], mj = an[j];
                 const bool pin = pj > 0.0 && pj < C, nin = mj > 0.0 && mj < C;
                 if (pin || nin) {
@@ -628,7 +733,7 @@ extern "C" int bq_smo_destroy(bq_smo *s) {
     if (s == nullptr) return BQ_OK;
     hipSetDevice(s->p->ctx->device);
     hipStreamSynchronize(s->p->ctx->stream);
-    for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->nz, (void *)s->sc})
+    for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->nz, (void *)s->cf, (void *)s->sc})
         if (ptr) hipFree(ptr);
     delete s;
     return BQ_OK;
@@ -671,6 +776,7 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
         if (e == hipSuccess) e = hipMemsetAsync(*v, 0, sizeof(double) * n, c->stream);
     }
     if (e == hipSuccess) e = hipMalloc(&s->nz, sizeof(int) * n);
+    if (e == hipSuccess) e = hipMalloc(&s->cf, sizeof(double) * n);
     if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_smo_scal));
     if (e == hipSuccess) e = hipMemcpyAsync(s->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
     memset(&s->host, 0, sizeof(s->host));
@@ -708,17 +814,17 @@ extern "C" int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, in
         if (s->task == BQ_SVC) {
             if (p->storage == BQ_F64)
                 smo_svc_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
-                                                                    s->a, s->err, s->nz, s->C, s->tol, s->sc);
+                                                                    s->a, s->err, SupGlobal{s->nz, s->cf}, s->C, s->tol, s->sc);
             else
                 smo_svc_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
-                                                                  s->a, s->err, s->nz, s->C, s->tol, s->sc);
+                                                                  s->a, s->err, SupGlobal{s->nz, s->cf}, s->C, s->tol, s->sc);
         } else {
             if (p->storage == BQ_F64)
                 smo_svr_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
-                                                                    s->a, s->am, s->err, s->nz, s->C, s->eps, s->tol, s->sc);
+                                                                    s->a, s->am, s->err, SupGlobal{s->nz, s->cf}, s->C, s->eps, s->tol, s->sc);
             else
                 smo_svr_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
-                                                                  s->a, s->am, s->err, s->nz, s->C, s->eps, s->tol, s->sc);
+                                                                  s->a, s->am, s->err, SupGlobal{s->nz, s->cf}, s->C, s->eps, s->tol, s->sc);
         }
         BQ_HIP(hipGetLastError());
         BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_smo_scal), hipMemcpyDeviceToHost, c->stream));
