@@ -4,7 +4,7 @@
 // (optiml/ml/svm/smo.py): classification (:99-357, Platt's SMO with the two-threshold rule of Keerthi et al.) and
 // regression (:386-797, Shevade et al.).  The algorithm is a sequential sweep over the samples with data-dependent
 // control flow, so it is latency-bound, not bandwidth-bound: ONE persistent 1024-thread workgroup runs a whole outer
-// iteration per launch.  Thread 0 carries the scalar pair logic; all threads share the three vector jobs of an examine:
+// iteration per launch.  Thread 0 carries the scalar pair logic; the other threads share the three vector jobs:
 //   (1) E_i = sum_j coef_j K[i][j] for a sample whose error is not cached — over a compact, ascending list of the
 //       samples with a non-zero coefficient (mirrored in LDS, kept current by in-place insert / erase / update after
 //       every pair step), so an examine costs O(n_sv / 1024) panel reads per thread instead of the reference's dense
@@ -51,22 +51,6 @@ struct KView {
     }
 };
 
-// block-wide deterministic reductions (fixed tree: lane shuffles, then the 16 wave results in order).  The order is part
-// of the contract: oracle/smo_oracle.py (dot='tree') reproduces it bit for bit — thread t adds its elements j = t,
-// t + 1024, ... in ascending order with separately rounded products, the 64 lanes of a wave fold by halves, the 16 wave
-// sums are added in wave order.
-__device__ __forceinline__ double smo_bsum(double v, double *sh) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double r = 0.0;
-#pragma unroll
-    for (int w = 0; w < SMO_T / 64; ++w) r += sh[w];
-    return r;
-}
-
 struct ValIdx {
     double v;
     long long i;
@@ -111,6 +95,9 @@ struct SmoShared {
     long long i1, next;
     int go, fail;
     int pos, found;               // sup_apply
+    long long i2;                 // the examined sample of a pair step
+    int used, stop;               // batch bookkeeping of the sweep drivers
+    double ba[SMO_T / 64], by[SMO_T / 64], bE[SMO_T / 64], bm[SMO_T / 64];   // batch: multiplier(s), label/target, error
     int mem1, mem2;               // new list membership of the two touched samples
     double cf1, cf2;              // and their new coefficients
     int nnz;                      // length of the support list
@@ -154,20 +141,6 @@ __device__ __forceinline__ void smo_rebuild(int64_t n, int *__restrict__ nz, Smo
     if (threadIdx.x == 0) S.nnz = total;
     __syncthreads();
 }
-
-// smallest index >= from that satisfies pred, or n (all threads get the same answer)
-template <typename Pred>
-__device__ __forceinline__ int64_t smo_next(int64_t from, int64_t n, SmoShared &S, Pred pred) {
-    for (int64_t base = from; base < n; base += SMO_T) {
-        const int64_t j = base + threadIdx.x;
-        ValIdx c{0.0, (j < n && pred(j)) ? (long long)j : -1};
-        // all values equal: the reduction returns the smallest valid index
-        c = smo_bbest(c, -1, S.bv, S.bi);
-        if (c.i >= 0) return c.i;
-    }
-    return n;
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Support list: the samples with a non-zero multiplier, ascending, with their coefficients c_j (alpha_j y_j, or
@@ -262,15 +235,173 @@ __device__ __forceinline__ void sup_apply(SupList &L, const SupGlobal &G, SmoSha
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Sweep drivers shared by both tasks.
+// Full sweep (every sample in index order): a batch of 16 samples is prepared at once, one per wave — the wave reads
+// the sample's multiplier(s) and, unless its error is cached, forms E = sum_q c_q K[s][idx_q] over the support list
+// (lane l adds list positions l, l + 64, ... in ascending order with separately rounded products, the 64 lanes fold
+// by halves: the order oracle/smo_oracle.py reproduces with dot='tree').  Thread 0 then examines the 16 samples IN
+// ORDER with exactly the reference's scalar logic; a successful pair step invalidates the rest of the batch (their
+// errors were formed with the old multipliers), which is simply prepared again after the step.  Most examined samples
+// are no violators, so a batch usually costs four barriers for 16 samples.
+// Free-set sweep (smo.py:336-342): only samples with a multiplier strictly inside the box, whose errors are cached —
+// thread 0 walks the support list (the free set is inside it) one sample at a time.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SMO_B = SMO_T / 64;
+
+template <typename T>
+__device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, const SupGlobal &G, int nnz, int64_t s) {
+    double part = 0.0;
+    for (int q = threadIdx.x & 63; q < nnz; q += 64) part = part + __dmul_rn(sup_cf(L, G, q), K.at(s, sup_idx(L, G, q)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    return part;   // complete in lane 0
+}
+
+// smallest list position whose sample index is >= idx (thread 0)
+__device__ __forceinline__ int sup_lower_bound(const SupList &L, const SupGlobal &G, int nnz, long long idx) {
+    int lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sup_idx(L, G, mid) < idx)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // classification (smo.py:130-319)
 // ---------------------------------------------------------------------------------------------------------------
+// thread 0: examine sample i2 (smo.py:278-319) and, if it violates, solve the pair (:130-224).  E2 is the sample's
+// error (cached, or just formed).  Returns true when a pair step was taken; its data is left in S for svc_after_step.
+template <typename T>
+__device__ __forceinline__ bool svc_examine(SmoShared &S, const KView<T> &K, const double *y, double *a, double *err,
+                                            double C, double tol, long long i2, double a2, double y2, double E2) {
+    const bool free2 = a2 > 0.0 && a2 < C;
+    const bool up2 = (y2 == 1.0 && a2 == 0.0) || (y2 == -1.0 && a2 == C);     // I1 or I2
+    const bool low2 = (y2 == 1.0 && a2 == C) || (y2 == -1.0 && a2 == 0.0);    // I3 or I4
+    if (!free2) {
+        err[i2] = E2;
+        if (up2 && E2 < S.b_up) {
+            S.b_up = E2;
+            S.i_up = i2;
+        } else if (low2 && E2 > S.b_low) {
+            S.b_low = E2;
+            S.i_low = i2;
+        }
+    }
+    long long i1 = -1;
+    if ((free2 || up2) && S.b_low - E2 > 2 * tol) i1 = S.i_low;
+    if ((free2 || low2) && E2 - S.b_up > 2 * tol) i1 = S.i_up;
+    if (i1 >= 0 && free2) i1 = (S.b_low - E2 > E2 - S.b_up) ? S.i_low : S.i_up;
+    if (i1 < 0 || i1 == i2) return false;
+    const double a1 = a[i1], y1 = y[i1], E1 = err[i1];
+    double L, H;
+    if (y1 != y2) {
+        L = fmax(0.0, a2 - a1);
+        H = fmin(C, C + a2 - a1);
+    } else {
+        L = fmax(0.0, a2 + a1 - C);
+        H = fmin(C, a2 + a1);
+    }
+    if (L == H) return false;
+    const double k11 = K.at(i1, i1), k22 = K.at(i2, i2), k12 = K.at(i1, i2);
+    const double eta = k11 + k22 - 2 * k12;
+    double n2;
+    if (eta > 0.0) {
+        n2 = fmax(L, fmin(a2 + __dmul_rn(y2, E1 - E2) / eta, H));
+    } else {
+        const double lo = __dmul_rn(__dmul_rn(y2, E1 - E2), L), hi = __dmul_rn(__dmul_rn(y2, E1 - E2), H);
+        n2 = lo > hi + 1e-12 ? L : (lo < hi - 1e-12 ? H : a2);
+    }
+    if (fabs(n2 - a2) < __dmul_rn(1e-12, n2 + a2 + 1e-12)) return false;
+    double n1 = a1 + __dmul_rn(__dmul_rn(y1, y2), a2 - n2);
+    const double c1 = __dmul_rn(y1, n1 - a1), c2 = __dmul_rn(y2, n2 - a2);
+    // own entries of the error cache, with the old multipliers (smo.py:203-204)
+    err[i1] = E1 + (__dmul_rn(c1, k11) + __dmul_rn(c2, k12));
+    err[i2] = E2 + (__dmul_rn(c1, k12) + __dmul_rn(c2, k22));
+    n2 = n2 > C - __dmul_rn(1e-8, C) ? C : (n2 <= __dmul_rn(1e-8, C) ? 0.0 : n2);
+    n1 = n1 > C - __dmul_rn(1e-8, C) ? C : (n1 <= __dmul_rn(1e-8, C) ? 0.0 : n1);
+    a[i1] = n1;
+    a[i2] = n2;
+    S.mem1 = n1 != 0.0;
+    S.mem2 = n2 != 0.0;
+    S.cf1 = __dmul_rn(n1, y1);
+    S.cf2 = __dmul_rn(n2, y2);
+    S.c1 = c1;
+    S.c2 = c2;
+    S.i1 = i1;
+    S.i2 = i2;
+    return true;
+}
+
+// all threads, after a pair step: support list, error cache of the free set, thresholds (smo.py:199-201, :241-271)
+template <typename T>
+__device__ __forceinline__ void svc_after_step(SmoShared &S, SupList &L, const SupGlobal &G, const KView<T> &K,
+                                               const double *y, double *a, double *err, double C) {
+    const int tid = threadIdx.x;
+    const long long i1 = S.i1, i2 = S.i2;
+    sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);   // the list now reflects the new multipliers
+    sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
+    const double c1 = S.c1, c2 = S.c2;
+    ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
+    for (int q = tid; q < S.nnz; q += SMO_T) {   // the free set is a subset of the support list
+        const int64_t j = sup_idx(L, G, q);
+        const double aj = a[j];
+        if (aj > 0.0 && aj < C) {
+            double e = err[j];
+            if (j != i1 && j != i2) {
+                e += __dmul_rn(c1, K.at(i1, j)) + __dmul_rn(c2, K.at(i2, j));
+                err[j] = e;
+            }
+            if (e > hi.v) hi = ValIdx{e, (long long)j};     // ascending j: first maximum / minimum kept
+            if (e < lo.v) lo = ValIdx{e, (long long)j};
+        }
+    }
+    hi = smo_bbest(hi, +1, S.bv, S.bi);
+    lo = smo_bbest(lo, -1, S.bv, S.bi);
+    if (tid == 0) {
+        S.b_up = DBL_MAX;
+        S.b_low = -DBL_MAX;
+        S.i_up = -1;
+        S.i_low = -1;
+        if (hi.i >= 0 && hi.v > S.b_low) {
+            S.b_low = hi.v;
+            S.i_low = hi.i;
+        }
+        if (lo.i >= 0 && lo.v < S.b_up) {
+            S.b_up = lo.v;
+            S.i_up = lo.i;
+        }
+        const long long pair[2] = {i1, i2};
+        for (int k = 0; k < 2; ++k) {   // the two touched samples when they left the free set (smo.py:253-268)
+            const long long i = pair[k];
+            const double ai = a[i], yi = y[i], ei = err[i];
+            if (ai > 0.0 && ai < C) continue;
+            const bool low_i = (yi == 1.0 && ai == C) || (yi == -1.0 && ai == 0.0);
+            if (low_i) {
+                if (ei > S.b_low) {
+                    S.b_low = ei;
+                    S.i_low = i;
+                }
+            } else if (ei < S.b_up) {
+                S.b_up = ei;
+                S.i_up = i;
+            }
+        }
+        if (S.i_low < 0 || S.i_up < 0) S.fail = 1;   // 'unexpected status'
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
                                                         double *a, double *err, SupGlobal G, double C,
                                                         double tol, bq_smo_scal *sc) {
     __shared__ SmoShared S;
     __shared__ SupList L;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) {
         S.b_up = sc->b_up;
         S.b_low = sc->b_low;
@@ -282,154 +413,78 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
     if (sc->finished) return;
     const bool sweep_all = sc->sweep_all != 0;
     long long changed = 0, steps = 0;
-    auto nonzero = [&](int64_t j) { return a[j] != 0.0; };
-    auto isfree = [&](int64_t j) { const double v = a[j]; return v > 0.0 && v < C; };
-    smo_rebuild(n, G.nz, S, nonzero);
+    smo_rebuild(n, G.nz, S, [&](int64_t j) { return a[j] != 0.0; });
     sup_fill(L, G, S, [&](int j) { return __dmul_rn(a[j], y[j]); });
-    // all samples in turn, or only the free ones (re-evaluated as the sweep goes, smo.py:336-338)
-    int64_t i2 = sweep_all ? 0 : smo_next(0, n, S, isfree);
-    while (i2 < n) {
-        const double a2 = a[i2], y2 = y[i2];
-        const bool free2 = a2 > 0.0 && a2 < C;
-        __syncthreads();   // every thread has read a[i2] before thread 0 may overwrite it below
-        const bool up2 = (y2 == 1.0 && a2 == 0.0) || (y2 == -1.0 && a2 == C);     // I1 or I2
-        const bool low2 = (y2 == 1.0 && a2 == C) || (y2 == -1.0 && a2 == 0.0);    // I3 or I4
-        // ---- E2 (smo.py:279-291) ----------------------------------------------------------------------------
-        if (!free2) {
-            double part = 0.0;
-            for (int q = tid; q < S.nnz; q += SMO_T)   // c_j = alpha_j y_j, rounded once; no fma: see smo_bsum
-                part = part + __dmul_rn(sup_cf(L, G, q), K.at(i2, sup_idx(L, G, q)));
-            const double dot = smo_bsum(part, S.red);
+    if (sweep_all) {
+        int64_t i = 0;
+        while (i < n) {
+            const int64_t s = i + wv;
+            if (s < n) {   // wave-uniform
+                const double as = a[s], ys = y[s];
+                double E = 0.0;
+                if (!(as > 0.0 && as < C)) E = wave_dot(K, L, G, S.nnz, s) - ys;
+                if (lane == 0) {
+                    S.ba[wv] = as;
+                    S.by[wv] = ys;
+                    S.bE[wv] = (as > 0.0 && as < C) ? err[s] : E;
+                }
+            }
+            __syncthreads();
             if (tid == 0) {
-                const double E2 = dot - y2;
-                err[i2] = E2;
-                S.E2 = E2;
-                if (up2 && E2 < S.b_up) {
-                    S.b_up = E2;
-                    S.i_up = i2;
-                } else if (low2 && E2 > S.b_low) {
-                    S.b_low = E2;
-                    S.i_low = i2;
+                const int B = n - i < SMO_B ? (int)(n - i) : SMO_B;
+                int used = B;
+                S.go = 0;
+                for (int w = 0; w < B; ++w) {
+                    if (svc_examine(S, K, y, a, err, C, tol, i + w, S.ba[w], S.by[w], S.bE[w])) {
+                        S.go = 1;
+                        used = w + 1;
+                        break;
+                    }
                 }
+                S.used = used;
             }
-        } else if (tid == 0) {
-            S.E2 = err[i2];
+            __syncthreads();
+            if (S.go) {
+                svc_after_step(S, L, G, K, y, a, err, C);
+                ++changed;
+                ++steps;
+            }
+            if (S.fail) break;
+            i += S.used;
+            __syncthreads();   // S.used / S.go are rewritten by thread 0 in the next round
         }
-        // ---- choose i1 and solve the pair (smo.py:293-319, :130-196) — thread 0 --------------------------------
-        if (tid == 0) {
-            const double E2 = S.E2;
-            long long i1 = -1;
-            if ((free2 || up2) && S.b_low - E2 > 2 * tol) i1 = S.i_low;
-            if ((free2 || low2) && E2 - S.b_up > 2 * tol) i1 = S.i_up;
-            if (i1 >= 0 && free2) i1 = (S.b_low - E2 > E2 - S.b_up) ? S.i_low : S.i_up;
-            int go = 0;
-            if (i1 >= 0 && i1 != i2) {
-                const double a1 = a[i1], y1 = y[i1], E1 = err[i1];
-                double L, H;
-                if (y1 != y2) {
-                    L = fmax(0.0, a2 - a1);
-                    H = fmin(C, C + a2 - a1);
-                } else {
-                    L = fmax(0.0, a2 + a1 - C);
-                    H = fmin(C, a2 + a1);
-                }
-                if (L != H) {
-                    const double k11 = K.at(i1, i1), k22 = K.at(i2, i2), k12 = K.at(i1, i2);
-                    const double eta = k11 + k22 - 2 * k12;
-                    double n2;
-                    if (eta > 0.0) {
-                        n2 = fmax(L, fmin(a2 + __dmul_rn(y2, E1 - E2) / eta, H));
-                    } else {
-                        const double lo = __dmul_rn(__dmul_rn(y2, E1 - E2), L), hi = __dmul_rn(__dmul_rn(y2, E1 - E2), H);
-                        n2 = lo > hi + 1e-12 ? L : (lo < hi - 1e-12 ? H : a2);
-                    }
-                    if (!(fabs(n2 - a2) < __dmul_rn(1e-12, n2 + a2 + 1e-12))) {
-                        double n1 = a1 + __dmul_rn(__dmul_rn(y1, y2), a2 - n2);
-                        const double c1 = __dmul_rn(y1, n1 - a1), c2 = __dmul_rn(y2, n2 - a2);
-                        // own entries of the error cache, with the old multipliers (smo.py:203-204)
-                        err[i1] = E1 + (__dmul_rn(c1, k11) + __dmul_rn(c2, k12));
-                        err[i2] = E2 + (__dmul_rn(c1, k12) + __dmul_rn(c2, k22));
-                        n2 = n2 > C - __dmul_rn(1e-8, C) ? C : (n2 <= __dmul_rn(1e-8, C) ? 0.0 : n2);
-                        n1 = n1 > C - __dmul_rn(1e-8, C) ? C : (n1 <= __dmul_rn(1e-8, C) ? 0.0 : n1);
-                        a[i1] = n1;
-                        a[i2] = n2;
-                        S.mem1 = n1 != 0.0;
-                        S.mem2 = n2 != 0.0;
-                        S.cf1 = __dmul_rn(n1, y1);
-                        S.cf2 = __dmul_rn(n2, y2);
-                        S.c1 = c1;
-                        S.c2 = c2;
-                        S.i1 = i1;
-                        go = 1;
-                    }
-                }
-            }
-            S.go = go;
-        }
-        __syncthreads();
-        if (S.go) {
-            // ---- error cache of the free set + thresholds over the free set (smo.py:199-201, :241-252) -----------
-            const long long i1 = S.i1;
-            sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);   // the list now reflects the new multipliers
-            sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
-            const double c1 = S.c1, c2 = S.c2;
-            ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
-            for (int q = tid; q < S.nnz; q += SMO_T) {   // the free set is a subset of the support list
-                const int64_t j = sup_idx(L, G, q);
-                const double aj = a[j];
-                if (aj > 0.0 && aj < C) {
-                    double e = err[j];
-                    if (j != i1 && j != i2) {
-                        e += __dmul_rn(c1, K.at(i1, j)) + __dmul_rn(c2, K.at(i2, j));
-                        err[j] = e;
-                    }
-                    if (e > hi.v) hi = ValIdx{e, (long long)j};     // ascending j: first maximum / minimum kept
-                    if (e < lo.v) lo = ValIdx{e, (long long)j};
-                }
-            }
-            hi = smo_bbest(hi, +1, S.bv, S.bi);
-            lo = smo_bbest(lo, -1, S.bv, S.bi);
+    } else {
+        long long last = -1;
+        while (true) {
             if (tid == 0) {
-                S.b_up = DBL_MAX;
-                S.b_low = -DBL_MAX;
-                S.i_up = -1;
-                S.i_low = -1;
-                if (hi.i >= 0 && hi.v > S.b_low) {
-                    S.b_low = hi.v;
-                    S.i_low = hi.i;
-                }
-                if (lo.i >= 0 && lo.v < S.b_up) {
-                    S.b_up = lo.v;
-                    S.i_up = lo.i;
-                }
-                const long long pair[2] = {i1, (long long)i2};
-                for (int k = 0; k < 2; ++k) {   // the two touched samples when they left the free set (smo.py:253-268)
-                    const long long i = pair[k];
-                    const double ai = a[i], yi = y[i], ei = err[i];
-                    if (ai > 0.0 && ai < C) continue;
-                    const bool low_i = (yi == 1.0 && ai == C) || (yi == -1.0 && ai == 0.0);
-                    if (low_i) {
-                        if (ei > S.b_low) {
-                            S.b_low = ei;
-                            S.i_low = i;
-                        }
-                    } else if (ei < S.b_up) {
-                        S.b_up = ei;
-                        S.i_up = i;
+                S.go = 0;
+                S.stop = 1;
+                for (int q = sup_lower_bound(L, G, S.nnz, last + 1); q < S.nnz; ++q) {
+                    const long long j = sup_idx(L, G, q);
+                    const double aj = a[j];
+                    if (aj > 0.0 && aj < C) {
+                        S.stop = 0;
+                        S.i2 = j;
+                        S.go = svc_examine(S, K, y, a, err, C, tol, j, aj, y[j], err[j]) ? 1 : 0;
+                        break;
                     }
                 }
-                if (S.i_low < 0 || S.i_up < 0) S.fail = 1;   // 'unexpected status'
             }
-            ++changed;
-            ++steps;
+            __syncthreads();
+            if (S.stop) break;
+            if (S.go) {
+                svc_after_step(S, L, G, K, y, a, err, C);
+                ++changed;
+                ++steps;
+            }
+            if (S.fail) break;
+            if (S.b_up > S.b_low - 2 * tol) {   // optimality on the free set (smo.py:339-342)
+                changed = 0;
+                break;
+            }
+            last = S.i2;
+            __syncthreads();
         }
-        __syncthreads();
-        if (S.fail) break;
-        if (!sweep_all && S.b_up > S.b_low - 2 * tol) {   // optimality on the free set (smo.py:339-342)
-            changed = 0;
-            break;
-        }
-        i2 = sweep_all ? i2 + 1 : smo_next(i2 + 1, n, S, isfree);
     }
     if (tid == 0) {
         sc->b_up = S.b_up;
@@ -470,13 +525,218 @@ __device__ __forceinline__ long long svr_pick(const SmoShared &S, double vlow, d
     return -1;
 }
 
+// thread 0: examine sample i2 (smo.py:677-758) and, if it violates, solve the pair (:447-600).  E2 is its error (cached,
+// or just formed).  Returns true when a pair step was taken; its data is left in S for svr_after_step.
+template <typename T>
+__device__ __forceinline__ bool svr_examine(SmoShared &S, const KView<T> &K, const double *y, double *ap, double *an,
+                                            double *err, double C, double eps, double tol, long long i2, double p2,
+                                            double m2, double E2) {
+    const int k2 = svr_kind(p2, m2, C);
+    if (k2 != 0) {
+        err[i2] = E2;
+        if (k2 == 1) {
+            if (E2 + eps < S.b_up) {
+                S.b_up = E2 + eps;
+                S.i_up = i2;
+            } else if (E2 - eps > S.b_low) {
+                S.b_low = E2 - eps;
+                S.i_low = i2;
+            }
+        } else if (k2 == 2 && E2 + eps > S.b_low) {
+            S.b_low = E2 + eps;
+            S.i_low = i2;
+        } else if (k2 == 3 && E2 - eps < S.b_up) {
+            S.b_up = E2 - eps;
+            S.i_up = i2;
+        }
+    }
+    long long i1 = -1;
+    if (k2 == 0) {
+        if (p2 > 0.0 && p2 < C)
+            i1 = svr_pick(S, E2 - eps, E2 - eps, tol);
+        else if (m2 > 0.0 && m2 < C)
+            i1 = svr_pick(S, E2 + eps, E2 + eps, tol);
+    } else if (k2 == 1) {
+        i1 = svr_pick(S, E2 + eps, E2 - eps, tol);
+    } else if (k2 == 2) {
+        if ((E2 + eps) - S.b_up > 2 * tol) i1 = S.i_up;
+    } else if (k2 == 3) {
+        if (S.b_low - (E2 - eps) > 2 * tol) i1 = S.i_low;
+    } else {
+        S.fail = 1;   // 'the index could not be found'
+        return false;
+    }
+    if (i1 < 0 || i1 == i2) return false;
+    const double p1o = ap[i1], m1o = an[i1];
+    double p1 = p1o, m1 = m1o, q2 = p2, r2 = m2;   // q2 / r2: working copies of alpha2+ / alpha2-
+    const double k11 = K.at(i1, i1), k22 = K.at(i2, i2), k12 = K.at(i1, i2);
+    const double eta = fmax(k11 + k22 - 2 * k12, 0.0);
+    const double gamma = p1 - m1 + q2 - r2;
+    double dE = err[i1] - E2;
+    bool tried[4] = {false, false, false, false};
+    bool moved = false, done = false;
+    while (!done) {   // at most three rounds (smo.py:471)
+        if (!tried[0] && (p1 > 0 || (m1 == 0 && dE > 0)) && (q2 > 0 || (r2 == 0 && dE < 0))) {
+            const double L = fmax(0.0, gamma - C), H = fmin(C, gamma);
+            if (L < H) {
+                const double v2 = svr_solve(L, H, q2, -dE, -dE, eta), v1 = p1 - (v2 - q2);
+                if (fabs(v1 - p1) > 1e-12 || fabs(v2 - q2) > 1e-12) {
+                    p1 = v1;
+                    q2 = v2;
+                    moved = true;
+                }
+            } else {
+                done = true;
+            }
+            tried[0] = true;
+        } else if (!tried[1] && (p1 > 0 || (m1 == 0 && dE > 2 * eps)) &&
+                   (r2 > 0 || (q2 == 0 && dE > 2 * eps))) {
+            const double L = fmax(0.0, -gamma), H = fmin(C, -gamma + C);
+            if (L < H) {
+                const double v2 = svr_solve(L, H, r2, dE - 2 * eps, -2 * eps + dE, eta), v1 = p1 + (v2 - r2);
+                if (fabs(v1 - p1) > 1e-12 || fabs(v2 - r2) > 1e-12) {
+                    p1 = v1;
+                    r2 = v2;
+                    moved = true;
+                }
+            } else {
+                done = true;
+            }
+            tried[1] = true;
+        } else if (!tried[2] && (m1 > 0 || (p1 == 0 && dE < -2 * eps)) &&
+                   (q2 > 0 || (r2 == 0 && dE < -2 * eps))) {
+            const double L = fmax(0.0, gamma), H = fmin(C, C + gamma);
+            if (L < H) {
+                const double v2 = svr_solve(L, H, q2, -(dE + 2 * eps), -(2 * eps + dE), eta);
+                const double v1 = m1 + (v2 - q2);
+                if (fabs(v1 - m1) > 1e-12 || fabs(v2 - q2) > 1e-12) {
+                    m1 = v1;
+                    q2 = v2;
+                    moved = true;
+                }
+            } else {
+                done = true;
+            }
+            tried[2] = true;
+        } else if (!tried[3] && (m1 > 0 || (p1 == 0 && dE < 0)) && (r2 > 0 || (q2 == 0 && dE > 0))) {
+            const double L = fmax(0.0, -gamma - C), H = fmin(C, -gamma);
+            if (L < H) {
+                const double v2 = svr_solve(L, H, r2, dE, dE, eta), v1 = m1 - (v2 - r2);
+                if (fabs(v1 - m1) > 1e-12 || fabs(v2 - r2) > 1e-12) {
+                    m1 = v1;
+                    r2 = v2;
+                    moved = true;
+                }
+            } else {
+                done = true;
+            }
+            tried[3] = true;
+        } else {
+            done = true;
+        }
+        dE += __dmul_rn(eta, (q2 - r2) - (p2 - m2));
+    }
+    if (moved) {
+        const double c1 = (p1o - m1o) - (p1 - m1), c2 = (p2 - m2) - (q2 - r2);
+        err[i1] = err[i1] + (__dmul_rn(c1, k11) + __dmul_rn(c2, k12));
+        err[i2] = E2 + (__dmul_rn(c1, k12) + __dmul_rn(c2, k22));
+        const double np1 = svr_clip(p1, C), nm1 = svr_clip(m1, C), np2 = svr_clip(q2, C), nm2 = svr_clip(r2, C);
+        ap[i1] = np1;
+        an[i1] = nm1;
+        ap[i2] = np2;
+        an[i2] = nm2;
+        S.mem1 = np1 != 0.0 || nm1 != 0.0;
+        S.mem2 = np2 != 0.0 || nm2 != 0.0;
+        S.cf1 = np1 - nm1;
+        S.cf2 = np2 - nm2;
+        S.c1 = c1;
+        S.c2 = c2;
+        S.i1 = i1;
+        S.i2 = i2;
+        return true;
+    }
+    return false;
+}
+
+// all threads, after a pair step: support list, error cache of the free set, thresholds (smo.py:601-675)
+template <typename T>
+__device__ __forceinline__ void svr_after_step(SmoShared &S, SupList &L, const SupGlobal &G, const KView<T> &K,
+                                               double *ap, double *an, double *err, double C, double eps) {
+    const int tid = threadIdx.x;
+    const long long i1 = S.i1, i2 = S.i2;
+    sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);
+    sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
+    const double c1 = S.c1, c2 = S.c2;
+    ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
+    for (int q = tid; q < S.nnz; q += SMO_T) {
+        const int64_t j = sup_idx(L, G, q);
+        const double pj = ap[j], mj = an[j];
+        const bool pin = pj > 0.0 && pj < C, nin = mj > 0.0 && mj < C;
+        if (pin || nin) {
+            double e = err[j];
+            if (j != i1 && j != i2) {
+                e += __dmul_rn(c1, K.at(i1, j)) + __dmul_rn(c2, K.at(i2, j));
+                err[j] = e;
+            }
+            // smo.py:641-653: alpha+ inside is tried first, alpha- inside only when that test fails
+            if (pin && e - eps > hi.v)
+                hi = ValIdx{e - eps, (long long)j};
+            else if (nin && e + eps > hi.v)
+                hi = ValIdx{e + eps, (long long)j};
+            if (pin && e - eps < lo.v)
+                lo = ValIdx{e - eps, (long long)j};
+            else if (nin && e + eps < lo.v)
+                lo = ValIdx{e + eps, (long long)j};
+        }
+    }
+    hi = smo_bbest(hi, +1, S.bv, S.bi);
+    lo = smo_bbest(lo, -1, S.bv, S.bi);
+    if (tid == 0) {
+        S.b_up = DBL_MAX;
+        S.b_low = -DBL_MAX;
+        S.i_up = -1;
+        S.i_low = -1;
+        if (hi.i >= 0 && hi.v > S.b_low) {
+            S.b_low = hi.v;
+            S.i_low = hi.i;
+        }
+        if (lo.i >= 0 && lo.v < S.b_up) {
+            S.b_up = lo.v;
+            S.i_up = lo.i;
+        }
+        const long long pair[2] = {i1, (long long)i2};
+        for (int k = 0; k < 2; ++k) {   // smo.py:654-668
+            const long long i = pair[k];
+            const int ki = svr_kind(ap[i], an[i], C);
+            const double ei = err[i];
+            if (ki == 0) continue;
+            if (ki == 2 && ei + eps > S.b_low) {
+                S.b_low = ei + eps;
+                S.i_low = i;
+            } else if (ki == 1 && ei - eps > S.b_low) {
+                S.b_low = ei - eps;
+                S.i_low = i;
+            }
+            if (ki == 3 && ei - eps < S.b_up) {
+                S.b_up = ei - eps;
+                S.i_up = i;
+            } else if (ki == 1 && ei + eps < S.b_up) {
+                S.b_up = ei + eps;
+                S.i_up = i;
+            }
+        }
+        if (S.i_low < 0 || S.i_up < 0) S.fail = 1;
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
                                                         double *ap, double *an, double *err, SupGlobal G,
                                                         double C, double eps, double tol, bq_smo_scal *sc) {
     __shared__ SmoShared S;
     __shared__ SupList L;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) {
         S.b_up = sc->b_up;
         S.b_low = sc->b_low;
@@ -488,228 +748,80 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
     if (sc->finished) return;
     const bool sweep_all = sc->sweep_all != 0;
     long long changed = 0, steps = 0;
-    auto nonzero = [&](int64_t j) { return ap[j] != 0.0 || an[j] != 0.0; };   // a superset of the free set
-    auto isfree = [&](int64_t j) { return svr_kind(ap[j], an[j], C) == 0; };
-    smo_rebuild(n, G.nz, S, nonzero);
+    smo_rebuild(n, G.nz, S, [&](int64_t j) { return ap[j] != 0.0 || an[j] != 0.0; });   // a superset of the free set
     sup_fill(L, G, S, [&](int j) { return ap[j] - an[j]; });
-    int64_t i2 = sweep_all ? 0 : smo_next(0, n, S, isfree);
-    while (i2 < n) {
-        const double p2 = ap[i2], m2 = an[i2];
-        const int k2 = svr_kind(p2, m2, C);
-        __syncthreads();   // every thread has read ap/an[i2] before thread 0 may overwrite them below
-        if (k2 != 0) {
-            double part = 0.0;
-            for (int q = tid; q < S.nnz; q += SMO_T)
-                part = part + __dmul_rn(sup_cf(L, G, q), K.at(i2, sup_idx(L, G, q)));
-            const double dot = smo_bsum(part, S.red);
+    if (sweep_all) {
+        int64_t i = 0;
+        while (i < n) {
+            const int64_t s = i + wv;
+            if (s < n) {   // wave-uniform
+                const double ps = ap[s], ms = an[s];
+                const bool cached = svr_kind(ps, ms, C) == 0;
+                double E = 0.0;
+                if (!cached) E = y[s] - wave_dot(K, L, G, S.nnz, s);
+                if (lane == 0) {
+                    S.ba[wv] = ps;
+                    S.bm[wv] = ms;
+                    S.bE[wv] = cached ? err[s] : E;
+                }
+            }
+            __syncthreads();
             if (tid == 0) {
-                const double E2 = y[i2] - dot;
-                err[i2] = E2;
-                S.E2 = E2;
-                if (k2 == 1) {
-                    if (E2 + eps < S.b_up) {
-                        S.b_up = E2 + eps;
-                        S.i_up = i2;
-                    } else if (E2 - eps > S.b_low) {
-                        S.b_low = E2 - eps;
-                        S.i_low = i2;
+                const int B = n - i < SMO_B ? (int)(n - i) : SMO_B;
+                int used = B;
+                S.go = 0;
+                for (int w = 0; w < B; ++w) {
+                    const bool took = svr_examine(S, K, y, ap, an, err, C, eps, tol, i + w, S.ba[w], S.bm[w], S.bE[w]);
+                    if (took || S.fail) {
+                        S.go = took ? 1 : 0;
+                        used = w + 1;
+                        break;
                     }
-                } else if (k2 == 2 && E2 + eps > S.b_low) {
-                    S.b_low = E2 + eps;
-                    S.i_low = i2;
-                } else if (k2 == 3 && E2 - eps < S.b_up) {
-                    S.b_up = E2 - eps;
-                    S.i_up = i2;
                 }
+                S.used = used;
             }
-        } else if (tid == 0) {
-            S.E2 = err[i2];
+            __syncthreads();
+            if (S.go) {
+                svr_after_step(S, L, G, K, ap, an, err, C, eps);
+                ++changed;
+                ++steps;
+            }
+            if (S.fail) break;
+            i += S.used;
+            __syncthreads();   // S.used / S.go are rewritten by thread 0 in the next round
         }
-        if (tid == 0) {
-            const double E2 = S.E2;
-            long long i1 = -1;
-            if (k2 == 0) {
-                if (p2 > 0.0 && p2 < C)
-                    i1 = svr_pick(S, E2 - eps, E2 - eps, tol);
-                else if (m2 > 0.0 && m2 < C)
-                    i1 = svr_pick(S, E2 + eps, E2 + eps, tol);
-            } else if (k2 == 1) {
-                i1 = svr_pick(S, E2 + eps, E2 - eps, tol);
-            } else if (k2 == 2) {
-                if ((E2 + eps) - S.b_up > 2 * tol) i1 = S.i_up;
-            } else if (k2 == 3) {
-                if (S.b_low - (E2 - eps) > 2 * tol) i1 = S.i_low;
-            } else {
-                S.fail = 1;   // 'the index could not be found'
-            }
-            int go = 0;
-            if (i1 >= 0 && i1 != i2 && !S.fail) {
-                const double p1o = ap[i1], m1o = an[i1];
-                double p1 = p1o, m1 = m1o, q2 = p2, r2 = m2;   // q2 / r2: working copies of alpha2+ / alpha2-
-                const double k11 = K.at(i1, i1), k22 = K.at(i2, i2), k12 = K.at(i1, i2);
-                const double eta = fmax(k11 + k22 - 2 * k12, 0.0);
-                const double gamma = p1 - m1 + q2 - r2;
-                double dE = err[i1] - E2;
-                bool tried[4] = {false, false, false, false};
-                bool moved = false, done = false;
-                while (!done) {   // at most three rounds (smo.py:471)
-                    if (!tried[0] && (p1 > 0 || (m1 == 0 && dE > 0)) && (q2 > 0 || (r2 == 0 && dE < 0))) {
-                        const double L = fmax(0.0, gamma - C), H = fmin(C, gamma);
-                        if (L < H) {
-                            const double v2 = svr_solve(L, H, q2, -dE, -dE, eta), v1 = p1 - (v2 - q2);
-                            if (fabs(v1 - p1) > 1e-12 || fabs(v2 - q2) > 1e-12) {
-                                p1 = v1;
-                                q2 = v2;
-                                moved = true;
-                            }
-                        } else {
-                            done = true;
-                        }
-                        tried[0] = true;
-                    } else if (!tried[1] && (p1 > 0 || (m1 == 0 && dE > 2 * eps)) &&
-                               (r2 > 0 || (q2 == 0 && dE > 2 * eps))) {
-                        const double L = fmax(0.0, -gamma), H = fmin(C, -gamma + C);
-                        if (L < H) {
-                            const double v2 = svr_solve(L, H, r2, dE - 2 * eps, -2 * eps + dE, eta), v1 = p1 + (v2 - r2);
-                            if (fabs(v1 - p1) > 1e-12 || fabs(v2 - r2) > 1e-12) {
-                                p1 = v1;
-                                r2 = v2;
-                                moved = true;
-                            }
-                        } else {
-                            done = true;
-                        }
-                        tried[1] = true;
-                    } else if (!tried[2] && (m1 > 0 || (p1 == 0 && dE < -2 * eps)) &&
-                               (q2 > 0 || (r2 == 0 && dE < -2 * eps))) {
-                        const double L = fmax(0.0, gamma), H = fmin(C, C + gamma);
-                        if (L < H) {
-                            const double v2 = svr_solve(L, H, q2, -(dE + 2 * eps), -(2 * eps + dE), eta);
-                            const double v1 = m1 + (v2 - q2);
-                            if (fabs(v1 - m1) > 1e-12 || fabs(v2 - q2) > 1e-12) {
-                                m1 = v1;
-                                q2 = v2;
-                                moved = true;
-                            }
-                        } else {
-                            done = true;
-                        }
-                        tried[2] = true;
-                    } else if (!tried[3] && (m1 > 0 || (p1 == 0 && dE < 0)) && (r2 > 0 || (q2 == 0 && dE > 0))) {
-                        const double L = fmax(0.0, -gamma - C), H = fmin(C, -gamma);
-                        if (L < H) {
-                            const double v2 = svr_solve(L, H, r2, dE, dE, eta), v1 = m1 - (v2 - r2);
-                            if (fabs(v1 - m1) > 1e-12 || fabs(v2 - r2) > 1e-12) {
-                                m1 = v1;
-                                r2 = v2;
-                                moved = true;
-                            }
-                        } else {
-                            done = true;
-                        }
-                        tried[3] = true;
-                    } else {
-                        done = true;
-                    }
-                    dE += __dmul_rn(eta, (q2 - r2) - (p2 - m2));
-                }
-                if (moved) {
-                    const double c1 = (p1o - m1o) - (p1 - m1), c2 = (p2 - m2) - (q2 - r2);
-                    err[i1] = err[i1] + (__dmul_rn(c1, k11) + __dmul_rn(c2, k12));
-                    err[i2] = E2 + (__dmul_rn(c1, k12) + __dmul_rn(c2, k22));
-                    const double np1 = svr_clip(p1, C), nm1 = svr_clip(m1, C), np2 = svr_clip(q2, C), nm2 = svr_clip(r2, C);
-                    ap[i1] = np1;
-                    an[i1] = nm1;
-                    ap[i2] = np2;
-                    an[i2] = nm2;
-                    S.mem1 = np1 != 0.0 || nm1 != 0.0;
-                    S.mem2 = np2 != 0.0 || nm2 != 0.0;
-                    S.cf1 = np1 - nm1;
-                    S.cf2 = np2 - nm2;
-                    S.c1 = c1;
-                    S.c2 = c2;
-                    S.i1 = i1;
-                    go = 1;
-                }
-            }
-            S.go = go;
-        }
-        __syncthreads();
-        if (S.go) {
-            const long long i1 = S.i1;
-            sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);
-            sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
-            const double c1 = S.c1, c2 = S.c2;
-            ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
-            for (int q = tid; q < S.nnz; q += SMO_T) {
-                const int64_t j = sup_idx(L, G, q);
-                const double pj = ap[j], mj = an[j];
-                const bool pin = pj > 0.0 && pj < C, nin = mj > 0.0 && mj < C;
-                if (pin || nin) {
-                    double e = err[j];
-                    if (j != i1 && j != i2) {
-                        e += __dmul_rn(c1, K.at(i1, j)) + __dmul_rn(c2, K.at(i2, j));
-                        err[j] = e;
-                    }
-                    // smo.py:641-653: alpha+ inside is tried first, alpha- inside only when that test fails
-                    if (pin && e - eps > hi.v)
-                        hi = ValIdx{e - eps, (long long)j};
-                    else if (nin && e + eps > hi.v)
-                        hi = ValIdx{e + eps, (long long)j};
-                    if (pin && e - eps < lo.v)
-                        lo = ValIdx{e - eps, (long long)j};
-                    else if (nin && e + eps < lo.v)
-                        lo = ValIdx{e + eps, (long long)j};
-                }
-            }
-            hi = smo_bbest(hi, +1, S.bv, S.bi);
-            lo = smo_bbest(lo, -1, S.bv, S.bi);
+    } else {
+        long long last = -1;
+        while (true) {
             if (tid == 0) {
-                S.b_up = DBL_MAX;
-                S.b_low = -DBL_MAX;
-                S.i_up = -1;
-                S.i_low = -1;
-                if (hi.i >= 0 && hi.v > S.b_low) {
-                    S.b_low = hi.v;
-                    S.i_low = hi.i;
-                }
-                if (lo.i >= 0 && lo.v < S.b_up) {
-                    S.b_up = lo.v;
-                    S.i_up = lo.i;
-                }
-                const long long pair[2] = {i1, (long long)i2};
-                for (int k = 0; k < 2; ++k) {   // smo.py:654-668
-                    const long long i = pair[k];
-                    const int ki = svr_kind(ap[i], an[i], C);
-                    const double ei = err[i];
-                    if (ki == 0) continue;
-                    if (ki == 2 && ei + eps > S.b_low) {
-                        S.b_low = ei + eps;
-                        S.i_low = i;
-                    } else if (ki == 1 && ei - eps > S.b_low) {
-                        S.b_low = ei - eps;
-                        S.i_low = i;
-                    }
-                    if (ki == 3 && ei - eps < S.b_up) {
-                        S.b_up = ei - eps;
-                        S.i_up = i;
-                    } else if (ki == 1 && ei + eps < S.b_up) {
-                        S.b_up = ei + eps;
-                        S.i_up = i;
+                S.go = 0;
+                S.stop = 1;
+                for (int q = sup_lower_bound(L, G, S.nnz, last + 1); q < S.nnz; ++q) {
+                    const long long j = sup_idx(L, G, q);
+                    const double pj = ap[j], mj = an[j];
+                    if (svr_kind(pj, mj, C) == 0) {
+                        S.stop = 0;
+                        S.i2 = j;
+                        S.go = svr_examine(S, K, y, ap, an, err, C, eps, tol, j, pj, mj, err[j]) ? 1 : 0;
+                        break;
                     }
                 }
-                if (S.i_low < 0 || S.i_up < 0) S.fail = 1;
             }
-            ++changed;
-            ++steps;
+            __syncthreads();
+            if (S.stop) break;
+            if (S.go) {
+                svr_after_step(S, L, G, K, ap, an, err, C, eps);
+                ++changed;
+                ++steps;
+            }
+            if (S.fail) break;
+            if (S.b_up > S.b_low - 2 * tol) {
+                changed = 0;
+                break;
+            }
+            last = S.i2;
+            __syncthreads();
         }
-        __syncthreads();
-        if (S.fail) break;
-        if (!sweep_all && S.b_up > S.b_low - 2 * tol) {
-            changed = 0;
-            break;
-        }
-        i2 = sweep_all ? i2 + 1 : smo_next(i2 + 1, n, S, isfree);
     }
     if (tid == 0) {
         sc->b_up = S.b_up;
