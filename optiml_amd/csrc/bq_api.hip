@@ -592,6 +592,10 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
                       (void *)s->mL, (void *)s->mU, (void *)s->partials, (void *)s->sc, (void *)s->stats})
         if (ptr) hipFree(ptr);
     if (s->chol) bq_chol_ws_destroy(s->chol);
+    if (s->flag_host) {
+        hipHostFree(s->flag_host);
+        hipEventDestroy(s->flag_event);
+    }
     bq_as_free(s);
     if (s->al) {
         bq_al_vecs &V = s->al->V;   // x, g, step (= s->d) and Qx (= s->Qd) are owned by the common slots above
@@ -827,6 +831,16 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
         BQ_HIP(hipMalloc(&s->stats, sizeof(bq_iter_stat) * max_steps));
         s->stats_cap = max_steps;
     }
+    if (s->flag_host == nullptr) {   // pinned flag + event of the lagged done-flag polling (best effort)
+        if (hipHostMalloc((void **)&s->flag_host, sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s->flag_event, hipEventDisableTiming) != hipSuccess) {
+            if (s->flag_host) hipHostFree(s->flag_host);
+            s->flag_host = nullptr;
+            (void)hipGetLastError();
+        } else {
+            *s->flag_host = 0;
+        }
+    }
     const long long base = s->host.iter;
     long long hdr[2] = {base, (long long)max_steps};
     BQ_HIP(hipMemcpyAsync(&s->sc->stat_base, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
@@ -845,12 +859,28 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
         poll = (int64_t)(2.0e-3 / iter_s);
         poll = poll < 1 ? 1 : (poll > 64 ? 64 : poll);
     }
+    // The product-bound solvers look at the flag with a LAG of one chunk: the copy of the flag is followed by an event,
+    // the next chunk is enqueued at once, and only then does the host wait for that event — the device never runs dry
+    // while the host decides (the extra chunk early-exits on the flag).  The factorising solvers enqueue O(n^3) work per
+    // iteration from the host and check before every iteration.
+    const bool lagged = poll > 0 && (s->kind == BQ_PG || s->kind == BQ_FW || s->kind == BQ_AL) && s->flag_host != nullptr;
+    bool pending = false;
     for (int64_t k = 0; k < max_steps; ++k) {
         BQ_TRY(solver_iterate(s));
         if ((k + 1) % poll == 0 && k + 1 < max_steps) {
-            BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));
-            BQ_HIP(hipStreamSynchronize(c->stream));
-            if (s->host.done) break;
+            if (lagged) {
+                if (pending) {
+                    BQ_HIP(hipEventSynchronize(s->flag_event));
+                    if (*s->flag_host) break;
+                }
+                BQ_HIP(hipMemcpyAsync(s->flag_host, &s->sc->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                BQ_HIP(hipEventRecord(s->flag_event, c->stream));
+                pending = true;
+            } else {
+                BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));
+                BQ_HIP(hipStreamSynchronize(c->stream));
+                if (s->host.done) break;
+            }
         }
     }
     BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));

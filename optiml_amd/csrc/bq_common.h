@@ -151,6 +151,8 @@ struct bq_solver {
     bq_chol_ws *chol = nullptr;
     void *as_ws = nullptr;
     bq_al_state *al = nullptr;
+    int *flag_host = nullptr;          // pinned copy of sc->done + its event (lagged polling in bq_solver_run)
+    hipEvent_t flag_event = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------
