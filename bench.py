@@ -40,8 +40,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--samples', '--n', dest='n', type=int, default=100000)
     ap.add_argument('--features', '--d', dest='d', type=int, default=128)
-    ap.add_argument('--solver', default='pg', choices=['pg', 'fw', 'adagrad'],
-                    help='adagrad: AdaGrad on the augmented Lagrangian of the reg_intercept=False dual (SURVEY 8f.3)')
+    ap.add_argument('--solver', default='pg', choices=['pg', 'fw', 'adagrad', 'smo'],
+                    help='adagrad: AdaGrad on the augmented Lagrangian of the reg_intercept=False dual (SURVEY 8f.3); '
+                         'smo: time-to-KKT-tol of SVC.fit(optimizer="smo") (SURVEY 8f.4; --steps/--warmup unused)')
     ap.add_argument('--task', default='svc', choices=['svc', 'svr'], help='svr: eps-insensitive dual, dim 2n (config 4)')
     ap.add_argument('--kernel', default='rbf', choices=['rbf', 'poly', 'linear'], help='poly: degree 3, coef0 1')
     ap.add_argument('--storage', default='f64', choices=['f64', 'f32', 'stream'],
@@ -137,8 +138,48 @@ def cpu_baseline_al(args, threads):
             'measured_iter_per_s_at_sample': rate, 'sample_n': ns}
 
 
+def bench_smo(args):
+    """BASELINE.json's second metric, time-to-KKT-tol, on the route that reaches it fastest: SVC.fit(optimizer='smo') end
+    to end (Gram build + sweeps) on one GPU; CPU baseline: the oracle's SMO sweeps at a bounded n (Gram excluded)."""
+    from oracle import smo_oracle as smo, svm_oracle as so
+    from optiml_amd import device
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm import SVC
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.ml.svm.losses import hinge
+    ctx = device.get_context()
+    X, y = make_blobs(args.n, args.d, seed=0)
+    t0 = time.perf_counter()
+    est = SVC(loss=hinge, kernel=gaussian, C=1., dual=True, optimizer='smo', tol=1e-3).fit(X, y)
+    dt = time.perf_counter() - t0
+    out = {'metric': 'time_to_kkt_tol', 'value': dt, 'unit': 's', 'n_gpus': 1, 'steps': int(est.optimizer.iter), 'warmup': 0,
+           'ms_per_step': 1e3 * dt / max(est.optimizer.iter, 1), 'higher_is_better': False, 'scaling': 'strong',
+           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': f'svc_hinge_rbf_smo_dual_n{args.n}_d{args.d}', 'n': args.n, 'd': args.d, 'C': 1.0,
+                      'tol': 1e-3, 'gamma': 'scale', 'solver': 'smo', 'device': ctx.name},
+           'roofline': None, 'pair_steps': int(est.optimizer.steps), 'outer_iterations': int(est.optimizer.iter),
+           'n_sv': int(len(est.support_))}
+    if not args.no_cpu:
+        ns = min(args.cpu_n, args.n)
+        K = so.gram('rbf', X[:ns])
+        yb = np.where(y[:ns] == np.unique(y)[-1], 1., -1.)
+        t0 = time.perf_counter()
+        r = smo.smo_svc(K, yb, 1., 1e-3)
+        dtc = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': dtc, 'unit': 's', 'cores': int(os.cpu_count() or 1), 'kind': 'port',
+                               'sample': f'oracle SMO sweeps (reference algorithm in NumPy, dense K on host, Gram build '
+                                         f'excluded) at n={ns}: {r["iter"]} outer iterations, {r["steps"]} pair steps'}
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.solver == 'smo':
+        if args.gpus != 1:
+            raise SystemExit('SMO walks the samples sequentially on one GPU (replicas only): --gpus 1')
+        return bench_smo(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world != args.gpus:

@@ -4,7 +4,7 @@
     python tools/bench_extra.py ip   --n 16000 --d 128 --iters 3     # InteriorPoint iteration / Cholesky rate
     python tools/bench_extra.py chol --n 8192                        # stand-alone dense Cholesky solve
     python tools/bench_extra.py fit  --n 20000 --d 64 --solver pg    # SVC.fit wall time (BASELINE config 2 shape)
-    python tools/bench_extra.py smo  --n 20000 --d 64 [--cpu-n 2000] # device SMO fit (+ the oracle timed at --cpu-n)
+    python tools/bench_extra.py smo  --n 20000 --d 64                # device SMO fit (CPU baseline: bench.py --solver smo)
 """
 import argparse
 import json
@@ -28,7 +28,6 @@ def main():
     ap.add_argument('--solver', default='pg')
     ap.add_argument('--task', choices=['svc', 'svr'], default='svc')
     ap.add_argument('--max-iter', type=int, default=1000)
-    ap.add_argument('--cpu-n', type=int, default=0, help='smo: also time the CPU oracle at this n')
     ap.add_argument('--tol', type=float, default=1e-3)
     ap.add_argument('--progress', action='store_true', help='print one line per solver iteration (long runs)')
     a = ap.parse_args()
@@ -66,16 +65,6 @@ def main():
         o = est.optimizer
         out.update(task=a.task, tol=a.tol, fit_s=dt, outer_iters=o.iter, pair_steps=o.steps, n_sv=int(len(est.support_)),
                    b=float(est.intercept_), steps_per_s=o.steps / dt, score=float(est.score(X[:5000], y[:5000])))
-        if a.cpu_n:
-            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-            from oracle import smo_oracle as smo, svm_oracle as so
-            Xs, ys = X[:a.cpu_n], y[:a.cpu_n]
-            K = so.gram('rbf', Xs)
-            t0 = time.perf_counter()
-            r = (smo.smo_svr(K, ys, 1., 0.1, a.tol) if a.task == 'svr' else smo.smo_svc(K, ys, 1., a.tol))
-            dtc = time.perf_counter() - t0
-            out.update(cpu_n=a.cpu_n, cpu_fit_s=dtc, cpu_outer_iters=r['iter'], cpu_pair_steps=r['steps'],
-                       cpu_steps_per_s=r['steps'] / dtc)
     elif a.what == 'ip':
         from optiml_amd.ml.svm.kernels import gaussian
         from optiml_amd.opti import KernelQuadratic
