@@ -12,6 +12,7 @@ struct bq_chol_ws {
     double *rhs = nullptr;    // right-hand side / solution (padded)
     double *tmp = nullptr;    // 128 scratch
     int *info = nullptr;      // 0 = ok, else 1 + index of the first non-positive pivot
+    unsigned int *ticket = nullptr;   // last-block ticket of the fused solve kernels
     double *mr_vec = nullptr; // 10 x cap scratch vectors of the MINRES fallback (allocated on first use)
     // look-ahead: the narrow work of pass p+1 (diagonal blocks, TRSM, column update) runs on a side stream that owns
     // a few reserved CUs while the wide trailing update of pass p runs on the rest of the chip

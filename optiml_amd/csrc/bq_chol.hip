@@ -118,9 +118,15 @@ __device__ __forceinline__ double wsum_c(double v) {
     return v;
 }
 
+__device__ __forceinline__ void diag_mv_body(const double *__restrict__ LinvT, int transpose, const double *in,
+                                             double *out);
+__device__ __forceinline__ bool chol_last_block(unsigned int *ticket);
+
 // tmp[r] = rhs[k0 + r] - sum_{c < k0} L[k0 + r][c] * rhs[c]      (one workgroup per row r)
-__global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0,
-                                                        const double *__restrict__ rhs, double *__restrict__ tmp) {
+// ... and the last block to finish applies the inverse of the diagonal block: rhs[k0 : k0+128) = Linv_kk tmp
+__global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0, double *rhs,
+                                                        double *tmp, const double *__restrict__ LinvT,
+                                                        unsigned int *ticket) {
     __shared__ double red[4];
     const int r = blockIdx.x, tid = threadIdx.x;
     const double *row = H + (k0 + r) * ldh;
@@ -134,50 +140,91 @@ __global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict
     if ((tid & 63) == 0) red[tid >> 6] = a;
     __syncthreads();
     if (tid == 0) tmp[r] = rhs[k0 + r] - (((red[0] + red[1]) + red[2]) + red[3]);
+    if (chol_last_block(ticket)) diag_mv_body(LinvT, 0, tmp, rhs + k0);
 }
 
 // out[i] = sum_j M[i][j] in[j] with M = Linv (transpose == 0) or Linv^T (transpose == 1); LinvT[k][j] = Linv[j][k].
 // Two threads per output element split the 128-long sum; reads of LinvT are coalesced in the non-transposed case
 // (consecutive i) and row-contiguous per thread in the transposed one (L2-resident 128 KB).
-__global__ __launch_bounds__(256) void diag_mv_kernel(const double *__restrict__ LinvT, int transpose,
-                                                      const double *__restrict__ in, double *__restrict__ out) {
+__device__ __forceinline__ void diag_mv_body(const double *__restrict__ LinvT, int transpose, const double *in,
+                                             double *out) {
     __shared__ double v[NB];
     __shared__ double half[2][NB];
     const int i = threadIdx.x & 127, h = threadIdx.x >> 7;
     if (threadIdx.x < NB) v[threadIdx.x] = in[threadIdx.x];
     __syncthreads();
-    double s = 0.0;
-    if (transpose) {
-        // Linv^T[i][j] = LinvT[i][j], non-zero for j >= i
-        const int j0 = h ? 64 : 0, j1 = h ? NB : 64;
-        for (int j = (j0 > i ? j0 : i); j < j1; ++j) s = fma(LinvT[i * NB + j], v[j], s);
-    } else {
-        // Linv[i][j] = LinvT[j][i], non-zero for j <= i
-        const int j0 = h ? 64 : 0, j1 = h ? NB : 64;
-        for (int j = j0; j < j1 && j <= i; ++j) s = fma(LinvT[j * NB + i], v[j], s);
+    // LinvT is a full 128 x 128 square (zeros outside the triangle), so the loops have fixed trip counts and are unrolled
+    // with independent accumulators: the 64 loads of a thread are in flight together (the triangular bounds made this a
+    // chain of dependent-latency loads: 24 us per call).
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int j0 = h * 64;
+    if (transpose) {   // Linv^T[i][j] = LinvT[i][j]: row i, contiguous
+        const bq_d2 *row = reinterpret_cast<const bq_d2 *>(LinvT + i * NB + j0);
+#pragma unroll 8
+        for (int jj = 0; jj < 32; jj += 2) {
+            const bq_d2 l0 = row[jj], l1 = row[jj + 1];
+            acc[0] = fma(l0.x, v[j0 + 2 * jj], acc[0]);
+            acc[1] = fma(l0.y, v[j0 + 2 * jj + 1], acc[1]);
+            acc[2] = fma(l1.x, v[j0 + 2 * jj + 2], acc[2]);
+            acc[3] = fma(l1.y, v[j0 + 2 * jj + 3], acc[3]);
+        }
+    } else {           // Linv[i][j] = LinvT[j][i]: column i, coalesced across the threads
+#pragma unroll 16
+        for (int jj = 0; jj < 64; jj += 4) {
+            acc[0] = fma(LinvT[(j0 + jj) * NB + i], v[j0 + jj], acc[0]);
+            acc[1] = fma(LinvT[(j0 + jj + 1) * NB + i], v[j0 + jj + 1], acc[1]);
+            acc[2] = fma(LinvT[(j0 + jj + 2) * NB + i], v[j0 + jj + 2], acc[2]);
+            acc[3] = fma(LinvT[(j0 + jj + 3) * NB + i], v[j0 + jj + 3], acc[3]);
+        }
     }
+    const double s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     half[h][i] = s;
     __syncthreads();
     if (threadIdx.x < NB) out[i] = half[0][i] + half[1][i];
 }
+__global__ __launch_bounds__(256) void diag_mv_kernel(const double *__restrict__ LinvT, int transpose, const double *in,
+                                                      double *out) {
+    diag_mv_body(LinvT, transpose, in, out);
+}
 
-// rhs[c] -= sum_{r < 128} L[k0 + r][c] * x[r]  for c < k0
+// the block that takes the last ticket of a launch runs the 128 x 128 product that depends on all of them (one launch
+// and one dependent-kernel gap less per block step of the solves)
+__device__ __forceinline__ bool chol_last_block(unsigned int *ticket) {
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        if (threadIdx.x == 0) *ticket = 0;
+    }
+    return last != 0;
+}
+
+// rhs[c] -= sum_{r < 128} L[k0 + r][c] * x[r]  for c < k0; the last block to finish then solves the next (previous)
+// diagonal block in place: rhs[k0-128 : k0) = Linv^T_{k-1} rhs[k0-128 : k0)
 __global__ __launch_bounds__(256) void bwd_update_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0,
-                                                         const double *__restrict__ xk, double *__restrict__ rhs) {
+                                                         const double *xk, double *rhs,
+                                                         const double *__restrict__ LinvT_prev, unsigned int *ticket) {
     __shared__ double x[NB];
     if (threadIdx.x < NB) x[threadIdx.x] = xk[threadIdx.x];
     __syncthreads();
     const int64_t c = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
-    if (c >= k0) return;
-    double a0 = 0.0, a1 = 0.0;
+    if (c < k0) {
+        double a0 = 0.0, a1 = 0.0;
 #pragma unroll 8
-    for (int r = 0; r < NB; ++r) {
-        const bq_d2 l = *reinterpret_cast<const bq_d2 *>(H + (k0 + r) * ldh + c);
-        a0 = fma(l.x, x[r], a0);
-        a1 = fma(l.y, x[r], a1);
+        for (int r = 0; r < NB; ++r) {
+            const bq_d2 l = *reinterpret_cast<const bq_d2 *>(H + (k0 + r) * ldh + c);
+            a0 = fma(l.x, x[r], a0);
+            a1 = fma(l.y, x[r], a1);
+        }
+        rhs[c] -= a0;
+        rhs[c + 1] -= a1;
     }
-    rhs[c] -= a0;
-    rhs[c + 1] -= a1;
+    if (chol_last_block(ticket)) diag_mv_body(LinvT_prev, 1, rhs + k0 - NB, rhs + k0 - NB);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,6 +248,8 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
     if (e == hipSuccess) e = hipMalloc(&ws->rhs, sizeof(double) * (ws->cap + NB));
     if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * NB);
     if (e == hipSuccess) e = hipMalloc(&ws->info, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&ws->ticket, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(ws->ticket, 0, sizeof(unsigned int));
     if (e == hipSuccess && bq_potrf_diag_setup() != BQ_OK) e = hipErrorUnknown;
     if (e != hipSuccess) {
         bq_set_error("factorisation workspace setup failed: %s", hipGetErrorString(e));
@@ -248,7 +297,7 @@ void bq_chol_ws_destroy(bq_chol_ws *ws) {
         if (e) hipEventDestroy(e);
     if (ws->s_main) hipStreamDestroy(ws->s_main);
     if (ws->s_side) hipStreamDestroy(ws->s_side);
-    for (void *p : {(void *)ws->H, (void *)ws->Wt, (void *)ws->LinvT, (void *)ws->rhs, (void *)ws->tmp, (void *)ws->info,
+    for (void *p : {(void *)ws->H, (void *)ws->Wt, (void *)ws->LinvT, (void *)ws->rhs, (void *)ws->tmp, (void *)ws->info, (void *)ws->ticket,
                     (void *)ws->mr_vec})
         if (p) hipFree(p);
     delete ws;
@@ -339,20 +388,16 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
 int bq_chol_solve(bq_chol_ws *ws, int64_t np) {
     hipStream_t st = ws->ctx->stream;
     const int64_t ldh = ws->ldh;
-    for (int64_t k0 = 0; k0 < np; k0 += NB) {
-        const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
-        const double *src = ws->rhs + k0;
-        if (k0 > 0) {
-            fwd_panel_kernel<<<NB, 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp);
-            src = ws->tmp;
-        }
-        diag_mv_kernel<<<1, 256, 0, st>>>(LinvT, 0, src, ws->rhs + k0);
-    }
-    for (int64_t k0 = np - NB; k0 >= 0; k0 -= NB) {
-        const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
-        diag_mv_kernel<<<1, 256, 0, st>>>(LinvT, 1, ws->rhs + k0, ws->rhs + k0);
-        if (k0 > 0) bwd_update_kernel<<<(unsigned)((k0 / 2 + 255) / 256), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs + k0, ws->rhs);
-    }
+    auto Linv = [&](int64_t k0) { return ws->LinvT + (k0 / NB) * NB * NB; };
+    // forward: y_k = Linv_kk (b_k - L_k,0:k y_0:k); one launch per block row (the panel product's last block applies Linv)
+    diag_mv_kernel<<<1, 256, 0, st>>>(Linv(0), 0, ws->rhs, ws->rhs);
+    for (int64_t k0 = NB; k0 < np; k0 += NB)
+        fwd_panel_kernel<<<NB, 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp, Linv(k0), ws->ticket);
+    // backward: x_k = Linv_kk^T y_k, then y_0:k -= L_k,0:k^T x_k (whose last block solves block k-1)
+    diag_mv_kernel<<<1, 256, 0, st>>>(Linv(np - NB), 1, ws->rhs + np - NB, ws->rhs + np - NB);
+    for (int64_t k0 = np - NB; k0 > 0; k0 -= NB)
+        bwd_update_kernel<<<(unsigned)((k0 / 2 + 255) / 256), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs + k0, ws->rhs,
+                                                                            Linv(k0 - NB), ws->ticket);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
