@@ -68,7 +68,7 @@ struct gram_params {
 // the strip keeps the row slice of the image hot and amortises the workgroup start over several tiles (one tile per
 // workgroup ran at 36 % MFMA-pipe utilisation: `profiles/r01/pmc_mfma_ip_n50000.txt`).
 constexpr int GRAM_STRIP = 8;
-template <typename T>
+template <typename T, int KIND>
 __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     const int64_t arow = P.arow0 + (int64_t)blockIdx.x * GT;
@@ -83,11 +83,17 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
     const int64_t I0 = P.arow0 / BQ_SYM_TILE;
+    __shared__ double rowsq[4][64];   // squared norms of each wave's 64 rows: through LDS on purpose (see below)
+    rowsq[wv][lane] = P.a2[arow + wr * 64 + lane];
     for (int64_t J = j0; J < j1; ++J) {
         const int64_t bcol = J * GT;
         bq_d4 acc[4][4];
         bq_tile_zero(acc);
         bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
+        // The row bases and norms of the epilogue do not depend on J; hoisted out of this loop they would stay live across
+        // the MFMA loop (32+ VGPRs) and spill.  An opaque zero makes them per-iteration values.
+        int64_t opaque = 0;
+        asm volatile("" : "+s"(opaque));
         // epilogue, row by row: one (packed or pitched) row base per accumulator row, then the kernel map per element
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -95,24 +101,24 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
             for (int v = 0; v < 4; ++v) {
                 const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
                 if (gi >= P.arow1) continue;
-                T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
-                const double ai = P.a2[gi];
+                T *rowp = out + opaque + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
+                const double ai = rowsq[wv][i * 16 + crow + 4 * v];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
                     if (gj >= P.n) continue;
                     const double dot = acc[i][j][v];
                     double kv;
-                    if (P.kernel == BQ_KERNEL_RBF) {
+                    if (KIND == BQ_KERNEL_RBF) {
                         double dist = -2.0 * dot;
                         dist += ai;
                         dist += P.b2[gj];
                         dist = fmax(dist, 0.0);
                         if (P.same && gi == gj) dist = 0.0;
                         kv = exp(-P.gamma * dist);
-                    } else if (P.kernel == BQ_KERNEL_POLY) {
+                    } else if (KIND == BQ_KERNEL_POLY) {
                         kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
-                    } else if (P.kernel == BQ_KERNEL_SIGMOID) {
+                    } else if (KIND == BQ_KERNEL_SIGMOID) {
                         kv = tanh(P.gamma * dot + P.coef0);
                     } else {
                         kv = dot;
@@ -239,10 +245,21 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
     } else {
         P.ntiles = tiles_m * tiles_n;
         dim3 grid((unsigned)tiles_m, (unsigned)((tiles_n + GRAM_STRIP - 1) / GRAM_STRIP));
-        if (storage == BQ_F64)
-            gram_mfma_kernel<double><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));
-        else
-            gram_mfma_kernel<float><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
+        // one instantiation per kernel map (all of exp / pow / tanh inlined in the 64-element epilogue costs registers)
+#define BQ_GRAM_LAUNCH(KIND)                                                                                           \
+    do {                                                                                                               \
+        if (storage == BQ_F64)                                                                                         \
+            gram_mfma_kernel<double, KIND><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<double *>(out));        \
+        else                                                                                                           \
+            gram_mfma_kernel<float, KIND><<<grid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));          \
+    } while (0)
+        switch (kernel) {
+            case BQ_KERNEL_RBF: BQ_GRAM_LAUNCH(BQ_KERNEL_RBF); break;
+            case BQ_KERNEL_POLY: BQ_GRAM_LAUNCH(BQ_KERNEL_POLY); break;
+            case BQ_KERNEL_SIGMOID: BQ_GRAM_LAUNCH(BQ_KERNEL_SIGMOID); break;
+            default: BQ_GRAM_LAUNCH(BQ_KERNEL_LINEAR); break;
+        }
+#undef BQ_GRAM_LAUNCH
     }
     BQ_HIP(hipGetLastError());
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_GRAM, e0, e1));
