@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
+                const int64_t gi = opaque + arow + wr * 64 + i * 16 + crow + 4 * v;
                 if (gi >= P.arow1) continue;
-                T *rowp = out + opaque + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
+                T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
                 const double ai = rowsq[wv][i * 16 + crow + 4 * v];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -428,13 +428,15 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
         bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
         __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's loads (w, norms) below the MFMA loop: hoisted above it
                                              // they stay live across it and spill
+        int64_t opaque = 0;                  // ... and keep the J-invariant row indices per-iteration values (same reason)
+        asm volatile("" : "+s"(opaque));
         // epilogue: kernel map, contraction with this tile's slice of w, fold over the 16 lanes that share a row; the
         // running row sums live in LDS so that no accumulator stays in registers across the MFMA loop
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int64_t gi = arow + wr * 64 + i * 16 + crow + 4 * v;
+                const int64_t gi = opaque + arow + wr * 64 + i * 16 + crow + 4 * v;
                 const double ai = KIND == BQ_KERNEL_RBF ? rowsq[wv][i * 16 + crow + 4 * v] : 0.0;
                 double part = 0.0;
 #pragma unroll
