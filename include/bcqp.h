@@ -161,7 +161,7 @@ enum { BQ_RULE_SGD = 0, BQ_RULE_ADAM = 1, BQ_RULE_AMSGRAD = 2, BQ_RULE_ADAMAX = 
 enum { BQ_MOM_NONE = 0, BQ_MOM_POLYAK = 1, BQ_MOM_NESTEROV = 2 };
 typedef struct bq_al_params {
     int32_t rule, momentum_type;   /* AdaGrad and AdaDelta have no momentum (the reference classes take none) */
-    double step_size, momentum;    /* scalars only (the reference also accepts schedules: host-side feature, not built) */
+    double step_size, momentum;    /* constants; per-iteration schedules: bq_al_solver_set_schedules */
     double beta1, beta2;           /* Adam, AMSGrad, AdaMax */
     double decay;                  /* AdaDelta, RMSProp */
     double offset;
@@ -172,6 +172,9 @@ typedef struct bq_al_params {
  * BQ_GET_DUAL) may be NULL = zeros.  The returned solver is driven by bq_solver_run / _state / _get / _destroy. */
 int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const double *a_eq, const double *lb,
                         const double *ub, const double *x0, const double *dual0, bq_solver **out);
+/* optional schedules (stochastic/schedules.py; the reference draws one value per iteration from an iterable step_size /
+ * momentum): entry k is used by iteration k, the last entry continues; either pointer may be NULL.  Before the first run. */
+int bq_al_solver_set_schedules(bq_solver *s, const double *step_sizes, const double *momenta, int64_t count);
 /* number of multipliers (length of BQ_GET_DUAL) */
 int bq_al_solver_dual_size(const bq_solver *s, int64_t *n_dual);
 

@@ -79,6 +79,7 @@ PROTOTYPES = {
     'bq_solver_get': (C.c_int, [_vp, C.c_int, _dp]),
     'bq_al_solver_create': (C.c_int, [_vp, C.POINTER(AlParams), _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     'bq_al_solver_dual_size': (C.c_int, [_vp, C.POINTER(_i64)]),
+    'bq_al_solver_set_schedules': (C.c_int, [_vp, _dp, _dp, _i64]),
     'bq_smo_create': (C.c_int, [_vp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.POINTER(_vp)]),
     'bq_smo_run': (C.c_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
     'bq_smo_get': (C.c_int, [_vp, C.c_int, _dp]),

@@ -62,8 +62,14 @@ __device__ __forceinline__ void al_check_body(bq_scal *sc, const bq_al_params &p
                                               const double *part, int64_t nblk, bq_iter_stat *stats);
 
 // nesterov: x += momentum * previous step, before the gradient is taken (gradient_descent.py:78-81 and the like)
-__global__ void al_jump_kernel(int64_t N, bq_al_vecs V, double mom, const bq_scal *sc) {
+// value of a schedule at the current iteration (the last entry continues), or the constant
+__device__ __forceinline__ double al_sched(const double *sched, long long len, long long it, double constant) {
+    return sched != nullptr ? sched[it < len ? it : len - 1] : constant;
+}
+
+__global__ void al_jump_kernel(int64_t N, bq_al_vecs V, double mom_const, const bq_scal *sc) {
     if (sc->done) return;
+    const double mom = al_sched(V.mom_sched, V.sched_len, sc->iter, mom_const);
     VEC_LOOP(i) {
         if (i < N) V.x[i] = V.x[i] + __dmul_rn(mom, V.step[i]);
     }
@@ -155,7 +161,9 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
     const bool last = sc->al_last != 0;   // 'stopped' at this evaluation: write its gradient, take no step
     if (sc->done && !last) return;
     __shared__ double sh[4];
-    const double ax = sc->al_ax, mu = sc->al_mu, rho = prm.rho, lr = prm.step_size;
+    const double ax = sc->al_ax, mu = sc->al_mu, rho = prm.rho;
+    const double lr = al_sched(V.lr_sched, V.sched_len, sc->iter, prm.step_size);
+    const double mom = al_sched(V.mom_sched, V.sched_len, sc->iter, prm.momentum);
     const bool eq_act = V.a != nullptr && ax != 0.0;
     const double t = (double)(sc->iter + 1);
     double c1 = 1.0, c2 = 1.0;   // bias corrections 1 - beta^t
@@ -244,10 +252,10 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
             // first term before the gradient was taken ------------------------------------------------------------
             double step = s, xn;
             if (prm.momentum_type == BQ_MOM_POLYAK) {
-                step = __dmul_rn(prm.momentum, V.step[i]) + s;
+                step = __dmul_rn(mom, V.step[i]) + s;
                 xn = x + step;
             } else if (prm.momentum_type == BQ_MOM_NESTEROV) {
-                step = __dmul_rn(prm.momentum, V.step[i]) + s;
+                step = __dmul_rn(mom, V.step[i]) + s;
                 xn = x + s;
             } else {
                 xn = x + step;

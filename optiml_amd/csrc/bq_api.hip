@@ -599,7 +599,8 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
     bq_as_free(s);
     if (s->al) {
         bq_al_vecs &V = s->al->V;   // x, g, step (= s->d) and Qx (= s->Qd) are owned by the common slots above
-        for (void *ptr : {(void *)V.xe, (void *)V.s1, (void *)V.s2, (void *)V.s3, (void *)V.a, (void *)V.llb, (void *)V.lub})
+        for (void *ptr : {(void *)V.xe, (void *)V.s1, (void *)V.s2, (void *)V.s3, (void *)V.a, (void *)V.llb, (void *)V.lub,
+                          (void *)V.lr_sched, (void *)V.mom_sched})
             if (ptr) hipFree(ptr);
         delete s->al;
     }
@@ -778,6 +779,35 @@ extern "C" int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const
         return BQ_ERR_HIP;
     }
     *out = s;
+    return BQ_OK;
+}
+
+extern "C" int bq_al_solver_set_schedules(bq_solver *s, const double *step_sizes, const double *momenta, int64_t count) {
+    BQ_ARG(s != nullptr && s->al != nullptr, "not an augmented-Lagrangian solver");
+    BQ_ARG(count >= 1 && (step_sizes || momenta), "count >= 1 and at least one schedule");
+    BQ_ARG(!s->initialised && s->host.iter == 0, "schedules are set before the first run");
+    bq_ctx *c = s->p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    for (int64_t i = 0; i < count; ++i) {
+        BQ_ARG(!step_sizes || step_sizes[i] > 0.0, "step sizes must be > 0");
+        BQ_ARG(!momenta || (momenta[i] >= 0.0 && momenta[i] < 1.0), "momentum must be between 0 and 1");
+    }
+    bq_al_vecs &V = s->al->V;
+    for (int k = 0; k < 2; ++k) {
+        const double *src = k == 0 ? step_sizes : momenta;
+        if (!src) continue;
+        double *dev = nullptr;
+        BQ_HIP(hipMalloc(&dev, sizeof(double) * count));
+        BQ_HIP(hipMemcpy(dev, src, sizeof(double) * count, hipMemcpyHostToDevice));
+        if (k == 0) {
+            if (V.lr_sched) hipFree((void *)V.lr_sched);
+            V.lr_sched = dev;
+        } else {
+            if (V.mom_sched) hipFree((void *)V.mom_sched);
+            V.mom_sched = dev;
+        }
+    }
+    V.sched_len = count;
     return BQ_OK;
 }
 

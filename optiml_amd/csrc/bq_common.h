@@ -128,6 +128,8 @@ struct bq_chol_ws;
 struct bq_al_vecs {
     double *x, *xe, *g, *Qx, *q, *step, *s1, *s2, *s3;
     double *a, *lb, *ub, *llb, *lub;   // equality row; bounds; their multipliers
+    const double *lr_sched, *mom_sched;   // optional per-iteration step sizes / momenta (index: iteration), else null
+    long long sched_len;
 };
 struct bq_al_state {
     bq_al_params prm;

@@ -1,5 +1,6 @@
-__all__ = ['StochasticOptimizer', 'StochasticMomentumOptimizer', 'StochasticGradientDescent', 'Adam', 'AMSGrad',
+__all__ = ['schedules', 'StochasticOptimizer', 'StochasticMomentumOptimizer', 'StochasticGradientDescent', 'Adam', 'AMSGrad',
            'AdaMax', 'AdaGrad', 'AdaDelta', 'RMSProp']
 
+from . import schedules
 from ._base import StochasticOptimizer, StochasticMomentumOptimizer
 from .rules import StochasticGradientDescent, Adam, AMSGrad, AdaMax, AdaGrad, AdaDelta, RMSProp

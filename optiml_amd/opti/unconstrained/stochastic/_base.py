@@ -8,10 +8,13 @@ the multiplier update of optiml/opti/_base.py:129-146) runs device-resident in l
 
 Scope: the objective is a `Quadratic` (plain rule, runs `epochs` iterations) or an
 `AugmentedLagrangianQuadratic` (the SVC/SVR dual branch, optiml/ml/svm/_base.py:638-723).  Such objectives have no
-samples to draw mini batches from (`f.args()` is empty), so `batch_size` must stay None as in the reference, and
-step-size / momentum schedules (callables, iterables) are not built: scalars only.
+samples to draw mini batches from (`f.args()` is empty), so `batch_size` must stay None as in the reference.
+`step_size` / `momentum` may be scalars, iterables (one value is drawn per iteration — `schedules.py`) or, for the
+step size, a callable returning an iterator (the reference calls it afresh every iteration and takes its first value,
+i.e. a constant: stochastic/_base.py:88-93).
 """
 import ctypes as C
+import itertools
 from abc import ABC
 from collections.abc import Iterable
 
@@ -45,6 +48,11 @@ class _AlDeviceSolver:
                                            max_steps, C.byref(n), C.byref(status)))
         return stats[:n.value], _lib.STATUS[status.value]
 
+    def set_schedules(self, steps, moms, count):
+        steps = None if steps is None else _lib.as_f64(steps, count, 'step sizes')
+        moms = None if moms is None else _lib.as_f64(moms, count, 'momenta')
+        _lib.check(self._lib.bq_al_solver_set_schedules(self._h, _lib.ptr(steps), _lib.ptr(moms), count))
+
     def state(self):
         it, st, f = C.c_int64(0), C.c_int(0), C.c_double(0)
         _lib.check(self._lib.bq_solver_state(self._h, C.byref(it), C.byref(st), C.byref(f)))
@@ -77,11 +85,16 @@ class StochasticOptimizer(Optimizer, ABC):
         super(StochasticOptimizer, self).__init__(f=f, x=x, eps=eps, tol=tol, max_iter=epochs, callback=callback,
                                                   callback_args=callback_args, random_state=random_state,
                                                   verbose=verbose)
-        if callable(step_size) or isinstance(step_size, Iterable):
-            raise NotImplementedError('step-size schedules are not built: pass a positive scalar')
-        if not step_size > 0:
-            raise ValueError('step_size must be > 0 or a callable or an iterator')
-        self.step_size = float(step_size)
+        self._step_schedule = None
+        if isinstance(step_size, Iterable):      # one value per iteration, drawn here (stochastic/_base.py:88-89)
+            self._step_schedule = self._draw(step_size, epochs, 'step_size')
+            self.step_size = float(self._step_schedule[0])
+        elif callable(step_size):                # called afresh every iteration: always its first value (:90-91)
+            self.step_size = float(next(iter(step_size(*f.args()))))
+        else:
+            if not step_size > 0:
+                raise ValueError('step_size must be > 0 or a callable or an iterator')
+            self.step_size = float(step_size)
         self.epochs = epochs
         self.epoch = 0
         self.shuffle = shuffle
@@ -90,6 +103,13 @@ class StochasticOptimizer(Optimizer, ABC):
             # a quadratic has no samples: the reference fails on len(f.args()[0]) here
             raise NotImplementedError('mini batches need a sampled objective: batch_size must be None')
         self.batch_size = None
+
+    @staticmethod
+    def _draw(values, count, name):
+        table = list(itertools.islice(iter(values), int(count)))
+        if len(table) < count:
+            raise ValueError(f'the {name} iterable ends after {len(table)} values, {count} are needed')
+        return np.asarray(table, dtype=float)
 
     def is_batch_end(self):
         return True   # full batch
@@ -139,6 +159,11 @@ class StochasticOptimizer(Optimizer, ABC):
         else:
             raise NotImplementedError('only Quadratic / AugmentedLagrangianQuadratic objectives run on the device')
         solver = _AlDeviceSolver(primal.device_problem(), self._params(), a, lb, ub, self.x, dual0)
+        steps, moms = self._step_schedule, getattr(self, '_momentum_schedule', None)
+        if getattr(self, 'momentum_type', 'none') == 'none':
+            moms = None
+        if steps is not None or moms is not None:
+            solver.set_schedules(steps, moms, int(self.epochs))
         self._print_header()
         step_mode = self._needs_state()
         stop = False
@@ -194,8 +219,11 @@ class StochasticMomentumOptimizer(StochasticOptimizer, ABC):
         if momentum_type not in ('polyak', 'nesterov', 'none'):
             raise ValueError(f'unknown momentum type {momentum_type}')
         self.momentum_type = momentum_type
-        if isinstance(momentum, Iterable):
-            raise NotImplementedError('momentum schedules are not built: pass a scalar in [0, 1)')
-        if not 0 <= momentum < 1:
-            raise ValueError('momentum must be between 0 and 1 or an iterator')
-        self.momentum = momentum
+        self._momentum_schedule = None
+        if isinstance(momentum, Iterable):   # one value per iteration (stochastic/_base.py:242-243)
+            self._momentum_schedule = self._draw(momentum, epochs, 'momentum')
+            self.momentum = float(self._momentum_schedule[0])
+        else:
+            if not 0 <= momentum < 1:
+                raise ValueError('momentum must be between 0 and 1 or an iterator')
+            self.momentum = momentum

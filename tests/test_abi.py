@@ -238,5 +238,8 @@ def test_lagrangian_surface_and_validation_mirror_reference():
         assert len(w) == 1
     with pytest.raises(NotImplementedError):
         st.AdaGrad(f=al, batch_size=2)                                           # no samples to batch
-    with pytest.raises(NotImplementedError):
-        st.AdaGrad(f=al, step_size=iter([1., .5]))                               # schedules: not built
+    sched = st.StochasticGradientDescent(f=al, epochs=3, step_size=st.schedules.decaying(1., .5),
+                                         momentum_type='polyak', momentum=st.schedules.sutskever_blend(0.9, 1))
+    np.testing.assert_array_equal(sched._step_schedule, [1., .5, .25])          # one value per iteration, drawn up front
+    np.testing.assert_allclose(sched._momentum_schedule, [0.75, 1 - 2 ** (-1 - np.log2(3)), 0.875])
+    assert st.AdaGrad(f=al, step_size=lambda: st.schedules.decaying(2., .5)).step_size == 2.   # callable: first value

@@ -260,3 +260,27 @@ def test_box_solvers_refuse_the_dual_without_rank_one(amd):
         InteriorPoint(quad=quad, ub=np.ones(64)).minimize()
     opt = ProjectedGradient(quad=quad, ub=np.ones(64), max_iter=5).minimize()   # products only: fine
     assert opt.iter == 5
+
+
+@pytest.mark.parametrize('name', ['sched_sgd_polyak', 'sched_rmsprop_nesterov'])
+def test_schedules(amd, name):
+    """iterable step_size / momentum: the optimizer draws one value per iteration (stochastic/_base.py:88-93, :242-245)
+    and hands the table to the device loop"""
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import AugmentedLagrangianQuadratic
+    from optiml_amd.opti.unconstrained.stochastic import schedules as sch
+    g = load_golden('al_dual.npz')
+    Q, q, a, lb, ub, rho = _al_rules_problem(g, True)
+    al = AugmentedLagrangianQuadratic(primal=Quadratic(Q, q), lb=lb, ub=ub, rho=rho)
+    rec = Rec()
+    if name == 'sched_sgd_polyak':
+        opt = _classes()['sgd'](f=al, x=g['rules_x0'].copy(), epochs=300, tol=1e-10, callback=rec,
+                                step_size=sch.decaying(0.002, 0.997), momentum_type='polyak',
+                                momentum=sch.sutskever_blend(0.9, 40)).minimize()
+    else:
+        opt = _classes()['rmsprop'](f=al, x=g['rules_x0'].copy(), epochs=300, tol=1e-10, callback=rec,
+                                    step_size=sch.linear_annealing(0.02, 0.002, 200), momentum_type='nesterov',
+                                    momentum=sch.repeater([0.2, 0.4, 0.6], 100)).minimize()
+    _cmp(opt, al, rec, g, name)
+    with pytest.raises(ValueError):    # an iterable that runs dry before `epochs` values
+        _classes()['sgd'](f=al, epochs=10, step_size=iter([0.1, 0.1]))

@@ -307,3 +307,26 @@ def test_smo_regression(golden, n, kname, tol):
     snap = _Snap(('ap', 'an'))
     res = smo.smo_svr(so.gram(kname, X), y, C=1., epsilon=0.1, tol=float(tol), spy=snap)
     _cmp_smo(res, snap, g, f'svr{n}_{kname}_tol{tol}', ('alphas_p', 'alphas_n'))
+
+
+def _sched_tables(epochs=300):
+    """the two schedule fixtures of tools/gen_golden.py, as tables (one value per iteration)"""
+    from optiml_amd.opti.unconstrained.stochastic import schedules as sch
+    import itertools
+    take = lambda it: np.array(list(itertools.islice(it, epochs)))   # noqa: E731
+    return {'sched_sgd_polyak': ('sgd', dict(step_size=take(sch.decaying(0.002, 0.997)), momentum_type='polyak',
+                                             momentum=take(sch.sutskever_blend(0.9, 40)))),
+            'sched_rmsprop_nesterov': ('rmsprop', dict(step_size=take(sch.linear_annealing(0.02, 0.002, 200)),
+                                                        momentum_type='nesterov',
+                                                        momentum=take(sch.repeater([0.2, 0.4, 0.6], 100))))}
+
+
+@pytest.mark.parametrize('name', ['sched_sgd_polyak', 'sched_rmsprop_nesterov'])
+def test_al_schedules(golden, name):
+    """iterable step_size / momentum (stochastic/schedules.py): one value drawn per iteration"""
+    g = golden('al_dual.npz')
+    Q, q, a, lb, ub, rho = _al_rules_problem(g, True)
+    rule, kw = _sched_tables()[name]
+    res = ao.minimize(ao.AugLag(Q, q, a=a, lb=lb, ub=ub, rho=rho), g['rules_x0'], rule, epochs=300, tol=1e-10,
+                      keep=(1, 2, 10, 100, 299), **kw)
+    _cmp_al(res, g, name)

@@ -373,6 +373,18 @@ def gen_lagrangian(out):
         r = run_al(cls, Qb, q, None, 0.05 * ub, ub, x0, rho=2.5, keep=keep, epochs=300, tol=1e-10, **kw)
         data.update(flat('rulesb_' + name, r))
         print(f"  rulesb {name}: iter={r['iter']} status={r['status']} f={r['f_x']:.8f} pf={r['pf_hist'][-1]:.8f}")
+    # schedules (stochastic/schedules.py): an iterable step size and an iterable momentum, one value drawn per iteration
+    from optiml.opti.unconstrained.stochastic import schedules as ref_sched
+    r = run_al(StochasticGradientDescent, Qb, q, None, 0.05 * ub, ub, x0, rho=2.5, keep=keep, epochs=300, tol=1e-10,
+               step_size=ref_sched.decaying(0.002, 0.997), momentum_type='polyak',
+               momentum=ref_sched.sutskever_blend(0.9, 40))
+    data.update(flat('sched_sgd_polyak', r))
+    print(f"  sched sgd polyak: iter={r['iter']} status={r['status']} f={r['f_x']:.8f}")
+    r = run_al(RMSProp, Qb, q, None, 0.05 * ub, ub, x0, rho=2.5, keep=keep, epochs=300, tol=1e-10,
+               step_size=ref_sched.linear_annealing(0.02, 0.002, 200), momentum_type='nesterov',
+               momentum=ref_sched.repeater([0.2, 0.4, 0.6], 100))
+    data.update(flat('sched_rmsprop_nesterov', r))
+    print(f"  sched rmsprop nesterov: iter={r['iter']} status={r['status']} f={r['f_x']:.8f}")
     # 'optimal' through the tolerance test (optiml/opti/_base.py:141-146)
     r = run_al(AdaGrad, Q, q, y, lb, ub, x0, rho=1., keep=(1, 10), epochs=20000, tol=2e-3, step_size=1.)
     data.update(flat('tol_adagrad', r))
