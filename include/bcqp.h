@@ -17,9 +17,12 @@
  *   - a bq_ctx is not thread-safe; every call returns after its HIP stream has been synchronised.
  *   - all host-visible vectors are fp64.  `storage` selects the dtype of the resident Hessian /
  *     Gram panel only (fp32 storage still accumulates in fp64).
- *   - multi-GPU: one process per GPU; rank r owns a contiguous block of rows of the panel, all
- *     n-vectors are replicated, and each product Q*v is completed by one all-gather of the row
- *     blocks (RCCL over xGMI, or a caller-supplied exchange callback).
+ *   - multi-GPU: one process per GPU; all n-vectors are replicated and each product Q*v is completed
+ *     by ONE collective (RCCL over xGMI, or a caller-supplied exchange callback): kernel-built
+ *     symmetric panels are split into tile rows with equal shares of the lower triangle
+ *     (bq_sym_row_block) and end in an all-reduce(sum); dense and streamed panels are split into
+ *     equal row blocks (bq_row_block) and end in an all-gather.  Solvers that factorise the Hessian
+ *     (InteriorPoint, ActiveSet) and SMO need a single-rank context.
  */
 #ifndef BCQP_H
 #define BCQP_H
