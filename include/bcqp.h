@@ -59,6 +59,11 @@ enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian 
  * reg_intercept=False duals Q = K*yy' and Q = [[K,-K],[-K,K]] (svm/_base.py:552-559, 1096-1099).  Products only:
  * InteriorPoint / ActiveSet refuse such a problem (the reference has no box solver for it either, :621-624). */
 #define BQ_NO_RANK_ONE 16
+/* OR-ed into the structure: keep the WHOLE n x n Gram panel (row blocks, pitch round_up(n, 1024)) instead of the packed
+ * lower-triangular tile rows: twice the memory and twice the bytes per product, but every row is contiguous and K keeps
+ * the reference's own (not exactly symmetric) rounding of the RBF distances.  An option, not a default: measured on SMO
+ * (single-row gathers) it changes nothing, n=100k fit 0.93 s either way — the sweeps are bound by one CU's gather rate. */
+#define BQ_FULL_PANEL 32
 enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3 };                 /* solver kind */
 enum { BQ_STATUS_UNKNOWN = 0, BQ_STATUS_OPTIMAL = 1, BQ_STATUS_STOPPED = 2 };
 /* BQ_GET_X / BQ_GET_G: the point (and gradient) the LAST ITERATION RECORD was evaluated at — what the

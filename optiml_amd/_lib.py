@@ -20,6 +20,7 @@ PG, FW, AS, IP = 0, 1, 2, 3
 STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
 GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW, GET_DUAL = range(10)
 NO_RANK_ONE = 16
+FULL_PANEL = 32
 SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS = range(3)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}

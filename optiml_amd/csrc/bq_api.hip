@@ -335,8 +335,8 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
                                         const double *y, int kernel, double gamma, double coef0, int degree,
                                         double diag_add, const double *q, int storage, bq_problem **out) {
     BQ_ARG(c && X && q && out, "NULL argument");
-    const bool no_rank_one = (structure & BQ_NO_RANK_ONE) != 0;
-    structure &= ~BQ_NO_RANK_ONE;
+    const bool no_rank_one = (structure & BQ_NO_RANK_ONE) != 0, full_panel = (structure & BQ_FULL_PANEL) != 0;
+    structure &= ~(BQ_NO_RANK_ONE | BQ_FULL_PANEL);
     BQ_ARG(structure == BQ_PLAIN || structure == BQ_SVC || structure == BQ_SVR, "structure");
     BQ_ARG(structure != BQ_SVC || y != nullptr, "labels required for BQ_SVC");
     BQ_ARG(kernel >= BQ_KERNEL_LINEAR && kernel <= BQ_KERNEL_LAPLACIAN, "kernel");
@@ -357,7 +357,8 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     p->diag_add = diag_add;
     p->d = d;
     p->streamed = storage == BQ_STREAM;
-    p->symmetric = !p->streamed;  // Gram panels are symmetric: store and stream only the tiles on/below the diagonal
+    p->symmetric = !p->streamed && !full_panel;  // Gram panels are symmetric: store and stream only the tiles on/below the
+                                                 // diagonal, unless the caller asked for whole rows (BQ_FULL_PANEL)
     int rc = problem_layout(p, n, structure == BQ_SVR ? 2 * n : n);
     if (rc == BQ_OK) rc = problem_alloc_common(p, q);
     if (rc != BQ_OK) {
@@ -380,7 +381,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     if (p->streamed)
         rc = bq_stream_prepare(c, p->X, n, d, p->r0, p->r1, &p->stream_img);
     else
-        rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld, true);
+        rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld, p->symmetric);
     if (rc != BQ_OK) {
         bq_problem_destroy(p);
         return rc;

@@ -14,8 +14,9 @@
 // The index sets I0..I4 of the reference are functions of (alpha, y) and are not stored.
 // TIE RULE: where the reference's `for i in self.I0` loop (CPython set order) decides between two free samples with
 // bit-identical cached errors, this kernel takes the smaller index (oracle/smo_oracle.py, tie='index').
-// K[i][j] comes from the packed lower-triangular tile-row panel (bq_sym_addr): the row part is contiguous, the
-// part right of the diagonal tile is read down the column of the later tile rows.
+// K[i][j] comes from the packed lower-triangular tile-row panel (bq_sym_addr: the row part is contiguous, the part right
+// of the diagonal tile is read down the column of the later tile rows — one page per support vector) or, preferably, from
+// a full square panel (BQ_FULL_PANEL: every row contiguous, one page per examined sample).
 #include <cfloat>
 #include <cmath>
 
@@ -45,7 +46,9 @@ struct bq_smo {
 template <typename T>
 struct KView {
     const T *panel;
+    int64_t ld;   // 0: packed lower-triangular tile rows; else the pitch of a full square panel (BQ_FULL_PANEL)
     __device__ __forceinline__ double at(int64_t i, int64_t j) const {
+        if (ld != 0) return (double)panel[i * ld + j];
         const int64_t ti = i / BQ_SYM_TILE, tj = j / BQ_SYM_TILE;
         return (double)(tj <= ti ? panel[bq_sym_addr(i, j, 0)] : panel[bq_sym_addr(j, i, 0)]);
     }
@@ -96,7 +99,7 @@ struct SmoShared {
     int go, fail;
     int pos, found;               // sup_apply
     long long i2;                 // the examined sample of a pair step
-    int used, stop;               // batch bookkeeping of the sweep drivers
+    int used, stop, fast;         // batch bookkeeping of the sweep drivers
     double ba[SMO_T / 64], by[SMO_T / 64], bE[SMO_T / 64], bm[SMO_T / 64];   // batch: multiplier(s), label/target, error
     int mem1, mem2;               // new list membership of the two touched samples
     double cf1, cf2;              // and their new coefficients
@@ -251,7 +254,21 @@ constexpr int SMO_B = SMO_T / 64;
 template <typename T>
 __device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, const SupGlobal &G, int nnz, int64_t s) {
     double part = 0.0;
-    for (int q = threadIdx.x & 63; q < nnz; q += 64) part = part + __dmul_rn(sup_cf(L, G, q), K.at(s, sup_idx(L, G, q)));
+    // eight panel entries of this lane are fetched together (independent loads in flight), then added in list order —
+    // the summation order is that of the plain loop; only the latency of the reads overlaps
+    for (int q0 = threadIdx.x & 63; q0 < nnz; q0 += 64 * 8) {
+        double kv[8], cf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + 64 * u;
+            const bool in = q < nnz;
+            cf[u] = in ? sup_cf(L, G, q) : 0.0;
+            kv[u] = in ? K.at(s, sup_idx(L, G, q)) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q0 + 64 * u < nnz) part = part + __dmul_rn(cf[u], kv[u]);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     return part;   // complete in lane 0
@@ -430,8 +447,54 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                const int B = n - i < SMO_B ? (int)(n - i) : SMO_B;
+            const int B = n - i < SMO_B ? (int)(n - i) : SMO_B;
+            // Fast path, wave 0, one lane per sample of the batch, no side effects until it is known to apply: within a
+            // batch without a pair step b_up only falls and b_low only rises (smo.py:285-291), so a sample that does not
+            // violate the thresholds the batch ENDS with violates none of the intermediate ones — then the sequential
+            // examine of the 16 samples reduces to storing the new errors and to a first-minimum / first-maximum over
+            // the batch, which 16 lanes do at once.  Any possible violator sends the batch down the sequential walk.
+            if (wv == 0) {
+                const int w = lane;
+                const bool in = w < B;
+                const double a2 = in ? S.ba[w] : 0.0, y2 = in ? S.by[w] : 0.0, E2 = in ? S.bE[w] : 0.0;
+                const bool free2 = in && a2 > 0.0 && a2 < C;
+                const bool up2 = in && ((y2 == 1.0 && a2 == 0.0) || (y2 == -1.0 && a2 == C));
+                const bool low2 = in && ((y2 == 1.0 && a2 == C) || (y2 == -1.0 && a2 == 0.0));
+                ValIdx lo{(up2 && !free2) ? E2 : DBL_MAX, (up2 && !free2) ? (long long)w : -1};
+                ValIdx hi{(low2 && !free2) ? E2 : -DBL_MAX, (low2 && !free2) ? (long long)w : -1};
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    ValIdx o;
+                    o.v = __shfl_xor(lo.v, off, 64);
+                    o.i = __shfl_xor(lo.i, off, 64);
+                    lo = better(lo, o, -1);
+                    o.v = __shfl_xor(hi.v, off, 64);
+                    o.i = __shfl_xor(hi.i, off, 64);
+                    hi = better(hi, o, +1);
+                }
+                const bool up_moves = lo.i >= 0 && lo.v < S.b_up, low_moves = hi.i >= 0 && hi.v > S.b_low;
+                const double bu = up_moves ? lo.v : S.b_up, bl = low_moves ? hi.v : S.b_low;
+                const bool viol = in && (((free2 || up2) && bl - E2 > 2 * tol) || ((free2 || low2) && E2 - bu > 2 * tol));
+                const bool fast = __ballot(viol) == 0ull;
+                if (fast) {
+                    if (in && !free2) err[i + w] = E2;
+                    if (lane == 0) {
+                        if (up_moves) {
+                            S.b_up = lo.v;
+                            S.i_up = i + lo.i;
+                        }
+                        if (low_moves) {
+                            S.b_low = hi.v;
+                            S.i_low = i + hi.i;
+                        }
+                        S.go = 0;
+                        S.used = B;
+                    }
+                }
+                if (lane == 0) S.fast = fast ? 1 : 0;
+            }
+            __syncthreads();
+            if (tid == 0 && !S.fast) {
                 int used = B;
                 S.go = 0;
                 for (int w = 0; w < B; ++w) {
@@ -855,7 +918,7 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
                              bq_smo **out) {
     BQ_ARG(p && y && out, "NULL argument");
     BQ_ARG(task == BQ_SVC || task == BQ_SVR, "task must be BQ_SVC or BQ_SVR");
-    BQ_ARG(p->kernel >= 0 && p->symmetric, "SMO needs a kernel-built problem (its Gram panel)");
+    BQ_ARG(p->kernel >= 0 && !p->streamed, "SMO needs a kernel-built problem with a resident Gram panel");
     BQ_ARG(C > 0.0, "C must be > 0");
     BQ_ARG(epsilon >= 0.0, "epsilon must be >= 0");
     BQ_ARG(tol > 0.0, "tol must be > 0");
@@ -925,17 +988,17 @@ extern "C" int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, in
     for (int64_t k = 0; k < max_outer && !s->host.finished; ++k) {
         if (s->task == BQ_SVC) {
             if (p->storage == BQ_F64)
-                smo_svc_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
+                smo_svc_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
                                                                     s->a, s->err, SupGlobal{s->nz, s->cf}, s->C, s->tol, s->sc);
             else
-                smo_svc_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
+                smo_svc_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
                                                                   s->a, s->err, SupGlobal{s->nz, s->cf}, s->C, s->tol, s->sc);
         } else {
             if (p->storage == BQ_F64)
-                smo_svr_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel}, s->n, s->y,
+                smo_svr_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
                                                                     s->a, s->am, s->err, SupGlobal{s->nz, s->cf}, s->C, s->eps, s->tol, s->sc);
             else
-                smo_svr_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel}, s->n, s->y,
+                smo_svr_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
                                                                   s->a, s->am, s->err, SupGlobal{s->nz, s->cf}, s->C, s->eps, s->tol, s->sc);
         }
         BQ_HIP(hipGetLastError());

@@ -181,7 +181,7 @@ class KernelQuadratic(Quadratic):
 
     _STRUCT = {'plain': _lib.PLAIN, 'svc': _lib.SVC, 'svr': _lib.SVR}
 
-    def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64', rank_one=True):
+    def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64', rank_one=True, full_panel=False):
         X = np.ascontiguousarray(X, dtype=float)
         if structure not in self._STRUCT:
             raise ValueError(f'unknown structure {structure}')
@@ -201,6 +201,7 @@ class KernelQuadratic(Quadratic):
         self.y = None if y is None else np.ascontiguousarray(y, dtype=float)
         self.diag = float(diag)
         self.rank_one = bool(rank_one)
+        self.full_panel = bool(full_panel)   # whole rows instead of the packed triangle (2x the memory)
         self.storage = storage
         self.kind, self.gamma, self.coef0, self.degree = kernel.device_spec(X)
         self._dev = None
@@ -210,7 +211,8 @@ class KernelQuadratic(Quadratic):
         h = C.c_void_p()
         n, d = self.X.shape
         _lib.check(lib.bq_problem_create_kernel(
-            ctx.handle, self._STRUCT[self.structure] | (0 if self.rank_one else _lib.NO_RANK_ONE), n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
+            ctx.handle, self._STRUCT[self.structure] | (0 if self.rank_one else _lib.NO_RANK_ONE) |
+            (_lib.FULL_PANEL if self.full_panel else 0), n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
             self.gamma, self.coef0, self.degree, self.diag, _lib.ptr(self.q),
             _lib.STORAGE[self.storage], C.byref(h)))
         return _DeviceProblem(ctx, h)
@@ -222,6 +224,8 @@ class KernelQuadratic(Quadratic):
         if dev.ctx.world != 1:
             raise RuntimeError('materialising K needs the whole panel: single-rank contexts only')
         L = dev.panel_rows()
+        if self.full_panel:
+            return L
         n = L.shape[0]
         tile = np.arange(n) // 256
         upper = tile[None, :] > tile[:, None]

@@ -125,8 +125,9 @@ def _check_against_reference(kind, got, g, p, K, y, tol, C=1., strictly_convex=T
     assert got.b_up > got.b_low - 2 * tol          # the stopping rule itself (smo.py:339-342)
 
 
+@pytest.mark.parametrize('full', [False, True], ids=['packed', 'square'])
 @pytest.mark.parametrize('n,kname,tol', SMO_SVC + [(200, 'rbf', 'C10')])
-def test_classifier(amd, n, kname, tol):
+def test_classifier(amd, n, kname, tol, full):
     from oracle import smo_oracle as smo, svm_oracle as so
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.ml.svm.smo import SMOClassifier
@@ -134,7 +135,8 @@ def test_classifier(amd, n, kname, tol):
     X, y = g[f'svc{n}_X'], g[f'svc{n}_y']
     yb = np.where(y == np.unique(y)[-1], 1., -1.)
     C, t, p = (10., 1e-3, f'svc{n}_{kname}_C10') if tol == 'C10' else (1., float(tol), f'svc{n}_{kname}_tol{tol}')
-    quad = KernelQuadratic(X, -np.ones(n), 'svc', _kernel(kname), y=yb, rank_one=False)
+    # packed lower-triangular panel, or the full square one that SVC.fit prefers for SMO (contiguous rows)
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', _kernel(kname), y=yb, rank_one=False, full_panel=full)
     opt = SMOClassifier(quad, X, yb, None, _kernel(kname), C, t).minimize()
     K = so.gram(kname, X)
     Kdev = quad.gram()
@@ -156,15 +158,16 @@ def test_classifier(amd, n, kname, tol):
     _check_against_reference('svc', opt, g, p, K, yb, t, C=C, strictly_convex=(kname == 'rbf'))
 
 
+@pytest.mark.parametrize('full', [False, True], ids=['packed', 'square'])
 @pytest.mark.parametrize('n,kname,tol', SMO_SVR + [(400, 'linear', '0.0001')])
-def test_regression(amd, n, kname, tol):
+def test_regression(amd, n, kname, tol, full):
     from oracle import smo_oracle as smo, svm_oracle as so
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.ml.svm.smo import SMORegression
     g = load_golden('smo.npz')
     X, y = g[f'svr{n}_X'], g[f'svr{n}_y']
     t, p = float(tol), f'svr{n}_{kname}_tol{tol}'
-    quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', _kernel(kname), rank_one=False)
+    quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', _kernel(kname), rank_one=False, full_panel=full)
     opt = SMORegression(quad, X, y, None, _kernel(kname), 1., 0.1, t).minimize()
     K = so.gram(kname, X)
     if (n, kname, tol) in SMO_SVR:    # (the 11 572-sweep case is checked against the reference's result only)
