@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--cpu-n', type=int, default=12000, help='sample size of the CPU baseline leg')
     ap.add_argument('--cpu-steps', type=int, default=150)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--cpu-study', action='store_true',
+                    help='CPU only (SURVEY 8d): the oracle timed at three sizes to check the n^2 (PG) / n^3 (Cholesky) laws '
+                         'behind the extrapolated baseline, plus a blocked Gram-streaming product at the full n')
     return ap.parse_args()
 
 
@@ -138,6 +141,89 @@ def cpu_baseline_al(args, threads):
             'measured_iter_per_s_at_sample': rate, 'sample_n': ns}
 
 
+def cpu_study(args):
+    """SURVEY 8(d), 'CPU baseline timed beside it': the reference formulation cannot be held on the host at the headline
+    size, so (1) time the oracle's PG at three sizes that fit and check the n^2 law the extrapolation rests on, (2) the
+    same for the dense Cholesky InteriorPoint / ActiveSet spend their time in (n^3), and (3) time a blocked,
+    Gram-streaming product (K never materialised, ONE product per iteration — the cheapest thing a CPU can do) at the
+    full n for a few iterations: a measured bound on the CPU rate that needs no extrapolation."""
+    import platform
+    import scipy.linalg as sla
+    from oracle import bcqp_oracle as bo
+    from oracle import svm_oracle as so
+    from optiml_amd.datasets import make_blobs
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [{k: p.get(k) for k in ('internal_api', 'num_threads', 'version')} for p in threadpool_info()]
+    except Exception:
+        pools = []
+    model = platform.processor()
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {'what': 'cpu_study', 'cpu_model': model, 'os_cpu_count': os.cpu_count(),
+           'sched_affinity': len(os.sched_getaffinity(0)), 'blas_pools': pools,
+           'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS'),
+           'OPENBLAS_NUM_THREADS': os.environ.get('OPENBLAS_NUM_THREADS'), 'd': args.d}
+    pg = []
+    for ns in (12000, 20000, 30000):
+        X, y = make_blobs(ns, args.d, seed=0)
+        Q, q, ub = so.svc_dual(so.gram('rbf', X), y, 1.0)
+        bo.projected_gradient(Q, q, ub, max_iter=2)
+        steps = max(10, int(40 * (12000 / ns) ** 2))
+        t0 = time.perf_counter()
+        res = bo.projected_gradient(Q, q, ub, max_iter=steps)
+        dt = (time.perf_counter() - t0) / res['iter']
+        pg.append({'n': ns, 'iters': int(res['iter']), 's_per_iter': dt, 'GBs': 3 * ns * ns * 8 / dt / 1e9})
+        print(f'[cpu-study] PG n={ns}: {dt * 1e3:.1f} ms/iter', file=sys.stderr, flush=True)
+        del Q
+    out['pg_reference_formulation'] = pg
+    out['pg_exponent'] = float(np.polyfit(np.log([r['n'] for r in pg]), np.log([r['s_per_iter'] for r in pg]), 1)[0])
+    out['pg_iter_per_s_extrapolated_to_n'] = {'n': args.n, 'value': 1.0 / (pg[-1]['s_per_iter'] * (args.n / pg[-1]['n']) ** 2)}
+    ch = []
+    for ns in (6000, 12000, 20000):
+        X, y = make_blobs(ns, args.d, seed=0)
+        H = so.gram('rbf', X)
+        H[np.diag_indices(ns)] += 1.0
+        t0 = time.perf_counter()
+        sla.cho_factor(H, overwrite_a=True, check_finite=False)
+        dt = time.perf_counter() - t0
+        ch.append({'n': ns, 's': dt, 'GFLOPs': ns ** 3 / 3 / dt / 1e9})
+        print(f'[cpu-study] cho_factor n={ns}: {dt:.2f} s', file=sys.stderr, flush=True)
+        del H
+    out['cholesky'] = ch
+    out['cholesky_exponent'] = float(np.polyfit(np.log([r['n'] for r in ch]), np.log([r['s'] for r in ch]), 1)[0])
+    out['cholesky_s_extrapolated'] = {str(m): ch[-1]['s'] * (m / ch[-1]['n']) ** 3 for m in (50000, 100000)}
+    # blocked Gram-streaming product at the full n: rows of K are formed block by block and applied at once
+    n, blk = args.n, 2000
+    X, y = make_blobs(n, args.d, seed=0)
+    gamma = so.resolve_gamma('scale', X)
+    sq = np.einsum('ij,ij->i', X, X)
+    v = np.random.RandomState(0).uniform(size=n) * y
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o = np.empty(n)
+        for r0 in range(0, n, blk):
+            r1 = min(n, r0 + blk)
+            D = X[r0:r1] @ X.T
+            D *= -2.0
+            D += sq[r0:r1, None]
+            D += sq[None, :]
+            np.maximum(D, 0.0, out=D)
+            D *= -gamma
+            np.exp(D, out=D)
+            o[r0:r1] = D @ v + v.sum()
+        times.append(time.perf_counter() - t0)
+        print(f'[cpu-study] streamed product n={n}: {times[-1]:.2f} s', file=sys.stderr, flush=True)
+    out['streamed_product_full_n'] = {'n': n, 'block_rows': blk, 's_per_product': times, 'best_iter_per_s_1_product': 1.0 / min(times)}
+    print(json.dumps(out), flush=True)
+
+
 def bench_smo(args):
     """BASELINE.json's second metric, time-to-KKT-tol, on the route that reaches it fastest: SVC.fit(optimizer='smo') end
     to end (Gram build + sweeps) on one GPU; CPU baseline: the oracle's SMO sweeps at a bounded n (Gram excluded)."""
@@ -176,6 +262,8 @@ def bench_smo(args):
 
 def main():
     args = parse()
+    if args.cpu_study:
+        return cpu_study(args)
     if args.solver == 'smo':
         if args.gpus != 1:
             raise SystemExit('SMO walks the samples sequentially on one GPU (replicas only): --gpus 1')
