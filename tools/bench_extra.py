@@ -109,6 +109,14 @@ def main():
         est.fit(X, y)
         dt = time.perf_counter() - t0
         o = est.optimizer
+        # the same optimality measure for every solver — the 2-norm of d = -g with ProjectedGradient's
+        # masks (projected_gradient.py:100-107), g = Qx + q taken from one more device product at the final point
+        x = np.asarray(o.x, float)
+        g = est.obj.jacobian(x)
+        dd = -g
+        dd[(np.asarray(o.ub) - x <= 1e-12) & (dd > 0)] = 0.
+        dd[(x - np.asarray(o.lb) <= 1e-12) & (dd < 0)] = 0.
+        out.update(proj_grad_norm=float(np.linalg.norm(dd)), f_recomputed=float(est.obj.function(x)))
         out.update(task=a.task, solver=a.solver, fit_s=dt, iters=o.iter, status=o.status, f=o.f_x,
                    n_sv=int(len(est.support_)), iter_per_s=o.iter / dt, score=float(est.score(X[:5000], y[:5000])))
     print(json.dumps(out), flush=True)
