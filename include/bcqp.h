@@ -64,7 +64,12 @@ enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian 
  * the reference's own (not exactly symmetric) rounding of the RBF distances.  An option, not a default: measured on SMO
  * (single-row gathers) it changes nothing, n=100k fit 0.93 s either way — the sweeps are bound by one CU's gather rate. */
 #define BQ_FULL_PANEL 32
-enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3 };                 /* solver kind */
+enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3,                   /* solver kind */
+       /* ActiveSet (active_set.py:82-237, same outer logic) whose restricted systems Q[A,A] xs = rhs are solved by
+        * conjugate gradients on the masked panel product instead of a dense Cholesky factor: no n_A x n_A copy, so it
+        * also runs on sharded (multi-rank), fp32-stored and streamed panels — SURVEY 7's plan for config 5.  The inner
+        * iteration stops at |r| <= rtol (|(Q x)_A| + |q_A|); a direction of non-positive curvature is BQ_ERR_NOT_PD. */
+       BQ_AS_CG = 5 };
 enum { BQ_STATUS_UNKNOWN = 0, BQ_STATUS_OPTIMAL = 1, BQ_STATUS_STOPPED = 2 };
 /* BQ_GET_X / BQ_GET_G: the point (and gradient) the LAST ITERATION RECORD was evaluated at — what the
  * reference's callback sees at the top of that iteration.  BQ_GET_X_NOW / BQ_GET_G_NOW: the current iterate
@@ -153,6 +158,10 @@ int bq_solver_destroy(bq_solver *s);
 int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stats, int64_t stats_cap,
                   int64_t *n_stats, int *status);
 int bq_solver_state(const bq_solver *s, int64_t *iter, int *status, double *f_x);
+/* BQ_AS_CG only: relative residual level (default 1e-13) and iteration cap (0 = 2 |A| + 50) of the inner conjugate
+ * gradients; total inner iterations so far (0 for the other solvers). */
+int bq_solver_set_inner(bq_solver *s, double rtol, int64_t max_iter);
+int bq_solver_inner_iters(bq_solver *s, int64_t *total);
 int bq_solver_get(bq_solver *s, int what, double *out);
 
 /* ---- augmented-Lagrangian dual + first-order update rules ------------------------------------

@@ -17,6 +17,7 @@ STORAGE = {'f64': 0, 'f32': 1, 'stream': 2}
 KERNEL_LINEAR, KERNEL_POLY, KERNEL_RBF, KERNEL_SIGMOID, KERNEL_LAPLACIAN = 0, 1, 2, 3, 4
 PLAIN, SVC, SVR = 0, 1, 2
 PG, FW, AS, IP = 0, 1, 2, 3
+AS_CG = 5   # ActiveSet with conjugate-gradient restricted solves (BQ_AS_CG)
 STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
 GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW, GET_DUAL = range(10)
 NO_RANK_ONE = 16
@@ -78,6 +79,8 @@ PROTOTYPES = {
     'bq_solver_run': (C.c_int, [_vp, _i64, C.POINTER(IterStat), _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
     'bq_solver_state': (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int), _dp]),
     'bq_solver_get': (C.c_int, [_vp, C.c_int, _dp]),
+    'bq_solver_set_inner': (C.c_int, [_vp, C.c_double, _i64]),
+    'bq_solver_inner_iters': (C.c_int, [_vp, C.POINTER(_i64)]),
     'bq_al_solver_create': (C.c_int, [_vp, C.POINTER(AlParams), _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     'bq_al_solver_dual_size': (C.c_int, [_vp, C.POINTER(_i64)]),
     'bq_al_solver_set_schedules': (C.c_int, [_vp, _dp, _dp, _i64]),

@@ -612,14 +612,16 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
 extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const double *ub, const double *x0,
                                 double eps, int64_t max_iter, double fw_t, bq_solver **out) {
     BQ_ARG(p && ub && out, "NULL argument");
-    BQ_ARG(kind == BQ_PG || kind == BQ_FW || kind == BQ_AS || kind == BQ_IP, "solver kind");
+    BQ_ARG(kind == BQ_PG || kind == BQ_FW || kind == BQ_AS || kind == BQ_IP || kind == BQ_AS_CG, "solver kind");
+    const bool as_cg = kind == BQ_AS_CG;   // ActiveSet on products only: none of the dense-factor restrictions below
+    if (as_cg) kind = BQ_AS;
     BQ_ARG(max_iter > 0, "max_iter must be > 0");             // optiml/opti/_base.py:73-74
     BQ_ARG(fw_t >= 0.0 && fw_t < 1.0, "t has to lie in [0, 1)");  // frank_wolfe.py:84-85
-    if ((kind == BQ_IP || kind == BQ_AS) && p->ctx->world > 1) {
+    if ((kind == BQ_IP || kind == BQ_AS) && !as_cg && p->ctx->world > 1) {
         bq_set_error("InteriorPoint/ActiveSet factorise the whole Hessian: use a single-rank context (replicas only)");
         return BQ_ERR_BADARG;
     }
-    if ((kind == BQ_IP || kind == BQ_AS) && p->streamed) {
+    if ((kind == BQ_IP || kind == BQ_AS) && !as_cg && p->streamed) {
         bq_set_error("InteriorPoint/ActiveSet assemble their systems from the resident panel: not available in the streamed mode");
         return BQ_ERR_BADARG;
     }
@@ -632,6 +634,7 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
     bq_solver *s = new bq_solver();
     s->p = p;
     s->kind = kind;
+    s->as_cg = as_cg;
     s->N = p->N;
     s->ldN = p->ldN;
     s->nblk = p->ldN / BQ_VEC_TILE;
@@ -677,7 +680,7 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
         bq_solver_destroy(s);
         return BQ_ERR_HIP;
     }
-    if (kind == BQ_IP || kind == BQ_AS) {
+    if ((kind == BQ_IP || kind == BQ_AS) && !as_cg) {
         // InteriorPoint on the SVR structure factorises the reduced n x n system (bq_ip.hip)
         rc = bq_chol_ws_create(c, (kind == BQ_IP && p->structure == BQ_SVR && bq_ip_svr_reduced()) ? p->n : s->N,
                                &s->chol);
@@ -687,6 +690,22 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
         }
     }
     *out = s;
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_set_inner(bq_solver *s, double rtol, int64_t max_iter) {
+    BQ_ARG(s, "NULL solver");
+    BQ_ARG(s->kind == BQ_AS && s->as_cg, "only the conjugate-gradient ActiveSet (BQ_AS_CG) has an inner iteration");
+    BQ_ARG(rtol > 0.0 && rtol < 1.0, "inner tolerance must lie in (0, 1)");
+    BQ_ARG(max_iter >= 0, "inner iteration cap must be >= 0 (0: 2 |A| + 50)");
+    s->inner_rtol = rtol;
+    s->inner_max = max_iter;
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_inner_iters(bq_solver *s, int64_t *total) {
+    BQ_ARG(s && total, "NULL argument");
+    *total = s->kind == BQ_AS ? bq_as_inner_iters(s) : 0;
     return BQ_OK;
 }
 

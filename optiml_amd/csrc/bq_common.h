@@ -152,6 +152,9 @@ struct bq_solver {
     bool started = false;      // an evaluation has run, so a pending step may exist
     bq_chol_ws *chol = nullptr;
     void *as_ws = nullptr;
+    bool as_cg = false;                // BQ_AS_CG: restricted systems by conjugate gradients instead of a dense factor
+    double inner_rtol = 1e-13;
+    long long inner_max = 0;           // 0: 2 |A| + 50
     bq_al_state *al = nullptr;
     int *flag_host = nullptr;          // pinned copy of sc->done + its event (lagged polling in bq_solver_run)
     hipEvent_t flag_event = nullptr;
@@ -216,6 +219,7 @@ int bq_as_iterate(bq_solver *s);
 void bq_as_free(bq_solver *s);
 int bq_al_iterate(bq_solver *s);   // bq_al.hip
 const double *bq_as_view(bq_solver *s, int what);
+long long bq_as_inner_iters(bq_solver *s);
 
 // bq_chol.hip
 int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out);

@@ -1,8 +1,8 @@
 __all__ = ['BoxConstrainedQuadraticOptimizer', 'AugmentedLagrangianQuadratic', 'ProjectedGradient', 'ActiveSet',
-           'FrankWolfe', 'InteriorPoint']
+           'FrankWolfe', 'InteriorPoint', 'ActiveSetCG']
 
 from ._base import BoxConstrainedQuadraticOptimizer, AugmentedLagrangianQuadratic
 from .projected_gradient import ProjectedGradient
-from .active_set import ActiveSet
+from .active_set import ActiveSet, ActiveSetCG
 from .frank_wolfe import FrankWolfe
 from .interior_point import InteriorPoint

@@ -58,6 +58,14 @@ class _DeviceSolver:
         _lib.check(self._lib.bq_solver_get(self._h, what, _lib.ptr(out)))
         return out
 
+    def set_inner(self, rtol, max_iter):
+        _lib.check(self._lib.bq_solver_set_inner(self._h, float(rtol), int(max_iter)))
+
+    def inner_iters(self):
+        n = C.c_int64(0)
+        _lib.check(self._lib.bq_solver_inner_iters(self._h, C.byref(n)))
+        return n.value
+
     def close(self):
         if self._h:
             self._lib.bq_solver_destroy(self._h)
@@ -110,6 +118,7 @@ class BoxConstrainedQuadraticOptimizer(Optimizer, ABC):
         dev = self.f.device_problem()
         solver = _DeviceSolver(dev, self._kind, self.lb, self.ub, self.x, self.eps, self.max_iter, self._solver_t())
         self._solver = solver
+        self._configure(solver)
         if self.verbose:
             print(self._header, end='')
         step_mode = self._needs_state()
@@ -147,6 +156,9 @@ class BoxConstrainedQuadraticOptimizer(Optimizer, ABC):
         if self.verbose:
             print('\n')
         return self
+
+    def _configure(self, solver):
+        """Solver-specific settings, applied before the first iteration."""
 
     def _finalize(self, solver):
         pass

@@ -1,7 +1,7 @@
 from ... import _lib
 from ._base import BoxConstrainedQuadraticOptimizer
 
-__all__ = ['ActiveSet']
+__all__ = ['ActiveSet', 'ActiveSetCG']
 
 
 class ActiveSet(BoxConstrainedQuadraticOptimizer):
@@ -34,3 +34,29 @@ class ActiveSet(BoxConstrainedQuadraticOptimizer):
     def _finalize(self, solver):
         self.L = solver.get(_lib.GET_MASK_L) > 0
         self.U = solver.get(_lib.GET_MASK_U) > 0
+
+
+class ActiveSetCG(ActiveSet):
+    """ActiveSet whose restricted systems are solved by conjugate gradients on the masked panel product (`BQ_AS_CG`).
+
+    Not a reference class: the reference re-factorises Q_AA by Cholesky in every iteration (active_set.py:141), which
+    needs an |A| x |A| dense copy and a single device.  This variant keeps the outer logic unchanged and replaces only
+    the linear solve, so ActiveSet also runs where the dense factor cannot: sharded over several GPUs, on fp32-stored
+    and on streamed panels (BASELINE config 5).  `inner_tol` is the relative residual the inner iteration stops at,
+    `inner_max_iter` its cap (0: 2 |A| + 50); `inner_iters` reports the total after `minimize()`.  Pass the class (or
+    a subclass with other settings) as `optimizer=` to SVC / SVR like any other.
+    """
+    _kind = _lib.AS_CG
+    inner_tol = 1e-13
+    inner_max_iter = 0
+
+    def _configure(self, solver):
+        if not 0 < self.inner_tol < 1:
+            raise ValueError('inner_tol has to lie in (0, 1)')
+        if self.inner_max_iter < 0:
+            raise ValueError('inner_max_iter must be >= 0')
+        solver.set_inner(self.inner_tol, self.inner_max_iter)
+
+    def _finalize(self, solver):
+        super()._finalize(solver)
+        self.inner_iters = solver.inner_iters()

@@ -103,6 +103,16 @@ def gpu_mode(exchange, outdir):
     res['stream_matvec'] = sq.device_problem().matvec(v)
     opt = FrankWolfe(quad=sq, ub=np.ones(n), max_iter=30).minimize()
     res['stream_fw_x'] = opt.x
+    # ActiveSet with conjugate-gradient restricted solves: the only ActiveSet that shards (no dense factor); squared
+    # hinge dual of BASELINE config 5 (ub = +inf, x0 = 1) on the dense row-block panel -> bit-identical for any world
+    from optiml_amd.opti.constrained import ActiveSetCG
+    Qs = Qd + np.eye(500) / 2
+    opt = ActiveSetCG(quad=Quadratic(Qs, -np.ones(500)), ub=np.full(500, np.inf), x=np.ones(500), max_iter=400).minimize()
+    res['ascg_x'], res['ascg_iter'], res['ascg_inner'] = opt.x, np.array(opt.iter), np.array(opt.inner_iters)
+    res['ascg_status'] = np.array(opt.status == 'optimal')
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, diag=0.5)
+    opt = ActiveSetCG(quad=quad, ub=np.full(n, np.inf), x=np.ones(n), max_iter=60).minimize()
+    res['ascg_kernel_x'], res['ascg_kernel_f'] = opt.x, np.array(opt.f_x)
     ms, cnt = ctx.profile_read(_lib.PROF_EXCH)
     comm.barrier()
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)

@@ -71,8 +71,12 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path):
     np.testing.assert_allclose(one['stream_matvec'], one['matvec'], rtol=1e-11, atol=1e-11)
     for r in two:
         # row-block panels end in an all-gather: bit-identical for any rank count
-        for key in ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'stream_matvec', 'stream_fw_x'):
+        for key in ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'stream_matvec', 'stream_fw_x', 'ascg_x', 'ascg_iter',
+                    'ascg_inner'):
             assert np.array_equal(r[key], one[key]), key
+        assert bool(r['ascg_status']) and int(r['ascg_inner']) > 0
+        np.testing.assert_allclose(r['ascg_kernel_x'], one['ascg_kernel_x'], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(r['ascg_kernel_f'], one['ascg_kernel_f'], rtol=1e-11)
         # symmetric tile panels end in an all-reduce(sum): same values up to the association of the rank sum
         for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f'):
             np.testing.assert_allclose(r[key], one[key], rtol=1e-12, atol=1e-12, err_msg=key)

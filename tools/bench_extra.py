@@ -5,6 +5,8 @@
     python tools/bench_extra.py chol --n 8192                        # stand-alone dense Cholesky solve
     python tools/bench_extra.py fit  --n 20000 --d 64 --solver pg    # SVC.fit wall time (BASELINE config 2 shape)
     python tools/bench_extra.py smo  --n 20000 --d 64                # device SMO fit (CPU baseline: bench.py --solver smo)
+    python tools/bench_extra.py cfg5 --n 250000 --d 256 --storage f32 --max-iter 200   # BASELINE config 5 shape on ONE GPU:
+                                      # squared-hinge dual, ub = +inf, x0 = 1, ActiveSet with conjugate-gradient solves
 """
 import argparse
 import json
@@ -21,7 +23,9 @@ FP64_MFMA_TF = 78.6
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['ip', 'chol', 'fit', 'smo'])
+    ap.add_argument('what', choices=['ip', 'chol', 'fit', 'smo', 'cfg5'])
+    ap.add_argument('--storage', default='f64', choices=['f64', 'f32', 'stream'])
+    ap.add_argument('--inner-tol', type=float, default=1e-13, help='cfg5 / ascg: residual level of the inner conjugate gradients')
     ap.add_argument('--n', type=int, default=8192)
     ap.add_argument('--d', type=int, default=128)
     ap.add_argument('--iters', type=int, default=3)
@@ -85,14 +89,43 @@ def main():
                    chol_tflops=a.n ** 3 / 3 / (ms / max(cnt, 1) * 1e-3) / 1e12, gap_last=float(rows['r2'][-1]))
         out['chol_frac_of_fp64_mfma_peak'] = out['chol_tflops'] / FP64_MFMA_TF
         s.close()
+    elif a.what == 'cfg5':
+        # SURVEY 8(c).6 / BASELINE config 5: ActiveSet(Quadratic(K*yy' + yy' + I/(2C), -1), ub = +inf, x = 1); the restricted
+        # systems by conjugate gradients on the (fp32-stored) panel — the reference's dense factor would need n^2 more
+        from optiml_amd.ml.svm.kernels import gaussian
+        from optiml_amd.opti import KernelQuadratic
+        from optiml_amd.opti.constrained import ActiveSetCG
+        X, y = make_blobs(a.n, a.d, seed=0)
+        quad = KernelQuadratic(X, -np.ones(a.n), 'svc', gaussian, y=y, diag=0.5, storage=a.storage)
+        t0 = time.perf_counter()
+        quad.device_problem()      # returns after the Gram build has finished
+        out['gram_s'] = time.perf_counter() - t0
+        ub = np.full(a.n, np.inf)
+        ActiveSetCG.inner_tol = a.inner_tol
+        if a.progress:
+            ActiveSetCG.chunk = 1
+        t0 = time.perf_counter()
+        o = ActiveSetCG(quad=quad, ub=ub, x=np.ones(a.n), max_iter=a.max_iter, verbose=bool(a.progress)).minimize()
+        dt = time.perf_counter() - t0
+        x = np.asarray(o.x, float)
+        g = quad.jacobian(x)
+        dd = -g
+        dd[(x <= 1e-12) & (dd < 0)] = 0.
+        out.update(storage=a.storage, inner_tol=a.inner_tol, solve_s=dt, iters=o.iter, status=o.status, f=o.f_x, inner_iters=int(o.inner_iters),
+                   outer_iter_per_s=o.iter / dt, products_per_outer=(o.inner_iters + 2 * o.iter) / max(o.iter, 1),
+                   n_bound=int(o.n_bound), proj_grad_norm=float(np.linalg.norm(dd)),
+                   free_grad_norm=float(np.linalg.norm(g[~(o.L | o.U)])))
     else:
         from optiml_amd.ml.svm import SVC
         from optiml_amd.ml.svm.kernels import gaussian
         from optiml_amd.ml.svm.losses import hinge
         from optiml_amd.opti.constrained import ProjectedGradient, FrankWolfe, InteriorPoint, ActiveSet
-        cls = {'pg': ProjectedGradient, 'fw': FrankWolfe, 'ip': InteriorPoint, 'as': ActiveSet}[a.solver]
+        from optiml_amd.opti.constrained import ActiveSetCG
+        cls = {'pg': ProjectedGradient, 'fw': FrankWolfe, 'ip': InteriorPoint, 'as': ActiveSet, 'ascg': ActiveSetCG}[a.solver]
         if a.progress:
             cls.chunk = 1      # one device run per iteration so that verbose lines appear as the solve advances
+        if a.solver == 'ascg':
+            cls.inner_tol = a.inner_tol
         if a.task == 'svr':
             from optiml_amd.ml.svm import SVR
             from optiml_amd.ml.svm.losses import epsilon_insensitive
@@ -117,6 +150,8 @@ def main():
         dd[(np.asarray(o.ub) - x <= 1e-12) & (dd > 0)] = 0.
         dd[(x - np.asarray(o.lb) <= 1e-12) & (dd < 0)] = 0.
         out.update(proj_grad_norm=float(np.linalg.norm(dd)), f_recomputed=float(est.obj.function(x)))
+        if hasattr(o, 'inner_iters'):
+            out['inner_iters'] = int(o.inner_iters)
         out.update(task=a.task, solver=a.solver, fit_s=dt, iters=o.iter, status=o.status, f=o.f_x,
                    n_sv=int(len(est.support_)), iter_per_s=o.iter / dt, score=float(est.score(X[:5000], y[:5000])))
     print(json.dumps(out), flush=True)
