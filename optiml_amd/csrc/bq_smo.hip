@@ -19,6 +19,8 @@
 // a full square panel (BQ_FULL_PANEL: every row contiguous, one page per examined sample).
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <algorithm>
 
 #include "bq_common.h"
 
@@ -41,7 +43,63 @@ struct bq_smo {
     double *cf = nullptr;                                                // n: and its coefficients
     bq_smo_scal *sc = nullptr;
     bq_smo_scal host;
+    // helper workgroups of the full sweeps (see "Helpers" below)
+    unsigned int *ctl = nullptr;       // SPEC_* words
+    long long *spec_dot = nullptr;     // n: bit pattern of sum_q c_q K[s][idx_q] formed by a helper
+    unsigned int *spec_tag = nullptr;  // n: list version spec_dot[s] belongs to (0: none)
+    unsigned int epoch = 0;            // launch counter
+    int helpers = 0;                   // helper workgroups per full-sweep launch (0: none)
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Helpers.  What a full sweep spends its time on is gathering panel entries: one error is n_sv scattered 8-byte reads,
+// and ONE workgroup lives on one CU, whose miss handling sustains about 0.44 G gathers/s — 127 ms for a quiet sweep over
+// n = 100 000 samples with 558 support vectors, with 255 CUs idle.  So a full-sweep launch carries `helpers` more
+// workgroups whose waves form the SAME sums (same list order, same lane assignment, same tree: bit-identical) for the
+// samples the walker (workgroup 0) is about to examine, out of the support list the walker keeps in global memory:
+//   * walker -> helpers: a control block {version, list length, position, window}.  The version is a sequence lock: odd
+//     while the walker edits the list (a pair step), bumped to the next even value afterwards.
+//   * helpers -> walker: spec_dot[s] tagged with the version it was formed under.  A helper wave re-reads the version
+//     after its gathers and drops the sum if the list moved meanwhile.
+//   * sample s of the window [position, position + window) belongs to helper wave ((s - base) mod 16 H), base = the
+//     walker's position when the version was published: consecutive samples go to different CUs, and right after a
+//     pair step (window H) it is wave 0 of each helper that forms one sum; every quiet batch doubles the window up to
+//     16 H samples.  Only wave 0 of a helper reads the control block in memory (every ~0.9 us when idle) and copies it
+//     into the workgroup's LDS for its other fifteen waves: 2048 waves polling one line slowed the walker's own stores
+//     2.6 times, and waves that back off instead wake too late to be ahead of the walk after a pair step.
+// Nobody waits for anybody: the walker polls the tag of its sample between the chunks of its own gather loop and takes
+// whichever result is there first, and the helpers leave when the walker publishes the end of the launch — a helper
+// that never gets scheduled costs nothing.  Trajectories do not depend on the helpers: a tagged sum is the same
+// double the walker would have formed.
+// ---------------------------------------------------------------------------------------------------------------
+enum { SPEC_VER = 0, SPEC_NNZ = 1, SPEC_WIN = 2, SPEC_DONE = 3, SPEC_POS = 4 /* 64-bit, words 4-5 */,
+       SPEC_BASE = 6 /* 64-bit: the walker's position when the version was published */, SPEC_WORDS = 8 };
+struct SmoSpec {
+    unsigned int *ctl;
+    long long *dot;
+    unsigned int *tag;
+    unsigned int epoch;
+    int helpers;
+};
+// Loads of the shared words.  Every lane of a wave reads the same address, but nothing makes the 64 lanes of one load
+// instruction observe the same store, and the code that follows branches on the value: lane 0's copy is broadcast so
+// that the whole wave takes one decision.
+__device__ __forceinline__ unsigned int ld_acq(const unsigned int *p) {
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned int ld_rlx(const unsigned int *p) {
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ long long ld_rlx64(const long long *p) {
+    const long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void st_rlx(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_rel(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_rlx64(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fence_acq() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 template <typename T>
 struct KView {
@@ -104,6 +162,8 @@ struct SmoShared {
     int mem1, mem2;               // new list membership of the two touched samples
     double cf1, cf2;              // and their new coefficients
     int nnz;                      // length of the support list
+    unsigned int ver;             // helpers: current (even) list version
+    unsigned int win;             // helpers: look-ahead window, in samples
     int scan[SMO_T / 64];
 };
 
@@ -249,14 +309,171 @@ __device__ __forceinline__ void sup_apply(SupList &L, const SupGlobal &G, SmoSha
 // Free-set sweep (smo.py:336-342): only samples with a multiplier strictly inside the box, whose errors are cached —
 // thread 0 walks the support list (the free set is inside it) one sample at a time.
 // ---------------------------------------------------------------------------------------------------------------
+// walker: bracket an edit of the global support list (all threads; no-ops without helpers).  `at` = the position the
+// walk continues from.
+__device__ __forceinline__ void spec_begin(const SmoSpec &P, SmoShared &S) {
+    if (P.helpers == 0) return;
+    if (threadIdx.x == 0) {
+        st_rlx(&P.ctl[SPEC_VER], S.ver + 1u);   // odd: the list is being edited
+        __threadfence();
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void spec_end(const SmoSpec &P, SmoShared &S, long long at) {
+    if (P.helpers == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's list stores have reached the L2 ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S.ver += 2u;
+        S.win = (unsigned int)P.helpers;   // one sample for wave 0 of every helper workgroup
+        st_rlx(&P.ctl[SPEC_NNZ], (unsigned int)S.nnz);
+        st_rlx(&P.ctl[SPEC_WIN], S.win);
+        st_rlx64((long long *)&P.ctl[SPEC_BASE], at);
+        st_rlx64((long long *)&P.ctl[SPEC_POS], at);
+        st_rel(&P.ctl[SPEC_VER], S.ver);   // ... and are written back device-wide before the new even version is
+    }
+    __syncthreads();
+}
+
+// what a helper workgroup knows about the walk: wave 0 copies the control block here every time it looks, the other
+// fifteen waves read this copy (LDS, on their own CU) instead of the shared line in memory
+struct HelpBoard {
+    unsigned int seq;   // sequence lock of this copy: odd while wave 0 rewrites it
+    unsigned int v, win, nnz, quit;
+    unsigned int pos_lo, pos_hi, base_lo, base_hi;
+};
+__device__ __forceinline__ unsigned int lds_uni(const volatile unsigned int *p) {
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)*p);
+}
+
+// the sums of this wave's samples in the window [pos, pos + win) under list version v; true if one was delivered
+template <typename T>
+__device__ __forceinline__ bool helper_sums(const KView<T> &K, int64_t n, const SupGlobal &G, const SmoSpec &P, unsigned int v,
+                                            unsigned int win, int nnz, long long pos, long long base, long long mine,
+                                            long long stride) {
+    const int lane = threadIdx.x & 63;
+    bool did = false;
+    long long s = base + mine;
+    if (s < pos) s += (pos - s + stride - 1) / stride * stride;
+    for (; s < n && s < pos + (long long)win; s += stride) {
+        if (ld_rlx(&P.tag[s]) == v) continue;
+        double part = 0.0;   // the sum of wave_dot, from the global copy of the list
+        for (int q0 = lane; q0 < nnz; q0 += 64 * 8) {
+            double kv[8], cf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + 64 * u;
+                const bool in = q < nnz;
+                cf[u] = in ? G.cf[q] : 0.0;
+                // while the walker edits the list an entry can be anything; the sum is dropped below, but the
+                // panel read must stay inside the panel
+                const unsigned int j = in ? (unsigned int)G.nz[q] : 0u;
+                kv[u] = in ? K.at(s, j < (unsigned long long)n ? (int64_t)j : 0) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + 64 * u < nnz) part = part + __dmul_rn(cf[u], kv[u]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        fence_acq();   // the list reads above are complete before the version is looked at again
+        if (ld_rlx(&P.ctl[SPEC_VER]) != v) break;   // the list moved under the gathers: drop the sum
+        if (lane == 0) {
+            st_rlx64(&P.dot[s], __double_as_longlong(part));
+            st_rel(&P.tag[s], v);
+        }
+        did = true;
+    }
+    return did;
+}
+
+// helper workgroups (see "Helpers" above): one barrier at the start, none afterwards — every wave runs on its own
+template <typename T>
+__device__ void smo_helper(const KView<T> &K, int64_t n, const SupGlobal &G, const SmoSpec &P) {
+    __shared__ HelpBoard HB;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long stride = (long long)P.helpers * (SMO_T / 64);
+    const long long mine = (long long)(blockIdx.x - 1) + (long long)P.helpers * wv;   // residue of (s - base) modulo stride
+    volatile HelpBoard *hb = &HB;
+    if (threadIdx.x == 0) {
+        hb->seq = 0u;
+        hb->v = 1u;   // odd: nothing to do yet
+        hb->win = 0u;
+        hb->quit = 0u;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        unsigned int seq = 0u;
+        while (true) {
+            const unsigned int quit = ld_rlx(&P.ctl[SPEC_DONE]) == P.epoch ? 1u : 0u;
+            const unsigned int v = ld_acq(&P.ctl[SPEC_VER]);
+            const unsigned int win = ld_rlx(&P.ctl[SPEC_WIN]);
+            const int nnz = (int)ld_rlx(&P.ctl[SPEC_NNZ]);
+            const long long pos = ld_rlx64((const long long *)&P.ctl[SPEC_POS]);
+            const long long base = ld_rlx64((const long long *)&P.ctl[SPEC_BASE]);
+            if (lane == 0) {
+                hb->seq = seq + 1u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                hb->v = v;
+                hb->win = win;
+                hb->nnz = (unsigned int)nnz;
+                hb->quit = quit;
+                hb->pos_lo = (unsigned int)pos;
+                hb->pos_hi = (unsigned int)((unsigned long long)pos >> 32);
+                hb->base_lo = (unsigned int)base;
+                hb->base_hi = (unsigned int)((unsigned long long)base >> 32);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                hb->seq = seq + 2u;
+            }
+            seq += 2u;
+            if (quit) break;
+            bool did = false;
+            if (!(v & 1u) && win != 0u) did = helper_sums(K, n, G, P, v, win, nnz, pos, base, mine, stride);
+            if (!did) __builtin_amdgcn_s_sleep(32);   // ~0.9 us between looks at the shared line
+        }
+    } else {
+        unsigned int seen = 0u;
+        while (true) {
+            const unsigned int s1 = lds_uni(&hb->seq);
+            if ((s1 & 1u) || s1 == seen) {   // being rewritten, or nothing new since the last pass
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const unsigned int v = lds_uni(&hb->v), win = lds_uni(&hb->win), nnz = lds_uni(&hb->nnz), quit = lds_uni(&hb->quit);
+            const unsigned int plo = lds_uni(&hb->pos_lo), phi = lds_uni(&hb->pos_hi);
+            const unsigned int blo = lds_uni(&hb->base_lo), bhi = lds_uni(&hb->base_hi);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lds_uni(&hb->seq) != s1) continue;   // wave 0 rewrote the copy meanwhile
+            seen = s1;
+            if (quit) break;
+            if ((v & 1u) || win == 0u) continue;
+            helper_sums(K, n, G, P, v, win, (int)nnz, (long long)(((unsigned long long)phi << 32) | plo),
+                        (long long)(((unsigned long long)bhi << 32) | blo), mine, stride);
+        }
+    }
+}
+
 constexpr int SMO_B = SMO_T / 64;
 
 template <typename T>
-__device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, const SupGlobal &G, int nnz, int64_t s) {
+__device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, const SupGlobal &G, int nnz, int64_t s,
+                                           const SmoSpec &P, unsigned int ver, bool ahead) {
     double part = 0.0;
     // eight panel entries of this lane are fetched together (independent loads in flight), then added in list order —
     // the summation order is that of the plain loop; only the latency of the reads overlaps
     for (int q0 = threadIdx.x & 63; q0 < nnz; q0 += 64 * 8) {
+        // Right after a pair step the tag of this sample travels with the chunk's gathers (one more load in flight, no
+        // extra round trip: the helpers have had no time yet).  Once the look-ahead has grown the helpers are ahead of
+        // the walk and the tag is looked at first — gathers the walker does not issue are what makes it fast.
+        unsigned int tag = 0u;
+        if (P.helpers != 0) {
+            tag = ld_rlx(&P.tag[s]);
+            if (ahead && tag == ver) {
+                fence_acq();
+                return __longlong_as_double(ld_rlx64(&P.dot[s]));
+            }
+        }
         double kv[8], cf[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -264,6 +481,10 @@ __device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, 
             const bool in = q < nnz;
             cf[u] = in ? sup_cf(L, G, q) : 0.0;
             kv[u] = in ? K.at(s, sup_idx(L, G, q)) : 0.0;
+        }
+        if (P.helpers != 0 && tag == ver) {   // wave-uniform: a helper has formed this very sum already
+            fence_acq();
+            return __longlong_as_double(ld_rlx64(&P.dot[s]));
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -356,11 +577,13 @@ __device__ __forceinline__ bool svc_examine(SmoShared &S, const KView<T> &K, con
 // all threads, after a pair step: support list, error cache of the free set, thresholds (smo.py:199-201, :241-271)
 template <typename T>
 __device__ __forceinline__ void svc_after_step(SmoShared &S, SupList &L, const SupGlobal &G, const KView<T> &K,
-                                               const double *y, double *a, double *err, double C) {
+                                               const double *y, double *a, double *err, double C, const SmoSpec &P) {
     const int tid = threadIdx.x;
     const long long i1 = S.i1, i2 = S.i2;
+    spec_begin(P, S);
     sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);   // the list now reflects the new multipliers
     sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
+    spec_end(P, S, i2 + 1);   // a full sweep continues behind the examined sample
     const double c1 = S.c1, c2 = S.c2;
     ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
     for (int q = tid; q < S.nnz; q += SMO_T) {   // the free set is a subset of the support list
@@ -412,10 +635,60 @@ __device__ __forceinline__ void svc_after_step(SmoShared &S, SupList &L, const S
     __syncthreads();
 }
 
+// One wave, one lane per sample of a batch of B <= 64 samples starting at i (lane w: multiplier a2, label y2, error E2;
+// `in` = w < B), no side effects until it is known to apply: within a batch without a pair step b_up only falls and
+// b_low only rises (smo.py:285-291), so a sample that does not violate the thresholds the batch ENDS with violates none
+// of the intermediate ones — then the sequential examine of the batch reduces to storing the new errors and to a
+// first-minimum / first-maximum over the batch, which the lanes do at once.  Returns false (nothing written) when any
+// sample is a possible violator: the batch then goes down the sequential walk.
+__device__ __forceinline__ bool svc_quiet_batch(SmoShared &S, double *err, double C, double tol, int64_t i, int B, bool in,
+                                                double a2, double y2, double E2) {
+    const int w = threadIdx.x & 63;
+    const bool free2 = in && a2 > 0.0 && a2 < C;
+    const bool up2 = in && ((y2 == 1.0 && a2 == 0.0) || (y2 == -1.0 && a2 == C));
+    const bool low2 = in && ((y2 == 1.0 && a2 == C) || (y2 == -1.0 && a2 == 0.0));
+    ValIdx lo{(up2 && !free2) ? E2 : DBL_MAX, (up2 && !free2) ? (long long)w : -1};
+    ValIdx hi{(low2 && !free2) ? E2 : -DBL_MAX, (low2 && !free2) ? (long long)w : -1};
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ValIdx o;
+        o.v = __shfl_xor(lo.v, off, 64);
+        o.i = __shfl_xor(lo.i, off, 64);
+        lo = better(lo, o, -1);
+        o.v = __shfl_xor(hi.v, off, 64);
+        o.i = __shfl_xor(hi.i, off, 64);
+        hi = better(hi, o, +1);
+    }
+    const bool up_moves = lo.i >= 0 && lo.v < S.b_up, low_moves = hi.i >= 0 && hi.v > S.b_low;
+    const double bu = up_moves ? lo.v : S.b_up, bl = low_moves ? hi.v : S.b_low;
+    const bool viol = in && (((free2 || up2) && bl - E2 > 2 * tol) || ((free2 || low2) && E2 - bu > 2 * tol));
+    const bool fast = __ballot(viol) == 0ull;
+    if (fast) {
+        if (in && !free2) err[i + w] = E2;
+        if (w == 0) {
+            if (up_moves) {
+                S.b_up = lo.v;
+                S.i_up = i + lo.i;
+            }
+            if (low_moves) {
+                S.b_low = hi.v;
+                S.i_low = i + hi.i;
+            }
+            S.go = 0;
+            S.used = B;
+        }
+    }
+    return fast;
+}
+
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
                                                         double *a, double *err, SupGlobal G, double C,
-                                                        double tol, bq_smo_scal *sc) {
+                                                        double tol, bq_smo_scal *sc, SmoSpec P) {
+    if (blockIdx.x != 0) {
+        smo_helper(K, n, G, P);
+        return;
+    }
     __shared__ SmoShared S;
     __shared__ SupList L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -425,21 +698,68 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
         S.i_up = sc->i_up;
         S.i_low = sc->i_low;
         S.fail = 0;
+        S.go = 0;
+        S.ver = P.helpers ? ld_rlx(&P.ctl[SPEC_VER]) : 0u;
+        S.win = 0;
     }
     __syncthreads();
-    if (sc->finished) return;
+    if (sc->finished) {
+        if (tid == 0 && P.helpers) st_rel(&P.ctl[SPEC_DONE], P.epoch);
+        return;
+    }
     const bool sweep_all = sc->sweep_all != 0;
     long long changed = 0, steps = 0;
+    spec_begin(P, S);
     smo_rebuild(n, G.nz, S, [&](int64_t j) { return a[j] != 0.0; });
     sup_fill(L, G, S, [&](int j) { return __dmul_rn(a[j], y[j]); });
+    spec_end(P, S, 0);
     if (sweep_all) {
         int64_t i = 0;
         while (i < n) {
+            if (tid == 0 && P.helpers) {   // where the walk stands; a batch without a pair step doubles the look-ahead
+                const unsigned int cap = (unsigned int)(P.helpers * SMO_B);
+                if (!S.go) S.win = S.win * 2u < cap ? S.win * 2u : cap;
+                st_rlx64((long long *)&P.ctl[SPEC_POS], (long long)i);
+                st_rlx(&P.ctl[SPEC_WIN], S.win);
+            }
+            if (P.helpers) {
+                // Once the look-ahead has grown, the helpers are ahead of the walk: wave 0 tries 64 samples at once, one per
+                // lane — multiplier, label, the helper's tagged sum (or the cached error) — and the same quiet-batch
+                // test as below.  A missing tag or a possible violator leaves everything to the 16-sample batch.
+                if (wv == 0) {
+                    bool wide = false;
+                    if (S.win > (unsigned int)SMO_B) {   // same wave as thread 0, which has just written it
+                        const int B = n - i < 64 ? (int)(n - i) : 64;
+                        const bool in = lane < B;
+                        const int64_t sw = i + lane;
+                        const double a2 = in ? a[sw] : 0.0, y2 = in ? y[sw] : 0.0;
+                        const bool free2 = in && a2 > 0.0 && a2 < C;
+                        const bool need = in && !free2;
+                        const unsigned int tag = need ? __hip_atomic_load(&P.tag[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.ver;
+                        if (__ballot(tag != S.ver) == 0ull) {
+                            fence_acq();
+                            double E2 = 0.0;
+                            if (need)
+                                E2 = __longlong_as_double(__hip_atomic_load(&P.dot[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - y2;
+                            else if (in)
+                                E2 = err[sw];
+                            wide = svc_quiet_batch(S, err, C, tol, i, B, in, a2, y2, E2);
+                        }
+                    }
+                    if (lane == 0) S.fast = wide ? 2 : 0;
+                }
+                __syncthreads();
+                if (S.fast == 2) {
+                    i += S.used;
+                    __syncthreads();   // S.fast / S.used are rewritten in the next round
+                    continue;
+                }
+            }
             const int64_t s = i + wv;
             if (s < n) {   // wave-uniform
                 const double as = a[s], ys = y[s];
                 double E = 0.0;
-                if (!(as > 0.0 && as < C)) E = wave_dot(K, L, G, S.nnz, s) - ys;
+                if (!(as > 0.0 && as < C)) E = wave_dot(K, L, G, S.nnz, s, P, S.ver, S.win > (unsigned int)SMO_B) - ys;
                 if (lane == 0) {
                     S.ba[wv] = as;
                     S.by[wv] = ys;
@@ -448,49 +768,11 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
             }
             __syncthreads();
             const int B = n - i < SMO_B ? (int)(n - i) : SMO_B;
-            // Fast path, wave 0, one lane per sample of the batch, no side effects until it is known to apply: within a
-            // batch without a pair step b_up only falls and b_low only rises (smo.py:285-291), so a sample that does not
-            // violate the thresholds the batch ENDS with violates none of the intermediate ones — then the sequential
-            // examine of the 16 samples reduces to storing the new errors and to a first-minimum / first-maximum over
-            // the batch, which 16 lanes do at once.  Any possible violator sends the batch down the sequential walk.
+            // fast path: wave 0 examines the whole batch at once when it holds no possible violator
             if (wv == 0) {
-                const int w = lane;
-                const bool in = w < B;
-                const double a2 = in ? S.ba[w] : 0.0, y2 = in ? S.by[w] : 0.0, E2 = in ? S.bE[w] : 0.0;
-                const bool free2 = in && a2 > 0.0 && a2 < C;
-                const bool up2 = in && ((y2 == 1.0 && a2 == 0.0) || (y2 == -1.0 && a2 == C));
-                const bool low2 = in && ((y2 == 1.0 && a2 == C) || (y2 == -1.0 && a2 == 0.0));
-                ValIdx lo{(up2 && !free2) ? E2 : DBL_MAX, (up2 && !free2) ? (long long)w : -1};
-                ValIdx hi{(low2 && !free2) ? E2 : -DBL_MAX, (low2 && !free2) ? (long long)w : -1};
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {
-                    ValIdx o;
-                    o.v = __shfl_xor(lo.v, off, 64);
-                    o.i = __shfl_xor(lo.i, off, 64);
-                    lo = better(lo, o, -1);
-                    o.v = __shfl_xor(hi.v, off, 64);
-                    o.i = __shfl_xor(hi.i, off, 64);
-                    hi = better(hi, o, +1);
-                }
-                const bool up_moves = lo.i >= 0 && lo.v < S.b_up, low_moves = hi.i >= 0 && hi.v > S.b_low;
-                const double bu = up_moves ? lo.v : S.b_up, bl = low_moves ? hi.v : S.b_low;
-                const bool viol = in && (((free2 || up2) && bl - E2 > 2 * tol) || ((free2 || low2) && E2 - bu > 2 * tol));
-                const bool fast = __ballot(viol) == 0ull;
-                if (fast) {
-                    if (in && !free2) err[i + w] = E2;
-                    if (lane == 0) {
-                        if (up_moves) {
-                            S.b_up = lo.v;
-                            S.i_up = i + lo.i;
-                        }
-                        if (low_moves) {
-                            S.b_low = hi.v;
-                            S.i_low = i + hi.i;
-                        }
-                        S.go = 0;
-                        S.used = B;
-                    }
-                }
+                const bool in = lane < B;
+                const bool fast = svc_quiet_batch(S, err, C, tol, i, B, in, in ? S.ba[lane] : 0.0, in ? S.by[lane] : 0.0,
+                                                  in ? S.bE[lane] : 0.0);
                 if (lane == 0) S.fast = fast ? 1 : 0;
             }
             __syncthreads();
@@ -508,7 +790,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
             }
             __syncthreads();
             if (S.go) {
-                svc_after_step(S, L, G, K, y, a, err, C);
+                svc_after_step(S, L, G, K, y, a, err, C, P);
                 ++changed;
                 ++steps;
             }
@@ -536,7 +818,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
             __syncthreads();
             if (S.stop) break;
             if (S.go) {
-                svc_after_step(S, L, G, K, y, a, err, C);
+                svc_after_step(S, L, G, K, y, a, err, C, P);
                 ++changed;
                 ++steps;
             }
@@ -561,6 +843,10 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
         sc->sweep_all = next_all;
         sc->outer += 1;
         sc->finished = (S.fail || !(changed > 0 || next_all)) ? 1 : 0;
+        if (P.helpers) {   // every exit path of the walker ends here (or in the early return above): release the helpers
+            st_rlx(&P.ctl[SPEC_WIN], 0u);
+            st_rel(&P.ctl[SPEC_DONE], P.epoch);
+        }
     }
 }
 
@@ -724,11 +1010,14 @@ __device__ __forceinline__ bool svr_examine(SmoShared &S, const KView<T> &K, con
 // all threads, after a pair step: support list, error cache of the free set, thresholds (smo.py:601-675)
 template <typename T>
 __device__ __forceinline__ void svr_after_step(SmoShared &S, SupList &L, const SupGlobal &G, const KView<T> &K,
-                                               double *ap, double *an, double *err, double C, double eps) {
+                                               double *ap, double *an, double *err, double C, double eps,
+                                               const SmoSpec &P) {
     const int tid = threadIdx.x;
     const long long i1 = S.i1, i2 = S.i2;
+    spec_begin(P, S);
     sup_apply(L, G, S, (int)i1, S.mem1 != 0, S.cf1);
     sup_apply(L, G, S, (int)i2, S.mem2 != 0, S.cf2);
+    spec_end(P, S, i2 + 1);   // a full sweep continues behind the examined sample
     const double c1 = S.c1, c2 = S.c2;
     ValIdx hi{-DBL_MAX, -1}, lo{DBL_MAX, -1};
     for (int q = tid; q < S.nnz; q += SMO_T) {
@@ -796,7 +1085,11 @@ __device__ __forceinline__ void svr_after_step(SmoShared &S, SupList &L, const S
 template <typename T>
 __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, const double *__restrict__ y,
                                                         double *ap, double *an, double *err, SupGlobal G,
-                                                        double C, double eps, double tol, bq_smo_scal *sc) {
+                                                        double C, double eps, double tol, bq_smo_scal *sc, SmoSpec P) {
+    if (blockIdx.x != 0) {
+        smo_helper(K, n, G, P);
+        return;
+    }
     __shared__ SmoShared S;
     __shared__ SupList L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -806,22 +1099,36 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
         S.i_up = sc->i_up;
         S.i_low = sc->i_low;
         S.fail = 0;
+        S.go = 0;
+        S.ver = P.helpers ? ld_rlx(&P.ctl[SPEC_VER]) : 0u;
+        S.win = 0;
     }
     __syncthreads();
-    if (sc->finished) return;
+    if (sc->finished) {
+        if (tid == 0 && P.helpers) st_rel(&P.ctl[SPEC_DONE], P.epoch);
+        return;
+    }
     const bool sweep_all = sc->sweep_all != 0;
     long long changed = 0, steps = 0;
+    spec_begin(P, S);
     smo_rebuild(n, G.nz, S, [&](int64_t j) { return ap[j] != 0.0 || an[j] != 0.0; });   // a superset of the free set
     sup_fill(L, G, S, [&](int j) { return ap[j] - an[j]; });
+    spec_end(P, S, 0);
     if (sweep_all) {
         int64_t i = 0;
         while (i < n) {
+            if (tid == 0 && P.helpers) {
+                const unsigned int cap = (unsigned int)(P.helpers * SMO_B);
+                if (!S.go) S.win = S.win * 2u < cap ? S.win * 2u : cap;
+                st_rlx64((long long *)&P.ctl[SPEC_POS], (long long)i);
+                st_rlx(&P.ctl[SPEC_WIN], S.win);
+            }
             const int64_t s = i + wv;
             if (s < n) {   // wave-uniform
                 const double ps = ap[s], ms = an[s];
                 const bool cached = svr_kind(ps, ms, C) == 0;
                 double E = 0.0;
-                if (!cached) E = y[s] - wave_dot(K, L, G, S.nnz, s);
+                if (!cached) E = y[s] - wave_dot(K, L, G, S.nnz, s, P, S.ver, S.win > (unsigned int)SMO_B);
                 if (lane == 0) {
                     S.ba[wv] = ps;
                     S.bm[wv] = ms;
@@ -845,7 +1152,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
             }
             __syncthreads();
             if (S.go) {
-                svr_after_step(S, L, G, K, ap, an, err, C, eps);
+                svr_after_step(S, L, G, K, ap, an, err, C, eps, P);
                 ++changed;
                 ++steps;
             }
@@ -873,7 +1180,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
             __syncthreads();
             if (S.stop) break;
             if (S.go) {
-                svr_after_step(S, L, G, K, ap, an, err, C, eps);
+                svr_after_step(S, L, G, K, ap, an, err, C, eps, P);
                 ++changed;
                 ++steps;
             }
@@ -898,6 +1205,10 @@ __global__ __launch_bounds__(SMO_T) void smo_svr_kernel(KView<T> K, int64_t n, c
         sc->sweep_all = next_all;
         sc->outer += 1;
         sc->finished = (S.fail || !(changed > 0 || next_all)) ? 1 : 0;
+        if (P.helpers) {   // every exit path of the walker ends here (or in the early return above): release the helpers
+            st_rlx(&P.ctl[SPEC_WIN], 0u);
+            st_rel(&P.ctl[SPEC_DONE], P.epoch);
+        }
     }
 }
 
@@ -908,7 +1219,8 @@ extern "C" int bq_smo_destroy(bq_smo *s) {
     if (s == nullptr) return BQ_OK;
     hipSetDevice(s->p->ctx->device);
     hipStreamSynchronize(s->p->ctx->stream);
-    for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->nz, (void *)s->cf, (void *)s->sc})
+    for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->nz, (void *)s->cf, (void *)s->sc,
+                      (void *)s->ctl, (void *)s->spec_dot, (void *)s->spec_tag})
         if (ptr) hipFree(ptr);
     delete s;
     return BQ_OK;
@@ -953,6 +1265,22 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
     if (e == hipSuccess) e = hipMalloc(&s->nz, sizeof(int) * n);
     if (e == hipSuccess) e = hipMalloc(&s->cf, sizeof(double) * n);
     if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_smo_scal));
+    // helper workgroups of the full sweeps: BQ_SMO_HELPERS (default: half the CUs; 0 = the walker alone)
+    int cus = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    s->helpers = cus / 2;
+    if (const char *env = getenv("BQ_SMO_HELPERS")) s->helpers = atoi(env);
+    s->helpers = std::max(0, std::min(s->helpers, cus - 1));
+    if (s->helpers < SMO_T / 64) s->helpers = 0;   // the first batch after a pair step wants one CU per sample
+    if (e == hipSuccess && s->helpers) {
+        const unsigned int ctl0[SPEC_WORDS] = {2u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // version 2: tag 0 never matches
+        e = hipMalloc(&s->ctl, sizeof(ctl0));
+        if (e == hipSuccess) e = hipMemcpyAsync(s->ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMalloc(&s->spec_dot, sizeof(long long) * n);
+        if (e == hipSuccess) e = hipMalloc(&s->spec_tag, sizeof(unsigned int) * n);
+        if (e == hipSuccess) e = hipMemsetAsync(s->spec_tag, 0, sizeof(unsigned int) * n, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // ctl0 lives on this stack frame
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(s->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
     memset(&s->host, 0, sizeof(s->host));
     s->host.sweep_all = 1;
@@ -986,20 +1314,26 @@ extern "C" int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, in
     bq_ctx *c = p->ctx;
     BQ_HIP(hipSetDevice(c->device));
     for (int64_t k = 0; k < max_outer && !s->host.finished; ++k) {
+        // full sweeps take the helper workgroups along; free-set sweeps walk the (short) support list alone
+        const int helpers = s->host.sweep_all ? s->helpers : 0;
+        const SmoSpec P{s->ctl, s->spec_dot, s->spec_tag, helpers ? ++s->epoch : 0u, helpers};
+        const dim3 grid(1 + helpers);
+        const SupGlobal G{s->nz, s->cf};
+        const int64_t ld = p->symmetric ? 0 : p->ld;
         if (s->task == BQ_SVC) {
             if (p->storage == BQ_F64)
-                smo_svc_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
-                                                                    s->a, s->err, SupGlobal{s->nz, s->cf}, s->C, s->tol, s->sc);
+                smo_svc_kernel<double><<<grid, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel, ld}, s->n, s->y, s->a,
+                                                                       s->err, G, s->C, s->tol, s->sc, P);
             else
-                smo_svc_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
-                                                                  s->a, s->err, SupGlobal{s->nz, s->cf}, s->C, s->tol, s->sc);
+                smo_svc_kernel<float><<<grid, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel, ld}, s->n, s->y, s->a,
+                                                                     s->err, G, s->C, s->tol, s->sc, P);
         } else {
             if (p->storage == BQ_F64)
-                smo_svr_kernel<double><<<1, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
-                                                                    s->a, s->am, s->err, SupGlobal{s->nz, s->cf}, s->C, s->eps, s->tol, s->sc);
+                smo_svr_kernel<double><<<grid, SMO_T, 0, c->stream>>>(KView<double>{(const double *)p->panel, ld}, s->n, s->y, s->a,
+                                                                       s->am, s->err, G, s->C, s->eps, s->tol, s->sc, P);
             else
-                smo_svr_kernel<float><<<1, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel, p->symmetric ? 0 : p->ld}, s->n, s->y,
-                                                                  s->a, s->am, s->err, SupGlobal{s->nz, s->cf}, s->C, s->eps, s->tol, s->sc);
+                smo_svr_kernel<float><<<grid, SMO_T, 0, c->stream>>>(KView<float>{(const float *)p->panel, ld}, s->n, s->y, s->a,
+                                                                     s->am, s->err, G, s->C, s->eps, s->tol, s->sc, P);
         }
         BQ_HIP(hipGetLastError());
         BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_smo_scal), hipMemcpyDeviceToHost, c->stream));
