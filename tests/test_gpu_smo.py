@@ -265,3 +265,32 @@ def test_smo_verbose_and_fp32_panel(amd, capsys):
     q32 = KernelQuadratic(X, -np.ones(200), 'svc', gaussian, y=yb, rank_one=False, storage='f32')
     o32 = SMOClassifier(q32, X, yb, None, gaussian, 1., 1e-3).minimize()
     assert abs(o32.b - opt.b) <= 1.5e-3 and abs(o32.alphas.sum() - opt.alphas.sum()) <= 0.05
+
+
+def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch):
+    """Full sweeps take helper workgroups along that form the walker's error sums ahead of it (csrc/bq_smo.hip,
+    "Helpers"): the sums are bit-identical to the walker's own, so the run must not depend on how many helpers there
+    are — none, the minimum of 16, the default (half the CUs), all but one CU."""
+    from optiml_amd.datasets import make_blobs, make_regression
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.smo import SMOClassifier, SMORegression
+    n = 6000
+    X, y = make_blobs(n, 16, seed=3)
+    yb = np.where(y == np.unique(y)[-1], 1., -1.)
+    Xr, yr = make_regression(3000, 8, seed=4)
+    yr = (yr - yr.mean()) / yr.std()
+    runs = []
+    for h in ('0', '16', None, '255'):
+        if h is None:
+            monkeypatch.delenv('BQ_SMO_HELPERS', raising=False)
+        else:
+            monkeypatch.setenv('BQ_SMO_HELPERS', h)
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', _kernel('rbf'), y=yb, rank_one=False)
+        c = SMOClassifier(quad, X, yb, None, _kernel('rbf'), 1., 1e-3).minimize()
+        quad = KernelQuadratic(Xr, np.hstack((-yr, yr)) + 0.1, 'svr', _kernel('rbf'), rank_one=False)
+        r = SMORegression(quad, Xr, yr, None, _kernel('rbf'), 1., 0.1, 1e-3).minimize()
+        runs.append((c.iter, c.steps, c.alphas, c.errors, c.b, r.iter, r.steps, r.alphas_p, r.alphas_n, r.b))
+    assert runs[0][1] > 1000 and runs[0][6] > 1000      # enough pair steps for the list to have been edited often
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a, b)
