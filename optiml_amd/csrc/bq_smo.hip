@@ -46,7 +46,7 @@ struct bq_smo {
     // helper workgroups of the full sweeps (see "Helpers" below)
     unsigned int *ctl = nullptr;       // SPEC_* words
     long long *spec_dot = nullptr;     // n: bit pattern of sum_q c_q K[s][idx_q] formed by a helper
-    unsigned int *spec_tag = nullptr;  // n: list version spec_dot[s] belongs to (0: none)
+    long long *spec_tag = nullptr;     // n: (list version << 32) | checksum of spec_dot[s]  (0: none)
     unsigned int epoch = 0;            // launch counter
     int helpers = 0;                   // helper workgroups per full-sweep launch (0: none)
 };
@@ -73,11 +73,12 @@ struct bq_smo {
 // double the walker would have formed.
 // ---------------------------------------------------------------------------------------------------------------
 enum { SPEC_VER = 0, SPEC_NNZ = 1, SPEC_WIN = 2, SPEC_DONE = 3, SPEC_POS = 4 /* 64-bit, words 4-5 */,
-       SPEC_BASE = 6 /* 64-bit: the walker's position when the version was published */, SPEC_WORDS = 8 };
+       SPEC_BASE = 6 /* 64-bit: the walker's position when the version was published */,
+       SPEC_HASH = 8 /* 64-bit: multiset hash of the list entries of the published version */, SPEC_WORDS = 12 };
 struct SmoSpec {
     unsigned int *ctl;
     long long *dot;
-    unsigned int *tag;
+    long long *tag;
     unsigned int epoch;
     int helpers;
 };
@@ -96,10 +97,33 @@ __device__ __forceinline__ long long ld_rlx64(const long long *p) {
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
+__device__ __forceinline__ long long ld_uni64(long long v) {   // lane 0's copy of a 64-bit value
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void st_rlx(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_rel(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_rlx64(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fence_acq() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// What makes a helper's sum acceptable does not rest on the caches alone (a load that was in flight across an
+// invalidate can leave a line of an older state behind, and such sums did change 1 SMO path in 50):
+//  * the walker publishes, with every list version, the sum over the list entries of a 64-bit mix of (index,
+//    coefficient bits) — order-free, so thread 0 keeps it current with one subtraction / addition per edit; a helper
+//    wave adds up the same mix over the entries it actually read and delivers only if the two agree;
+//  * a delivered sum is tagged (version << 32 | checksum of its own bits), so a tag of the current version next to a
+//    stale double is recognised as well.
+__device__ __forceinline__ unsigned long long entry_mix(unsigned int idx, double c) {
+    unsigned long long x = (unsigned long long)__double_as_longlong(c) ^ ((unsigned long long)idx * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    return x;
+}
+__device__ __forceinline__ unsigned int dot_check(long long bits) {
+    const unsigned long long u = (unsigned long long)bits * 0x9E3779B97F4A7C15ull;
+    return (unsigned int)(u >> 32) ^ 0x5bd1e995u;
+}
 
 template <typename T>
 struct KView {
@@ -163,6 +187,8 @@ struct SmoShared {
     double cf1, cf2;              // and their new coefficients
     int nnz;                      // length of the support list
     unsigned int ver;             // helpers: current (even) list version
+    unsigned long long hash;      // helpers: sum of entry_mix over the list (thread 0)
+    double oldcf;                 // sup_apply: coefficient of the entry found
     unsigned int win;             // helpers: look-ahead window, in samples
     int scan[SMO_T / 64];
 };
@@ -235,9 +261,22 @@ __device__ __forceinline__ void sup_put(SupList &L, const SupGlobal &G, int q, i
 // after smo_rebuild filled G.nz: coefficients + LDS mirror
 template <typename Coef>
 __device__ __forceinline__ void sup_fill(SupList &L, const SupGlobal &G, SmoShared &S, Coef coef) {
+    unsigned long long h = 0ull;
     for (int q = threadIdx.x; q < S.nnz; q += SMO_T) {
         const int j = G.nz[q];
-        sup_put(L, G, q, j, coef(j));
+        const double c = coef(j);
+        sup_put(L, G, q, j, c);
+        h += entry_mix((unsigned int)j, c);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) h += (unsigned long long)__shfl_down((long long)h, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) S.bi[threadIdx.x >> 6] = (long long)h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0ull;
+        for (int w = 0; w < SMO_T / 64; ++w) t += (unsigned long long)S.bi[w];
+        S.hash = t;
     }
     __syncthreads();
 }
@@ -256,6 +295,8 @@ __device__ __forceinline__ void sup_apply(SupList &L, const SupGlobal &G, SmoSha
         }
         S.pos = lo;
         S.found = (lo < S.nnz && sup_idx(L, G, lo) == idx) ? 1 : 0;
+        if (S.found) S.hash -= entry_mix((unsigned int)idx, sup_cf(L, G, lo));
+        if (member) S.hash += entry_mix((unsigned int)idx, c);
     }
     __syncthreads();
     const int pos = S.pos, nnz = S.nnz;
@@ -330,6 +371,7 @@ __device__ __forceinline__ void spec_end(const SmoSpec &P, SmoShared &S, long lo
         st_rlx(&P.ctl[SPEC_WIN], S.win);
         st_rlx64((long long *)&P.ctl[SPEC_BASE], at);
         st_rlx64((long long *)&P.ctl[SPEC_POS], at);
+        st_rlx64((long long *)&P.ctl[SPEC_HASH], (long long)S.hash);
         st_rel(&P.ctl[SPEC_VER], S.ver);   // ... and are written back device-wide before the new even version is
     }
     __syncthreads();
@@ -356,19 +398,27 @@ __device__ __forceinline__ bool helper_sums(const KView<T> &K, int64_t n, const 
     long long s = base + mine;
     if (s < pos) s += (pos - s + stride - 1) / stride * stride;
     for (; s < n && s < pos + (long long)win; s += stride) {
-        if (ld_rlx(&P.tag[s]) == v) continue;
+        if ((unsigned int)((unsigned long long)ld_rlx64(&P.tag[s]) >> 32) == v) continue;
         double part = 0.0;   // the sum of wave_dot, from the global copy of the list
+        unsigned long long seen = 0ull;   // entry_mix over the entries this lane read
         for (int q0 = lane; q0 < nnz; q0 += 64 * 8) {
             double kv[8], cf[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int q = q0 + 64 * u;
                 const bool in = q < nnz;
-                cf[u] = in ? G.cf[q] : 0.0;
+                // The list is read with agent-scope loads, not through this CU's L1 / this XCD's L2: those are refreshed
+                // only when wave 0 of the workgroup looks at the version, and a fill that was in flight across that
+                // invalidate can leave a line of the previous list behind — a sum from it would carry the new version
+                // (seen as a 1-in-50-runs change of an SVR path before these loads were made coherent).
+                cf[u] = in ? __longlong_as_double(__hip_atomic_load((const long long *)&G.cf[q], __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT))
+                           : 0.0;
                 // while the walker edits the list an entry can be anything; the sum is dropped below, but the
                 // panel read must stay inside the panel
-                const unsigned int j = in ? (unsigned int)G.nz[q] : 0u;
+                const unsigned int j = in ? (unsigned int)__hip_atomic_load(&G.nz[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 kv[u] = in ? K.at(s, j < (unsigned long long)n ? (int64_t)j : 0) : 0.0;
+                if (in) seen += entry_mix(j, cf[u]);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -376,11 +426,18 @@ __device__ __forceinline__ bool helper_sums(const KView<T> &K, int64_t n, const 
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-        fence_acq();   // the list reads above are complete before the version is looked at again
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) seen += (unsigned long long)__shfl_down((long long)seen, off, 64);
+        seen = (unsigned long long)ld_uni64((long long)seen);
+        fence_acq();   // the list reads above are complete before the control block is looked at again
+        const unsigned long long want = (unsigned long long)ld_rlx64((const long long *)&P.ctl[SPEC_HASH]);
         if (ld_rlx(&P.ctl[SPEC_VER]) != v) break;   // the list moved under the gathers: drop the sum
+        if (seen != want) continue;                 // some entry read was not of this version: drop the sum
         if (lane == 0) {
-            st_rlx64(&P.dot[s], __double_as_longlong(part));
-            st_rel(&P.tag[s], v);
+            const long long bits = __double_as_longlong(part);
+            st_rlx64(&P.dot[s], bits);
+            __hip_atomic_store(&P.tag[s], (long long)(((unsigned long long)v << 32) | dot_check(bits)), __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
         did = true;
     }
@@ -466,12 +523,13 @@ __device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, 
         // Right after a pair step the tag of this sample travels with the chunk's gathers (one more load in flight, no
         // extra round trip: the helpers have had no time yet).  Once the look-ahead has grown the helpers are ahead of
         // the walk and the tag is looked at first — gathers the walker does not issue are what makes it fast.
-        unsigned int tag = 0u;
+        long long tag = 0;
         if (P.helpers != 0) {
-            tag = ld_rlx(&P.tag[s]);
-            if (ahead && tag == ver) {
+            tag = ld_rlx64(&P.tag[s]);
+            if (ahead && (unsigned int)((unsigned long long)tag >> 32) == ver) {
                 fence_acq();
-                return __longlong_as_double(ld_rlx64(&P.dot[s]));
+                const long long bits = ld_rlx64(&P.dot[s]);
+                if (dot_check(bits) == (unsigned int)tag) return __longlong_as_double(bits);
             }
         }
         double kv[8], cf[8];
@@ -482,9 +540,10 @@ __device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, 
             cf[u] = in ? sup_cf(L, G, q) : 0.0;
             kv[u] = in ? K.at(s, sup_idx(L, G, q)) : 0.0;
         }
-        if (P.helpers != 0 && tag == ver) {   // wave-uniform: a helper has formed this very sum already
+        if (P.helpers != 0 && (unsigned int)((unsigned long long)tag >> 32) == ver) {   // wave-uniform: a helper has formed this very sum
             fence_acq();
-            return __longlong_as_double(ld_rlx64(&P.dot[s]));
+            const long long bits = ld_rlx64(&P.dot[s]);
+            if (dot_check(bits) == (unsigned int)tag) return __longlong_as_double(bits);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -735,15 +794,18 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                         const double a2 = in ? a[sw] : 0.0, y2 = in ? y[sw] : 0.0;
                         const bool free2 = in && a2 > 0.0 && a2 < C;
                         const bool need = in && !free2;
-                        const unsigned int tag = need ? __hip_atomic_load(&P.tag[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.ver;
-                        if (__ballot(tag != S.ver) == 0ull) {
+                        const long long tag = need ? __hip_atomic_load(&P.tag[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                        if (__ballot(need && (unsigned int)((unsigned long long)tag >> 32) != S.ver) == 0ull) {
                             fence_acq();
-                            double E2 = 0.0;
-                            if (need)
-                                E2 = __longlong_as_double(__hip_atomic_load(&P.dot[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - y2;
-                            else if (in)
-                                E2 = err[sw];
-                            wide = svc_quiet_batch(S, err, C, tol, i, B, in, a2, y2, E2);
+                            const long long bits = need ? __hip_atomic_load(&P.dot[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                            if (__ballot(need && dot_check(bits) != (unsigned int)tag) == 0ull) {
+                                double E2 = 0.0;
+                                if (need)
+                                    E2 = __longlong_as_double(bits) - y2;
+                                else if (in)
+                                    E2 = err[sw];
+                                wide = svc_quiet_batch(S, err, C, tol, i, B, in, a2, y2, E2);
+                            }
                         }
                     }
                     if (lane == 0) S.fast = wide ? 2 : 0;
@@ -1273,12 +1335,12 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
     s->helpers = std::max(0, std::min(s->helpers, cus - 1));
     if (s->helpers < SMO_T / 64) s->helpers = 0;   // the first batch after a pair step wants one CU per sample
     if (e == hipSuccess && s->helpers) {
-        const unsigned int ctl0[SPEC_WORDS] = {2u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // version 2: tag 0 never matches
+        const unsigned int ctl0[SPEC_WORDS] = {2u};   // version 2: tag 0 never matches
         e = hipMalloc(&s->ctl, sizeof(ctl0));
         if (e == hipSuccess) e = hipMemcpyAsync(s->ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMalloc(&s->spec_dot, sizeof(long long) * n);
-        if (e == hipSuccess) e = hipMalloc(&s->spec_tag, sizeof(unsigned int) * n);
-        if (e == hipSuccess) e = hipMemsetAsync(s->spec_tag, 0, sizeof(unsigned int) * n, c->stream);
+        if (e == hipSuccess) e = hipMalloc(&s->spec_tag, sizeof(long long) * n);
+        if (e == hipSuccess) e = hipMemsetAsync(s->spec_tag, 0, sizeof(long long) * n, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // ctl0 lives on this stack frame
     }
     if (e == hipSuccess) e = hipMemcpyAsync(s->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);

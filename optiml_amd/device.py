@@ -52,10 +52,16 @@ class Context:
         elif exchange == 'rccl':
             self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'rccl'
             uid = C.create_string_buffer(128)
+            failure = None
             if comm.rank == 0:
-                _lib.check(lib.bq_comm_unique_id(uid))
-            raw = comm.broadcast_bytes(uid.raw, src=0)
-            uid = C.create_string_buffer(raw, 128)
+                try:
+                    _lib.check(lib.bq_comm_unique_id(uid))
+                except _lib.BcqpError as err:   # e.g. librccl.so missing: tell the other ranks instead of leaving them in the broadcast
+                    failure = err
+            raw = comm.broadcast_bytes((b'\0' if failure else b'\1') + uid.raw, src=0)
+            if raw[:1] != b'\1':
+                raise failure if failure is not None else RuntimeError('rank 0 could not create an RCCL unique id')
+            uid = C.create_string_buffer(raw[1:], 128)
             _lib.check(lib.bq_ctx_create_rccl(device, comm.rank, comm.world_size, uid, C.byref(self._h)))
         elif exchange == 'host':
             self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'host'

@@ -267,7 +267,8 @@ def test_smo_verbose_and_fp32_panel(amd, capsys):
     assert abs(o32.b - opt.b) <= 1.5e-3 and abs(o32.alphas.sum() - opt.alphas.sum()) <= 0.05
 
 
-def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch):
+@pytest.mark.parametrize('attempt', [0, 1, 2, 3, 4, 5])
+def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch, attempt):
     """Full sweeps take helper workgroups along that form the walker's error sums ahead of it (csrc/bq_smo.hip,
     "Helpers"): the sums are bit-identical to the walker's own, so the run must not depend on how many helpers there
     are — none, the minimum of 16, the default (half the CUs), all but one CU."""
@@ -275,7 +276,7 @@ def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch):
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.ml.svm.smo import SMOClassifier, SMORegression
     n = 6000
-    X, y = make_blobs(n, 16, seed=3)
+    X, y = make_blobs(n, 16, seed=3 + attempt)
     yb = np.where(y == np.unique(y)[-1], 1., -1.)
     Xr, yr = make_regression(3000, 8, seed=4)
     yr = (yr - yr.mean()) / yr.std()
