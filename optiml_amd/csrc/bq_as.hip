@@ -15,6 +15,16 @@
 // silently switches to scipy's minres on the normal equations (:142-151): here a persistent single-workgroup MINRES
 // kernel (bq_minres.hip) takes over for |A| <= 8192.
 //
+// Factor re-use (default for |A| >= 1024; BQ_AS_SCHUR=0 re-factorises every iteration as the reference does): between
+// two consecutive iterations the free set changes by one or a few indices, so the Cholesky factor of a BASE set A0 is
+// kept and the current restricted system is solved through its Schur complement — variables of A0 that have reached a
+// bound since are pinned by a multiplier row (x_k = bound), variables released since are bordered on:
+//     [ Q00  U ] [y]   [b0]        U = [ Q[A0, added] | e_removed ],  V = [ Q[added, added] 0 ; 0 0 ]
+//     [ U'   V ] [w] = [b1]        C = V - U' Q00^-1 U  (m x m, m <= 96),  w = C^-1 (b1 - U' Q00^-1 b0),  y = Q00^-1 (b0 - U w)
+// One new column Q00^-1 u (two triangular sweeps) per changed index and one Q00^-1 b0 per iteration replace the
+// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 changes, when C
+// is numerically singular, or when the classic path is needed (non-positive pivot -> the reference's minres branch).
+//
 // BQ_AS_CG (SURVEY 7 "hard parts": ActiveSet beyond the sizes a dense factor fits): the same outer logic, but the
 // restricted system is solved by conjugate gradients on the masked panel operator v -> m.(Q (m.v)), m = indicator of
 // A — no H, no factorisation, one panel product per inner iteration, so it runs on sharded, fp32-stored and streamed
@@ -22,7 +32,12 @@
 // iteration starts from the current point (delta = 0), which after a one-index change of A is already close.
 #include <cmath>
 
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
 #include "bq_chol.h"
+#include "bq_qelem.h"
 
 #define ACT_TOL 1e-12
 
@@ -49,8 +64,10 @@ struct as_ws {
     double *Qz = nullptr;      // (ldN)
     double *x_eval = nullptr;  // x / g at the top of the current iteration (what a callback must see)
     double *g_eval = nullptr;
-    int host_ints[8];
+    int host_ints[32];
     long long minres_calls = 0;
+    struct as_schur *sch = nullptr;   // factor re-use (Schur-complement updates of a base factorisation)
+    int last_branch = -1;             // what the previous iteration did: 1 release, 0 ratio step + absorb, -1 nothing yet
     // conjugate-gradient inner solver (BQ_AS_CG)
     double *dlt = nullptr, *r = nullptr, *pv = nullptr, *Qp = nullptr, *sol = nullptr;
     as_cg_scal *cg = nullptr;
@@ -59,6 +76,11 @@ struct as_ws {
 };
 
 
+__device__ __forceinline__ double as_wsum_any(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
 __device__ __forceinline__ double as_wmin(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
@@ -239,15 +261,25 @@ __global__ __launch_bounds__(256) void as_absorb_kernel(int64_t N, unsigned char
                                                         const double *__restrict__ lb, const double *__restrict__ ub,
                                                         bq_scal *sc, int *__restrict__ ints, bq_iter_stat *stats) {
     __shared__ int cl[256], cu[256];
+    __shared__ int rec;
+    if (threadIdx.x == 0) rec = 0;
+    __syncthreads();
     int nl = 0, nu = 0;
     for (int64_t i = threadIdx.x; i < N; i += 256) {
         if (mL[i] | mU[i]) continue;
+        bool hit = false;
         if (x[i] <= lb[i] + ACT_TOL) {
             mL[i] = 1;
             ++nl;
+            hit = true;
         } else if (x[i] >= ub[i] - ACT_TOL) {
             mU[i] = 1;
             ++nu;
+            hit = true;
+        }
+        if (hit) {   // the first 16 absorbed indices, for the factor re-use (ints[8] = how many there were)
+            const int slot = atomicAdd(&rec, 1);
+            if (slot < 16) ints[9 + slot] = (int)i;
         }
     }
     cl[threadIdx.x] = nl;
@@ -263,6 +295,7 @@ __global__ __launch_bounds__(256) void as_absorb_kernel(int64_t N, unsigned char
     if (threadIdx.x == 0) {
         ints[5] = cl[0];
         ints[6] = cu[0];
+        ints[8] = rec;
         const long long row = sc->iter - sc->stat_base;
         if (row >= 0 && row < sc->stat_cap) {
             stats[row].r2 = 0.0;
@@ -434,12 +467,433 @@ __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__r
     if (a < ints[0] && a < N) sol[a] = x[idx[a]] + dlt[idx[a]];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// factor re-use: Schur-complement updates of a base factorisation (see the header comment)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int AS_SCHUR_MAX = 96;   // changed indices carried before the base is re-factorised
+
+struct as_schur {
+    bool valid = false;
+    int64_t n0 = 0, np0 = 0, cap = 0;
+    int *idx0 = nullptr;              // device: the base set, ascending
+    int *pos0 = nullptr;              // device: variable -> position in the base, -1 outside
+    std::vector<int> hpos0;           // host mirror of pos0
+    std::vector<int> kind, var;       // slots: kind 0 = base variable now at a bound, 1 = variable freed since
+    std::vector<double> C;            // AS_SCHUR_MAX x AS_SCHUR_MAX, symmetric, host
+    double *U = nullptr, *W = nullptr;   // device: AS_SCHUR_MAX x cap columns u_k and Q00^-1 u_k
+    double *y0 = nullptr, *y = nullptr;  // device: cap
+    double *small = nullptr;          // device: AS_SCHUR_MAX results / coefficients
+    int *meta = nullptr;              // device: kind[], var[] of the slots (2 x AS_SCHUR_MAX)
+    long long refreshes = 0, reused = 0;
+    bool y0_valid = false;   // y0 = Q00^-1 b0 is current: b0 only moves when a variable OUTSIDE the base changes sides
+};
+
+__global__ void as_schur_pos_kernel(int64_t N, int64_t n0, const int *__restrict__ idx0, int *__restrict__ pos0, int pass) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pass == 0) {
+        if (t < N) pos0[t] = -1;
+    } else if (t < n0) {
+        pos0[idx0[t]] = (int)t;
+    }
+}
+
+// z = the bound value on every bound variable OUTSIDE the base (those inside are pinned by a multiplier row), else 0
+__global__ void as_schur_z_kernel(int64_t N, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                  const double *__restrict__ lb, const double *__restrict__ ub,
+                                  const int *__restrict__ pos0, double *__restrict__ z) {
+    VEC_LOOP(i) {
+        if (i < N) z[i] = (pos0[i] < 0 && (mL[i] | mU[i])) ? (mU[i] ? ub[i] : lb[i]) : 0.0;
+    }
+}
+
+__global__ void as_schur_rhs0_kernel(int64_t n0, int64_t np0, const int *__restrict__ idx0, const double *__restrict__ q,
+                                     const double *__restrict__ Qz, double *__restrict__ rhs) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < np0) rhs[a] = a < n0 ? -(q[idx0[a]] + Qz[idx0[a]]) : 0.0;
+}
+
+// the column of a new slot: e_pos for a base variable that reached a bound, Q[A0, var] for a freed variable
+template <typename T>
+__global__ void as_schur_col_kernel(int kind, int var, int pos, int64_t n0, int64_t np0, const int *__restrict__ idx0,
+                                    int structure, const T *__restrict__ panel, int64_t ldp, int packed, int64_t n,
+                                    const double *__restrict__ sgn, double diag_add, double *__restrict__ out) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= np0) return;
+    double v = 0.0;
+    if (kind == 0)
+        v = a == pos ? 1.0 : 0.0;
+    else if (a < n0)
+        v = bq_q_elem(structure, panel, ldp, packed, n, sgn, diag_add, (int64_t)idx0[a], (int64_t)var);
+    out[a] = v;
+}
+
+// block i: out[i] = extra_i - U[i]'v.  mode 0 (v = W[k]): extra = V_ik = Q[var_i, var_k] when both were freed, else 0.
+// mode 1 (v = y0): extra = the right-hand side of row i: the bound of a pinned variable, -(q + Qz) of a freed one.
+template <typename T>
+__global__ __launch_bounds__(256) void as_schur_dots_kernel(int mode, int k, const double *__restrict__ U,
+                                                            const double *__restrict__ v, int64_t cap, int64_t np0,
+                                                            const int *__restrict__ meta, int structure,
+                                                            const T *__restrict__ panel, int64_t ldp, int packed, int64_t n,
+                                                            const double *__restrict__ sgn, double diag_add,
+                                                            const unsigned char *__restrict__ mU,
+                                                            const double *__restrict__ lb, const double *__restrict__ ub,
+                                                            const double *__restrict__ q, const double *__restrict__ Qz,
+                                                            double *__restrict__ out) {
+    __shared__ double sh[4];
+    const int i = blockIdx.x;
+    const double *u = U + (int64_t)i * cap;
+    double s = 0.0;
+    for (int64_t a = threadIdx.x; a < np0; a += 256) s += __dmul_rn(u[a], v[a]);
+    s = as_wsum_any(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double dot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        const int ki = meta[i], vi = meta[AS_SCHUR_MAX + i];
+        double extra = 0.0;
+        if (mode == 0) {
+            const int kk = meta[k], vk = meta[AS_SCHUR_MAX + k];
+            if (ki == 1 && kk == 1) extra = bq_q_elem(structure, panel, ldp, packed, n, sgn, diag_add, (int64_t)vi, (int64_t)vk);
+        } else {
+            extra = ki == 0 ? (mU[vi] ? ub[vi] : lb[vi]) : -(q[vi] + Qz[vi]);
+        }
+        out[i] = extra - dot;
+    }
+}
+
+// y = y0 - sum_k coef[k] W[k]
+__global__ void as_schur_combine_kernel(int64_t np0, int m, const double *__restrict__ y0, const double *__restrict__ W,
+                                        int64_t cap, const double *__restrict__ coef, double *__restrict__ y) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= np0) return;
+    double v = y0[a];
+    for (int k = 0; k < m; ++k) v -= __dmul_rn(coef[k], W[(int64_t)k * cap + a]);
+    y[a] = v;
+}
+
+// cand = bound values on L and U, y on the base variables that are still free, the bordered unknowns on the freed
+// ones; ints[2] = every free coordinate inside [lb - tol, ub + tol]   (single block)
+__global__ __launch_bounds__(256) void as_schur_candidate_kernel(int64_t N, int64_t n0, int m, const int *__restrict__ idx0,
+                                                                 const int *__restrict__ meta,
+                                                                 const unsigned char *__restrict__ mL,
+                                                                 const unsigned char *__restrict__ mU,
+                                                                 const double *__restrict__ lb, const double *__restrict__ ub,
+                                                                 const double *__restrict__ y, const double *__restrict__ coef,
+                                                                 double *__restrict__ cand, int *__restrict__ ints) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < N; i += 256) cand[i] = mU[i] ? ub[i] : (mL[i] ? lb[i] : 0.0);
+    __syncthreads();
+    int mybad = 0;
+    for (int64_t a = threadIdx.x; a < n0; a += 256) {
+        const int i = idx0[a];
+        if (mL[i] | mU[i]) continue;
+        const double v = y[a];
+        cand[i] = v;
+        if (!(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL)) mybad = 1;
+    }
+    for (int k = threadIdx.x; k < m; k += 256) {
+        if (meta[k] != 1) continue;
+        const int i = meta[AS_SCHUR_MAX + k];
+        const double v = coef[k];
+        cand[i] = v;
+        if (!(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL)) mybad = 1;
+    }
+    if (mybad) bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) ints[2] = bad ? 0 : 1;
+}
+
+// dense m x m solve on the host (partial pivoting); false when a pivot is negligible or the result is not finite
+static bool as_small_solve(int m, const std::vector<double> &C, const double *t, double *w) {
+    std::vector<double> A((size_t)m * m);
+    std::vector<double> b(t, t + m);
+    double scale = 0.0;
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+            A[(size_t)i * m + j] = C[(size_t)i * AS_SCHUR_MAX + j];
+            scale = std::max(scale, std::fabs(A[(size_t)i * m + j]));
+        }
+    for (int c = 0; c < m; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < m; ++r)
+            if (std::fabs(A[(size_t)r * m + c]) > std::fabs(A[(size_t)piv * m + c])) piv = r;
+        if (!(std::fabs(A[(size_t)piv * m + c]) > 1e-13 * scale)) return false;
+        if (piv != c) {
+            for (int j = 0; j < m; ++j) std::swap(A[(size_t)piv * m + j], A[(size_t)c * m + j]);
+            std::swap(b[piv], b[c]);
+        }
+        for (int r = c + 1; r < m; ++r) {
+            const double f = A[(size_t)r * m + c] / A[(size_t)c * m + c];
+            if (f == 0.0) continue;
+            for (int j = c; j < m; ++j) A[(size_t)r * m + j] -= f * A[(size_t)c * m + j];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = m - 1; r >= 0; --r) {
+        double v = b[r];
+        for (int j = r + 1; j < m; ++j) v -= A[(size_t)r * m + j] * w[j];
+        w[r] = v / A[(size_t)r * m + r];
+        if (!std::isfinite(w[r])) return false;
+    }
+    return true;
+}
+
 static as_ws *get_ws(bq_solver *s) { return reinterpret_cast<as_ws *>(s->as_ws); }
 
 static int eval_f(bq_solver *s, double *g_out) {
     // Qd = Q x ; f = 1/2 x'Qx + q'x -> sc->f ; optionally g = Qx + q
     BQ_TRY(bq_problem_apply(s->p, s->x, s->Qd, nullptr));
     return bq_vec_eval_f(s->p, s->x, s->Qd, g_out, &s->sc->f);
+}
+
+// ---- factor re-use: host side --------------------------------------------------------------------------------
+static int as_schur_min() {   // read per iteration: tests switch it between solves
+    const char *e = getenv("BQ_AS_SCHUR_MIN");
+    return e ? atoi(e) : 1024;
+}
+static bool as_schur_enabled() {
+    const char *e = getenv("BQ_AS_SCHUR");
+    return e ? atoi(e) != 0 : true;
+}
+
+#define AS_PANEL_ARGS(T) p->structure, (const T *)p->panel, p->ld, p->symmetric ? 1 : 0, p->n, p->sgn, p->diag_add
+
+static void as_schur_free(as_ws *w) {
+    as_schur *c = w->sch;
+    if (!c) return;
+    for (void *ptr : {(void *)c->idx0, (void *)c->pos0, (void *)c->U, (void *)c->W, (void *)c->y0, (void *)c->y,
+                      (void *)c->small, (void *)c->meta})
+        if (ptr) hipFree(ptr);
+    delete c;
+    w->sch = nullptr;
+}
+
+static int as_schur_setup(bq_solver *s, as_ws *w) {
+    if (w->sch) return BQ_OK;
+    as_schur *c = new as_schur();
+    w->sch = c;
+    c->cap = s->chol->cap;
+    BQ_HIP(hipMalloc(&c->idx0, sizeof(int) * (s->N + 1)));
+    BQ_HIP(hipMalloc(&c->pos0, sizeof(int) * (s->N + 1)));
+    BQ_HIP(hipMalloc(&c->U, sizeof(double) * AS_SCHUR_MAX * c->cap));
+    BQ_HIP(hipMalloc(&c->W, sizeof(double) * AS_SCHUR_MAX * c->cap));
+    BQ_HIP(hipMalloc(&c->y0, sizeof(double) * c->cap));
+    BQ_HIP(hipMalloc(&c->y, sizeof(double) * c->cap));
+    BQ_HIP(hipMalloc(&c->small, sizeof(double) * 2 * AS_SCHUR_MAX));
+    BQ_HIP(hipMalloc(&c->meta, sizeof(int) * 2 * AS_SCHUR_MAX));
+    c->hpos0.assign((size_t)s->N, -1);
+    c->C.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
+    return BQ_OK;
+}
+
+// base := the current free set (w->idx holds it, compacted at the top of this iteration); *ok = false when its
+// factorisation meets a non-positive pivot (the classic path then takes the reference's minres branch)
+static int as_schur_refresh(bq_solver *s, as_ws *w, int64_t nA, bool *ok) {
+    as_schur *c = w->sch;
+    bq_chol_ws *ws = s->chol;
+    hipStream_t st = s->p->ctx->stream;
+    const int64_t N = s->N;
+    c->valid = false;
+    std::vector<int> hidx((size_t)nA);
+    BQ_HIP(hipMemcpyAsync(c->idx0, w->idx, sizeof(int) * nA, hipMemcpyDeviceToDevice, st));
+    BQ_HIP(hipMemcpyAsync(hidx.data(), w->idx, sizeof(int) * nA, hipMemcpyDeviceToHost, st));
+    as_schur_pos_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(N, nA, c->idx0, c->pos0, 0);
+    as_schur_pos_kernel<<<(unsigned)((nA + 255) / 256), 256, 0, st>>>(N, nA, c->idx0, c->pos0, 1);
+    int64_t np0 = 0;
+    BQ_TRY(bq_chol_build_h(ws, s->p, c->idx0, nA, nullptr, &np0));
+    BQ_TRY(bq_chol_factor(ws, np0));
+    int info = 0;
+    BQ_HIP(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipStreamSynchronize(st));
+    if (info != 0) {
+        *ok = false;
+        return BQ_OK;
+    }
+    std::fill(c->hpos0.begin(), c->hpos0.end(), -1);
+    for (int64_t a = 0; a < nA; ++a) c->hpos0[(size_t)hidx[(size_t)a]] = (int)a;
+    c->n0 = nA;
+    c->np0 = np0;
+    c->kind.clear();
+    c->var.clear();
+    c->valid = true;
+    c->y0_valid = false;
+    c->refreshes += 1;
+    *ok = true;
+    return BQ_OK;
+}
+
+// drop slot j (swap with the last one): metadata, its row / column of C, its two device columns
+static int as_schur_drop(bq_solver *s, as_schur *c, int j) {
+    const int last = (int)c->kind.size() - 1;
+    if (j != last) {
+        hipStream_t st = s->p->ctx->stream;
+        c->kind[j] = c->kind[last];
+        c->var[j] = c->var[last];
+        for (int i = 0; i <= last; ++i) c->C[(size_t)j * AS_SCHUR_MAX + i] = c->C[(size_t)last * AS_SCHUR_MAX + i];
+        for (int i = 0; i <= last; ++i) c->C[(size_t)i * AS_SCHUR_MAX + j] = c->C[(size_t)i * AS_SCHUR_MAX + last];
+        c->C[(size_t)j * AS_SCHUR_MAX + j] = c->C[(size_t)last * AS_SCHUR_MAX + last];
+        BQ_HIP(hipMemcpyAsync(c->U + (int64_t)j * c->cap, c->U + (int64_t)last * c->cap, sizeof(double) * c->np0,
+                              hipMemcpyDeviceToDevice, st));
+        BQ_HIP(hipMemcpyAsync(c->W + (int64_t)j * c->cap, c->W + (int64_t)last * c->cap, sizeof(double) * c->np0,
+                              hipMemcpyDeviceToDevice, st));
+    }
+    c->kind.pop_back();
+    c->var.pop_back();
+    return BQ_OK;
+}
+
+// what the previous iteration did to the free set -> slots.  *computed = slots whose columns exist (the new ones are
+// appended behind them); *ok = false when the change cannot be carried (too many indices at once)
+static int as_schur_event(bq_solver *s, as_ws *w, int *computed, bool *ok) {
+    as_schur *c = w->sch;
+    const int64_t N = s->N;
+    std::vector<int> freed, bound;
+    if (w->last_branch == 1) {
+        const int hl = w->host_ints[3], hu = w->host_ints[4];
+        if (hl < N)
+            freed.push_back(hl);
+        else if (hu < N)
+            freed.push_back(hu);
+    } else if (w->last_branch == 0) {
+        const int cnt = w->host_ints[8];
+        if (cnt > 16) {
+            *ok = false;
+            return BQ_OK;
+        }
+        for (int k = 0; k < cnt; ++k) bound.push_back(w->host_ints[9 + k]);
+    }
+    auto find = [&](int kind, int v) {
+        for (size_t j = 0; j < c->kind.size(); ++j)
+            if (c->kind[j] == kind && c->var[j] == v) return (int)j;
+        return -1;
+    };
+    // removals of slots first (everything still in the list has its columns), then the new slots at the end
+    std::vector<std::pair<int, int>> add;
+    for (int v : freed) {
+        const int j = find(0, v);
+        if (j >= 0) {
+            BQ_TRY(as_schur_drop(s, c, j));
+        } else {
+            add.push_back({1, v});
+            c->y0_valid = false;   // a variable outside the base left its bound: z, and with it b0, moves
+        }
+    }
+    for (int v : bound) {
+        const int j = find(1, v);
+        if (j >= 0) {
+            BQ_TRY(as_schur_drop(s, c, j));
+            c->y0_valid = false;
+        } else {
+            add.push_back({0, v});
+        }
+    }
+    *computed = (int)c->kind.size();
+    for (auto &kv : add) {
+        if (kv.first == 0 && c->hpos0[(size_t)kv.second] < 0) {   // cannot happen: a variable that reached a bound was free
+            *ok = false;
+            return BQ_OK;
+        }
+        c->kind.push_back(kv.first);
+        c->var.push_back(kv.second);
+    }
+    *ok = (int)c->kind.size() <= AS_SCHUR_MAX;
+    return BQ_OK;
+}
+
+template <typename T>
+static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
+    as_schur *c = w->sch;
+    bq_chol_ws *ws = s->chol;
+    bq_problem *p = s->p;
+    hipStream_t st = p->ctx->stream;
+    const int64_t N = s->N, np0 = c->np0, n0 = c->n0;
+    const int m = (int)c->kind.size();
+    const unsigned gb = (unsigned)((np0 + 255) / 256);
+    *good = false;
+    int hmeta[2 * AS_SCHUR_MAX] = {0};
+    for (int k = 0; k < m; ++k) {
+        hmeta[k] = c->kind[k];
+        hmeta[AS_SCHUR_MAX + k] = c->var[k];
+    }
+    BQ_HIP(hipMemcpyAsync(c->meta, hmeta, sizeof(hmeta), hipMemcpyHostToDevice, st));
+    BQ_HIP(hipStreamSynchronize(st));   // hmeta is on this stack frame
+    if (!c->y0_valid) {   // while only base variables reach bounds, b0 and Q00^-1 b0 stay what they were
+        as_schur_z_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, c->pos0, w->z);
+        BQ_TRY(bq_problem_apply(p, w->z, w->Qz, nullptr));
+        as_schur_rhs0_kernel<<<gb, 256, 0, st>>>(n0, np0, c->idx0, p->q, w->Qz, ws->rhs);
+        BQ_TRY(bq_chol_solve(ws, np0));
+        BQ_HIP(hipMemcpyAsync(c->y0, ws->rhs, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
+        c->y0_valid = true;
+    }
+    double host_small[AS_SCHUR_MAX];
+    for (int k = computed; k < m; ++k) {   // the columns of the new slots and their rows of C
+        double *uk = c->U + (int64_t)k * c->cap, *wk = c->W + (int64_t)k * c->cap;
+        as_schur_col_kernel<T><<<gb, 256, 0, st>>>(c->kind[k], c->var[k], c->kind[k] == 0 ? c->hpos0[(size_t)c->var[k]] : -1, n0,
+                                                  np0, c->idx0, AS_PANEL_ARGS(T), uk);
+        BQ_HIP(hipMemcpyAsync(ws->rhs, uk, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
+        BQ_TRY(bq_chol_solve(ws, np0));
+        BQ_HIP(hipMemcpyAsync(wk, ws->rhs, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
+        as_schur_dots_kernel<T><<<k + 1, 256, 0, st>>>(0, k, c->U, wk, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                      s->ub, p->q, w->Qz, c->small);
+        BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
+        BQ_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i <= k; ++i) {
+            if (!std::isfinite(host_small[i])) return BQ_OK;
+            c->C[(size_t)i * AS_SCHUR_MAX + k] = host_small[i];
+            c->C[(size_t)k * AS_SCHUR_MAX + i] = host_small[i];
+        }
+    }
+    double coef[AS_SCHUR_MAX] = {0};
+    if (m > 0) {
+        as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                  s->ub, p->q, w->Qz, c->small);
+        BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+        BQ_HIP(hipStreamSynchronize(st));
+        if (!as_small_solve(m, c->C, host_small, coef)) return BQ_OK;
+        BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
+        BQ_HIP(hipStreamSynchronize(st));   // coef is on this stack frame
+    }
+    as_schur_combine_kernel<<<gb, 256, 0, st>>>(np0, m, c->y0, c->W, c->cap, c->small + AS_SCHUR_MAX, c->y);
+    as_schur_candidate_kernel<<<1, 256, 0, st>>>(N, n0, m, c->idx0, c->meta, s->mL, s->mU, s->lb, s->ub, c->y,
+                                                 c->small + AS_SCHUR_MAX, w->cand, w->ints);
+    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipStreamSynchronize(st));
+    BQ_HIP(hipGetLastError());
+    *good = true;
+    return BQ_OK;
+}
+
+// one restricted solve through the kept factor; *solved = false leaves the iteration to the classic path
+static int as_schur_step(bq_solver *s, as_ws *w, int64_t nA, bool *solved) {
+    *solved = false;
+    BQ_TRY(as_schur_setup(s, w));
+    as_schur *c = w->sch;
+    int computed = 0;
+    bool ok = c->valid;
+    if (ok) BQ_TRY(as_schur_event(s, w, &computed, &ok));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!ok) {
+            BQ_TRY(as_schur_refresh(s, w, nA, &ok));
+            if (!ok) return BQ_OK;   // not positive definite: classic path (minres branch)
+            computed = 0;
+        } else if (attempt == 0) {
+            c->reused += 1;
+        }
+        bool good = false;
+        if (s->p->storage == BQ_F64)
+            BQ_TRY(as_schur_solve_t<double>(s, w, computed, &good));
+        else
+            BQ_TRY(as_schur_solve_t<float>(s, w, computed, &good));
+        if (good) {
+            *solved = true;
+            return BQ_OK;
+        }
+        ok = false;   // numerically singular update: start again from a fresh factor of the current set
+    }
+    c->valid = false;
+    return BQ_OK;
 }
 
 // the restricted solve of one outer iteration by conjugate gradients; leaves the candidate in w->cand and the
@@ -485,7 +939,7 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
     }
     as_cg_gather_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->x, w->dlt, w->sol, N);
     as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, w->sol, w->z, N, s->lb, s->ub, w->cand);
-    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     return BQ_OK;
 }
@@ -496,8 +950,8 @@ int bq_as_start(bq_solver *s) {
     s->as_ws = w;
     BQ_HIP(hipMalloc(&w->idx, sizeof(int) * (s->N + 1)));
     BQ_HIP(hipMemsetAsync(w->idx, 0, sizeof(int) * (s->N + 1), ctx->stream));
-    BQ_HIP(hipMalloc(&w->ints, sizeof(int) * 8));
-    BQ_HIP(hipMemsetAsync(w->ints, 0, sizeof(int) * 8, ctx->stream));
+    BQ_HIP(hipMalloc(&w->ints, sizeof(int) * 32));
+    BQ_HIP(hipMemsetAsync(w->ints, 0, sizeof(int) * 32, ctx->stream));
     for (double **v : {&w->cand, &w->z, &w->Qz, &w->x_eval, &w->g_eval}) {
         BQ_HIP(hipMalloc(v, sizeof(double) * s->ldN));
         BQ_HIP(hipMemsetAsync(*v, 0, sizeof(double) * s->ldN, ctx->stream));
@@ -526,6 +980,7 @@ void bq_as_free(bq_solver *s) {
                     (void *)w->cg})
         if (p) hipFree(p);
     if (w->cg_flag_host) hipHostFree(w->cg_flag_host);
+    as_schur_free(w);
     delete w;
     s->as_ws = nullptr;
 }
@@ -556,7 +1011,7 @@ int bq_as_iterate(bq_solver *s) {
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, w->g_eval);
         s->started = true;
     }
-    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     if (s->host.done) return BQ_OK;
@@ -564,6 +1019,23 @@ int bq_as_iterate(bq_solver *s) {
 
     if (s->as_cg) {
         BQ_TRY(as_cg_solve(s, w));
+        if (w->host_ints[2]) {
+            as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
+            BQ_TRY(eval_f(s, s->g));
+            as_release_kernel<<<1, 256, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
+        } else {
+            as_step_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, w->cand, s->lb, s->ub, s->x, s->sc);
+            BQ_TRY(eval_f(s, nullptr));
+            as_absorb_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, s->x, s->lb, s->ub, s->sc, w->ints, s->stats);
+        }
+        BQ_HIP(hipGetLastError());
+        return BQ_OK;
+    }
+    bool solved = false;
+    if (as_schur_enabled() && nA >= as_schur_min()) BQ_TRY(as_schur_step(s, w, nA, &solved));
+    if (!solved && w->sch) w->sch->valid = false;   // the classic path below overwrites the kept factor
+    if (solved) {
+        w->last_branch = w->host_ints[2] ? 1 : 0;
         if (w->host_ints[2]) {
             as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
             BQ_TRY(eval_f(s, s->g));
@@ -586,7 +1058,7 @@ int bq_as_iterate(bq_solver *s) {
     as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, ws->rhs, w->z, N, s->lb, s->ub, w->cand);
     int info = 0;
     BQ_HIP(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     if (info != 0) {
         // Q[A,A] is not positive definite: the reference's bare `except` switches to scipy's minres on the normal
@@ -602,10 +1074,11 @@ int bq_as_iterate(bq_solver *s) {
         as_gather_rhs_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->p->q, w->Qz, ws->rhs, np);
         BQ_TRY(bq_minres_normal(ws, w->ints, ws->cap, ws->mr_vec, w->ints + 7));
         as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, ws->rhs, w->z, N, s->lb, s->ub, w->cand);
-        BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+        BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
         BQ_HIP(hipStreamSynchronize(st));
         w->minres_calls += 1;
     }
+    w->last_branch = w->host_ints[2] ? 1 : 0;
     if (w->host_ints[2]) {
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
         BQ_TRY(eval_f(s, s->g));

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "bq_chol.h"
+#include "bq_qelem.h"
 #include "bq_mfma_tile.h"
 
 constexpr int NB = 128;
@@ -420,29 +421,10 @@ __global__ void build_h_kernel(int structure, const T *__restrict__ panel, int64
         if (a >= m || b >= m) {   // pad rows AND pad columns (a full build visits b > a): never index idx[] there
             v = (a == b) ? 1.0 : 0.0;
         } else {
-            int64_t i = idx ? idx[a] : a, jj = idx ? idx[b] : b;
-            if (jj > i) {   // upper half of a full symmetric build: mirror (panels hold the lower tiles)
-                const int64_t t = i;
-                i = jj;
-                jj = t;
-            }
-            // kernel-built panels keep only the tiles on/below the diagonal: always read (max, min)
-            if (structure == BQ_PLAIN) {
-                v = (double)panel[packed ? bq_sym_addr(i, jj, 0) : i * ldp + jj];
-            } else if (structure == BQ_SVC) {
-                v = sgn[i] * sgn[jj] * ((double)panel[bq_sym_addr(i, jj, 0)] + 1.0);
-            } else if (structure == BQ_H_KPLUS1) {   // K + 1 of an n x n block (reduced SVR Newton system)
-                v = (double)panel[bq_sym_addr(i, jj, 0)] + 1.0;
-            } else {
-                const int64_t ii = i >= n ? i - n : i, jn = jj >= n ? jj - n : jj;
-                const int64_t hi = ii > jn ? ii : jn, lo = ii > jn ? jn : ii;
-                const double pv = (double)panel[bq_sym_addr(hi, lo, 0)] + 1.0;
-                v = ((i >= n) == (jj >= n)) ? pv : -pv;
-            }
-            if (i == jj) {
-                if (diag_add != 0.0) v += diag_add;
-                if (hd) v += hd[a];
-            }
+            const int64_t i = idx ? idx[a] : a, jj = idx ? idx[b] : b;
+            // (a full symmetric build visits the upper half too: bq_q_elem mirrors, panels hold the lower tiles)
+            v = bq_q_elem(structure, panel, ldp, packed, n, sgn, diag_add, i, jj);
+            if (i == jj && hd) v += hd[a];
         }
         H[a * ldh + b] = v;
     }

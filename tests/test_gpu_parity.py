@@ -31,6 +31,18 @@ def _solvers():
 AS_KINDS = ['as', 'ascg']
 
 
+@pytest.fixture(params=['refactor', 'reuse'])
+def as_factor_mode(request, monkeypatch):
+    """The dense-factor ActiveSet either re-factorises Q[A,A] in every iteration (what the reference does) or keeps the
+    factor of a base set and carries the changes through a Schur complement (csrc/bq_as.hip; the default from |A| = 1024
+    on — BQ_AS_SCHUR_MIN=0 switches it on for the small fixtures).  Both must follow the reference's trajectory."""
+    if request.param == 'reuse':
+        monkeypatch.setenv('BQ_AS_SCHUR_MIN', '0')
+    else:
+        monkeypatch.setenv('BQ_AS_SCHUR', '0')
+    return request.param
+
+
 # ---------------------------------------------------------------------------------------------------------
 # panel product / objective
 # ---------------------------------------------------------------------------------------------------------
@@ -392,7 +404,7 @@ def test_fit_svr_ip(amd, n, kname):
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('kind', AS_KINDS)
 @pytest.mark.parametrize('tag', ['nd2', 'nd5', 'nd64'])
-def test_reference_unit_problems_as(amd, tag, kind):
+def test_reference_unit_problems_as(amd, tag, kind, as_factor_mode):
     from optiml_amd.opti import Quadratic
     g = load_golden('unit_problems.npz')
     hist = []
@@ -402,7 +414,7 @@ def test_reference_unit_problems_as(amd, tag, kind):
 
 
 @pytest.mark.parametrize('kind', AS_KINDS)
-def test_trajectory_svc_dense_as(amd, kind):
+def test_trajectory_svc_dense_as(amd, kind, as_factor_mode):
     from optiml_amd.opti import Quadratic
     g = load_golden('traj_svc_rbf_n256.npz')
     snaps, hist = {}, []
@@ -421,7 +433,7 @@ def test_trajectory_svc_dense_as(amd, kind):
 
 
 @pytest.mark.parametrize('kind', AS_KINDS)
-def test_trajectory_as_lb_and_warm_start(amd, kind):
+def test_trajectory_as_lb_and_warm_start(amd, kind, as_factor_mode):
     from optiml_amd.opti import Quadratic
     g = load_golden('traj_svc_rbf_n256.npz')
     hist = []
@@ -433,7 +445,7 @@ def test_trajectory_as_lb_and_warm_start(amd, kind):
 
 
 @pytest.mark.parametrize('kind,storage', [('as', 'f64'), ('ascg', 'f64'), ('ascg', 'stream')])
-def test_cfg5_squared_hinge_active_set(amd, kind, storage):
+def test_cfg5_squared_hinge_active_set(amd, kind, storage, as_factor_mode):
     """BASELINE config 5's oracle: ActiveSet on K*yy' + yy' + I/(2C) with ub = +inf, x0 = 1; the
     conjugate-gradient variant also on the streamed (panel-free) product, where no dense factor could be assembled."""
     from optiml_amd.opti import KernelQuadratic
@@ -452,7 +464,7 @@ def test_cfg5_squared_hinge_active_set(amd, kind, storage):
 
 @pytest.mark.parametrize('kind', AS_KINDS)
 @pytest.mark.parametrize('n', [200, 600])
-def test_fit_svc_as(amd, n, kind):
+def test_fit_svc_as(amd, n, kind, as_factor_mode):
     from optiml_amd.ml.svm import SVC
     from optiml_amd.ml.svm.kernels import gaussian
     from optiml_amd.ml.svm.losses import hinge
@@ -488,7 +500,7 @@ def test_active_set_cg_fp32_panel_and_errors(amd):
         s.minimize()
 
 
-def test_active_set_singular_system_uses_minres(amd):
+def test_active_set_singular_system_uses_minres(amd, as_factor_mode):
     """Linear kernel, n > d + 1: Q[A,A] is singular, the reference's Cholesky raises and it falls back to scipy's
     minres on the normal equations (active_set.py:142-151).  The device path takes the same branch (persistent MINRES
     kernel).  minres stops at rtol 1e-5 and the branch is decided by rounding, so parity is loose: the objective
