@@ -271,7 +271,7 @@ def test_smo_verbose_and_fp32_panel(amd, capsys):
 def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch, attempt):
     """Full sweeps take helper workgroups along that form the walker's error sums ahead of it (csrc/bq_smo.hip,
     "Helpers"): the sums are bit-identical to the walker's own, so the run must not depend on how many helpers there
-    are — none, the minimum of 16, the default (half the CUs), all but one CU."""
+    are — none, the minimum of 16, the default (48), half the CUs, all but one CU."""
     from optiml_amd.datasets import make_blobs, make_regression
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.ml.svm.smo import SMOClassifier, SMORegression
@@ -281,7 +281,7 @@ def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch, attempt):
     Xr, yr = make_regression(3000, 8, seed=4)
     yr = (yr - yr.mean()) / yr.std()
     runs = []
-    for h in ('0', '16', None, '255'):
+    for h in ('0', '16', None, '128', '255'):
         if h is None:
             monkeypatch.delenv('BQ_SMO_HELPERS', raising=False)
         else:
