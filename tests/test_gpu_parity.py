@@ -477,6 +477,36 @@ def test_fit_svc_as(amd, n, kind, as_factor_mode):
     _check_fit(est, g, 'rbf_as', g['Xtest'], hist_tol=1e-9 if kind == 'as' else 1e-6)
 
 
+def test_active_set_factor_reuse_across_refreshes(amd, monkeypatch):
+    """n = 1500 (above the default threshold of the factor re-use), 450 iterations from the reference's start x = ub/2:
+    several base re-factorisations (one per 96 changed indices), variables reaching bounds and — in the second run,
+    started next to the solution — variables being released again.  The kept-factor run must reproduce the run that
+    re-factorises Q[A,A] in every iteration: same events, iterates to 1e-9."""
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.kernels import gaussian
+    n = 1500
+    X, y = make_blobs(n, 10, seed=11)
+    yb = np.where(y == np.unique(y)[-1], 1., -1.)
+    rs = np.random.RandomState(5)
+    x_near = np.where(rs.uniform(size=n) < 0.85, 0., rs.uniform(size=n))   # mostly at the lower bound: releases happen
+    for x0, iters in ((None, 450), (x_near, 300)):
+        runs = []
+        for mode in ('0', '1'):
+            monkeypatch.setenv('BQ_AS_SCHUR', mode)
+            hist = []
+            cb = lambda o: hist.append((o.f_x, o.n_bound))
+            cb._bq_needs_state = False
+            quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=yb)
+            opt = _solvers()['as'](quad=quad, ub=np.ones(n), x=x0, max_iter=iters, callback=cb).minimize()
+            runs.append((np.array(hist), opt.x, opt.iter, opt.status))
+        (h0, x_ref, it0, st0), (h1, x_new, it1, st1) = runs
+        assert it0 == it1 and st0 == st1
+        assert np.array_equal(h0[:, 1], h1[:, 1])                      # the same number of bound variables all along
+        np.testing.assert_allclose(h1[:, 0], h0[:, 0], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(x_new, x_ref, rtol=1e-9, atol=1e-11)
+
+
 def test_active_set_cg_fp32_panel_and_errors(amd):
     """The conjugate-gradient ActiveSet on an fp32-stored panel (BASELINE config 5's storage): same active-set path as
     the fp64 reference within the fp32 tolerance SURVEY 8(d) states (alpha rtol 1e-4 / atol 1e-5, objective 1e-6); an
