@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--cpu-n', type=int, default=12000, help='sample size of the CPU baseline leg')
     ap.add_argument('--cpu-steps', type=int, default=150)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--sigma', type=float, default=8.0, help='blob spread of the synthetic data (SURVEY 8d: 8 overlapping, 3 separable)')
     ap.add_argument('--cpu-study', action='store_true',
                     help='CPU only (SURVEY 8d): the oracle timed at three sizes to check the n^2 (PG) / n^3 (Cholesky) laws '
                          'behind the extrapolated baseline, plus a blocked Gram-streaming product at the full n')
@@ -234,7 +235,7 @@ def bench_smo(args):
     from optiml_amd.ml.svm.kernels import gaussian
     from optiml_amd.ml.svm.losses import hinge
     ctx = device.get_context()
-    X, y = make_blobs(args.n, args.d, seed=0)
+    X, y = make_blobs(args.n, args.d, seed=0, sigma=args.sigma)
     t0 = time.perf_counter()
     est = SVC(loss=hinge, kernel=gaussian, C=1., dual=True, optimizer='smo', tol=1e-3).fit(X, y)
     dt = time.perf_counter() - t0
@@ -319,7 +320,7 @@ def main():
     kern = {'rbf': gaussian, 'poly': PolyKernel(3, 'scale', 1.0), 'linear': linear}[args.kernel]
     al = args.solver == 'adagrad'   # reg_intercept=False dual: no rank-one term, equality row handled by the multiplier
     if args.task == 'svc':
-        X, y = make_blobs(n, d, seed=0)
+        X, y = make_blobs(n, d, seed=0, sigma=args.sigma)
         quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage, rank_one=not al)
         a_eq = y
     else:   # eps-insensitive SVR dual: 2n variables on one n x n panel (BASELINE config 4 shape)
@@ -385,7 +386,7 @@ def main():
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64' if args.storage in ('f64', 'stream') else 'f32-storage/f64-accumulate', 'data': 'synthetic',
             'config': {'workload': workload, 'n': n, 'd': d, 'dual_dim': N, 'C': 1.0,
-                       'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange,
+                       'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange, 'blob_sigma': args.sigma,
                        'rows_per_gpu': r1 - r0, 'device': ctx.name},
             'roofline': {'bound': 'hbm', 'kernel': 'symv_tiles_kernel (symmetric panel product Q*d)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
