@@ -108,7 +108,17 @@ def cpu_baseline(args):
     its = res['iter']
     rate = its / dt
     scaled = rate * (ns / args.n) ** 2
-    return {'value': scaled, 'unit': 'iter/s', 'cores': int(threads), 'kind': 'port',
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {'value': scaled, 'unit': 'iter/s', 'cores': int(threads), 'kind': 'port', 'cpu_model': model,
+            'os_cpu_count': os.cpu_count(), 'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS'),
+            'OPENBLAS_NUM_THREADS': os.environ.get('OPENBLAS_NUM_THREADS'),
             'sample': f'oracle {args.solver.upper()} (dense fp64 Q on host, 3 products/iter), n={ns} d={args.d}, '
                       f'{its} iterations in {dt:.2f}s = {rate:.3f} iter/s measured; value scaled by (n_s/n)^2 to '
                       f'n={args.n}; Gram+Q assembly {t_build:.2f}s excluded',
