@@ -833,7 +833,8 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         as_schur_col_kernel<T><<<gb, 256, 0, st>>>(c->kind[k], c->var[k], c->kind[k] == 0 ? c->hpos0[(size_t)c->var[k]] : -1, n0,
                                                   np0, c->idx0, AS_PANEL_ARGS(T), uk);
         BQ_HIP(hipMemcpyAsync(ws->rhs, uk, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
-        BQ_TRY(bq_chol_solve(ws, np0));
+        // a pinned base variable's column is a unit vector: the forward sweep starts at its row
+        BQ_TRY(bq_chol_solve(ws, np0, c->kind[k] == 0 ? (int64_t)c->hpos0[(size_t)c->var[k]] : 0));
         BQ_HIP(hipMemcpyAsync(wk, ws->rhs, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
         as_schur_dots_kernel<T><<<k + 1, 256, 0, st>>>(0, k, c->U, wk, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
                                                       s->ub, p->q, w->Qz, c->small);

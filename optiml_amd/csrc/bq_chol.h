@@ -22,7 +22,7 @@ struct bq_chol_ws {
 };
 
 int bq_chol_factor(bq_chol_ws *ws, int64_t np);
-int bq_chol_solve(bq_chol_ws *ws, int64_t np);
+int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero = 0);   // rhs[0:first_nonzero) is known to be zero
 constexpr int BQ_H_KPLUS1 = 3;   // internal H-assembly mode: entries K_ij + 1 of the n x n panel
 int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out,
                     bool full = false, int structure_override = -1);

@@ -127,12 +127,13 @@ __device__ __forceinline__ bool chol_last_block(unsigned int *ticket);
 // ... and the last block to finish applies the inverse of the diagonal block: rhs[k0 : k0+128) = Linv_kk tmp
 __global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0, double *rhs,
                                                         double *tmp, const double *__restrict__ LinvT,
-                                                        unsigned int *ticket) {
+                                                        unsigned int *ticket, int64_t c0) {
     __shared__ double red[4];
     const int r = blockIdx.x, tid = threadIdx.x;
     const double *row = H + (k0 + r) * ldh;
     double a = 0.0;
-    for (int64_t c = 2 * tid; c < k0; c += 512) {  // k0 is a multiple of 128 -> pairs never straddle k0
+    // c0: the right-hand side is known to vanish before column c0 (a multiple of 128)
+    for (int64_t c = c0 + 2 * tid; c < k0; c += 512) {  // k0 is a multiple of 128 -> pairs never straddle k0
         const bq_d2 l = *reinterpret_cast<const bq_d2 *>(row + c);
         const bq_d2 y = *reinterpret_cast<const bq_d2 *>(rhs + c);
         a = fma(l.y, y.y, fma(l.x, y.x, a));
@@ -386,14 +387,17 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
 }
 
 // solve (L L^T) x = ws->rhs in place (ws->rhs padded to np, pad entries zero)
-int bq_chol_solve(bq_chol_ws *ws, int64_t np) {
+int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero) {
     hipStream_t st = ws->ctx->stream;
     const int64_t ldh = ws->ldh;
     auto Linv = [&](int64_t k0) { return ws->LinvT + (k0 / NB) * NB * NB; };
-    // forward: y_k = Linv_kk (b_k - L_k,0:k y_0:k); one launch per block row (the panel product's last block applies Linv)
-    diag_mv_kernel<<<1, 256, 0, st>>>(Linv(0), 0, ws->rhs, ws->rhs);
-    for (int64_t k0 = NB; k0 < np; k0 += NB)
-        fwd_panel_kernel<<<NB, 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp, Linv(k0), ws->ticket);
+    // forward: y_k = Linv_kk (b_k - L_k,0:k y_0:k); one launch per block row (the panel product's last block applies Linv).
+    // A right-hand side that vanishes before row first_nonzero (a unit vector: the ActiveSet update columns) leaves
+    // y = 0 there, so the sweep starts at that row's block.
+    const int64_t kb = (first_nonzero / NB) * NB;
+    diag_mv_kernel<<<1, 256, 0, st>>>(Linv(kb), 0, ws->rhs + kb, ws->rhs + kb);
+    for (int64_t k0 = kb + NB; k0 < np; k0 += NB)
+        fwd_panel_kernel<<<NB, 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp, Linv(k0), ws->ticket, kb);
     // backward: x_k = Linv_kk^T y_k, then y_0:k -= L_k,0:k^T x_k (whose last block solves block k-1)
     diag_mv_kernel<<<1, 256, 0, st>>>(Linv(np - NB), 1, ws->rhs + np - NB, ws->rhs + np - NB);
     for (int64_t k0 = np - NB; k0 > 0; k0 -= NB)
