@@ -208,21 +208,34 @@ __device__ __forceinline__ bool chol_last_block(unsigned int *ticket) {
 
 // rhs[c] -= sum_{r < 128} L[k0 + r][c] * x[r]  for c < k0; the last block to finish then solves the next (previous)
 // diagonal block in place: rhs[k0-128 : k0) = Linv^T_{k-1} rhs[k0-128 : k0)
+// One workgroup per 128 columns: 64 column pairs x 4 groups of 32 rows, a thread's 32 row loads in flight together, the
+// four partial sums combined in a fixed order through LDS.  (Its first version gave a workgroup 512 columns and every
+// thread all 128 rows: k0/512 workgroups, each pulling 512 KB through one CU — 19 us per launch in the ActiveSet trace.)
 __global__ __launch_bounds__(256) void bwd_update_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0,
                                                          const double *xk, double *rhs,
                                                          const double *__restrict__ LinvT_prev, unsigned int *ticket) {
     __shared__ double x[NB];
+    __shared__ double part[3][NB];
     if (threadIdx.x < NB) x[threadIdx.x] = xk[threadIdx.x];
     __syncthreads();
-    const int64_t c = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
-    if (c < k0) {
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < NB; ++r) {
-            const bq_d2 l = *reinterpret_cast<const bq_d2 *>(H + (k0 + r) * ldh + c);
-            a0 = fma(l.x, x[r], a0);
-            a1 = fma(l.y, x[r], a1);
-        }
+    const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * NB + 2 * cp;   // k0 is a multiple of 128: the slab never straddles k0
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+        const int r = rg * 32 + rr;
+        const bq_d2 l = *reinterpret_cast<const bq_d2 *>(H + (k0 + r) * ldh + c);
+        a0 = fma(l.x, x[r], a0);
+        a1 = fma(l.y, x[r], a1);
+    }
+    if (rg > 0) {
+        part[rg - 1][2 * cp] = a0;
+        part[rg - 1][2 * cp + 1] = a1;
+    }
+    __syncthreads();
+    if (rg == 0) {
+        a0 = ((a0 + part[0][2 * cp]) + part[1][2 * cp]) + part[2][2 * cp];
+        a1 = ((a1 + part[0][2 * cp + 1]) + part[1][2 * cp + 1]) + part[2][2 * cp + 1];
         rhs[c] -= a0;
         rhs[c + 1] -= a1;
     }
@@ -401,8 +414,8 @@ int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero) {
     // backward: x_k = Linv_kk^T y_k, then y_0:k -= L_k,0:k^T x_k (whose last block solves block k-1)
     diag_mv_kernel<<<1, 256, 0, st>>>(Linv(np - NB), 1, ws->rhs + np - NB, ws->rhs + np - NB);
     for (int64_t k0 = np - NB; k0 > 0; k0 -= NB)
-        bwd_update_kernel<<<(unsigned)((k0 / 2 + 255) / 256), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs + k0, ws->rhs,
-                                                                            Linv(k0 - NB), ws->ticket);
+        bwd_update_kernel<<<(unsigned)(k0 / NB), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs + k0, ws->rhs, Linv(k0 - NB),
+                                                               ws->ticket);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
