@@ -12,6 +12,7 @@
 //                   MFMA kernel — n^3/3 flops, the MFMA-bound bulk of every interior-point iteration.
 // The solves walk the block columns with one row-panel product + one 128x128 product per block (forward
 // left-looking, backward right-looking), all with fixed reduction orders.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -123,17 +124,21 @@ __device__ __forceinline__ void diag_mv_body(const double *__restrict__ LinvT, i
                                              double *out);
 __device__ __forceinline__ bool chol_last_block(unsigned int *ticket);
 
-// tmp[r] = rhs[k0 + r] - sum_{c < k0} L[k0 + r][c] * rhs[c]      (one workgroup per row r)
-// ... and the last block to finish applies the inverse of the diagonal block: rhs[k0 : k0+128) = Linv_kk tmp
+// part[s][r] = sum_{c in slice s of [c0, k0)} L[k0 + r][c] * rhs[c]      (workgroup (r, s): row r, column slice s)
+// ... and the last workgroup to finish forms tmp = rhs[k0 : k0+128) - sum_s part[s] (fixed order) and applies the inverse
+// of the diagonal block: rhs[k0 : k0+128) = Linv_kk tmp.  Long rows are cut into up to four slices so that no single
+// CU has to pull a whole 400 KB row (n = 50 000) by itself.
 __global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict__ H, int64_t ldh, int64_t k0, double *rhs,
-                                                        double *tmp, const double *__restrict__ LinvT,
-                                                        unsigned int *ticket, int64_t c0) {
+                                                        double *part, const double *__restrict__ LinvT,
+                                                        unsigned int *ticket, int64_t c0, int64_t slice) {
     __shared__ double red[4];
+    __shared__ double comb[NB];
     const int r = blockIdx.x, tid = threadIdx.x;
     const double *row = H + (k0 + r) * ldh;
+    const int64_t lo = c0 + (int64_t)blockIdx.y * slice, hi = lo + slice < k0 ? lo + slice : k0;
     double a = 0.0;
     // c0: the right-hand side is known to vanish before column c0 (a multiple of 128)
-    for (int64_t c = c0 + 2 * tid; c < k0; c += 512) {  // k0 is a multiple of 128 -> pairs never straddle k0
+    for (int64_t c = lo + 2 * tid; c < hi; c += 512) {  // slices are multiples of 512, k0 of 128: pairs never straddle
         const bq_d2 l = *reinterpret_cast<const bq_d2 *>(row + c);
         const bq_d2 y = *reinterpret_cast<const bq_d2 *>(rhs + c);
         a = fma(l.y, y.y, fma(l.x, y.x, a));
@@ -141,8 +146,16 @@ __global__ __launch_bounds__(256) void fwd_panel_kernel(const double *__restrict
     a = wsum_c(a);
     if ((tid & 63) == 0) red[tid >> 6] = a;
     __syncthreads();
-    if (tid == 0) tmp[r] = rhs[k0 + r] - (((red[0] + red[1]) + red[2]) + red[3]);
-    if (chol_last_block(ticket)) diag_mv_body(LinvT, 0, tmp, rhs + k0);
+    if (tid == 0) part[(int64_t)blockIdx.y * NB + r] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (chol_last_block(ticket)) {
+        if (tid < NB) {
+            double sum = part[tid];
+            for (unsigned int sl = 1; sl < gridDim.y; ++sl) sum += part[(int64_t)sl * NB + tid];
+            comb[tid] = rhs[k0 + tid] - sum;
+        }
+        __syncthreads();
+        diag_mv_body(LinvT, 0, comb, rhs + k0);
+    }
 }
 
 // out[i] = sum_j M[i][j] in[j] with M = Linv (transpose == 0) or Linv^T (transpose == 1); LinvT[k][j] = Linv[j][k].
@@ -196,7 +209,7 @@ __device__ __forceinline__ bool chol_last_block(unsigned int *ticket) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+        last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1 : 0;
     }
     __syncthreads();
     if (last) {
@@ -261,7 +274,7 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
     if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * 4 * NB * ws->ldh);
     if (e == hipSuccess) e = hipMalloc(&ws->LinvT, sizeof(double) * nblk * NB * NB);
     if (e == hipSuccess) e = hipMalloc(&ws->rhs, sizeof(double) * (ws->cap + NB));
-    if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * NB);
+    if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * 4 * NB);   // up to four column slices of a block row
     if (e == hipSuccess) e = hipMalloc(&ws->info, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&ws->ticket, sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemset(ws->ticket, 0, sizeof(unsigned int));
@@ -409,8 +422,13 @@ int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero) {
     // y = 0 there, so the sweep starts at that row's block.
     const int64_t kb = (first_nonzero / NB) * NB;
     diag_mv_kernel<<<1, 256, 0, st>>>(Linv(kb), 0, ws->rhs + kb, ws->rhs + kb);
-    for (int64_t k0 = kb + NB; k0 < np; k0 += NB)
-        fwd_panel_kernel<<<NB, 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp, Linv(k0), ws->ticket, kb);
+    for (int64_t k0 = kb + NB; k0 < np; k0 += NB) {
+        const int64_t span = k0 - kb;
+        const int slices = (int)std::min<int64_t>(4, (span + 16383) / 16384);
+        const int64_t slice = ((span + slices - 1) / slices + 511) / 512 * 512;
+        fwd_panel_kernel<<<dim3(NB, (unsigned)slices), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs, ws->tmp, Linv(k0), ws->ticket, kb,
+                                                                    slice);
+    }
     // backward: x_k = Linv_kk^T y_k, then y_0:k -= L_k,0:k^T x_k (whose last block solves block k-1)
     diag_mv_kernel<<<1, 256, 0, st>>>(Linv(np - NB), 1, ws->rhs + np - NB, ws->rhs + np - NB);
     for (int64_t k0 = np - NB; k0 > 0; k0 -= NB)
