@@ -24,6 +24,21 @@
 
 #include "bq_common.h"
 
+// -DBQ_SMO_STAMPS: thread 0 of the SVC walker accumulates the time of each phase of a full-sweep round (100 MHz
+// wall clock) and prints the totals at the end of the launch — diagnostic builds only
+#ifdef BQ_SMO_STAMPS
+#include <cstdio>
+#define SMO_STAMP(k)                                  \
+    if (threadIdx.x == 0) {                           \
+        const unsigned long long _t = wall_clock64(); \
+        stamp_acc[k] += _t - stamp_t;                 \
+        stamp_cnt[k] += 1;                            \
+        stamp_t = _t;                                 \
+    }
+#else
+#define SMO_STAMP(k)
+#endif
+
 constexpr int SMO_T = 1024;
 
 struct bq_smo_scal {
@@ -774,7 +789,11 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
     spec_end(P, S, 0);
     if (sweep_all) {
         int64_t i = 0;
+#ifdef BQ_SMO_STAMPS
+        unsigned long long stamp_acc[8] = {0}, stamp_cnt[8] = {0}, stamp_t = wall_clock64();
+#endif
         while (i < n) {
+            SMO_STAMP(7)   // loop tail of the previous round
             if (tid == 0 && P.helpers) {   // where the walk stands; a batch without a pair step doubles the look-ahead
                 const unsigned int cap = (unsigned int)(P.helpers * SMO_B);
                 if (!S.go) S.win = S.win * 2u < cap ? S.win * 2u : cap;
@@ -812,10 +831,12 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                 }
                 __syncthreads();
                 if (S.fast == 2) {
+                    SMO_STAMP(0)   // a wide quiet round
                     i += S.used;
                     __syncthreads();   // S.fast / S.used are rewritten in the next round
                     continue;
                 }
+                SMO_STAMP(1)       // a wide attempt that fell through
             }
             const int64_t s = i + wv;
             if (s < n) {   // wave-uniform
@@ -829,6 +850,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                 }
             }
             __syncthreads();
+            SMO_STAMP(2)   // the sixteen errors of the batch
             const int B = n - i < SMO_B ? (int)(n - i) : SMO_B;
             // fast path: wave 0 examines the whole batch at once when it holds no possible violator
             if (wv == 0) {
@@ -838,6 +860,7 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                 if (lane == 0) S.fast = fast ? 1 : 0;
             }
             __syncthreads();
+            SMO_STAMP(3)   // quiet-batch test
             if (tid == 0 && !S.fast) {
                 int used = B;
                 S.go = 0;
@@ -851,15 +874,27 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                 S.used = used;
             }
             __syncthreads();
+            SMO_STAMP(4)   // sequential walk of the batch (incl. the pair solve)
             if (S.go) {
                 svc_after_step(S, L, G, K, y, a, err, C, P);
                 ++changed;
                 ++steps;
+                SMO_STAMP(5)   // list edit, error cache, thresholds
             }
             if (S.fail) break;
             i += S.used;
             __syncthreads();   // S.used / S.go are rewritten by thread 0 in the next round
         }
+#ifdef BQ_SMO_STAMPS
+        if (tid == 0) {
+            // phases: 0 wide quiet round, 1 wide attempt that fell through, 2 the sixteen errors of a batch, 3 quiet-batch
+            // test, 4 sequential walk + pair solve, 5 after a step (list edit, error cache, thresholds), 7 loop tail
+            for (int k = 0; k < 8; ++k)
+                if (stamp_cnt[k])
+                    printf("[smo stamps] phase %d: %llu x %.2f us = %.2f ms\n", k, stamp_cnt[k],
+                           0.01 * (double)stamp_acc[k] / (double)stamp_cnt[k], 1e-5 * (double)stamp_acc[k]);
+        }
+#endif
     } else {
         long long last = -1;
         while (true) {
