@@ -767,3 +767,57 @@ def test_streamed_fit_follows_the_reference(amd):
     with pytest.raises(_lib.BcqpError):
         SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=InteriorPoint,
             storage='stream').fit(g['X'], g['y'])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ragged sizes: dual dimensions around the padding / tile boundaries (128-row factor blocks, 256-row tiles, 1024-element
+# vector tiles), general lower bounds, dense and kernel-built Hessians — device against the oracle on the same input
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n', [2, 3, 127, 129, 255, 257, 1023, 1025])
+def test_ragged_sizes_dense(amd, n):
+    from oracle import bcqp_oracle as bo
+    from optiml_amd.opti import Quadratic
+    rs = np.random.RandomState(100 + n)
+    G = rs.standard_normal((n, n + 3))
+    Q = G @ G.T / n + 0.05 * np.eye(n)
+    q = rs.standard_normal(n)
+    ub = rs.uniform(0.5, 2.0, n)
+    lb = -rs.uniform(0.0, 0.5, n)
+    for s, fn, kw, iters in (('pg', bo.projected_gradient, {}, 40), ('fw', bo.frank_wolfe, {}, 60),
+                             ('ip', bo.interior_point, {}, 200), ('as', bo.active_set, {}, min(3 * n + 50, 500)),
+                             ('ascg', bo.active_set, {}, min(3 * n + 50, 500))):
+        ref = fn(Q, q, ub, lb=lb, max_iter=iters, **kw)
+        hist = []
+        cb = lambda o: hist.append(o.f_x)
+        cb._bq_needs_state = False
+        opt = _solvers()[s](quad=Quadratic(Q, q), ub=ub, lb=lb, max_iter=iters, callback=cb).minimize()
+        assert opt.status == ref['status'] and opt.iter == ref['iter'], (s, n)
+        np.testing.assert_allclose(hist, ref['f_hist'], rtol=1e-8, atol=1e-10, err_msg=f'{s} n={n}')
+        np.testing.assert_allclose(opt.x, ref['x'], rtol=1e-6, atol=1e-8, err_msg=f'{s} n={n}')
+
+
+@pytest.mark.parametrize('n', [129, 257, 513, 1025])
+def test_ragged_sizes_kernel_panels(amd, n, monkeypatch):
+    """Kernel-built (packed symmetric) panels at sizes one past a tile boundary; SVC and SVR structure; ActiveSet with the
+    kept factor switched on from the first iteration."""
+    from oracle import bcqp_oracle as bo, svm_oracle as so
+    from optiml_amd.datasets import make_blobs, make_regression
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.kernels import gaussian
+    monkeypatch.setenv('BQ_AS_SCHUR_MIN', '0')
+    X, y = make_blobs(n, 7, seed=n)
+    Q, q, ub = so.svc_dual(so.gram('rbf', X), y, 1.0)
+    for s, fn, iters in (('fw', bo.frank_wolfe, 50), ('ip', bo.interior_point, 200), ('as', bo.active_set, 120)):
+        ref = fn(Q, q, ub, max_iter=iters)
+        opt = _solvers()[s](quad=KernelQuadratic(X, q, 'svc', gaussian, y=y), ub=ub, max_iter=iters).minimize()
+        assert opt.status == ref['status'] and opt.iter == ref['iter'], (s, n)
+        np.testing.assert_allclose(opt.f_x, ref['f_x'], rtol=1e-8, err_msg=f'{s} n={n}')
+        np.testing.assert_allclose(opt.x, ref['x'], rtol=1e-6, atol=1e-8, err_msg=f'{s} n={n}')
+    Xr, yr = make_regression(n, 5, seed=n)
+    Q, q, ub = so.svr_dual(so.gram('rbf', Xr), yr, 1.0, 0.1)
+    for s, fn, iters in (('fw', bo.frank_wolfe, 50), ('ip', bo.interior_point, 200)):
+        ref = fn(Q, q, ub, max_iter=iters)
+        opt = _solvers()[s](quad=KernelQuadratic(Xr, q, 'svr', gaussian), ub=ub, max_iter=iters).minimize()
+        assert opt.status == ref['status'] and opt.iter == ref['iter'], (s, n)
+        np.testing.assert_allclose(opt.f_x, ref['f_x'], rtol=1e-8, err_msg=f'svr {s} n={n}')
+        np.testing.assert_allclose(opt.x, ref['x'], rtol=1e-6, atol=1e-8, err_msg=f'svr {s} n={n}')
