@@ -20,9 +20,9 @@
 // kept and the current restricted system is solved through its Schur complement — variables of A0 that have reached a
 // bound since are pinned by a multiplier row (x_k = bound), variables released since are bordered on:
 //     [ Q00  U ] [y]   [b0]        U = [ Q[A0, added] | e_removed ],  V = [ Q[added, added] 0 ; 0 0 ]
-//     [ U'   V ] [w] = [b1]        C = V - U' Q00^-1 U  (m x m, m <= 96),  w = C^-1 (b1 - U' Q00^-1 b0),  y = Q00^-1 (b0 - U w)
+//     [ U'   V ] [w] = [b1]        C = V - U' Q00^-1 U  (m x m, m <= 96 ... 192),  w = C^-1 (b1 - U' Q00^-1 b0),  y = Q00^-1 (b0 - U w)
 // One new column Q00^-1 u (two triangular sweeps) per changed index and one Q00^-1 b0 per iteration replace the
-// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 changes, when C
+// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 (|A| < 40 000) to 192 (|A| >= 80 000) changes, when C
 // is numerically singular, or when the classic path is needed (non-positive pivot -> the reference's minres branch).
 //
 // BQ_AS_CG (SURVEY 7 "hard parts": ActiveSet beyond the sizes a dense factor fits): the same outer logic, but the
@@ -470,7 +470,10 @@ __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__r
 // ---------------------------------------------------------------------------------------------------------------
 // factor re-use: Schur-complement updates of a base factorisation (see the header comment)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int AS_SCHUR_MAX = 96;   // changed indices carried before the base is re-factorised
+constexpr int AS_SCHUR_MAX = 192;   // capacity of the update slots
+// changed indices carried before the base is re-factorised: the larger the factor, the longer it is worth keeping
+// (n^3/3 to rebuild against one more small-system row per carried index)
+static int as_schur_limit(int64_t np0) { return np0 < 40000 ? 96 : (np0 < 80000 ? 144 : 192); }
 
 struct as_schur {
     bool valid = false;
@@ -798,7 +801,7 @@ static int as_schur_event(bq_solver *s, as_ws *w, int *computed, bool *ok) {
         c->kind.push_back(kv.first);
         c->var.push_back(kv.second);
     }
-    *ok = (int)c->kind.size() <= AS_SCHUR_MAX;
+    *ok = (int)c->kind.size() <= as_schur_limit(c->np0);
     return BQ_OK;
 }
 
