@@ -473,7 +473,10 @@ __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__r
 constexpr int AS_SCHUR_MAX = 192;   // capacity of the update slots
 // changed indices carried before the base is re-factorised: the larger the factor, the longer it is worth keeping
 // (n^3/3 to rebuild against one more small-system row per carried index)
-static int as_schur_limit(int64_t np0) { return np0 < 40000 ? 96 : (np0 < 80000 ? 144 : 192); }
+static int as_schur_limit(int64_t np0) {
+    if (const char *e = getenv("BQ_AS_SCHUR_LIMIT")) return std::max(1, std::min(atoi(e), AS_SCHUR_MAX));   // tests
+    return np0 < 40000 ? 96 : (np0 < 80000 ? 144 : 192);
+}
 
 struct as_schur {
     bool valid = false;

@@ -107,8 +107,8 @@ def test_config2_shape_against_the_oracle():
 
 
 def test_active_set_kept_factor_at_config2_shape(monkeypatch):
-    """BASELINE config 2's shape (n=20 000, d=64), ActiveSet from the reference's start: 130 iterations with the factor
-    of a base set kept (two base factorisations, 96 + 33 changed indices carried through the Schur complement) against
+    """BASELINE config 2's shape (n=20 000, d=64), ActiveSet from the reference's start: 230 iterations with the factor
+    of a base set kept (base factorisations every 96 changed indices, or every 192 as for the largest factors) against
     the same iterations with Q[A,A] re-factorised every time, as the reference does — same events, objectives to 1e-11."""
     from optiml_amd.datasets import make_blobs
     from optiml_amd.ml.svm.kernels import gaussian
@@ -117,19 +117,24 @@ def test_active_set_kept_factor_at_config2_shape(monkeypatch):
     n, d = 20000, 64
     X, y = make_blobs(n, d, seed=0)
     runs = []
-    for mode in ('0', '1'):
+    for mode, limit in (('0', None), ('1', None), ('1', '192')):   # 192: what factors of 80 000 rows and more carry
         monkeypatch.setenv('BQ_AS_SCHUR', mode)
+        if limit is None:
+            monkeypatch.delenv('BQ_AS_SCHUR_LIMIT', raising=False)
+        else:
+            monkeypatch.setenv('BQ_AS_SCHUR_LIMIT', limit)
         hist = []
         cb = lambda o: hist.append((o.f_x, o.n_bound))
         cb._bq_needs_state = False
         quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
-        opt = ActiveSet(quad=quad, ub=np.ones(n), max_iter=130, callback=cb).minimize()
+        opt = ActiveSet(quad=quad, ub=np.ones(n), max_iter=230, callback=cb).minimize()
         runs.append((np.array(hist), opt.x))
         quad.release()
-    (h0, x0), (h1, x1) = runs
-    assert np.array_equal(h0[:, 1], h1[:, 1])
-    np.testing.assert_allclose(h1[:, 0], h0[:, 0], rtol=1e-11)
-    np.testing.assert_allclose(x1, x0, rtol=1e-9, atol=1e-12)
+    (h0, x0) = runs[0]
+    for h1, x1 in runs[1:]:
+        assert np.array_equal(h0[:, 1], h1[:, 1])
+        np.testing.assert_allclose(h1[:, 0], h0[:, 0], rtol=1e-11)
+        np.testing.assert_allclose(x1, x0, rtol=1e-9, atol=1e-12)
 
 
 # ---------------------------------------------------------------------------------------------------------------
