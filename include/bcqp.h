@@ -151,7 +151,7 @@ int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms);
  * eps: stopping accuracy; max_iter: as the reference; fw_t: FrankWolfe trust radius in [0,1).
  * BQ_AS (active_set.py:82-237): same masks, candidate / ratio step, Bland release and tolerances as the reference; the
  * restricted system of line :141 is solved from a Cholesky factor that is KEPT across iterations (the free set moves by
- * one index at a time: the changes are carried through a Schur complement on a base factor, which is rebuilt every 96 to 192
+ * one index at a time: the changes are carried through a Schur complement on a base factor, which is rebuilt every 96 to 512
  * changes; environment BQ_AS_SCHUR=0 re-factorises in every iteration like the reference).  A non-positive pivot takes
  * the reference's minres branch (:142-151). */
 int bq_solver_create(bq_problem *p, int kind, const double *lb, const double *ub, const double *x0,

@@ -20,9 +20,9 @@
 // kept and the current restricted system is solved through its Schur complement — variables of A0 that have reached a
 // bound since are pinned by a multiplier row (x_k = bound), variables released since are bordered on:
 //     [ Q00  U ] [y]   [b0]        U = [ Q[A0, added] | e_removed ],  V = [ Q[added, added] 0 ; 0 0 ]
-//     [ U'   V ] [w] = [b1]        C = V - U' Q00^-1 U  (m x m, m <= 96 ... 192),  w = C^-1 (b1 - U' Q00^-1 b0),  y = Q00^-1 (b0 - U w)
+//     [ U'   V ] [w] = [b1]        C = V - U' Q00^-1 U  (m x m, m <= 96 ... 512),  w = C^-1 (b1 - U' Q00^-1 b0),  y = Q00^-1 (b0 - U w)
 // One new column Q00^-1 u (two triangular sweeps) per changed index and one Q00^-1 b0 per iteration replace the
-// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 (|A| < 40 000) to 192 (|A| >= 80 000) changes, when C
+// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 (|A| < 40 000) to 512 (|A| >= 80 000) changes, when C
 // is numerically singular, or when the classic path is needed (non-positive pivot -> the reference's minres branch).
 //
 // BQ_AS_CG (SURVEY 7 "hard parts": ActiveSet beyond the sizes a dense factor fits): the same outer logic, but the
@@ -470,12 +470,12 @@ __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__r
 // ---------------------------------------------------------------------------------------------------------------
 // factor re-use: Schur-complement updates of a base factorisation (see the header comment)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int AS_SCHUR_MAX = 192;   // capacity of the update slots
+constexpr int AS_SCHUR_MAX = 512;   // capacity of the update slots
 // changed indices carried before the base is re-factorised: the larger the factor, the longer it is worth keeping
 // (n^3/3 to rebuild against one more small-system row per carried index)
 static int as_schur_limit(int64_t np0) {
     if (const char *e = getenv("BQ_AS_SCHUR_LIMIT")) return std::max(1, std::min(atoi(e), AS_SCHUR_MAX));   // tests
-    return np0 < 40000 ? 96 : (np0 < 80000 ? 144 : 192);
+    return np0 < 40000 ? 96 : (np0 < 80000 ? 256 : 512);
 }
 
 struct as_schur {
@@ -486,6 +486,8 @@ struct as_schur {
     std::vector<int> hpos0;           // host mirror of pos0
     std::vector<int> kind, var;       // slots: kind 0 = base variable now at a bound, 1 = variable freed since
     std::vector<double> C;            // AS_SCHUR_MAX x AS_SCHUR_MAX, symmetric, host
+    std::vector<double> Lc, Dc;       // C = Lc diag(Dc) Lc' of its leading ldl_n rows (unit lower Lc, no pivoting: C is
+    int ldl_n = 0;                    // symmetric quasi-definite), grown by one row per new slot
     double *U = nullptr, *W = nullptr;   // device: AS_SCHUR_MAX x cap columns u_k and Q00^-1 u_k
     double *y0 = nullptr, *y = nullptr;  // device: cap
     double *small = nullptr;          // device: AS_SCHUR_MAX results / coefficients
@@ -611,6 +613,62 @@ __global__ __launch_bounds__(256) void as_schur_candidate_kernel(int64_t N, int6
     if (threadIdx.x == 0) ints[2] = bad ? 0 : 1;
 }
 
+// C = L D L' of the m x m Schur complement, kept on the host and grown by one row per new slot (O(m^2)); C is symmetric
+// quasi-definite — minus a positive definite block for the pinned variables, a positive definite one for the freed —
+// so it factorises without pivoting in any order.  as_ldl_solve checks the residual; on failure the caller falls back
+// to the pivoted elimination below (and from there to a fresh base factor).
+static bool as_ldl_extend(as_schur *c, int m) {
+    const size_t ld = AS_SCHUR_MAX;
+    for (int k = c->ldl_n; k < m; ++k) {
+        double *lk = &c->Lc[(size_t)k * ld];
+        // L z = C[0:k, k]  (forward), l = z / D, d = C[k][k] - sum l z
+        for (int i = 0; i < k; ++i) {
+            double v = c->C[(size_t)i * ld + k];
+            const double *li = &c->Lc[(size_t)i * ld];
+            for (int j = 0; j < i; ++j) v -= li[j] * lk[j] * c->Dc[j];   // lk[j] already holds l_j
+            lk[i] = v / c->Dc[i];
+        }
+        double d = c->C[(size_t)k * ld + k];
+        for (int j = 0; j < k; ++j) d -= lk[j] * lk[j] * c->Dc[j];
+        if (!std::isfinite(d) || d == 0.0) return false;
+        c->Dc[k] = d;
+        lk[k] = 1.0;
+        c->ldl_n = k + 1;
+    }
+    return true;
+}
+
+static bool as_ldl_solve(as_schur *c, int m, const double *t, double *w) {
+    if (!as_ldl_extend(c, m)) return false;
+    const size_t ld = AS_SCHUR_MAX;
+    std::vector<double> y(t, t + m);
+    for (int i = 0; i < m; ++i) {
+        const double *li = &c->Lc[(size_t)i * ld];
+        double v = y[i];
+        for (int j = 0; j < i; ++j) v -= li[j] * y[j];
+        y[i] = v;
+    }
+    for (int i = 0; i < m; ++i) y[i] /= c->Dc[i];
+    for (int i = m - 1; i >= 0; --i) {
+        double v = y[i];
+        for (int j = i + 1; j < m; ++j) v -= c->Lc[(size_t)j * ld + i] * w[j];
+        w[i] = v;
+    }
+    // residual against the stored C
+    double worst = 0.0, scale = 0.0;
+    for (int i = 0; i < m; ++i) {
+        double r = t[i], s = std::fabs(t[i]);
+        for (int j = 0; j < m; ++j) {
+            r -= c->C[(size_t)i * ld + j] * w[j];
+            s += std::fabs(c->C[(size_t)i * ld + j] * w[j]);
+        }
+        if (!std::isfinite(r)) return false;
+        worst = std::max(worst, std::fabs(r));
+        scale = std::max(scale, s);
+    }
+    return worst <= 1e-11 * scale;
+}
+
 // dense m x m solve on the host (partial pivoting); false when a pivot is negligible or the result is not finite
 static bool as_small_solve(int m, const std::vector<double> &C, const double *t, double *w) {
     std::vector<double> A((size_t)m * m);
@@ -691,6 +749,8 @@ static int as_schur_setup(bq_solver *s, as_ws *w) {
     BQ_HIP(hipMalloc(&c->meta, sizeof(int) * 2 * AS_SCHUR_MAX));
     c->hpos0.assign((size_t)s->N, -1);
     c->C.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
+    c->Lc.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
+    c->Dc.assign((size_t)AS_SCHUR_MAX, 0.0);
     return BQ_OK;
 }
 
@@ -723,6 +783,7 @@ static int as_schur_refresh(bq_solver *s, as_ws *w, int64_t nA, bool *ok) {
     c->np0 = np0;
     c->kind.clear();
     c->var.clear();
+    c->ldl_n = 0;
     c->valid = true;
     c->y0_valid = false;
     c->refreshes += 1;
@@ -747,6 +808,7 @@ static int as_schur_drop(bq_solver *s, as_schur *c, int j) {
     }
     c->kind.pop_back();
     c->var.pop_back();
+    c->ldl_n = 0;   // a removed row / column: the small factorisation starts again
     return BQ_OK;
 }
 
@@ -858,7 +920,10 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
                                                   s->ub, p->q, w->Qz, c->small);
         BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * m, hipMemcpyDeviceToHost, st));
         BQ_HIP(hipStreamSynchronize(st));
-        if (!as_small_solve(m, c->C, host_small, coef)) return BQ_OK;
+        if (!as_ldl_solve(c, m, host_small, coef)) {   // incremental factorisation first, pivoted elimination as the fallback
+            c->ldl_n = 0;
+            if (!as_small_solve(m, c->C, host_small, coef)) return BQ_OK;
+        }
         BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
         BQ_HIP(hipStreamSynchronize(st));   // coef is on this stack frame
     }

@@ -108,7 +108,8 @@ def test_config2_shape_against_the_oracle():
 
 def test_active_set_kept_factor_at_config2_shape(monkeypatch):
     """BASELINE config 2's shape (n=20 000, d=64), ActiveSet from the reference's start: 230 iterations with the factor
-    of a base set kept (base factorisations every 96 changed indices, or every 192 as for the largest factors) against
+    of a base set kept (base factorisations every 96 changed indices, or none at all within these iterations — the largest
+    factors carry 512) against
     the same iterations with Q[A,A] re-factorised every time, as the reference does — same events, objectives to 1e-11."""
     from optiml_amd.datasets import make_blobs
     from optiml_amd.ml.svm.kernels import gaussian
@@ -117,7 +118,7 @@ def test_active_set_kept_factor_at_config2_shape(monkeypatch):
     n, d = 20000, 64
     X, y = make_blobs(n, d, seed=0)
     runs = []
-    for mode, limit in (('0', None), ('1', None), ('1', '192')):   # 192: what factors of 80 000 rows and more carry
+    for mode, limit in (('0', None), ('1', None), ('1', '512')):   # 512: what factors of 80 000 rows and more carry
         monkeypatch.setenv('BQ_AS_SCHUR', mode)
         if limit is None:
             monkeypatch.delenv('BQ_AS_SCHUR_LIMIT', raising=False)
