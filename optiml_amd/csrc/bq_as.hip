@@ -22,7 +22,7 @@
 //     [ Q00  U ] [y]   [b0]        U = [ Q[A0, added] | e_removed ],  V = [ Q[added, added] 0 ; 0 0 ]
 //     [ U'   V ] [w] = [b1]        C = V - U' Q00^-1 U  (m x m, m <= 96 ... 512),  w = C^-1 (b1 - U' Q00^-1 b0),  y = Q00^-1 (b0 - U w)
 // One new column Q00^-1 u (two triangular sweeps) per changed index and one Q00^-1 b0 per iteration replace the
-// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 (|A| < 40 000) to 512 (|A| >= 80 000) changes, when C
+// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 (|A| < 8 192) to 512 (|A| >= 80 000) changes, when C
 // is numerically singular, or when the classic path is needed (non-positive pivot -> the reference's minres branch).
 //
 // BQ_AS_CG (SURVEY 7 "hard parts": ActiveSet beyond the sizes a dense factor fits): the same outer logic, but the
@@ -475,7 +475,7 @@ constexpr int AS_SCHUR_MAX = 512;   // capacity of the update slots
 // (n^3/3 to rebuild against one more small-system row per carried index)
 static int as_schur_limit(int64_t np0) {
     if (const char *e = getenv("BQ_AS_SCHUR_LIMIT")) return std::max(1, std::min(atoi(e), AS_SCHUR_MAX));   // tests
-    return np0 < 40000 ? 96 : (np0 < 80000 ? 256 : 512);
+    return np0 < 8192 ? 96 : (np0 < 40000 ? 192 : (np0 < 80000 ? 256 : 512));
 }
 
 struct as_schur {
