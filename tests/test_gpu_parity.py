@@ -477,7 +477,8 @@ def test_fit_svc_as(amd, n, kind, as_factor_mode):
     _check_fit(est, g, 'rbf_as', g['Xtest'], hist_tol=1e-9 if kind == 'as' else 1e-6)
 
 
-def test_active_set_factor_reuse_across_refreshes(amd, monkeypatch):
+@pytest.mark.parametrize('storage', ['f64', 'f32'])
+def test_active_set_factor_reuse_across_refreshes(amd, monkeypatch, storage):
     """n = 1500 (above the default threshold of the factor re-use), 450 iterations from the reference's start x = ub/2:
     several base re-factorisations (one per 96 changed indices), variables reaching bounds and — in the second run,
     started next to the solution — variables being released again.  The kept-factor run must reproduce the run that
@@ -497,7 +498,7 @@ def test_active_set_factor_reuse_across_refreshes(amd, monkeypatch):
             hist = []
             cb = lambda o: hist.append((o.f_x, o.n_bound))
             cb._bq_needs_state = False
-            quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=yb)
+            quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=yb, storage=storage)
             opt = _solvers()['as'](quad=quad, ub=np.ones(n), x=x0, max_iter=iters, callback=cb).minimize()
             runs.append((np.array(hist), opt.x, opt.iter, opt.status))
         (h0, x_ref, it0, st0), (h1, x_new, it1, st1) = runs
