@@ -40,9 +40,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--samples', '--n', dest='n', type=int, default=100000)
     ap.add_argument('--features', '--d', dest='d', type=int, default=128)
-    ap.add_argument('--solver', default='pg', choices=['pg', 'fw', 'adagrad', 'smo'],
+    ap.add_argument('--solver', default='pg', choices=['pg', 'fw', 'adagrad', 'smo', 'ip', 'as'],
                     help='adagrad: AdaGrad on the augmented Lagrangian of the reg_intercept=False dual (SURVEY 8f.3); '
-                         'smo: time-to-KKT-tol of SVC.fit(optimizer="smo") (SURVEY 8f.4; --steps/--warmup unused)')
+                         'smo: time-to-KKT-tol of SVC.fit(optimizer="smo") (SURVEY 8f.4; --steps/--warmup unused); '
+                         'ip / as: time-to-KKT-tol of SVC.fit with InteriorPoint / ActiveSet (their own stop tests; pick '
+                         '--samples to taste: n=100000 takes 473 s with ip)')
     ap.add_argument('--task', default='svc', choices=['svc', 'svr'], help='svr: eps-insensitive dual, dim 2n (config 4)')
     ap.add_argument('--kernel', default='rbf', choices=['rbf', 'poly', 'linear'], help='poly: degree 3, coef0 1')
     ap.add_argument('--storage', default='f64', choices=['f64', 'f32', 'stream'],
@@ -271,10 +273,54 @@ def bench_smo(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_kkt(args):
+    """BASELINE.json's second metric, time-to-KKT-tol, for the two box solvers that reach their own stop test:
+    SVC.fit(optimizer=InteriorPoint | ActiveSet) end to end on one GPU.  CPU baseline: the oracle (reference algorithm,
+    dense Q on the host, scipy's cho_factor per iteration) at a bounded n — its measured seconds, not extrapolated."""
+    from oracle import bcqp_oracle as bo, svm_oracle as so
+    from optiml_amd import device
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm import SVC
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.ml.svm.losses import hinge
+    from optiml_amd.opti.constrained import ActiveSet, InteriorPoint
+    ctx = device.get_context()
+    X, y = make_blobs(args.n, args.d, seed=0, sigma=args.sigma)
+    cls = InteriorPoint if args.solver == 'ip' else ActiveSet
+    t0 = time.perf_counter()
+    est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls, max_iter=10 ** 7).fit(X, y)
+    dt = time.perf_counter() - t0
+    o = est.optimizer
+    out = {'metric': 'time_to_kkt_tol', 'value': dt, 'unit': 's', 'n_gpus': 1, 'steps': int(o.iter), 'warmup': 0,
+           'ms_per_step': 1e3 * dt / max(o.iter, 1), 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None,
+           'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': f'svc_hinge_rbf_{args.solver}_dual_n{args.n}_d{args.d}', 'n': args.n, 'd': args.d, 'C': 1.0,
+                      'gamma': 'scale', 'solver': args.solver, 'device': ctx.name},
+           'roofline': None, 'status': o.status, 'f': float(o.f_x), 'n_sv': int(len(est.support_))}
+    if not args.no_cpu:
+        ns = min(args.cpu_n, args.n, 3000)
+        Q, q, ub = so.svc_dual(so.gram('rbf', X[:ns]), y[:ns], 1.0)
+        fn = bo.interior_point if args.solver == 'ip' else bo.active_set
+        t0 = time.perf_counter()
+        r = fn(Q, q, ub, max_iter=10 ** 7)
+        dtc = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': dtc, 'unit': 's', 'cores': int(os.cpu_count() or 1), 'kind': 'port',
+                               'sample': f'oracle {args.solver.upper()} (reference algorithm in NumPy/SciPy, dense Q on host, Gram '
+                                         f'and Q assembly excluded) run to its stop test at n={ns}: {r["iter"]} iterations, '
+                                         f'status {r["status"]}'}
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_study:
         return cpu_study(args)
+    if args.solver in ('ip', 'as'):
+        if args.gpus != 1:
+            raise SystemExit('InteriorPoint / ActiveSet factorise on one GPU (replicas only): --gpus 1')
+        return bench_kkt(args)
     if args.solver == 'smo':
         if args.gpus != 1:
             raise SystemExit('SMO walks the samples sequentially on one GPU (replicas only): --gpus 1')
