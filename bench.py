@@ -298,7 +298,8 @@ def bench_kkt(args):
                       'gamma': 'scale', 'solver': args.solver, 'device': ctx.name},
            'roofline': None, 'status': o.status, 'f': float(o.f_x), 'n_sv': int(len(est.support_))}
     if not args.no_cpu:
-        ns = min(args.cpu_n, args.n, 3000)
+        # bounded CPU samples: ActiveSet needs ~n iterations of an n^3/3 factorisation each — minutes already at n=3000
+        ns = min(args.cpu_n, args.n, 3000 if args.solver == 'ip' else 800)
         Q, q, ub = so.svc_dual(so.gram('rbf', X[:ns]), y[:ns], 1.0)
         fn = bo.interior_point if args.solver == 'ip' else bo.active_set
         t0 = time.perf_counter()
