@@ -132,6 +132,9 @@ int bq_problem_create_dense(bq_ctx *ctx, int64_t n, const double *Q, const doubl
 int bq_problem_create_kernel(bq_ctx *ctx, int structure, int64_t n, int64_t d, const double *X,
                              const double *y, int kernel, double gamma, double coef0, int degree,
                              double diag_add, const double *q, int storage, bq_problem **out);
+/* destroy: device memory goes back to the driver, except that a context keeps the ONE most recently released panel of
+ * >= 1 GB for the next problem of about that size (a large hipMalloc right after a large hipFree costs seconds on this
+ * platform); it is released when an allocation fails and with the context. */
 int bq_problem_destroy(bq_problem *p);
 int bq_problem_dims(const bq_problem *p, int64_t *n_dual, int64_t *n_rows, int64_t *row_begin,
                     int64_t *row_end);

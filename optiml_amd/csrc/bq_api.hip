@@ -95,6 +95,7 @@ extern "C" int bq_ctx_destroy(bq_ctx *c) {
         }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->pinned) hipHostFree(c->pinned);
+    bq_ctx_drop_cache(c);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return BQ_OK;
@@ -258,8 +259,23 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
     const size_t elems = p->symmetric ? (size_t)(bq_sym_off(p->I1) - bq_sym_off(p->I0))
                                       : (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld;
     const size_t bytes = (elems > 0 ? elems : 1) * esz;
-    hipError_t e = hipMalloc(&p->panel, bytes);
+    hipError_t e = hipSuccess;
+    if (c->panel_cache && c->panel_cache_bytes >= bytes && c->panel_cache_bytes - bytes <= bytes / 4) {
+        p->panel = c->panel_cache;   // the panel a destroyed problem left behind
+        p->panel_bytes = c->panel_cache_bytes;
+        c->panel_cache = nullptr;
+        c->panel_cache_bytes = 0;
+    } else {
+        e = hipMalloc(&p->panel, bytes);
+        if (e != hipSuccess && c->panel_cache) {
+            (void)hipGetLastError();
+            bq_ctx_drop_cache(c);
+            e = hipMalloc(&p->panel, bytes);
+        }
+        p->panel_bytes = bytes;
+    }
     if (e != hipSuccess) {
+        p->panel = nullptr;
         bq_set_error("cannot allocate the %lld x %lld panel (%.1f GB): %s", (long long)rows, (long long)p->ld,
                      bytes / 1e9, hipGetErrorString(e));
         return BQ_ERR_NOMEM;
@@ -268,10 +284,22 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
     return BQ_OK;
 }
 
+void bq_ctx_drop_cache(bq_ctx *c) {
+    if (c->panel_cache) hipFree(c->panel_cache);
+    c->panel_cache = nullptr;
+    c->panel_cache_bytes = 0;
+}
+
 extern "C" int bq_problem_destroy(bq_problem *p) {
     if (p == nullptr) return BQ_OK;
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
+    if (p->panel && p->panel_bytes >= ((size_t)1 << 30)) {   // keep one large panel for the next problem (see bq_ctx)
+        bq_ctx_drop_cache(p->ctx);
+        p->ctx->panel_cache = p->panel;
+        p->ctx->panel_cache_bytes = p->panel_bytes;
+        p->panel = nullptr;
+    }
     for (void *ptr : {(void *)p->panel, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
                       (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab})
         if (ptr) hipFree(ptr);

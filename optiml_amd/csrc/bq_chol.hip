@@ -265,6 +265,11 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
     ws->ldh = ws->cap;
     const int64_t nblk = ws->cap / NB;
     hipError_t e = hipMalloc(&ws->H, sizeof(double) * ws->ldh * ws->cap);
+    if (e != hipSuccess && ctx->panel_cache) {   // a panel kept for re-use may be what is in the way
+        (void)hipGetLastError();
+        bq_ctx_drop_cache(ctx);
+        e = hipMalloc(&ws->H, sizeof(double) * ws->ldh * ws->cap);
+    }
     if (e != hipSuccess) {
         bq_set_error("cannot allocate the %lld x %lld factorisation workspace (%.1f GB): %s", (long long)ws->cap,
                      (long long)ws->cap, 8e-9 * ws->ldh * ws->cap, hipGetErrorString(e));

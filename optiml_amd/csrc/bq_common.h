@@ -74,6 +74,11 @@ struct bq_ctx {
     bool profiling = false;
     bq_prof_slot prof[BQ_PROF_COUNT];
     std::vector<hipEvent_t> event_pool;
+    // One released panel is kept for the next problem of about the same size: on this platform a 40 GB hipMalloc issued
+    // right after a 40 GB hipFree takes 1-2 s instead of 0.04 s (measured), and fits in a loop — multi-class, parameter
+    // sweeps, cross-validation — create panels of the same size over and over.  Dropped when any allocation fails.
+    void *panel_cache = nullptr;
+    size_t panel_cache_bytes = 0;
 };
 
 struct bq_problem {
@@ -87,6 +92,7 @@ struct bq_problem {
     int64_t r0 = 0, r1 = 0, blk = 0;  // my rows [r0,r1) and the per-rank block size (row-block mode)
     // symmetric mode (kernel-built panels): only tiles on/below the diagonal are stored and streamed; this rank owns
     // the 256-row tile rows [I0, I1) of nb, panel row 0 is global row I0*256
+    size_t panel_bytes = 0;    // allocated size of `panel`
     bool symmetric = false;
     bool streamed = false;     // BQ_STREAM: no panel, Gram tiles recomputed inside every product (stream_img)
     void *stream_img = nullptr;
@@ -168,6 +174,7 @@ int bq_prof_begin(bq_ctx *ctx, int which, hipEvent_t *e0, hipEvent_t *e1);
 int bq_prof_end(bq_ctx *ctx, int which, hipEvent_t e0, hipEvent_t e1);
 int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0, int64_t r1);
 int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count);  // all-reduce(sum) of a replicated-length vector
+void bq_ctx_drop_cache(bq_ctx *ctx);   // give the cached panel back to the driver (called before retrying a failed allocation)
 
 // bq_symv.hip: symmetric tile product over tile rows [I0, I1) -> out (nb*256 partial sums)
 constexpr int64_t BQ_SYM_TILE = 256;
