@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: dual-QP iterations/sec of the device-resident ProjectedGradient solver on the RBF SVC
-Wolfe dual, n=100 000, d=128, fp64 (BASELINE.json `metric`), on N GPUs of one node.
+Wolfe dual, n=100 000, d=128, fp64 (BASELINE.json `metric`), on N GPUs of one node, plus BASELINE's second metric,
+time-to-KKT-tol, as sub-records of the same JSON line (N = 1).
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns N fresh rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # ... or runs as one rank of a launcher
 
 A "step" is one solver iteration: one symmetric panel product Q d (this rank's lower-triangle tiles, streamed once)
-+ the fused O(n) kernels + one all-reduce of the n-vector for N > 1.  The Gram panel is built once before the timed
++ the fused O(n) kernels + ONE collective for N > 1 (RCCL all-gather of the per-segment partial vectors, which every rank
+adds in a fixed order: iterates are bit-identical for N = 1, 2, 4, 8).  The Gram panel is built once before the timed
 region and stays resident in HBM (its build time is reported separately).  N > 1: one process per GPU, rank r owns a
-balanced triangular share of the tile rows, RCCL all-reduce per product; total work is fixed as N grows ("strong"
-scaling).  torch.distributed (gloo) is used only for rendezvous / barrier / max-over-ranks — no torch tensor touches
-the compute path.
+balanced triangular share of the tile rows; total work is fixed as N grows ("strong" scaling).  torch.distributed
+(gloo) is used only for rendezvous / barrier / max-over-ranks — no torch tensor touches the compute path.  If the RCCL
+communicator cannot be created the run FAILS (exit 3) unless --allow-host-exchange is given.
 
 Rank 0 prints ONE JSON line with `roofline` (HIP-event timing of the panel-product kernel on its own stream against
-8 TB/s HBM, on the bytes that kernel has to move: its tiles + partial-product slab; `row_block_equivalent_GBs` restates
-the rate in SURVEY 8(d)'s n^2*s bytes) and `cpu_baseline` (the NumPy oracle in the reference formulation on a bounded
-sample).
+8 TB/s HBM, on the bytes that kernel has to move: its lower-triangle tiles + partial-product slab; `frac_survey_8d_bytes`
+restates it in SURVEY 8(d)'s n^2*s bytes, which the kernel does not move), `cpu_baseline` (the NumPy oracle in the reference
+formulation timed at two sizes that fit the host and extrapolated with the fitted exponent) and `time_to_kkt`.
+
+Other workloads: --config c2|c3|c4|c5 (BASELINE.json configs), --solver fw|adagrad|ascg|smo|ip|as, --task svr, ...
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,85 +37,107 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+FP64_MFMA_PEAK_TF = 78.6
+
+CONFIGS = {   # BASELINE.json `configs` (C2 .. C5) and the headline
+    'headline': dict(n=100000, d=128, solver='pg', task='svc', kernel='rbf', storage='f64'),
+    'c2': dict(n=20000, d=64, solver='pg', task='svc', kernel='rbf', storage='f64'),
+    'c3': dict(n=50000, d=128, solver='ip', task='svc', kernel='rbf', storage='f64'),
+    'c4': dict(n=100000, d=128, solver='fw', task='svr', kernel='poly', storage='f64'),
+    'c5': dict(n=250000, d=256, solver='ascg', task='svc', kernel='rbf', storage='f32'),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--samples', '--n', dest='n', type=int, default=100000)
-    ap.add_argument('--features', '--d', dest='d', type=int, default=128)
-    ap.add_argument('--solver', default='pg', choices=['pg', 'fw', 'adagrad', 'smo', 'ip', 'as'],
+    ap.add_argument('--config', default=None, choices=sorted(CONFIGS), help='preset of --samples/--features/--solver/--task/--kernel/--storage')
+    ap.add_argument('--samples', '--n', dest='n', type=int, default=None)
+    ap.add_argument('--features', '--d', dest='d', type=int, default=None)
+    ap.add_argument('--solver', default=None, choices=['pg', 'fw', 'adagrad', 'ascg', 'smo', 'ip', 'as'],
                     help='adagrad: AdaGrad on the augmented Lagrangian of the reg_intercept=False dual (SURVEY 8f.3); '
+                         'ascg: ActiveSet with conjugate-gradient restricted solves on the squared-hinge dual (BASELINE config 5: '
+                         'a step is one OUTER iteration = tens of panel products); '
                          'smo: time-to-KKT-tol of SVC.fit(optimizer="smo") (SURVEY 8f.4; --steps/--warmup unused); '
                          'ip / as: time-to-KKT-tol of SVC.fit with InteriorPoint / ActiveSet (their own stop tests; pick '
                          '--samples to taste: n=100000 takes 473 s with ip)')
-    ap.add_argument('--task', default='svc', choices=['svc', 'svr'], help='svr: eps-insensitive dual, dim 2n (config 4)')
-    ap.add_argument('--kernel', default='rbf', choices=['rbf', 'poly', 'linear'], help='poly: degree 3, coef0 1')
-    ap.add_argument('--storage', default='f64', choices=['f64', 'f32', 'stream'],
+    ap.add_argument('--task', default=None, choices=['svc', 'svr'], help='svr: eps-insensitive dual, dim 2n (config 4)')
+    ap.add_argument('--kernel', default=None, choices=['rbf', 'poly', 'linear'], help='poly: degree 3, coef0 1')
+    ap.add_argument('--storage', default=None, choices=['f64', 'f32', 'stream'],
                     help='stream: no resident panel, Gram tiles recomputed on the MFMA inside every product')
     ap.add_argument('--exchange', default='rccl', choices=['rccl', 'host'])
-    ap.add_argument('--cpu-n', type=int, default=12000, help='sample size of the CPU baseline leg')
-    ap.add_argument('--cpu-steps', type=int, default=150)
+    ap.add_argument('--sym-exchange', default='gather', choices=['gather', 'allreduce'],
+                    help='closing collective of a symmetric product: all-gather of segment partials + ordered sum (default, '
+                         'bit-identical for any N) or one all-reduce(sum)')
+    ap.add_argument('--allow-host-exchange', action='store_true',
+                    help='fall back to the host (gloo) exchange when the RCCL communicator cannot be created (default: exit 3)')
+    ap.add_argument('--cpu-sizes', default='20000,30000', help='sample sizes of the CPU baseline leg (SURVEY 8d)')
+    ap.add_argument('--cpu-seconds', type=float, default=6.0, help='timed seconds per CPU sample size')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--kkt', default='all', choices=['none', 'smo', 'ip', 'all'],
+                    help="time_to_kkt sub-records of the default line (N=1): smo = SVC.fit(optimizer='smo') at the workload's "
+                         'n (tol 1e-3), ip = InteriorPoint at BASELINE config 3 shape n=50000 d=128 (gap 1e-10, ~50 s)')
     ap.add_argument('--sigma', type=float, default=8.0, help='blob spread of the synthetic data (SURVEY 8d: 8 overlapping, 3 separable)')
+    ap.add_argument('--inner-tol', type=float, default=1e-8, help='ascg: relative residual of the inner conjugate gradients')
     ap.add_argument('--cpu-study', action='store_true',
                     help='CPU only (SURVEY 8d): the oracle timed at three sizes to check the n^2 (PG) / n^3 (Cholesky) laws '
                          'behind the extrapolated baseline, plus a blocked Gram-streaming product at the full n')
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config or 'headline']
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
 
 
-def measured_traffic(workload, world):
-    """HBM bytes per launch of the panel-product kernel from the committed PMC passes (profiles/rNN/pmc_traffic_*.json,
-    produced by tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
-    command); None when no pass matches this workload."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', 'pmc_traffic_*.json'))):
-        try:
-            rec = json.load(open(path))
-        except Exception:
-            continue
-        meta = rec.get('meta', {})
-        if meta.get('workload') != workload or int(meta.get('n_gpus', 1)) != world:
-            continue
-        for name, k in rec.get('kernels', {}).items():
-            if name.startswith('symv_tiles'):
-                best = {'hbm_bytes': k['hbm_bytes'], 'source': os.path.relpath(path, REPO)}
-    return best
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: python bench.py --gpus N from a plain shell
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """Start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relay them.  This
+    parent process never loads the HIP library or touches the GPU: it only waits, forwards rank 0's JSON line and returns the
+    worst exit code.  A rank that dies takes the others down (their collectives could never complete)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))   # rank 0 prints the JSON line
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if bad:
+                rc = rc or bad[0]
+                for q in procs:          # exact PIDs of our own children
+                    if q.poll() is None:
+                        q.kill()
+        for p in procs:
+            if p.returncode != 0:
+                rc = rc or p.returncode
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc if rc >= 0 else 1
 
 
-def cpu_baseline(args):
-    """The oracle (NumPy restatement of the reference: dense Q on the host, 3 products per PG iteration) timed on
-    this host's cores at a bounded n, then scaled by (n_sample / n)^2 to the headline size (the per-iteration
-    cost is 3 streams of the n x n fp64 Hessian)."""
-    from oracle import bcqp_oracle as bo
-    from oracle import svm_oracle as so
-    from optiml_amd.datasets import make_blobs
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU legs (the oracle is imported HERE only: it is the thing timed beside the device path, never part of it)
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_info():
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         threads = os.cpu_count() or 1
-    ns = min(args.cpu_n, args.n)
-    from optiml_amd.datasets import make_regression
-    X, y = make_blobs(ns, args.d, seed=0) if args.task == 'svc' else make_regression(ns, args.d, seed=0)
-    t0 = time.perf_counter()
-    K = so.gram(args.kernel, X, None, 'scale', 1.0 if args.kernel == 'poly' else 0.0, 3)
-    Q, q, ub = so.svc_dual(K, y, 1.0) if args.task == 'svc' else so.svr_dual(K, y, 1.0, 0.1)
-    del K
-    t_build = time.perf_counter() - t0
-    if args.solver == 'adagrad':
-        return cpu_baseline_al(args, threads)
-    solve = bo.projected_gradient if args.solver == 'pg' else bo.frank_wolfe
-    solve(Q, q, ub, max_iter=2)  # warm
-    t0 = time.perf_counter()
-    res = solve(Q, q, ub, max_iter=args.cpu_steps)
-    dt = time.perf_counter() - t0
-    its = res['iter']
-    rate = its / dt
-    scaled = rate * (ns / args.n) ** 2
     model = ''
     try:
         for line in open('/proc/cpuinfo'):
@@ -118,21 +146,89 @@ def cpu_baseline(args):
                 break
     except OSError:
         pass
-    return {'value': scaled, 'unit': 'iter/s', 'cores': int(threads), 'kind': 'port', 'cpu_model': model,
-            'os_cpu_count': os.cpu_count(), 'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS'),
-            'OPENBLAS_NUM_THREADS': os.environ.get('OPENBLAS_NUM_THREADS'),
-            'sample': f'oracle {args.solver.upper()} (dense fp64 Q on host, 3 products/iter), n={ns} d={args.d}, '
-                      f'{its} iterations in {dt:.2f}s = {rate:.3f} iter/s measured; value scaled by (n_s/n)^2 to '
-                      f'n={args.n}; Gram+Q assembly {t_build:.2f}s excluded',
-            'measured_iter_per_s_at_sample': rate, 'sample_n': ns}
+    return {'cores': int(threads), 'cpu_model': model, 'os_cpu_count': os.cpu_count(),
+            'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS'), 'OPENBLAS_NUM_THREADS': os.environ.get('OPENBLAS_NUM_THREADS')}
 
 
-def cpu_baseline_al(args, threads):
+def cpu_baseline(args):
+    """The oracle (NumPy restatement of the reference: dense fp64 Q on the host, 3 products per PG/FW iteration) timed on
+    this host's cores at the sizes SURVEY 8(d) names (n = 20 000 and 30 000: the reference formulation cannot hold n = 100 000),
+    then EXTRAPOLATED to the workload's n: with the exponent fitted between the two samples (`value`) and, next to it, with the
+    n^2 law of a bandwidth-bound product (`value_n2_law`)."""
+    from oracle import bcqp_oracle as bo
+    from oracle import svm_oracle as so
+    from optiml_amd.datasets import make_blobs, make_regression
+    info = _cpu_info()
+    if args.solver == 'adagrad':
+        return cpu_baseline_al(args, info)
+    if args.solver == 'ascg':
+        return cpu_baseline_as(args, info)
+    sizes = sorted({min(int(s), args.n) for s in args.cpu_sizes.split(',') if s})
+    solve = bo.projected_gradient if args.solver == 'pg' else bo.frank_wolfe
+    samples = []
+    for ns in sizes:
+        X, y = make_blobs(ns, args.d, seed=0) if args.task == 'svc' else make_regression(ns, args.d, seed=0)
+        t0 = time.perf_counter()
+        K = so.gram(args.kernel, X, None, 'scale', 1.0 if args.kernel == 'poly' else 0.0, 3)
+        Q, q, ub = so.svc_dual(K, y, 1.0) if args.task == 'svc' else so.svr_dual(K, y, 1.0, 0.1)
+        del K
+        t_build = time.perf_counter() - t0
+        solve(Q, q, ub, max_iter=2)  # warm
+        its, dt = 0, 0.0
+        chunk = 4
+        while dt < args.cpu_seconds and its < 400:
+            t0 = time.perf_counter()
+            res = solve(Q, q, ub, max_iter=chunk)
+            dt += time.perf_counter() - t0
+            its += res['iter']
+        # each call restarts from the mid-box point: per-iteration cost is what is timed (3 dense products), not progress
+        samples.append({'n': ns, 'iters': int(its), 's_per_iter': dt / its, 'build_s': t_build,
+                        'GBs_of_Q': 3 * (len(q) ** 2) * 8 / (dt / its) / 1e9})
+        del Q
+    last = samples[-1]
+    n2 = 1.0 / (last['s_per_iter'] * (args.n / last['n']) ** 2)
+    if len(samples) >= 2 and samples[0]['n'] != last['n']:
+        expo = float(np.polyfit(np.log([s['n'] for s in samples]), np.log([s['s_per_iter'] for s in samples]), 1)[0])
+    else:
+        expo = 2.0
+    fitted = 1.0 / (last['s_per_iter'] * (args.n / last['n']) ** expo) if args.n > last['n'] else 1.0 / last['s_per_iter']
+    desc = ', '.join(f"n={s['n']}: {s['iters']} it, {1e3 * s['s_per_iter']:.1f} ms/it ({s['GBs_of_Q']:.0f} GB/s of Q)" for s in samples)
+    out = {'value': fitted, 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': args.n > last['n'],
+           'fitted_exponent': expo, 'value_n2_law': n2,
+           'sample': f'oracle {args.solver.upper()} (reference formulation: dense fp64 Q on host, 3 products/iter), d={args.d}: {desc}; '
+                     f'value = rate at n={last["n"]} scaled to n={args.n} with the fitted exponent {expo:.2f} '
+                     f'(value_n2_law: with exponent 2); Gram+Q assembly excluded',
+           'samples': samples}
+    out.update(info)
+    return out
+
+
+def cpu_baseline_as(args, info):
+    """Config 5 on the CPU: the reference ActiveSet (dense Cholesky of Q[A,A] in every iteration) on the squared-hinge dual at
+    a bounded n, scaled by the n^3 law of the factorisation to the workload's n — labelled, never a raw time."""
+    from oracle import bcqp_oracle as bo, svm_oracle as so
+    from optiml_amd.datasets import make_blobs
+    ns = min(args.n, 4000)
+    X, y = make_blobs(ns, args.d, seed=0)
+    K = so.gram('rbf', X)
+    Q = K * np.outer(y, y) + np.outer(y, y) + np.eye(ns) / 2.0
+    t0 = time.perf_counter()
+    res = bo.active_set(Q, -np.ones(ns), np.full(ns, np.inf), x0=np.ones(ns), max_iter=12)
+    dt = (time.perf_counter() - t0) / max(res['iter'], 1)
+    out = {'value': 1.0 / (dt * (args.n / ns) ** 3), 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': True,
+           'sample': f'oracle ActiveSet (reference algorithm: cho_factor of Q[A,A] per iteration, dense fp64 Q on host) on the '
+                     f'squared-hinge dual at n={ns} d={args.d}: {res["iter"]} iterations, {dt:.3f} s/it; value scaled by (n_s/n)^3 to n={args.n}',
+           'measured_iter_per_s_at_sample': 1.0 / dt, 'sample_n': ns}
+    out.update(info)
+    return out
+
+
+def cpu_baseline_al(args, info):
     """Oracle AdaGrad on the augmented Lagrangian in the reference formulation: dense Q and the dense stacked
     constraint matrix [a; -I; I] ((2N+1) x N), three products with Q per iteration."""
     from oracle import al_oracle as ao, svm_oracle as so
     from optiml_amd.datasets import make_blobs, make_regression
-    ns = min(args.cpu_n, args.n, 4000)
+    ns = min(args.n, 4000)
     X, y = make_blobs(ns, args.d, seed=0) if args.task == 'svc' else make_regression(ns, args.d, seed=0)
     K = so.gram(args.kernel, X, None, 'scale', 1.0 if args.kernel == 'poly' else 0.0, 3)
     if args.task == 'svc':
@@ -142,16 +238,17 @@ def cpu_baseline_al(args, threads):
         a = np.hstack((np.ones(ns), -np.ones(ns)))
     N = len(q)
     al = ao.AugLag(Q, q, a=a, lb=np.zeros(N), ub=np.ones(N), rho=1.)
-    steps = max(10, args.cpu_steps // 5)
     t0 = time.perf_counter()
-    res = ao.minimize(al, np.random.RandomState(0).uniform(size=N), 'adagrad', epochs=steps + 1, step_size=1.)
+    res = ao.minimize(al, np.random.RandomState(0).uniform(size=N), 'adagrad', epochs=31, step_size=1.)
     dt = time.perf_counter() - t0
     rate = res['iter'] / dt
-    return {'value': rate * (ns / args.n) ** 2, 'unit': 'iter/s', 'cores': int(threads), 'kind': 'port',
-            'sample': f'oracle AdaGrad on the augmented Lagrangian (dense fp64 Q and dense [a;-I;I] on host), n={ns} '
-                      f'd={args.d}, {res["iter"]} iterations in {dt:.2f}s = {rate:.3f} iter/s measured; value scaled '
-                      f'by (n_s/n)^2 to n={args.n}',
-            'measured_iter_per_s_at_sample': rate, 'sample_n': ns}
+    out = {'value': rate * (ns / args.n) ** 2, 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': True,
+           'sample': f'oracle AdaGrad on the augmented Lagrangian (dense fp64 Q and dense [a;-I;I] on host), n={ns} '
+                     f'd={args.d}, {res["iter"]} iterations in {dt:.2f}s = {rate:.3f} iter/s measured; value scaled '
+                     f'by (n_s/n)^2 to n={args.n}',
+           'measured_iter_per_s_at_sample': rate, 'sample_n': ns}
+    out.update(info)
+    return out
 
 
 def cpu_study(args):
@@ -160,7 +257,6 @@ def cpu_study(args):
     same for the dense Cholesky InteriorPoint / ActiveSet spend their time in (n^3), and (3) time a blocked,
     Gram-streaming product (K never materialised, ONE product per iteration — the cheapest thing a CPU can do) at the
     full n for a few iterations: a measured bound on the CPU rate that needs no extrapolation."""
-    import platform
     import scipy.linalg as sla
     from oracle import bcqp_oracle as bo
     from oracle import svm_oracle as so
@@ -170,18 +266,8 @@ def cpu_study(args):
         pools = [{k: p.get(k) for k in ('internal_api', 'num_threads', 'version')} for p in threadpool_info()]
     except Exception:
         pools = []
-    model = platform.processor()
-    try:
-        for line in open('/proc/cpuinfo'):
-            if line.startswith('model name'):
-                model = line.split(':', 1)[1].strip()
-                break
-    except OSError:
-        pass
-    out = {'what': 'cpu_study', 'cpu_model': model, 'os_cpu_count': os.cpu_count(),
-           'sched_affinity': len(os.sched_getaffinity(0)), 'blas_pools': pools,
-           'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS'),
-           'OPENBLAS_NUM_THREADS': os.environ.get('OPENBLAS_NUM_THREADS'), 'd': args.d}
+    out = {'what': 'cpu_study', 'sched_affinity': len(os.sched_getaffinity(0)), 'blas_pools': pools, 'd': args.d}
+    out.update(_cpu_info())
     pg = []
     for ns in (12000, 20000, 30000):
         X, y = make_blobs(ns, args.d, seed=0)
@@ -237,153 +323,191 @@ def cpu_study(args):
     print(json.dumps(out), flush=True)
 
 
-def bench_smo(args):
-    """BASELINE.json's second metric, time-to-KKT-tol, on the route that reaches it fastest: SVC.fit(optimizer='smo') end
-    to end (Gram build + sweeps) on one GPU; CPU baseline: the oracle's SMO sweeps at a bounded n (Gram excluded)."""
-    from oracle import smo_oracle as smo, svm_oracle as so
+# ---------------------------------------------------------------------------------------------------------------------
+# time-to-KKT-tol records (BASELINE.json's second metric): the routes that reach a stop test
+# ---------------------------------------------------------------------------------------------------------------------
+def kkt_smo(n, d, sigma, X=None, y=None, cpu=True, cpu_n=3000):
+    """SVC.fit(optimizer='smo') end to end (Gram build + sweeps, tol 1e-3) on one GPU; CPU: the oracle's SMO sweeps at a
+    bounded n, reported AT that n and scaled (pair steps grow ~linearly with n and each costs O(n): n^2), labelled."""
     from optiml_amd import device
     from optiml_amd.datasets import make_blobs
     from optiml_amd.ml.svm import SVC
     from optiml_amd.ml.svm.kernels import gaussian
     from optiml_amd.ml.svm.losses import hinge
-    ctx = device.get_context()
-    X, y = make_blobs(args.n, args.d, seed=0, sigma=args.sigma)
+    if X is None:
+        X, y = make_blobs(n, d, seed=0, sigma=sigma)
     t0 = time.perf_counter()
     est = SVC(loss=hinge, kernel=gaussian, C=1., dual=True, optimizer='smo', tol=1e-3).fit(X, y)
     dt = time.perf_counter() - t0
-    out = {'metric': 'time_to_kkt_tol', 'value': dt, 'unit': 's', 'n_gpus': 1, 'steps': int(est.optimizer.iter), 'warmup': 0,
-           'ms_per_step': 1e3 * dt / max(est.optimizer.iter, 1), 'higher_is_better': False, 'scaling': 'strong',
-           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-           'config': {'workload': f'svc_hinge_rbf_smo_dual_n{args.n}_d{args.d}', 'n': args.n, 'd': args.d, 'C': 1.0,
-                      'tol': 1e-3, 'gamma': 'scale', 'solver': 'smo', 'device': ctx.name},
-           'roofline': None, 'pair_steps': int(est.optimizer.steps), 'outer_iterations': int(est.optimizer.iter),
-           'n_sv': int(len(est.support_))}
-    # `value` is the first fit of a fresh process (it includes the first 40 GB device allocation, which varies from 0.05 to
-    # 1 s between boxes); the same fit again in the warm process is reported next to it
+    rec = {'route': "SVC.fit(optimizer='smo')", 'n': n, 'd': d, 'tol': 1e-3, 'value': dt, 'unit': 's',
+           'outer_iterations': int(est.optimizer.iter), 'pair_steps': int(est.optimizer.steps), 'n_sv': int(len(est.support_)),
+           'includes': 'Gram build + sweeps + intercept', 'roofline': None,
+           'roofline_note': 'sequential pair steps: latency-bound (one walking workgroup + helper workgroups), no roofline applies'}
+    est.obj.release()
+    # `value` is the first fit of a fresh process (it includes the first large device allocation); the same fit again
     t0 = time.perf_counter()
-    SVC(loss=hinge, kernel=gaussian, C=1., dual=True, optimizer='smo', tol=1e-3).fit(X, y)
-    out['second_fit_s'] = time.perf_counter() - t0
-    if not args.no_cpu:
-        ns = min(args.cpu_n, args.n)
+    est = SVC(loss=hinge, kernel=gaussian, C=1., dual=True, optimizer='smo', tol=1e-3).fit(X, y)
+    rec['second_fit_s'] = time.perf_counter() - t0
+    est.obj.release()
+    if cpu:
+        from oracle import smo_oracle as smo, svm_oracle as so
+        ns = min(cpu_n, n)
         K = so.gram('rbf', X[:ns])
         yb = np.where(y[:ns] == np.unique(y)[-1], 1., -1.)
         t0 = time.perf_counter()
         r = smo.smo_svc(K, yb, 1., 1e-3)
         dtc = time.perf_counter() - t0
-        out['cpu_baseline'] = {'value': dtc, 'unit': 's', 'cores': int(os.cpu_count() or 1), 'kind': 'port',
-                               'sample': f'oracle SMO sweeps (reference algorithm in NumPy, dense K on host, Gram build '
-                                         f'excluded) at n={ns}: {r["iter"]} outer iterations, {r["steps"]} pair steps'}
-    else:
-        out['cpu_baseline'] = None
-    print(json.dumps(out), flush=True)
+        rec['cpu_baseline'] = {'value': dtc * (n / ns) ** 2, 'unit': 's', 'kind': 'port (extrapolated)', 'extrapolated': n > ns,
+                               'cores': 1, 'measured_s_at_sample': dtc, 'sample_n': ns,
+                               'sample': f'oracle SMO sweeps (reference algorithm in NumPy, dense K on host, Gram build excluded) at '
+                                         f'n={ns}: {r["iter"]} outer iterations, {r["steps"]} pair steps in {dtc:.2f} s; value scaled '
+                                         f'by (n/n_s)^2 to n={n}'}
+    return rec
 
 
-def bench_kkt(args):
-    """BASELINE.json's second metric, time-to-KKT-tol, for the two box solvers that reach their own stop test:
-    SVC.fit(optimizer=InteriorPoint | ActiveSet) end to end on one GPU.  CPU baseline: the oracle (reference algorithm,
-    dense Q on the host, scipy's cho_factor per iteration) at a bounded n — its measured seconds, not extrapolated."""
-    from oracle import bcqp_oracle as bo, svm_oracle as so
-    from optiml_amd import device
+def kkt_box(solver, n, d, sigma, cpu=True):
+    """SVC.fit(optimizer=InteriorPoint | ActiveSet) end to end on one GPU, to the solver's own stop test.  roofline: fp64 MFMA
+    fraction of the Cholesky factorisations (n^3/3 flop each, HIP-event time of the factorisation kernels).  CPU: the oracle's
+    per-iteration cost at a bounded n scaled by the n^3 law to THIS n, times the iteration count — labelled."""
+    from optiml_amd import _lib, device
     from optiml_amd.datasets import make_blobs
     from optiml_amd.ml.svm import SVC
     from optiml_amd.ml.svm.kernels import gaussian
     from optiml_amd.ml.svm.losses import hinge
     from optiml_amd.opti.constrained import ActiveSet, InteriorPoint
     ctx = device.get_context()
-    X, y = make_blobs(args.n, args.d, seed=0, sigma=args.sigma)
-    cls = InteriorPoint if args.solver == 'ip' else ActiveSet
+    X, y = make_blobs(n, d, seed=0, sigma=sigma)
+    cls = InteriorPoint if solver == 'ip' else ActiveSet
+    ctx.profile(True)
+    ctx.profile_read(_lib.PROF_CHOL, reset=True)
     t0 = time.perf_counter()
     est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls, max_iter=10 ** 7).fit(X, y)
     dt = time.perf_counter() - t0
     o = est.optimizer
-    out = {'metric': 'time_to_kkt_tol', 'value': dt, 'unit': 's', 'n_gpus': 1, 'steps': int(o.iter), 'warmup': 0,
-           'ms_per_step': 1e3 * dt / max(o.iter, 1), 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None,
+    ch_ms, ch_cnt = ctx.profile_read(_lib.PROF_CHOL, reset=True)
+    rec = {'route': f'SVC.fit(optimizer={cls.__name__})', 'n': n, 'd': d, 'value': dt, 'unit': 's', 'iterations': int(o.iter),
+           'status': o.status, 'f': float(o.f_x), 'n_sv': int(len(est.support_)), 's_per_iteration': dt / max(o.iter, 1),
+           'stop_test': 'relative gap <= 1e-10' if solver == 'ip' else 'no wrong-sign multiplier (exact)',
+           'includes': 'Gram build + iterations + intercept'}
+    if solver == 'ip' and ch_cnt:
+        flops = n ** 3 / 3.0
+        tf = flops / (ch_ms / ch_cnt * 1e-3) / 1e12
+        rec['roofline'] = {'bound': 'mfma', 'kernel': 'blocked Cholesky of H = Q + diag (syrk/trsm on v_mfma_f64_16x16x4_f64)',
+                           'achieved': tf, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TF,
+                           'traffic': None, 'flops_per_launch': flops, 'avg_factor_ms': ch_ms / ch_cnt, 'factorisations': ch_cnt,
+                           'factor_share_of_wall': ch_ms * 1e-3 / dt}
+    elif ch_cnt:
+        rec['roofline'] = {'bound': 'mfma', 'kernel': 'base-set Cholesky factorisations (kept across iterations, Schur updates between)',
+                           'achieved': None, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None,
+                           'avg_factor_ms': ch_ms / ch_cnt, 'factorisations': ch_cnt, 'factor_share_of_wall': ch_ms * 1e-3 / dt,
+                           'note': 'the free set differs per factorisation, so n_A^3/3 is not a fixed flop count'}
+    else:
+        rec['roofline'] = None
+    est.obj.release()
+    if cpu:
+        from oracle import bcqp_oracle as bo, svm_oracle as so
+        ns = min(n, 6000 if solver == 'ip' else 2500)
+        Q, q, ub = so.svc_dual(so.gram('rbf', X[:ns]), y[:ns], 1.0)
+        fn = bo.interior_point if solver == 'ip' else bo.active_set
+        k = 4 if solver == 'ip' else 12
+        t0 = time.perf_counter()
+        r = fn(Q, q, ub, max_iter=k)
+        per = (time.perf_counter() - t0) / max(r['iter'], 1)
+        rec['cpu_baseline'] = {'value': per * (n / ns) ** 3 * o.iter, 'unit': 's', 'kind': 'port (extrapolated)', 'extrapolated': n > ns,
+                               'cores': _cpu_info()['cores'], 'measured_s_per_iteration_at_sample': per, 'sample_n': ns,
+                               'sample': f'oracle {solver.upper()} (reference algorithm in NumPy/SciPy: cho_factor per iteration, dense Q on '
+                                         f'host) at n={ns}: {per:.3f} s/iteration over {r["iter"]} iterations; value = that x (n/n_s)^3 x '
+                                         f'the {o.iter} iterations the device run needed at n={n}; Gram and Q assembly excluded'}
+    return rec
+
+
+def bench_kkt_line(args):
+    """--solver smo | ip | as: one JSON line with metric time_to_kkt_tol."""
+    from optiml_amd import device
+    ctx = device.get_context()
+    if args.solver == 'smo':
+        rec = kkt_smo(args.n, args.d, args.sigma, cpu=not args.no_cpu)
+    else:
+        rec = kkt_box(args.solver, args.n, args.d, args.sigma, cpu=not args.no_cpu)
+    steps = rec.get('iterations', rec.get('outer_iterations', 0))
+    out = {'metric': 'time_to_kkt_tol', 'value': rec['value'], 'unit': 's', 'n_gpus': 1, 'steps': int(steps), 'warmup': 0,
+           'ms_per_step': 1e3 * rec['value'] / max(steps, 1), 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None,
            'dtype': 'f64', 'data': 'synthetic',
            'config': {'workload': f'svc_hinge_rbf_{args.solver}_dual_n{args.n}_d{args.d}', 'n': args.n, 'd': args.d, 'C': 1.0,
                       'gamma': 'scale', 'solver': args.solver, 'device': ctx.name},
-           'roofline': None, 'status': o.status, 'f': float(o.f_x), 'n_sv': int(len(est.support_))}
-    if not args.no_cpu:
-        # bounded CPU samples: ActiveSet needs ~n iterations of an n^3/3 factorisation each — minutes already at n=3000
-        ns = min(args.cpu_n, args.n, 3000 if args.solver == 'ip' else 800)
-        Q, q, ub = so.svc_dual(so.gram('rbf', X[:ns]), y[:ns], 1.0)
-        fn = bo.interior_point if args.solver == 'ip' else bo.active_set
-        t0 = time.perf_counter()
-        r = fn(Q, q, ub, max_iter=10 ** 7)
-        dtc = time.perf_counter() - t0
-        out['cpu_baseline'] = {'value': dtc, 'unit': 's', 'cores': int(os.cpu_count() or 1), 'kind': 'port',
-                               'sample': f'oracle {args.solver.upper()} (reference algorithm in NumPy/SciPy, dense Q on host, Gram '
-                                         f'and Q assembly excluded) run to its stop test at n={ns}: {r["iter"]} iterations, '
-                                         f'status {r["status"]}'}
-    else:
-        out['cpu_baseline'] = None
+           'roofline': rec.pop('roofline', None), 'cpu_baseline': rec.pop('cpu_baseline', None)}
+    out.update({k: v for k, v in rec.items() if k not in ('value', 'unit', 'n', 'd')})
     print(json.dumps(out), flush=True)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if args.cpu_study:
         return cpu_study(args)
-    if args.solver in ('ip', 'as'):
+    if args.solver in ('ip', 'as', 'smo'):
         if args.gpus != 1:
-            raise SystemExit('InteriorPoint / ActiveSet factorise on one GPU (replicas only): --gpus 1')
-        return bench_kkt(args)
-    if args.solver == 'smo':
-        if args.gpus != 1:
-            raise SystemExit('SMO walks the samples sequentially on one GPU (replicas only): --gpus 1')
-        return bench_smo(args)
+            raise SystemExit('InteriorPoint / ActiveSet factorise on one GPU and SMO walks the samples sequentially '
+                             '(replicas only): --gpus 1')
+        return bench_kkt_line(args)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))   # before anything in this process touches HIP
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}')
 
     from optiml_amd import _lib
     from optiml_amd import device
-    from optiml_amd.datasets import make_blobs
-    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.datasets import make_blobs, make_regression
+    from optiml_amd.ml.svm.kernels import PolyKernel, gaussian, linear
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.opti.constrained._base import _DeviceSolver
 
     comm = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         from optiml_amd.dist import TorchComm
         comm = TorchComm()
-        # RCCL over xGMI is the data path.  If the communicator cannot be created on every rank (reported, never
-        # silent), the row-block exchange falls back to the host (gloo) transport so that the run still measures the
-        # sharded GPU path; `config.exchange` in the JSON line says which transport was used.
+        # RCCL over xGMI is the data path.  A communicator that cannot be created on EVERY rank ends the run with exit code
+        # 3 — a scaling number must never silently be a host-transport number — unless --allow-host-exchange asks for the
+        # gloo fallback (reported in config.exchange).
         exchange, ctx, err = args.exchange, None, ''
         if exchange == 'rccl':
             try:
-                ctx = device.Context(comm=comm, exchange='rccl')
+                ctx = device.Context(comm=comm, exchange='rccl', sym_exchange=args.sym_exchange)
             except Exception as exc:  # noqa: BLE001
                 err = repr(exc)
             if comm.max_float(0.0 if ctx is not None else 1.0) > 0.0:
-                print(f'[bench] rank {rank}: RCCL context unavailable ({err or "failed on another rank"}); '
-                      'using the host exchange', file=sys.stderr, flush=True)
+                print(f'[bench] rank {rank}: RCCL context unavailable ({err or "failed on another rank"})', file=sys.stderr, flush=True)
                 if ctx is not None:
                     ctx.close()
+                if not args.allow_host_exchange:
+                    dist.destroy_process_group()
+                    raise SystemExit(3)
+                print(f'[bench] rank {rank}: --allow-host-exchange: using the host (gloo) exchange', file=sys.stderr, flush=True)
                 ctx, exchange = None, 'host'
         if ctx is None:
-            ctx = device.Context(comm=comm, exchange=exchange)
+            ctx = device.Context(comm=comm, exchange=exchange, sym_exchange=args.sym_exchange)
         device.set_context(ctx)
     else:
         ctx = device.get_context()
+    cinfo = ctx.comm_info()
 
     def barrier():
         if comm is not None:
             comm.barrier()
 
     n, d = args.n, args.d
-    from optiml_amd.datasets import make_regression
-    from optiml_amd.ml.svm.kernels import PolyKernel, linear
     kern = {'rbf': gaussian, 'poly': PolyKernel(3, 'scale', 1.0), 'linear': linear}[args.kernel]
     al = args.solver == 'adagrad'   # reg_intercept=False dual: no rank-one term, equality row handled by the multiplier
+    ascg = args.solver == 'ascg'    # squared-hinge dual: K*yy' + yy' + I/(2C), ub = +inf, x0 = 1 (SURVEY 8c.6)
     if args.task == 'svc':
         X, y = make_blobs(n, d, seed=0, sigma=args.sigma)
-        quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage, rank_one=not al)
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage, rank_one=not al,
+                               diag=0.5 if ascg else 0.0)
         a_eq = y
     else:   # eps-insensitive SVR dual: 2n variables on one n x n panel (BASELINE config 4 shape)
         X, y = make_regression(n, d, seed=0)
@@ -403,6 +527,9 @@ def main():
         prm = _lib.AlParams(rule=_lib.RULE_ADAGRAD, momentum_type=0, step_size=1., momentum=0., beta1=0., beta2=0.,
                             decay=0., offset=1e-8, rho=1., tol=1e-12, epochs=10 ** 9)
         solver = _AlDeviceSolver(dev, prm, a_eq, np.zeros(N), ub, np.random.RandomState(0).uniform(size=N), None)
+    elif ascg:
+        solver = _DeviceSolver(dev, _lib.AS_CG, np.zeros(N), np.full(N, np.inf), np.ones(N), 1e-6, 10 ** 9)
+        solver.set_inner(args.inner_tol, 0)
     else:
         kind = _lib.PG if args.solver == 'pg' else _lib.FW
         solver = _DeviceSolver(dev, kind, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
@@ -410,6 +537,7 @@ def main():
     rows, status = solver.run(max(args.warmup, 1))      # includes the start-up gradient product
     ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     ctx.profile_read(_lib.PROF_EXCH, reset=True)
+    inner0 = solver.inner_iters() if ascg else 0
     barrier()
     t0 = time.perf_counter()
     rows, status = solver.run(args.steps)                # device-resident; returns after the stream has drained
@@ -421,14 +549,16 @@ def main():
     done = len(rows)
     mv_ms, mv_cnt = ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     ex_ms, ex_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
+    inner = (solver.inner_iters() - inner0) if ascg else 0
 
     esz = 8 if args.storage == 'f64' else 4
     probe = (0.0, 0.0)
     if rank == 0:
-        try:   # outside the timed region: what a plain streaming read / copy reaches on this GPU (8 GiB scratch)
+        try:   # outside the timed region: what a plain streaming read / copy reaches on this GPU (4 GiB scratch)
             probe = ctx.probe_bandwidth(4 << 30, 5)
         except Exception as exc:  # noqa: BLE001  (e.g. not enough free HBM beside a very large panel)
             print(f'[bench] bandwidth probe skipped: {exc!r}', file=sys.stderr, flush=True)
+    out = None
     if rank == 0:
         avg_ms = mv_ms / max(mv_cnt, 1)
         # the dominant kernel is the symmetric tile product: this rank streams the 256 x 256 tiles on/below the
@@ -438,38 +568,71 @@ def main():
         tiles = i1 * (i1 + 1) // 2 - i0 * (i0 + 1) // 2
         alg_bytes = tiles * (T * T * esz + T * 8) + (tiles // 8 + i1 - i0) * T * 8 + 2 * n * 8   # tiles + col parts + row parts
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        full_equiv = ((r1 - r0) * n * esz + 3 * n * 8) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        workload = (f'svc_hinge_{args.kernel}_{args.solver}_dual_n{n}_d{d}' if args.task == 'svc' else
-                    f'svr_epsins_{args.kernel}_{args.solver}_dual_n{n}_d{d}')
-        traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
+        # SURVEY 8(d)'s per-product bytes for a row-block panel, n^2 s / G + 3 n s per GPU — twice what this kernel moves
+        survey_bytes = n * n * esz / world + 3 * n * 8
+        full_equiv = survey_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        if args.task == 'svc':
+            loss = 'sqhinge' if ascg else 'hinge'
+            workload = f'svc_{loss}_{args.kernel}_{args.solver}_dual_n{n}_d{d}'
+        else:
+            workload = f'svr_epsins_{args.kernel}_{args.solver}_dual_n{n}_d{d}'
         out = {
             'metric': 'dual_qp_iterations_per_sec', 'value': done / elapsed, 'unit': 'iter/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(done, 1),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64' if args.storage in ('f64', 'stream') else 'f32-storage/f64-accumulate', 'data': 'synthetic',
             'config': {'workload': workload, 'n': n, 'd': d, 'dual_dim': N, 'C': 1.0,
-                       'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange, 'blob_sigma': args.sigma,
+                       'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange, 'rccl_ranks': cinfo['rccl_ranks'],
+                       'sym_exchange': cinfo['sym_exchange'] if world > 1 else 'none', 'blob_sigma': args.sigma,
                        'rows_per_gpu': r1 - r0, 'device': ctx.name},
             'roofline': {'bound': 'hbm', 'kernel': 'symv_tiles_kernel (symmetric panel product Q*d)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic['hbm_bytes'] if traffic else None,
-                         'traffic_source': traffic['source'] if traffic else None, 'avg_launch_ms': avg_ms, 'launches': mv_cnt,
+                         'traffic': None, 'traffic_source': None, 'avg_launch_ms': avg_ms, 'launches': mv_cnt,
                          'algorithmic_bytes_per_launch': alg_bytes, 'tiles_per_launch': tiles,
-                         'row_block_equivalent_GBs': full_equiv, 'measured_stream_read_GBs': probe[0],
-                         'measured_copy_GBs': probe[1],
+                         'survey_8d_bytes_per_launch': survey_bytes, 'survey_8d_equivalent_GBs': full_equiv,
+                         'frac_survey_8d_bytes': full_equiv / HBM_PEAK_GBS,
+                         'note': 'frac is on the bytes the kernel moves: lower-triangle tiles only (the Gram panel is symmetric; '
+                                 'both contributions of a tile are formed from one read). frac_survey_8d_bytes prices the same '
+                                 'launch at SURVEY 8(d)\'s n^2*s row-block bytes, which are never read — it can exceed 1.',
+                         'measured_stream_read_GBs': probe[0], 'measured_copy_GBs': probe[1],
                          'frac_of_measured_stream_read': (achieved / probe[0]) if probe[0] else None},
             'steps_done': done, 'solver_status': status,
             'f_last': float(rows['f'][-1]) if done else None,
             'kkt_resid_last': float(rows['r1'][-1]) if done and args.solver == 'pg' else None,
             'gram_build_s': gram_ms * 1e-3, 'problem_setup_s': t_gram_total,
-            'exchange_ms_per_step': (ex_ms / max(ex_cnt, 1)) if ex_cnt else 0.0,
+            'exchange_ms_per_step': (ex_ms / max(done, 1)) if ex_cnt else 0.0,
+            'exchange_ms_per_product': (ex_ms / ex_cnt) if ex_cnt else 0.0,
         }
+        if ascg:
+            out['inner_products_per_step'] = inner / max(done, 1)
+            out['inner_tol'] = args.inner_tol
+            out['products_per_sec'] = mv_cnt / elapsed
+        traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
+        if traffic:
+            out['roofline']['traffic'] = traffic['hbm_bytes']
+            out['roofline']['traffic_source'] = traffic['source']
+            out['roofline']['traffic_note'] = 'PMC pass (FETCH_SIZE x2 per the gfx950 note, + WRITE_SIZE) of this command, committed file'
         if args.storage == 'stream':   # no panel: the product is the fused Gram-tile x vector kernel, MFMA-bound
             flops = 2.0 * (-(-(r1 - r0) // 128) * 128) * (-(-n // 128) * 128) * (-(-d // 16) * 16)
             tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gram_stream_kernel (Gram tiles recomputed, fused with the product)',
-                               'achieved': tf, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': tf / 78.6, 'traffic': None,
+                               'achieved': tf, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TF, 'traffic': None,
                                'avg_launch_ms': avg_ms, 'launches': mv_cnt, 'flops_per_launch': flops}
+    barrier()
+    solver.close()
+    quad.release()
+    if rank == 0:
+        if world == 1 and args.kkt != 'none' and args.solver == 'pg' and args.task == 'svc' and args.storage == 'f64':
+            # BASELINE's second metric in the same line: the routes that reach a KKT tolerance
+            kk = {}
+            try:
+                if args.kkt in ('smo', 'all'):
+                    kk['smo'] = kkt_smo(n, d, args.sigma, X=X, y=y, cpu=not args.no_cpu)
+                if args.kkt in ('ip', 'all'):
+                    kk['ip_config3'] = kkt_box('ip', 50000, 128, args.sigma, cpu=not args.no_cpu)
+            except Exception as exc:  # noqa: BLE001 — the headline number must survive a failing side record
+                kk['error'] = repr(exc)
+            out['time_to_kkt'] = kk
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(args)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
@@ -477,10 +640,29 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     barrier()
-    solver.close()
     if comm is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def measured_traffic(workload, world):
+    """HBM bytes per launch of the panel-product kernel from the committed PMC passes (profiles/rNN/pmc_traffic_*.json,
+    produced by tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
+    command); the newest round that matches this workload, None when none does."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', 'pmc_traffic_*.json'))):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        meta = rec.get('meta', {})
+        if meta.get('workload') != workload or int(meta.get('n_gpus', 1)) != world:
+            continue
+        for name, k in rec.get('kernels', {}).items():
+            if name.startswith('symv_tiles'):
+                best = {'hbm_bytes': k['hbm_bytes'], 'source': os.path.relpath(path, REPO)}
+    return best
 
 
 if __name__ == '__main__':

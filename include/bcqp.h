@@ -20,9 +20,11 @@
  *   - multi-GPU: one process per GPU; all n-vectors are replicated and each product Q*v is completed
  *     by ONE collective (RCCL over xGMI, or a caller-supplied exchange callback): kernel-built
  *     symmetric panels are split into tile rows with equal shares of the lower triangle
- *     (bq_sym_row_block) and end in an all-reduce(sum); dense and streamed panels are split into
- *     equal row blocks (bq_row_block) and end in an all-gather.  Solvers that factorise the Hessian
- *     (InteriorPoint, ActiveSet) and SMO need a single-rank context.
+ *     (bq_sym_row_block: runs of 8 canonical segments) and end in an all-gather of the per-segment
+ *     partial vectors, which every rank adds in segment order — bit-identical iterates for 1/2/4/8
+ *     ranks (BQ_SYM_EXCHANGE=allreduce: one all-reduce(sum) instead); dense and streamed panels are
+ *     split into equal row blocks (bq_row_block) and end in an all-gather.  Solvers that factorise
+ *     the Hessian (InteriorPoint, ActiveSet) and SMO need a single-rank context.
  */
 #ifndef BCQP_H
 #define BCQP_H
@@ -90,8 +92,9 @@ typedef struct bq_iter_stat {
 
 /* Exchange callback for multi-process runs without RCCL (tests; hosts without xGMI).  Return 0 on success.
  *   op 0 (gather): on entry buf holds this rank's rows [row_begin,row_end) of an n-vector; on return the whole
- *                  vector must be filled with every rank's rows            (row-block panels: dense Q)
- *   op 1 (sum):    on return buf[0:n) must hold the element-wise sum over ranks   (symmetric tile panels) */
+ *                  vector must be filled with every rank's rows   (row-block panels; the segment partials of the
+ *                  symmetric tile panels: n = world * chunk, equal chunks)
+ *   op 1 (sum):    on return buf[0:n) must hold the element-wise sum over ranks   (BQ_SYM_EXCHANGE=allreduce) */
 typedef int (*bq_exchange_fn)(void *user, double *buf, int64_t n, int64_t row_begin, int64_t row_end, int op);
 
 int bq_abi_version(void);
@@ -106,6 +109,13 @@ int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_c
 int bq_ctx_create_exchange(int device, int rank, int world, bq_exchange_fn fn, void *user, bq_ctx **out);
 int bq_ctx_destroy(bq_ctx *ctx);
 int bq_ctx_info(const bq_ctx *ctx, int *device, int *rank, int *world, char *name, size_t name_cap);
+/* the exchange behind a multi-rank context: kind 0 none / 1 RCCL / 2 callback; comm_ranks = ncclCommCount of the live
+ * communicator (0 without RCCL); sym_allreduce = 1 when symmetric products end in an all-reduce (BQ_SYM_EXCHANGE=allreduce)
+ * instead of the default all-gather of segment partials summed in a fixed order (bit-identical for any rank count) */
+int bq_ctx_comm_info(const bq_ctx *ctx, int *kind, int *comm_ranks, int *sym_allreduce);
+/* choose the closing collective of symmetric products (before the first problem is created): 0 = all-gather of segment
+ * partials + ordered sum (default), 1 = all-reduce(sum) */
+int bq_ctx_set_sym_allreduce(bq_ctx *ctx, int on);
 /* HIP-event timing of the dominant kernels (on the stream they run on).  which: 0 = Q*v panel
  * product, 1 = Gram build, 2 = Cholesky factorisation, 3 = row-block exchange. */
 int bq_ctx_profile(bq_ctx *ctx, int enable);
@@ -213,7 +223,10 @@ int bq_al_solver_dual_size(const bq_solver *s, int64_t *n_dual);
 typedef struct bq_smo bq_smo;
 enum { BQ_SMO_ALPHAS = 0,   /* n (BQ_SVC) or [alpha+; alpha-] 2n (BQ_SVR) */
        BQ_SMO_ERRORS = 1,   /* n: the error cache */
-       BQ_SMO_SCALARS = 2   /* 6: b_up, b_low, b_up_idx, b_low_idx, successful pair steps, intercept b */ };
+       BQ_SMO_SCALARS = 2,  /* 6: b_up, b_low, b_up_idx, b_low_idx, successful pair steps, intercept b */
+       BQ_SMO_STATS = 3     /* 4: helper workgroups per full sweep, error sums they delivered, sums rejected because the list
+                             * entries read did not hash to the published value, results rejected by their own checksum —
+                             * the two rejection counts are self-checks of the inter-workgroup hand-off and must be 0 */ };
 int bq_smo_create(bq_problem *p, int task, const double *y, double C, double epsilon, double tol, bq_smo **out);
 int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, int *finished);
 int bq_smo_get(bq_smo *s, int what, double *out);

@@ -22,7 +22,7 @@ STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
 GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW, GET_DUAL = range(10)
 NO_RANK_ONE = 16
 FULL_PANEL = 32
-SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS = range(3)
+SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS, SMO_STATS = range(4)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
@@ -59,6 +59,8 @@ PROTOTYPES = {
     'bq_ctx_create_exchange': (C.c_int, [C.c_int, C.c_int, C.c_int, EXCHANGE_FN, _vp, C.POINTER(_vp)]),
     'bq_ctx_destroy': (C.c_int, [_vp]),
     'bq_ctx_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    'bq_ctx_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'bq_ctx_set_sym_allreduce': (C.c_int, [_vp, C.c_int]),
     'bq_ctx_profile': (C.c_int, [_vp, C.c_int]),
     'bq_ctx_profile_read': (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i64), C.c_int]),
     'bq_ctx_probe_bandwidth': (C.c_int, [_vp, _i64, C.c_int, _dp, _dp]),

@@ -44,6 +44,8 @@ static int ctx_new(int device, bq_ctx **out) {
     c->num_cu = prop.multiProcessorCount;
     snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
     BQ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const char *mode = getenv("BQ_SYM_EXCHANGE");
+    c->sym_allreduce = mode != nullptr && strcmp(mode, "allreduce") == 0;
     *out = c;
     return BQ_OK;
 }
@@ -52,6 +54,7 @@ extern "C" int bq_ctx_create(int device, bq_ctx **out) { return ctx_new(device, 
 
 int bq_comm_init_rccl(bq_ctx *ctx, const void *uid128);  // bq_comm.cpp
 void bq_comm_destroy(bq_ctx *ctx);
+int bq_comm_size(const bq_ctx *ctx);
 
 extern "C" int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_ctx **out) {
     BQ_ARG(world >= 1 && rank >= 0 && rank < world, "rank/world");
@@ -107,6 +110,20 @@ extern "C" int bq_ctx_info(const bq_ctx *c, int *device, int *rank, int *world, 
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
     if (name && cap) snprintf(name, cap, "%s", c->name);
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_comm_info(const bq_ctx *c, int *kind, int *comm_ranks, int *sym_allreduce) {
+    BQ_ARG(c != nullptr, "ctx is NULL");
+    if (kind) *kind = c->comm_kind;
+    if (comm_ranks) *comm_ranks = bq_comm_size(c);
+    if (sym_allreduce) *sym_allreduce = c->sym_allreduce ? 1 : 0;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_set_sym_allreduce(bq_ctx *c, int on) {
+    BQ_ARG(c != nullptr, "ctx is NULL");
+    c->sym_allreduce = on != 0;
     return BQ_OK;
 }
 
@@ -178,17 +195,32 @@ extern "C" int bq_row_block(int64_t n, int rank, int world, int64_t *begin, int6
     return BQ_OK;
 }
 
-// Balanced triangular partition of nb tile rows: rank k owns [I_k, I_k+1) with I_k = round(nb * sqrt(k / G)), so every
-// rank streams about nb^2 / (2 G) tiles of the lower triangle.
+// Balanced triangular partition of nb tile rows into S canonical segments: segment s starts at round(nb * sqrt(s / S)), so
+// every segment holds about nb^2 / (2 S) tiles of the lower triangle.  Rank k of G owns the segments
+// [floor(k S / G), floor((k+1) S / G)) — for G dividing S that is I_k = round(nb * sqrt(k / G)), equal tile counts per rank.
+int64_t bq_sym_seg_cut(int64_t nb, int s, int S) {
+    if (s <= 0) return 0;
+    if (s >= S) return nb;
+    int64_t v = (int64_t)std::llround((double)nb * std::sqrt((double)s / (double)S));
+    return v < 0 ? 0 : (v > nb ? nb : v);
+}
+
 static void sym_tile_rows(int64_t nb, int rank, int world, int64_t *I0, int64_t *I1) {
-    auto cut = [&](int k) -> int64_t {
-        if (k <= 0) return 0;
-        if (k >= world) return nb;
-        int64_t v = (int64_t)std::llround((double)nb * std::sqrt((double)k / (double)world));
-        return v < 0 ? 0 : (v > nb ? nb : v);
-    };
-    *I0 = cut(rank);
-    *I1 = cut(rank + 1);
+    const int S = bq_sym_segments(world);
+    *I0 = bq_sym_seg_cut(nb, bq_sym_seg_first(rank, world, S), S);
+    *I1 = bq_sym_seg_cut(nb, bq_sym_seg_first(rank + 1, world, S), S);
+}
+
+void bq_sym_seg_table(const bq_problem *p, bq_seg_table *tab) {
+    const int world = p->ctx->world;
+    tab->count = p->seg_count;
+    tab->lo = p->seg_lo;
+    tab->hi = p->seg_hi;
+    for (int s = 0; s <= p->seg_count; ++s) tab->cut[s] = bq_sym_seg_cut(p->nb, s, p->seg_count);
+    for (int k = 0; k < world; ++k) {
+        const int lo = bq_sym_seg_first(k, world, p->seg_count), hi = bq_sym_seg_first(k + 1, world, p->seg_count);
+        for (int s = lo; s < hi; ++s) tab->slot[s] = k * p->seg_cmax + (s - lo);
+    }
 }
 
 extern "C" int bq_sym_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end) {
@@ -223,6 +255,11 @@ static int problem_alloc_common(bq_problem *p, const double *q_host) {
     const int64_t slen = bq_round_up(std::max(p->blk * c->world, p->nb * BQ_SYM_TILE), BQ_PAD);
     if (p->symmetric) {
         BQ_HIP(hipMalloc(&p->slab, sizeof(double) * p->nb * p->nb * BQ_SYM_TILE));
+        if (c->world > 1) {   // the gathered segment vectors of every rank
+            const size_t gl = sizeof(double) * (size_t)c->world * p->seg_cmax * p->nb * BQ_SYM_TILE;
+            BQ_HIP(hipMalloc(&p->gath, gl));
+            BQ_HIP(hipMemsetAsync(p->gath, 0, gl, c->stream));
+        }
     }
     BQ_HIP(hipMalloc(&p->s, sizeof(double) * slen));
     BQ_HIP(hipMemsetAsync(p->s, 0, sizeof(double) * slen, c->stream));
@@ -246,6 +283,10 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
     if (p->symmetric) {
         p->nb = (n + BQ_SYM_TILE - 1) / BQ_SYM_TILE;
         sym_tile_rows(p->nb, c->rank, c->world, &p->I0, &p->I1);
+        p->seg_count = bq_sym_segments(c->world);
+        p->seg_lo = bq_sym_seg_first(c->rank, c->world, p->seg_count);
+        p->seg_hi = bq_sym_seg_first(c->rank + 1, c->world, p->seg_count);
+        p->seg_cmax = (p->seg_count + c->world - 1) / c->world;
         p->r0 = std::min(n, p->I0 * BQ_SYM_TILE);
         p->r1 = std::min(n, p->I1 * BQ_SYM_TILE);
         rows = (p->I1 - p->I0) * BQ_SYM_TILE;  // whole tiles, zero rows past n
@@ -301,7 +342,7 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
         p->panel = nullptr;
     }
     for (void *ptr : {(void *)p->panel, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
-                      (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab})
+                      (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab, (void *)p->gath})
         if (ptr) hipFree(ptr);
     bq_stream_free(p->stream_img);
     delete p;
@@ -517,12 +558,13 @@ extern "C" int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms) 
     BQ_HIP(hipEventCreate(&e1));
     const bool prof = c->profiling;
     c->profiling = false;
+    bq_seg_table tab;
+    if (p->symmetric) bq_sym_seg_table(p, &tab);
     auto local = [&]() {
         if (p->streamed)
             return bq_stream_product(c, p->stream_img, p->n, p->r0, p->r1, p->kernel, p->gamma, p->coef0, p->degree,
                                      p->add_one, p->w, p->s + p->r0, nullptr);
-        return p->symmetric ? bq_launch_symv(c, p->panel, p->storage, p->add_one, p->I0, p->I1, p->nb, p->ld, p->w,
-                                             p->slab, p->s, nullptr)
+        return p->symmetric ? bq_launch_symv(c, p->panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr)
                             : bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w,
                                              p->s + p->r0, nullptr);
     };

@@ -66,6 +66,8 @@ struct bq_ctx {
     char name[128] = {0};
     hipStream_t stream = nullptr;
     int comm_kind = BQ_COMM_NONE;
+    bool sym_allreduce = false;   // BQ_SYM_EXCHANGE=allreduce: symmetric products end in ncclAllReduce instead of the
+                                  // deterministic segment all-gather
     void *nccl_comm = nullptr;
     bq_exchange_fn exch_fn = nullptr;
     void *exch_user = nullptr;
@@ -98,7 +100,10 @@ struct bq_problem {
     void *stream_img = nullptr;
     int64_t I0 = 0, I1 = 0, nb = 0;
     double *slab = nullptr;   // nb x nb x 256 partial products
-    double *part = nullptr;   // nb*256: this rank's partial K w (all-reduced across ranks)
+    // canonical segments of the tile rows (bq_sym_segments): this rank owns segments [seg_lo, seg_hi) of seg_count; the
+    // per-segment partial products are gathered into gath[world][seg_cmax][nb*256] and summed in segment order
+    int seg_count = 0, seg_lo = 0, seg_hi = 0, seg_cmax = 0;
+    double *gath = nullptr;
     void *panel = nullptr;
     double *q = nullptr;    // ldN
     double *sgn = nullptr;  // ld (labels, BQ_SVC) or null
@@ -174,6 +179,8 @@ int bq_prof_begin(bq_ctx *ctx, int which, hipEvent_t *e0, hipEvent_t *e1);
 int bq_prof_end(bq_ctx *ctx, int which, hipEvent_t e0, hipEvent_t e1);
 int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0, int64_t r1);
 int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count);  // all-reduce(sum) of a replicated-length vector
+// in-place all-gather of equal chunks: buf holds world*chunk doubles, this rank's chunk (at rank*chunk) is fresh on entry
+int bq_exchange_gather(bq_ctx *ctx, double *buf, int64_t chunk);
 void bq_ctx_drop_cache(bq_ctx *ctx);   // give the cached panel back to the driver (called before retrying a failed allocation)
 
 // bq_symv.hip: symmetric tile product over tile rows [I0, I1) -> out (nb*256 partial sums)
@@ -187,8 +194,30 @@ __host__ __device__ inline int64_t bq_sym_addr(int64_t i, int64_t j, int64_t I0)
     const int64_t I = i / BQ_SYM_TILE;
     return bq_sym_off(I) - bq_sym_off(I0) + (i - I * BQ_SYM_TILE) * bq_sym_pitch(I) + j;
 }
-int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
-                   int64_t ld, const double *w, double *slab, double *out, const int *done);
+// Canonical segments of a symmetric panel's tile rows.  The partial products of the lower-triangle tiles are summed per
+// SEGMENT (a contiguous range of tile rows holding 1/S of the triangle's tiles, boundaries a function of nb and S only) and the
+// S segment vectors are then added in segment order on every rank, so the product is bit-identical for any number of
+// ranks that own whole segments: 1, 2, 4 and 8 GPUs see the same iterates.  S = 8 up to 8 ranks.
+constexpr int BQ_SYM_SEG = 8;
+constexpr int BQ_SYM_SEG_MAX = 64;
+static inline int bq_sym_segments(int world) { return BQ_SYM_SEG * ((world + BQ_SYM_SEG - 1) / BQ_SYM_SEG); }
+int64_t bq_sym_seg_cut(int64_t nb, int s, int S);                              // first tile row of segment s (s = S: nb)
+static inline int bq_sym_seg_first(int rank, int world, int S) { return (int)((int64_t)rank * S / world); }
+struct bq_seg_table {
+    int count;                              // S
+    int lo, hi;                             // the segments summed by this launch (this rank's)
+    int slot[BQ_SYM_SEG_MAX];               // segment -> slot of the gathered buffer (owner rank * cmax + local index)
+    long long cut[BQ_SYM_SEG_MAX + 1];      // tile-row boundaries
+};
+// tiles of the segments [tab.lo, tab.hi) + their sum in segment order -> out (nb*256)
+int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
+                   const double *w, double *slab, double *out, const int *done);
+// the same with the segment partials written to `gath` (slots of this rank) instead of one summed vector; and the closing
+// sum of all S gathered segment vectors -> out
+int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
+                            const double *w, double *slab, double *gath, const int *done);
+int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done);
+void bq_sym_seg_table(const bq_problem *p, bq_seg_table *tab);
 int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done);  // -> p->s (complete on all ranks)
 
 // bq_gemv.hip: s[r0 + i] = sum_j elem(panel[i][j]) * w[j], i in [0, nrows)

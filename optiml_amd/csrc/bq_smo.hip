@@ -60,8 +60,8 @@ struct bq_smo {
     bq_smo_scal host;
     // helper workgroups of the full sweeps (see "Helpers" below)
     unsigned int *ctl = nullptr;       // SPEC_* words
-    long long *spec_dot = nullptr;     // n: bit pattern of sum_q c_q K[s][idx_q] formed by a helper
-    long long *spec_tag = nullptr;     // n: (list version << 32) | checksum of spec_dot[s]  (0: none)
+    void *spec_res = nullptr;          // n x 16 bytes: {bit pattern of sum_q c_q K[s][idx_q] formed by a helper, the list
+                                       // version it was formed under, checksum of the bits} — ONE 16-byte store / load
     unsigned int epoch = 0;            // launch counter
     int helpers = 0;                   // helper workgroups per full-sweep launch (0: none)
 };
@@ -74,8 +74,9 @@ struct bq_smo {
 // samples the walker (workgroup 0) is about to examine, out of the support list the walker keeps in global memory:
 //   * walker -> helpers: a control block {version, list length, position, window}.  The version is a sequence lock: odd
 //     while the walker edits the list (a pair step), bumped to the next even value afterwards.
-//   * helpers -> walker: spec_dot[s] tagged with the version it was formed under.  A helper wave re-reads the version
-//     after its gathers and drops the sum if the list moved meanwhile.
+//   * helpers -> walker: res[s] = {sum bits, version it was formed under, checksum}, one 16-byte write-through store
+//     (the data is its own flag: no fence on either side).  A helper wave re-reads the version after its gathers and
+//     drops the sum if the list moved meanwhile.
 //   * sample s of the window [position, position + window) belongs to helper wave ((s - base) mod 16 H), base = the
 //     walker's position when the version was published: consecutive samples go to different CUs, and right after a
 //     pair step (window H) it is wave 0 of each helper that forms one sum; every quiet batch doubles the window up to
@@ -89,25 +90,55 @@ struct bq_smo {
 // ---------------------------------------------------------------------------------------------------------------
 enum { SPEC_VER = 0, SPEC_NNZ = 1, SPEC_WIN = 2, SPEC_DONE = 3, SPEC_POS = 4 /* 64-bit, words 4-5 */,
        SPEC_BASE = 6 /* 64-bit: the walker's position when the version was published */,
-       SPEC_HASH = 8 /* 64-bit: multiset hash of the list entries of the published version */, SPEC_WORDS = 12 };
+       SPEC_HASH = 8 /* 64-bit: multiset hash of the list entries of the published version */,
+       // diagnostics, accumulated over the launches of a fit (bq_smo_get BQ_SMO_STATS): sums a helper formed under a stable
+       // version whose entries did not hash to the published value (a torn list: must stay 0), results whose checksum did
+       // not match their bits on the walker's side (a torn 16-byte granule: must stay 0), sums delivered
+       SPEC_REJ_HASH = 10, SPEC_REJ_CHK = 11, SPEC_DELIVERED = 12, SPEC_WORDS = 16 };
+typedef unsigned int smo_u4 __attribute__((ext_vector_type(4)));
 struct SmoSpec {
     unsigned int *ctl;
-    long long *dot;
-    long long *tag;
+    smo_u4 *res;
+    unsigned int res_bytes;
     unsigned int epoch;
     int helpers;
 };
+// res[s]: one naturally aligned 16-byte granule, written by ONE write-through (sc1) store of one lane and read by ONE sc1
+// load (MI355X_MICROARCH.md, inter-workgroup visibility: R2 — the data is the flag)
+__device__ __forceinline__ smo_u4 res_load(const SmoSpec &P, int64_t s) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)P.res, 0, (int)P.res_bytes, 0x00020000);
+    // aux: bit 4 = sc1, bit 31 = volatile (every call is a fresh load: the walker polls these words inside its gather loop)
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(s * 16), 0, (int)(0x80000000u | 16u));
+}
+__device__ __forceinline__ smo_u4 res_load_uni(const SmoSpec &P, int64_t s) {   // wave-uniform address: lane 0's copy
+    const smo_u4 v = res_load(P, s);
+    smo_u4 o;
+    o.x = (unsigned int)__builtin_amdgcn_readfirstlane((int)v.x);
+    o.y = (unsigned int)__builtin_amdgcn_readfirstlane((int)v.y);
+    o.z = (unsigned int)__builtin_amdgcn_readfirstlane((int)v.z);
+    o.w = (unsigned int)__builtin_amdgcn_readfirstlane((int)v.w);
+    return o;
+}
+__device__ __forceinline__ void res_store(const SmoSpec &P, int64_t s, long long bits, unsigned int ver, unsigned int chk) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)P.res, 0, (int)P.res_bytes, 0x00020000);
+    const smo_u4 v = {(unsigned int)bits, (unsigned int)((unsigned long long)bits >> 32), ver, chk};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(s * 16), 0, 16);
+}
+__device__ __forceinline__ long long res_bits(const smo_u4 &v) { return (long long)(((unsigned long long)v.y << 32) | v.x); }
 // Loads of the shared words.  Every lane of a wave reads the same address, but nothing makes the 64 lanes of one load
 // instruction observe the same store, and the code that follows branches on the value: lane 0's copy is broadcast so
 // that the whole wave takes one decision.
-__device__ __forceinline__ unsigned int ld_acq(const unsigned int *p) {
-    return (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-}
+// Every shared word is accessed through a GLOBAL (address space 1) pointer: global_load / global_store ... sc1, never flat_
+// (flat operations complete out of order with respect to the vmcnt the hand-off waits on).
+typedef __attribute__((address_space(1))) unsigned int smo_gu32;
+typedef __attribute__((address_space(1))) long long smo_gi64;
+#define SMO_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 __device__ __forceinline__ unsigned int ld_rlx(const unsigned int *p) {
-    return (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return (unsigned int)__builtin_amdgcn_readfirstlane(
+        (int)__hip_atomic_load((const smo_gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ long long ld_rlx64(const long long *p) {
-    const long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long v = __hip_atomic_load((const smo_gi64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
@@ -117,17 +148,34 @@ __device__ __forceinline__ long long ld_uni64(long long v) {   // lane 0's copy 
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ void st_rlx(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_rel(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_rlx64(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_rlx(unsigned int *p, unsigned int v) {
+    __hip_atomic_store((smo_gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_rlx64(long long *p, long long v) {
+    __hip_atomic_store((smo_gi64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a flag behind everything this WORKGROUP stored before its last barrier: agent-scope release (L2 write-back), an explicit
+// wait (the compiler may drop the fence's own), then the write-through store
+__device__ __forceinline__ void st_rel(unsigned int *p, unsigned int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    SMO_DRAIN();
+    __hip_atomic_store((smo_gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void fence_acq() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-// What makes a helper's sum acceptable does not rest on the caches alone (a load that was in flight across an
-// invalidate can leave a line of an older state behind, and such sums did change 1 SMO path in 50):
+// Ordering (MI355X_MICROARCH.md, inter-workgroup visibility).  Walker -> helpers: the list is edited with plain stores by all
+// sixteen waves; EVERY wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier, then thread 0 issues the
+// agent-scope release (L2 write-back), waits for it, stores the control words write-through, waits again, and only then
+// the new even version.  (Round 1 had a workgroup-scope fence in front of the barrier: it compiles to nothing another CU
+// can observe, so fifteen waves' list stores could still be in flight when the version appeared — a helper then formed a
+// sum from old entries under the new version: the 1-in-3-runs path change with 240+ helpers.)  Helpers: wave 0 polls
+// the version relaxed and runs ONE agent-scope acquire when it moves; every consuming wave runs its own acquire when it
+// picks a new version up, reads the list with agent-scope loads, runs an acquire between those loads and the re-check
+// of the version, and delivers only under an unchanged even version.
+// On top of that the results validate themselves, and the validations are COUNTED (they must never fire):
 //  * the walker publishes, with every list version, the sum over the list entries of a 64-bit mix of (index,
 //    coefficient bits) — order-free, so thread 0 keeps it current with one subtraction / addition per edit; a helper
-//    wave adds up the same mix over the entries it actually read and delivers only if the two agree;
-//  * a delivered sum is tagged (version << 32 | checksum of its own bits), so a tag of the current version next to a
-//    stale double is recognised as well.
+//    wave adds up the same mix over the entries it actually read and delivers only if the two agree (SPEC_REJ_HASH);
+//  * a delivered result carries a checksum of its own bits (SPEC_REJ_CHK on the walker's side).
 __device__ __forceinline__ unsigned long long entry_mix(unsigned int idx, double c) {
     unsigned long long x = (unsigned long long)__double_as_longlong(c) ^ ((unsigned long long)idx * 0x9E3779B97F4A7C15ull);
     x ^= x >> 29;
@@ -370,16 +418,18 @@ __device__ __forceinline__ void sup_apply(SupList &L, const SupGlobal &G, SmoSha
 __device__ __forceinline__ void spec_begin(const SmoSpec &P, SmoShared &S) {
     if (P.helpers == 0) return;
     if (threadIdx.x == 0) {
-        st_rlx(&P.ctl[SPEC_VER], S.ver + 1u);   // odd: the list is being edited
-        __threadfence();
+        st_rlx(&P.ctl[SPEC_VER], S.ver + 1u);   // odd: the list is being edited (write-through store)
+        SMO_DRAIN();                            // ... and has left this CU before any edit store is issued
     }
     __syncthreads();
 }
 __device__ __forceinline__ void spec_end(const SmoSpec &P, SmoShared &S, long long at) {
     if (P.helpers == 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's list stores have reached the L2 ...
+    SMO_DRAIN();   // EVERY wave: its list stores have reached the L2
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // write the XCD's dirty lines back device-wide ...
+        SMO_DRAIN();                                         // ... and wait for it (the compiler may drop the fence's own wait)
         S.ver += 2u;
         S.win = (unsigned int)P.helpers;   // one sample for wave 0 of every helper workgroup
         st_rlx(&P.ctl[SPEC_NNZ], (unsigned int)S.nnz);
@@ -387,7 +437,8 @@ __device__ __forceinline__ void spec_end(const SmoSpec &P, SmoShared &S, long lo
         st_rlx64((long long *)&P.ctl[SPEC_BASE], at);
         st_rlx64((long long *)&P.ctl[SPEC_POS], at);
         st_rlx64((long long *)&P.ctl[SPEC_HASH], (long long)S.hash);
-        st_rel(&P.ctl[SPEC_VER], S.ver);   // ... and are written back device-wide before the new even version is
+        SMO_DRAIN();                                         // the words of this version are out before the version itself
+        st_rlx(&P.ctl[SPEC_VER], S.ver);
     }
     __syncthreads();
 }
@@ -407,13 +458,13 @@ __device__ __forceinline__ unsigned int lds_uni(const volatile unsigned int *p) 
 template <typename T>
 __device__ __forceinline__ bool helper_sums(const KView<T> &K, int64_t n, const SupGlobal &G, const SmoSpec &P, unsigned int v,
                                             unsigned int win, int nnz, long long pos, long long base, long long mine,
-                                            long long stride) {
+                                            long long stride, unsigned int &delivered) {
     const int lane = threadIdx.x & 63;
     bool did = false;
     long long s = base + mine;
     if (s < pos) s += (pos - s + stride - 1) / stride * stride;
     for (; s < n && s < pos + (long long)win; s += stride) {
-        if ((unsigned int)((unsigned long long)ld_rlx64(&P.tag[s]) >> 32) == v) continue;
+        if (res_load_uni(P, s).z == v) continue;   // already delivered under this version
         double part = 0.0;   // the sum of wave_dot, from the global copy of the list
         unsigned long long seen = 0ull;   // entry_mix over the entries this lane read
         for (int q0 = lane; q0 < nnz; q0 += 64 * 8) {
@@ -422,16 +473,14 @@ __device__ __forceinline__ bool helper_sums(const KView<T> &K, int64_t n, const 
             for (int u = 0; u < 8; ++u) {
                 const int q = q0 + 64 * u;
                 const bool in = q < nnz;
-                // The list is read with agent-scope loads, not through this CU's L1 / this XCD's L2: those are refreshed
-                // only when wave 0 of the workgroup looks at the version, and a fill that was in flight across that
-                // invalidate can leave a line of the previous list behind — a sum from it would carry the new version
-                // (seen as a 1-in-50-runs change of an SVR path before these loads were made coherent).
-                cf[u] = in ? __longlong_as_double(__hip_atomic_load((const long long *)&G.cf[q], __ATOMIC_RELAXED,
+                // The list is read with agent-scope (sc1) loads, which do not go through this CU's L1
+                cf[u] = in ? __longlong_as_double(__hip_atomic_load((const smo_gi64 *)&G.cf[q], __ATOMIC_RELAXED,
                                                                     __HIP_MEMORY_SCOPE_AGENT))
                            : 0.0;
                 // while the walker edits the list an entry can be anything; the sum is dropped below, but the
                 // panel read must stay inside the panel
-                const unsigned int j = in ? (unsigned int)__hip_atomic_load(&G.nz[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const unsigned int j = in ? (unsigned int)__hip_atomic_load((const __attribute__((address_space(1))) int *)&G.nz[q],
+                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 kv[u] = in ? K.at(s, j < (unsigned long long)n ? (int64_t)j : 0) : 0.0;
                 if (in) seen += entry_mix(j, cf[u]);
             }
@@ -447,14 +496,16 @@ __device__ __forceinline__ bool helper_sums(const KView<T> &K, int64_t n, const 
         fence_acq();   // the list reads above are complete before the control block is looked at again
         const unsigned long long want = (unsigned long long)ld_rlx64((const long long *)&P.ctl[SPEC_HASH]);
         if (ld_rlx(&P.ctl[SPEC_VER]) != v) break;   // the list moved under the gathers: drop the sum
-        if (seen != want) continue;                 // some entry read was not of this version: drop the sum
+        if (seen != want) {                         // entries of another version under a stable version: must not happen
+            if (lane == 0) atomicAdd(&P.ctl[SPEC_REJ_HASH], 1u);
+            continue;
+        }
         if (lane == 0) {
             const long long bits = __double_as_longlong(part);
-            st_rlx64(&P.dot[s], bits);
-            __hip_atomic_store(&P.tag[s], (long long)(((unsigned long long)v << 32) | dot_check(bits)), __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            res_store(P, s, bits, v, dot_check(bits));
         }
         did = true;
+        ++delivered;
     }
     return did;
 }
@@ -474,11 +525,16 @@ __device__ void smo_helper(const KView<T> &K, int64_t n, const SupGlobal &G, con
         hb->quit = 0u;
     }
     __syncthreads();
+    unsigned int delivered = 0u;
     if (wv == 0) {
-        unsigned int seq = 0u;
+        unsigned int seq = 0u, last_v = 1u;
         while (true) {
             const unsigned int quit = ld_rlx(&P.ctl[SPEC_DONE]) == P.epoch ? 1u : 0u;
-            const unsigned int v = ld_acq(&P.ctl[SPEC_VER]);
+            const unsigned int v = ld_rlx(&P.ctl[SPEC_VER]);   // ONE relaxed poll ...
+            if (v != last_v) {
+                fence_acq();                                    // ... ONE agent-scope acquire when the version has moved
+                last_v = v;
+            }
             const unsigned int win = ld_rlx(&P.ctl[SPEC_WIN]);
             const int nnz = (int)ld_rlx(&P.ctl[SPEC_NNZ]);
             const long long pos = ld_rlx64((const long long *)&P.ctl[SPEC_POS]);
@@ -500,11 +556,11 @@ __device__ void smo_helper(const KView<T> &K, int64_t n, const SupGlobal &G, con
             seq += 2u;
             if (quit) break;
             bool did = false;
-            if (!(v & 1u) && win != 0u) did = helper_sums(K, n, G, P, v, win, nnz, pos, base, mine, stride);
+            if (!(v & 1u) && win != 0u) did = helper_sums(K, n, G, P, v, win, nnz, pos, base, mine, stride, delivered);
             if (!did) __builtin_amdgcn_s_sleep(32);   // ~0.9 us between looks at the shared line
         }
     } else {
-        unsigned int seen = 0u;
+        unsigned int seen = 0u, last_v = 1u;
         while (true) {
             const unsigned int s1 = lds_uni(&hb->seq);
             if ((s1 & 1u) || s1 == seen) {   // being rewritten, or nothing new since the last pass
@@ -520,10 +576,16 @@ __device__ void smo_helper(const KView<T> &K, int64_t n, const SupGlobal &G, con
             seen = s1;
             if (quit) break;
             if ((v & 1u) || win == 0u) continue;
+            if (v != last_v) {   // this wave's own agent-scope acquire for the version it is about to read the list under
+                fence_acq();
+                last_v = v;
+            }
             helper_sums(K, n, G, P, v, win, (int)nnz, (long long)(((unsigned long long)phi << 32) | plo),
-                        (long long)(((unsigned long long)bhi << 32) | blo), mine, stride);
+                        (long long)(((unsigned long long)bhi << 32) | blo), mine, stride, delivered);
         }
     }
+    delivered = (unsigned int)__builtin_amdgcn_readfirstlane((int)delivered);
+    if (lane == 0 && delivered) atomicAdd(&P.ctl[SPEC_DELIVERED], delivered);
 }
 
 constexpr int SMO_B = SMO_T / 64;
@@ -538,13 +600,12 @@ __device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, 
         // Right after a pair step the tag of this sample travels with the chunk's gathers (one more load in flight, no
         // extra round trip: the helpers have had no time yet).  Once the look-ahead has grown the helpers are ahead of
         // the walk and the tag is looked at first — gathers the walker does not issue are what makes it fast.
-        long long tag = 0;
+        smo_u4 res = {0u, 0u, 0u, 0u};
         if (P.helpers != 0) {
-            tag = ld_rlx64(&P.tag[s]);
-            if (ahead && (unsigned int)((unsigned long long)tag >> 32) == ver) {
-                fence_acq();
-                const long long bits = ld_rlx64(&P.dot[s]);
-                if (dot_check(bits) == (unsigned int)tag) return __longlong_as_double(bits);
+            res = res_load_uni(P, s);
+            if (ahead && res.z == ver) {
+                if (dot_check(res_bits(res)) == res.w) return __longlong_as_double(res_bits(res));
+                if ((threadIdx.x & 63) == 0) atomicAdd(&P.ctl[SPEC_REJ_CHK], 1u);
             }
         }
         double kv[8], cf[8];
@@ -555,10 +616,9 @@ __device__ __forceinline__ double wave_dot(const KView<T> &K, const SupList &L, 
             cf[u] = in ? sup_cf(L, G, q) : 0.0;
             kv[u] = in ? K.at(s, sup_idx(L, G, q)) : 0.0;
         }
-        if (P.helpers != 0 && (unsigned int)((unsigned long long)tag >> 32) == ver) {   // wave-uniform: a helper has formed this very sum
-            fence_acq();
-            const long long bits = ld_rlx64(&P.dot[s]);
-            if (dot_check(bits) == (unsigned int)tag) return __longlong_as_double(bits);
+        if (P.helpers != 0 && !ahead && res.z == ver) {   // wave-uniform: a helper has formed this very sum
+            if (dot_check(res_bits(res)) == res.w) return __longlong_as_double(res_bits(res));
+            if ((threadIdx.x & 63) == 0) atomicAdd(&P.ctl[SPEC_REJ_CHK], 1u);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -813,11 +873,13 @@ __global__ __launch_bounds__(SMO_T) void smo_svc_kernel(KView<T> K, int64_t n, c
                         const double a2 = in ? a[sw] : 0.0, y2 = in ? y[sw] : 0.0;
                         const bool free2 = in && a2 > 0.0 && a2 < C;
                         const bool need = in && !free2;
-                        const long long tag = need ? __hip_atomic_load(&P.tag[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                        if (__ballot(need && (unsigned int)((unsigned long long)tag >> 32) != S.ver) == 0ull) {
-                            fence_acq();
-                            const long long bits = need ? __hip_atomic_load(&P.dot[sw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                            if (__ballot(need && dot_check(bits) != (unsigned int)tag) == 0ull) {
+                        smo_u4 res = {0u, 0u, 0u, 0u};
+                        if (need) res = res_load(P, sw);
+                        const long long bits = res_bits(res);
+                        if (__ballot(need && res.z != S.ver) == 0ull) {
+                            const unsigned long long bad = __ballot(need && dot_check(bits) != res.w);
+                            if (bad != 0ull && lane == 0) atomicAdd(&P.ctl[SPEC_REJ_CHK], (unsigned int)__popcll(bad));
+                            if (bad == 0ull) {
                                 double E2 = 0.0;
                                 if (need)
                                     E2 = __longlong_as_double(bits) - y2;
@@ -1317,7 +1379,7 @@ extern "C" int bq_smo_destroy(bq_smo *s) {
     hipSetDevice(s->p->ctx->device);
     hipStreamSynchronize(s->p->ctx->stream);
     for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->nz, (void *)s->cf, (void *)s->sc,
-                      (void *)s->ctl, (void *)s->spec_dot, (void *)s->spec_tag})
+                      (void *)s->ctl, (void *)s->spec_res})
         if (ptr) hipFree(ptr);
     delete s;
     return BQ_OK;
@@ -1372,12 +1434,12 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
     s->helpers = std::max(0, std::min(s->helpers, cus - 1));
     if (s->helpers < SMO_T / 64) s->helpers = 0;   // the first batch after a pair step wants one CU per sample
     if (e == hipSuccess && s->helpers) {
-        const unsigned int ctl0[SPEC_WORDS] = {2u};   // version 2: tag 0 never matches
+        const unsigned int ctl0[SPEC_WORDS] = {2u};   // version 2: a zeroed result (version 0) never matches
         e = hipMalloc(&s->ctl, sizeof(ctl0));
         if (e == hipSuccess) e = hipMemcpyAsync(s->ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMalloc(&s->spec_dot, sizeof(long long) * n);
-        if (e == hipSuccess) e = hipMalloc(&s->spec_tag, sizeof(long long) * n);
-        if (e == hipSuccess) e = hipMemsetAsync(s->spec_tag, 0, sizeof(long long) * n, c->stream);
+        if (n * 16 >= ((int64_t)1 << 31)) e = hipErrorInvalidValue;   // 32-bit byte offsets of the result buffer
+        if (e == hipSuccess) e = hipMalloc(&s->spec_res, (size_t)16 * n);
+        if (e == hipSuccess) e = hipMemsetAsync(s->spec_res, 0, (size_t)16 * n, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // ctl0 lives on this stack frame
     }
     if (e == hipSuccess) e = hipMemcpyAsync(s->y, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
@@ -1415,7 +1477,7 @@ extern "C" int bq_smo_run(bq_smo *s, int64_t max_outer, int64_t *outer_iters, in
     for (int64_t k = 0; k < max_outer && !s->host.finished; ++k) {
         // full sweeps take the helper workgroups along; free-set sweeps walk the (short) support list alone
         const int helpers = s->host.sweep_all ? s->helpers : 0;
-        const SmoSpec P{s->ctl, s->spec_dot, s->spec_tag, helpers ? ++s->epoch : 0u, helpers};
+        const SmoSpec P{s->ctl, (smo_u4 *)s->spec_res, (unsigned int)(16 * s->n), helpers ? ++s->epoch : 0u, helpers};
         const dim3 grid(1 + helpers);
         const SupGlobal G{s->nz, s->cf};
         const int64_t ld = p->symmetric ? 0 : p->ld;
@@ -1468,6 +1530,15 @@ extern "C" int bq_smo_get(bq_smo *s, int what, double *out) {
             out[4] = (double)s->host.steps;
             out[5] = s->task == BQ_SVC ? -(s->host.b_low + s->host.b_up) / 2 : (s->host.b_low + s->host.b_up) / 2;
             break;
+        case BQ_SMO_STATS: {
+            unsigned int w[SPEC_WORDS] = {0};
+            if (s->ctl) BQ_HIP(hipMemcpy(w, s->ctl, sizeof(w), hipMemcpyDeviceToHost));
+            out[0] = (double)s->helpers;
+            out[1] = (double)w[SPEC_DELIVERED];
+            out[2] = (double)w[SPEC_REJ_HASH];
+            out[3] = (double)w[SPEC_REJ_CHK];
+            break;
+        }
         default:
             bq_set_error("bad argument: what");
             return BQ_ERR_BADARG;

@@ -12,8 +12,11 @@
 // step are accumulated over the whole strip and then reduced across the 64 lanes with a halving butterfly
 // (4 row sums in 7 shuffle-adds).  Slab traffic is about n^2*8/T*(1/2 + 1/(2 JG)) bytes each way (~1 % of the tile bytes).
 //
-// Multi-GPU: rank r owns the tile rows [I_r, I_r+1) of a balanced triangular partition and therefore produces
-// partial sums for every output block; the partial vectors are combined by one all-reduce(sum) per product.
+// Multi-GPU: the tile rows are cut into S canonical SEGMENTS with equal shares of the triangle's tiles (bq_common.h); a rank
+// owns a contiguous run of segments and produces, per segment, a partial vector for every output block.  One in-place
+// all-gather per product hands every rank all S segment vectors, which are then added in segment order — the same
+// association for any rank count, so 1/2/4/8-GPU iterates are bit-identical.  (BQ_SYM_EXCHANGE=allreduce: each rank adds
+// its own segments and the rank partials meet in one ncclAllReduce — the sum's association then depends on the ring.)
 #include <cstdlib>
 
 #include "bq_common.h"
@@ -183,23 +186,17 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
     }
 }
 
-// out[a*T + r] = sum of the slab entries S[a][b] this rank produced, b ascending:
-//   row parts live at b = first tile of a strip (b % JG == 0, b <= a) when tile row a is ours,
-//   col parts at every b > a that is one of our tile rows.
+// Partial sum of output block a over the slab entries S[a][b] that the tile rows [c0, c1) produced, b ascending:
+//   row parts live at b = first tile of a strip (b % JG == 0, b <= a) when tile row a lies in [c0, c1),
+//   col parts at every b > a inside [c0, c1).
+// 1024 threads: thread (r, q) sums every 4th entry of that fixed entry list (two independent chains each for load-level
+// parallelism); the four partial sums are combined in the fixed order q = 0..3.  Every thread returns the combined value.
 template <int JG>
-__global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, int64_t I0,
-                                                           int64_t I1, double *__restrict__ out,
-                                                           const int *__restrict__ done) {
-    if (done != nullptr && *done) return;
-    // 1024 threads: thread (r, q) sums every 4th entry of the fixed entry list of output block a (two independent
-    // chains each for load-level parallelism); the four partial sums are combined in the fixed order q = 0..3
-    __shared__ double part[4][ST];
-    const int64_t a = blockIdx.x;
-    const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
-    const double *p = slab + a * nb * ST + r;
+__device__ __forceinline__ double seg_partial(const double *__restrict__ p, int64_t a, int64_t c0, int64_t c1, int q, int r,
+                                              double (*part)[ST]) {
     double s0 = 0.0, s1 = 0.0;
     int64_t e = 0;   // running index over the entry list: row parts (b = 0, JG, 2JG, ... <= a) then col parts (b > a)
-    if (a >= I0 && a < I1) {
+    if (a >= c0 && a < c1) {
         const int64_t nrow = a / JG + 1;
         for (int64_t k = q; k < nrow; k += 8) {
             s0 += p[(k * JG) * ST];
@@ -207,8 +204,8 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
         }
         e = nrow;
     }
-    const int64_t bs = (a + 1 > I0) ? a + 1 : I0;
-    const int64_t ncol = I1 > bs ? I1 - bs : 0;
+    const int64_t bs = (a + 1 > c0) ? a + 1 : c0;
+    const int64_t ncol = c1 > bs ? c1 - bs : 0;
     // keep the q-assignment a function of the position in the whole list (row parts first)
     const int64_t shift = (4 - (e & 3)) & 3;
     for (int64_t k = (q + shift) & 3; k < ncol; k += 8) {
@@ -217,13 +214,55 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
     }
     part[q][r] = s0 + s1;
     __syncthreads();
-    if (q == 0) out[a * ST + r] = ((part[0][r] + part[1][r]) + part[2][r]) + part[3][r];
+    const double v = ((part[0][r] + part[1][r]) + part[2][r]) + part[3][r];
+    __syncthreads();
+    return v;
+}
+
+// out[a*T + r] = sum over the segments [tab.lo, tab.hi) of their partial sums, in segment order — the canonical order of
+// the product: the same association whether the segments were summed here (one rank) or gathered from their owners
+template <int JG>
+__global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, bq_seg_table tab,
+                                                           double *__restrict__ out, const int *__restrict__ done) {
+    if (done != nullptr && *done) return;
+    __shared__ double part[4][ST];
+    const int64_t a = blockIdx.x;
+    const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
+    const double *p = slab + a * nb * ST + r;
+    double acc = 0.0;
+    for (int s = tab.lo; s < tab.hi; ++s) acc += seg_partial<JG>(p, a, tab.cut[s], tab.cut[s + 1], q, r, part);
+    if (q == 0) out[a * ST + r] = acc;
+}
+
+// the per-segment partial vectors of this rank's segments, each to its slot of the gathered buffer
+template <int JG>
+__global__ __launch_bounds__(1024) void symv_reduce_seg_kernel(const double *__restrict__ slab, int64_t nb, bq_seg_table tab,
+                                                               double *__restrict__ gath, const int *__restrict__ done) {
+    if (done != nullptr && *done) return;
+    __shared__ double part[4][ST];
+    const int64_t a = blockIdx.x;
+    const int s = tab.lo + (int)blockIdx.y;
+    const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
+    const double v = seg_partial<JG>(slab + a * nb * ST + r, a, tab.cut[s], tab.cut[s + 1], q, r, part);
+    if (q == 0) gath[((int64_t)tab.slot[s] * nb + a) * ST + r] = v;
+}
+
+// out = sum of all S gathered segment vectors in segment order (every rank: identical bits)
+__global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restrict__ gath, int64_t len, bq_seg_table tab,
+                                                          double *__restrict__ out, const int *__restrict__ done) {
+    if (done != nullptr && *done) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    double acc = 0.0;
+    for (int s = 0; s < tab.count; ++s) acc += gath[(int64_t)tab.slot[s] * len + i];
+    out[i] = acc;
 }
 
 template <int JG, int SR>
-static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
-                          int64_t ld, const double *w, double *slab, double *out, const int *done) {
+static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
+                        const double *w, double *slab, const int *done) {
     const int64_t nstrips = strips_before<JG>(I1) - strips_before<JG>(I0);
+    const int64_t ld = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
     if (nstrips > 0) {
@@ -241,27 +280,55 @@ static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_
         }
     }
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
-    symv_reduce_kernel<JG><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, I0, I1, out, done);
+    return BQ_OK;
+}
+
+// mode 0: tiles + the sum over this launch's segments -> out (nb*256);  mode 1: tiles + one vector per segment -> gath slots
+template <int JG, int SR>
+static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
+                          const double *w, double *slab, double *out, int mode, const int *done) {
+    BQ_TRY((launch_tiles<JG, SR>(ctx, panel, storage, add_one, tab.cut[tab.lo], tab.cut[tab.hi], nb, w, slab, done)));
+    if (mode == 0)
+        symv_reduce_kernel<JG><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done);
+    else if (tab.hi > tab.lo)
+        symv_reduce_seg_kernel<JG><<<dim3((unsigned)nb, (unsigned)(tab.hi - tab.lo)), 1024, 0, ctx->stream>>>(slab, nb, tab, out, done);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
 
-int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
-                   int64_t ld, const double *w, double *slab, double *out, const int *done) {
+static int launch_any(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
+                      const double *w, double *slab, double *out, int mode, const int *done) {
     // BQ_SYMV_VARIANT=<tiles per strip><rows per step> selects a tuning variant (benchmarking only)
     static const int variant = [] {
         const char *e = getenv("BQ_SYMV_VARIANT");
         return e ? atoi(e) : 84;
     }();
     switch (variant) {
-        case 44: return launch_variant<4, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
-        case 48: return launch_variant<4, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
-        case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
-        case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
-        case 88: return launch_variant<8, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+        case 44: return launch_variant<4, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+        case 48: return launch_variant<4, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+        case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+        case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+        case 88: return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
         default:
             // fp32 tiles are half as wide in bytes: 8 rows per step keep the same bytes in flight per lane
-            if (storage == BQ_F32) return launch_variant<8, 8>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
-            return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, I0, I1, nb, ld, w, slab, out, done);
+            if (storage == BQ_F32) return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+            return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
     }
+}
+
+int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
+                   const double *w, double *slab, double *out, const int *done) {
+    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, out, 0, done);
+}
+
+int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
+                            const double *w, double *slab, double *gath, const int *done) {
+    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, gath, 1, done);
+}
+
+int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done) {
+    const int64_t len = nb * ST;
+    symv_segsum_kernel<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(gath, len, tab, out, done);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
 }

@@ -94,7 +94,8 @@ __global__ void finish_kernel(int structure, int64_t n, int64_t N, double diag_a
 }
 
 // p->s = P w on every rank, P the resident panel (elements optionally +1).  Row-block panels: local rows + all-gather;
-// symmetric tile panels: local lower-triangle tiles (both contributions) + all-reduce(sum).
+// symmetric tile panels: local lower-triangle tiles (both contributions), one partial vector per canonical segment,
+// all-gather of the segment vectors + their sum in segment order (or, BQ_SYM_EXCHANGE=allreduce, one all-reduce(sum)).
 int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done) {
     bq_ctx *ctx = p->ctx;
     if (p->streamed) {   // no panel: Gram tiles recomputed inside the product (bq_gram.hip), row blocks + all-gather
@@ -103,8 +104,18 @@ int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *do
         return bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1);
     }
     if (p->symmetric) {
-        BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->I0, p->I1, p->nb, p->ld, w, p->slab, p->s, done));
-        if (ctx->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_sum(ctx, p->s, p->nb * BQ_SYM_TILE));
+        bq_seg_table tab;
+        bq_sym_seg_table(p, &tab);
+        if (ctx->comm_kind == BQ_COMM_NONE) {
+            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->s, done));
+        } else if (ctx->sym_allreduce) {   // rank partials meet in one all-reduce(sum): association depends on the transport
+            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->s, done));
+            BQ_TRY(bq_exchange_sum(ctx, p->s, p->nb * BQ_SYM_TILE));
+        } else {   // default: all-gather of the segment vectors, summed in segment order on every rank (bit-identical for any world)
+            BQ_TRY(bq_launch_symv_segments(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->gath, done));
+            BQ_TRY(bq_exchange_gather(ctx, p->gath, (int64_t)p->seg_cmax * p->nb * BQ_SYM_TILE));
+            BQ_TRY(bq_launch_symv_segsum(ctx, p->nb, tab, p->gath, p->s, done));
+        }
     } else {
         BQ_TRY(bq_launch_gemv(ctx, p->panel, p->storage, add_one, p->r1 - p->r0, p->ld, w, p->s + p->r0, done));
         if (ctx->comm_kind != BQ_COMM_NONE) BQ_TRY(bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1));

@@ -34,7 +34,11 @@ def row_block(n, rank, world, symmetric=False):
 
 
 class Context:
-    def __init__(self, device=None, comm=None, exchange='rccl'):
+    def __init__(self, device=None, comm=None, exchange='rccl', sym_exchange=None):
+        """exchange: 'rccl' (RCCL over xGMI) or 'host' (the communicator's host collectives; tests).  sym_exchange: how the
+        products of symmetric kernel panels are closed — 'gather' (default: all-gather of the per-segment partial vectors,
+        added in segment order on every rank, bit-identical iterates for any rank count) or 'allreduce' (one all-reduce(sum);
+        the association of the rank sum then belongs to the transport).  None: the BQ_SYM_EXCHANGE environment variable."""
         lib = _lib.load()
         self._lib = lib
         self._h = C.c_void_p()
@@ -83,6 +87,10 @@ class Context:
             _lib.check(lib.bq_ctx_create_exchange(device, comm.rank, comm.world_size, self._cb, None, C.byref(self._h)))
         else:
             raise ValueError(f"unknown exchange '{exchange}' (use 'rccl' or 'host')")
+        if sym_exchange is not None:
+            if sym_exchange not in ('gather', 'allreduce'):
+                raise ValueError(f"unknown sym_exchange '{sym_exchange}' (use 'gather' or 'allreduce')")
+            _lib.check(lib.bq_ctx_set_sym_allreduce(self._h, 1 if sym_exchange == 'allreduce' else 0))
 
     @property
     def handle(self):
@@ -95,6 +103,14 @@ class Context:
         buf = C.create_string_buffer(128)
         _lib.check(self._lib.bq_ctx_info(self.handle, None, None, None, buf, 128))
         return buf.value.decode()
+
+    def comm_info(self):
+        """{'kind': 'none'|'rccl'|'callback', 'rccl_ranks': ncclCommCount of the live communicator (0 without RCCL),
+        'sym_exchange': 'gather'|'allreduce'}"""
+        kind, ranks, ar = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self._lib.bq_ctx_comm_info(self.handle, C.byref(kind), C.byref(ranks), C.byref(ar)))
+        return {'kind': ('none', 'rccl', 'callback')[kind.value], 'rccl_ranks': ranks.value,
+                'sym_exchange': 'allreduce' if ar.value else 'gather'}
 
     def profile(self, enable=True):
         _lib.check(self._lib.bq_ctx_profile(self.handle, 1 if enable else 0))
@@ -139,6 +155,6 @@ def set_context(ctx):
     return ctx
 
 
-def init_distributed(comm, exchange='rccl', device=None):
+def init_distributed(comm, exchange='rccl', device=None, sym_exchange=None):
     """Make the default context a multi-rank one (call once per process, before building problems)."""
-    return set_context(Context(device=device, comm=comm, exchange=exchange))
+    return set_context(Context(device=device, comm=comm, exchange=exchange, sym_exchange=sym_exchange))

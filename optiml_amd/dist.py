@@ -3,10 +3,11 @@
 A communicator provides: rank, world_size, broadcast_bytes(data, src), allgather_rows(buf, r0, r1),
 allreduce_sum(buf), barrier(), max_float(x).  `TorchComm` rides on an initialised torch.distributed process group (gloo on the host; the
 launcher `python -m torch.distributed.run` sets RANK/WORLD_SIZE/MASTER_*); `SocketComm` is a dependency-free
-TCP star for environments without torch.  torch is plumbing here, never on the compute path.
+TCP star for environments without torch (loopback by default, HMAC hello handshake, raw length-bounded frames).  torch is plumbing here, never on the compute path.
 """
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
@@ -82,9 +83,18 @@ class TorchComm(_Base):
         return float(t.item())
 
 
-def _send_msg(sock, obj):
-    data = pickle.dumps(obj, protocol=4)
-    sock.sendall(struct.pack('!Q', len(data)) + data)
+# Wire format of SocketComm: a fixed 16-byte header (magic, kind, payload length) followed by raw bytes — byte strings and
+# float64 arrays only, length-bounded; nothing received is ever unpickled or evaluated.
+_MAGIC = b'BQRV'
+_HDR = struct.Struct('!4sIQ')
+_K_NONE, _K_BYTES, _K_F64, _K_ROWS, _K_HELLO = range(5)
+_MAX_MSG = 1 << 31
+
+
+def _send_msg(sock, kind, payload=b''):
+    if len(payload) > _MAX_MSG:
+        raise ValueError('rendezvous message too large')
+    sock.sendall(_HDR.pack(_MAGIC, kind, len(payload)) + payload)
 
 
 def _recv_exact(sock, n):
@@ -98,13 +108,26 @@ def _recv_exact(sock, n):
     return b''.join(chunks)
 
 
-def _recv_msg(sock):
-    (n,) = struct.unpack('!Q', _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+def _recv_msg(sock, expect=None):
+    magic, kind, n = _HDR.unpack(_recv_exact(sock, _HDR.size))
+    if magic != _MAGIC or n > _MAX_MSG or (expect is not None and kind not in expect):
+        raise ConnectionError('malformed rendezvous message')
+    return kind, _recv_exact(sock, n)
+
+
+def _secret(port):
+    """Shared secret of the hello handshake: BQ_RENDEZVOUS_SECRET, or a token of (port, uid) so that unrelated jobs of one
+    host do not cross-connect.  Set the variable on every rank when the rendezvous port is reachable by others."""
+    tok = os.environ.get('BQ_RENDEZVOUS_SECRET')
+    if tok is None:
+        tok = 'bq-%d-%d' % (port, os.getuid() if hasattr(os, 'getuid') else 0)
+    return hashlib.sha256(tok.encode()).digest()
 
 
 class SocketComm(_Base):
-    """TCP star through rank 0 (gather + scatter); small control-plane messages only."""
+    """TCP star through rank 0 (gather + scatter); small control-plane messages only.  Rank 0 binds the given address
+    (loopback by default), admits a peer only after an HMAC handshake on the shared secret, and exchanges nothing but
+    length-bounded byte strings / float64 arrays."""
 
     def __init__(self, rank, world_size, addr='127.0.0.1', port=29533, timeout=120.0):
         self.rank, self.world_size = rank, world_size
@@ -112,6 +135,7 @@ class SocketComm(_Base):
         self._sock = None
         if world_size == 1:
             return
+        key = _secret(port)
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -121,8 +145,19 @@ class SocketComm(_Base):
             peers = {}
             while len(peers) < world_size - 1:
                 conn, _ = srv.accept()
+                conn.settimeout(timeout)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                peers[_recv_msg(conn)] = conn
+                try:   # challenge / response: the peer proves it holds the secret before anything else is read from it
+                    nonce = os.urandom(16)
+                    _send_msg(conn, _K_HELLO, nonce)
+                    _, reply = _recv_msg(conn, (_K_HELLO,))
+                    r, mac = struct.unpack('!I', reply[:4])[0], reply[4:]
+                    good = hmac.compare_digest(mac, hmac.new(key, nonce + reply[:4], hashlib.sha256).digest())
+                    if not good or not (0 < r < world_size) or r in peers:
+                        raise ConnectionError('rendezvous handshake refused')
+                    peers[r] = conn
+                except (ConnectionError, struct.error, socket.timeout):
+                    conn.close()
             srv.close()
             self._peers = [peers[r] for r in range(1, world_size)]
         else:
@@ -137,53 +172,71 @@ class SocketComm(_Base):
                     time.sleep(0.05)
             s.settimeout(timeout)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send_msg(s, rank)
+            _, nonce = _recv_msg(s, (_K_HELLO,))
+            me = struct.pack('!I', rank)
+            _send_msg(s, _K_HELLO, me + hmac.new(key, nonce + me, hashlib.sha256).digest())
             self._sock = s
 
-    def _gather(self, obj):
+    def _gather(self, kind, payload):
+        """rank 0: list of every rank's payload (own first); other ranks: None"""
         if self.world_size == 1:
-            return [obj]
+            return [payload]
         if self.rank == 0:
-            return [obj] + [_recv_msg(p) for p in self._peers]
-        _send_msg(self._sock, obj)
+            return [payload] + [_recv_msg(p, (kind,))[1] for p in self._peers]
+        _send_msg(self._sock, kind, payload)
         return None
 
-    def _bcast(self, obj):
+    def _bcast(self, kind, payload):
         if self.world_size == 1:
-            return obj
+            return payload
         if self.rank == 0:
             for p in self._peers:
-                _send_msg(p, obj)
-            return obj
-        return _recv_msg(self._sock)
+                _send_msg(p, kind, payload)
+            return payload
+        return _recv_msg(self._sock, (kind,))[1]
 
     def broadcast_bytes(self, data, src=0):
         if src != 0:
             raise ValueError('SocketComm broadcasts from rank 0 only')
-        return self._bcast(bytes(data) if self.rank == 0 else None)
+        return self._bcast(_K_BYTES, bytes(data) if self.rank == 0 else b'')
 
     def allgather_rows(self, buf, r0, r1):
-        parts = self._gather((r0, r1, np.array(buf[r0:r1], copy=True)))
-        parts = self._bcast(parts)
-        for b, e, arr in parts:
+        mine = struct.pack('!qq', r0, r1) + np.ascontiguousarray(buf[r0:r1], dtype=np.float64).tobytes()
+        parts = self._gather(_K_ROWS, mine)
+        blob = self._bcast(_K_ROWS, b''.join(struct.pack('!Q', len(p)) + p for p in parts) if parts is not None else b'')
+        off = 0
+        while off < len(blob):
+            (ln,) = struct.unpack_from('!Q', blob, off)
+            b, e = struct.unpack_from('!qq', blob, off + 8)
+            if not (0 <= b <= e <= buf.shape[0]) or ln != 16 + 8 * (e - b):
+                raise ConnectionError('malformed row block in the rendezvous exchange')
             if e > b:
-                buf[b:e] = arr
+                buf[b:e] = np.frombuffer(blob, dtype=np.float64, count=e - b, offset=off + 24)
+            off += 8 + ln
 
     def allreduce_sum(self, buf):
-        parts = self._gather(np.array(buf, copy=True))
-        total = None
+        parts = self._gather(_K_F64, np.ascontiguousarray(buf, dtype=np.float64).tobytes())
+        total = b''
         if parts is not None:
-            total = parts[0].copy()
+            acc = np.frombuffer(parts[0], dtype=np.float64).copy()
             for p in parts[1:]:      # fixed rank order -> deterministic
-                total += p
-        buf[:] = self._bcast(total)
+                if len(p) != acc.nbytes:
+                    raise ConnectionError('length mismatch in the rendezvous all-reduce')
+                acc += np.frombuffer(p, dtype=np.float64)
+            total = acc.tobytes()
+        out = self._bcast(_K_F64, total)
+        if len(out) != 8 * buf.shape[0]:
+            raise ConnectionError('length mismatch in the rendezvous all-reduce')
+        buf[:] = np.frombuffer(out, dtype=np.float64)
 
     def barrier(self):
-        self._bcast(self._gather(None) and None)
+        self._gather(_K_NONE, b'')
+        self._bcast(_K_NONE, b'')
 
     def max_float(self, x):
-        vals = self._gather(float(x))
-        return self._bcast(max(vals) if vals is not None else None)
+        vals = self._gather(_K_F64, struct.pack('!d', float(x)))
+        out = self._bcast(_K_F64, struct.pack('!d', max(struct.unpack('!d', v)[0] for v in vals)) if vals is not None else b'')
+        return struct.unpack('!d', out)[0]
 
     def close(self):
         for p in self._peers:

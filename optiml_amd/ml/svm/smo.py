@@ -75,6 +75,11 @@ class SMO(ABC):
             _lib.check(lib.bq_smo_get(h, _lib.SMO_SCALARS, _lib.ptr(sc)))
             self.b_up, self.b_low, self.b_up_idx, self.b_low_idx = sc[0], sc[1], int(sc[2]), int(sc[3])
             self.steps, self.b = int(sc[4]), sc[5]
+            st = np.empty(4)
+            _lib.check(lib.bq_smo_get(h, _lib.SMO_STATS, _lib.ptr(st)))
+            # self-checks of the helper hand-off (bq_smo.hip): the two rejection counts must be 0
+            self.helper_stats = {'helpers': int(st[0]), 'delivered': int(st[1]), 'rejected_list_hash': int(st[2]),
+                                 'rejected_checksum': int(st[3])}
             _lib.check(lib.bq_smo_get(h, _lib.SMO_ERRORS, _lib.ptr(self.errors)))
             if isinstance(self.kernel, LinearKernel):
                 self.w = self._coefficients() @ self.X      # smo.py:193-196 / :595-598 accumulated over the steps

@@ -4,6 +4,7 @@ usage: python tests/_dist_worker.py MODE OUTDIR      with RANK / WORLD_SIZE / MA
   cpu-torch / cpu-socket : communicator primitives + a row-sharded product with the CPU oracle's Hessian (no GPU)
   gpu-host               : every rank on GPU 0, row-block panels, host (gloo) exchange, PG + FW solves
   gpu-rccl               : RCCL exchange (world size 1 on a one-GPU box exercises init / all-gather / destroy)
+  gpu-host-allreduce / gpu-rccl-allreduce : the same with sym_exchange='allreduce'
 """
 import os
 import sys
@@ -48,17 +49,18 @@ def cpu_mode(kind, outdir):
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)
 
 
-def gpu_mode(exchange, outdir):
+def gpu_mode(exchange, outdir, sym_exchange=None):
     from optiml_amd import device, _lib
     from optiml_amd.datasets import make_blobs, make_regression
     from optiml_amd.ml.svm.kernels import gaussian, PolyKernel
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.opti.constrained import ProjectedGradient, FrankWolfe
     comm = make_comm('torch')
-    ctx = device.init_distributed(comm, exchange=exchange, device=0)
+    ctx = device.init_distributed(comm, exchange=exchange, device=0, sym_exchange=sym_exchange)
     assert ctx.world == comm.world_size
     assert ctx.exchange == (exchange if (comm.world_size > 1 or exchange == 'rccl') else 'none')
-    res = {}
+    info = ctx.comm_info()
+    res = {'rccl_ranks': np.array(info['rccl_ranks']), 'sym_exchange': np.array(info['sym_exchange'])}
     n = 700
     X, y = make_blobs(n, 12, seed=5)
     quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
@@ -118,6 +120,29 @@ def gpu_mode(exchange, outdir):
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)
 
 
+def gpu_c4(outdir):
+    """BASELINE config 4's shape (SVR eps-insensitive, poly(3, scale, 1), FrankWolfe) at n=20 000, d=128, on this rank's
+    share of the symmetric panel, host exchange."""
+    from optiml_amd import device
+    from optiml_amd.datasets import make_regression
+    from optiml_amd.ml.svm.kernels import PolyKernel
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import FrankWolfe
+    comm = make_comm('torch')
+    device.init_distributed(comm, exchange='host', device=0)
+    n, d = 20000, 128
+    X, y = make_regression(n, d, seed=0)
+    quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', PolyKernel(3, 'scale', 1.0))
+    res = {'matvec': quad.device_problem().matvec(np.random.RandomState(2).standard_normal(2 * n))}
+    hist = []
+    cb = lambda o: hist.append(o.f_x)
+    cb._bq_needs_state = False
+    opt = FrankWolfe(quad=quad, ub=np.ones(2 * n), max_iter=25, callback=cb).minimize()
+    res['fw_x'], res['fw_hist'] = opt.x, np.array(hist)
+    comm.barrier()
+    np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)
+
+
 if __name__ == '__main__':
     mode, outdir = sys.argv[1], sys.argv[2]
     if mode == 'cpu-torch':
@@ -128,5 +153,11 @@ if __name__ == '__main__':
         gpu_mode('host', outdir)
     elif mode == 'gpu-rccl':
         gpu_mode('rccl', outdir)
+    elif mode == 'gpu-host-c4':
+        gpu_c4(outdir)
+    elif mode == 'gpu-host-allreduce':
+        gpu_mode('host', outdir, 'allreduce')
+    elif mode == 'gpu-rccl-allreduce':
+        gpu_mode('rccl', outdir, 'allreduce')
     else:
         raise SystemExit('unknown mode ' + mode)

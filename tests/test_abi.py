@@ -69,6 +69,21 @@ def test_symmetric_row_blocks_balance_the_triangle(lib, n, world):
         assert max(tiles) <= 1.06 * (sum(tiles) / world)
 
 
+@pytest.mark.parametrize('n', [700, 20000, 100000, 250000])
+def test_symmetric_partitions_nest_on_the_eight_canonical_segments(lib, n):
+    """1, 2, 4 and 8 ranks own whole runs of the same 8 segments (the unit of the fixed-order sum that makes the product
+    bit-identical across rank counts); 3 ranks own 2 + 3 + 3 of them."""
+    from optiml_amd.device import row_block
+    cuts8 = [row_block(n, r, 8, symmetric=True)[0] for r in range(8)] + [n]
+    for world in (1, 2, 4):
+        step = 8 // world
+        for r in range(world):
+            assert row_block(n, r, world, symmetric=True) == (cuts8[r * step], cuts8[(r + 1) * step])
+    firsts = [0, 2, 5, 8]
+    for r in range(3):
+        assert row_block(n, r, 3, symmetric=True) == (cuts8[firsts[r]], cuts8[firsts[r + 1]])
+
+
 def test_bad_arguments_are_reported_not_crashed(lib):
     import ctypes as C
     from optiml_amd import _lib

@@ -2,8 +2,9 @@
 
 CPU (always run): world_size-2 gloo and socket communicators — rendezvous, the 128-byte id broadcast, the row-block
 all-gather that completes a sharded Q v, barrier / max — with the CPU oracle's Hessian standing in for the panel.
-GPU (-m gpu): two ranks on GPU 0 with row-block Gram panels and the host exchange must reproduce the single-rank
-solver iterates BIT FOR BIT; a single-rank RCCL context exercises ncclCommInitRank / ncclAllGather / destroy.
+GPU (-m gpu): two and three ranks on GPU 0 (host exchange) must reproduce the single-rank solver iterates BIT FOR BIT —
+row-block panels (all-gather of slices) and symmetric kernel panels (all-gather of the per-segment partial vectors, added
+in segment order) alike; a single-rank RCCL context exercises ncclCommInitRank / ncclAllGather / ncclAllReduce / destroy.
 """
 import os
 import socket
@@ -58,9 +59,19 @@ def test_two_rank_row_block_exchange_cpu(tmp_path, kind):
         assert np.array_equal(res[0][f'gathered_{n}'], res[1][f'gathered_{n}'])
 
 
+SYM_KEYS = ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_dual', 'al_f', 'ascg_kernel_x',
+            'ascg_kernel_f')
+ROW_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'stream_matvec', 'stream_fw_x', 'ascg_x', 'ascg_iter', 'ascg_inner')
+
+
+@pytest.fixture(scope='module')
+def one_rank(tmp_path_factory):
+    return _launch('gpu-host', 1, tmp_path_factory.mktemp('w1'))[0]
+
+
 @pytest.mark.gpu
-def test_two_ranks_reproduce_single_rank_bitwise(tmp_path):
-    one = _launch('gpu-host', 1, tmp_path / 'w1')[0]
+def test_two_ranks_reproduce_single_rank_bitwise(tmp_path, one_rank):
+    one = one_rank
     two = _launch('gpu-host', 2, tmp_path / 'w2')
     # kernel panels: symmetric tile storage, balanced triangular partition (700 rows = 3 tile rows -> 2 + 1)
     assert tuple(two[0]['rows']) == (0, 512) and tuple(two[1]['rows']) == (512, 700)
@@ -70,39 +81,50 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path):
     assert tuple(two[0]['stream_rows']) == (0, 384) and tuple(two[1]['stream_rows']) == (384, 700)
     np.testing.assert_allclose(one['stream_matvec'], one['matvec'], rtol=1e-11, atol=1e-11)
     for r in two:
-        # row-block panels end in an all-gather: bit-identical for any rank count
-        for key in ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'stream_matvec', 'stream_fw_x', 'ascg_x', 'ascg_iter',
-                    'ascg_inner'):
+        assert str(r['sym_exchange']) == 'gather'
+        # row-block panels end in an all-gather of disjoint slices; symmetric tile panels in an all-gather of the per-segment
+        # partial vectors, added in segment order on every rank: both bit-identical for any rank count
+        for key in ROW_KEYS + SYM_KEYS:
             assert np.array_equal(r[key], one[key]), key
         assert bool(r['ascg_status']) and int(r['ascg_inner']) > 0
-        np.testing.assert_allclose(r['ascg_kernel_x'], one['ascg_kernel_x'], rtol=1e-8, atol=1e-10)
-        np.testing.assert_allclose(r['ascg_kernel_f'], one['ascg_kernel_f'], rtol=1e-11)
-        # symmetric tile panels end in an all-reduce(sum): same values up to the association of the rank sum
-        for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f'):
-            np.testing.assert_allclose(r[key], one[key], rtol=1e-12, atol=1e-12, err_msg=key)
-        for key in ('pg_x', 'fw_x', 'al_x', 'al_dual'):
-            np.testing.assert_allclose(r[key], one[key], rtol=1e-9, atol=1e-11, err_msg=key)
-    for key in ('matvec', 'pg_x', 'fw_x', 'dense_pg_x', 'al_x', 'dense_al_x'):     # and the ranks agree with each other exactly
-        assert np.array_equal(two[0][key], two[1][key]), key
 
 
 @pytest.mark.gpu
-def test_rccl_context_single_rank(tmp_path):
-    ref = _launch('gpu-host', 1, tmp_path / 'ref')[0]
+def test_rccl_context_single_rank(tmp_path, one_rank):
     got = _launch('gpu-rccl', 1, tmp_path / 'rccl')[0]
+    assert int(got['rccl_ranks']) == 1
     for key in ('matvec', 'pg_x', 'pg_hist', 'fw_x', 'dense_matvec', 'dense_pg_x', 'al_x', 'dense_al_x'):
-        assert np.array_equal(got[key], ref[key]), key
+        assert np.array_equal(got[key], one_rank[key]), key
+    # the all-reduce variant of the symmetric exchange (ncclAllReduce on one rank)
+    got = _launch('gpu-rccl-allreduce', 1, tmp_path / 'rccl_ar')[0]
+    assert str(got['sym_exchange']) == 'allreduce'
+    for key in ('matvec', 'pg_x', 'fw_x'):
+        assert np.array_equal(got[key], one_rank[key]), key
 
 
 @pytest.mark.gpu
-def test_three_ranks_uneven_partitions(tmp_path):
-    """World size 3: uneven triangular / row-block partitions (700 rows -> tile rows 2 + 0 + 1; 500 rows -> 256+244+0)."""
-    one = _launch('gpu-host', 1, tmp_path / 'w1')[0]
+def test_three_ranks_uneven_partitions(tmp_path, one_rank):
+    """World size 3: uneven partitions (700 rows = 3 tile rows -> segments 2 + 3 + 3 of the canonical 8 = tile rows
+    2 + 0 + 1; 500 dense rows -> 256 + 244 + 0) — still bit-identical to one rank."""
     three = _launch('gpu-host', 3, tmp_path / 'w3')
+    assert [tuple(r['rows']) for r in three] == [(0, 512), (512, 512), (512, 700)]
     for r in three:
-        assert np.array_equal(r['dense_pg_x'], one['dense_pg_x'])
-        np.testing.assert_allclose(r['matvec'], one['matvec'], rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(r['pg_x'], one['pg_x'], rtol=1e-9, atol=1e-11)
-        np.testing.assert_allclose(r['fw_x'], one['fw_x'], rtol=1e-9, atol=1e-11)
-        np.testing.assert_allclose(r['al_x'], one['al_x'], rtol=1e-9, atol=1e-11)
-        assert np.array_equal(r['dense_al_x'], one['dense_al_x'])
+        for key in ROW_KEYS + SYM_KEYS:
+            assert np.array_equal(r[key], one_rank[key]), key
+
+
+@pytest.mark.gpu
+def test_allreduce_variant_of_the_symmetric_exchange(tmp_path, one_rank):
+    """sym_exchange='allreduce' (rank partials added by the transport, the collective BASELINE's north star names): the
+    same values up to the association of the rank sum."""
+    two = _launch('gpu-host-allreduce', 2, tmp_path / 'w2ar')
+    for r in two:
+        assert str(r['sym_exchange']) == 'allreduce'
+        for key in ROW_KEYS:
+            assert np.array_equal(r[key], one_rank[key]), key
+        for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f'):
+            np.testing.assert_allclose(r[key], one_rank[key], rtol=1e-12, atol=1e-12, err_msg=key)
+        for key in ('pg_x', 'fw_x', 'al_x', 'al_dual'):
+            np.testing.assert_allclose(r[key], one_rank[key], rtol=1e-9, atol=1e-11, err_msg=key)
+    for key in ('matvec', 'pg_x', 'fw_x'):
+        assert np.array_equal(two[0][key], two[1][key]), key

@@ -204,3 +204,261 @@ def test_augmented_lagrangian_records_are_consistent_at_full_size(headline):
         assert np.isfinite(opt.g_x).all() and opt.g_x.shape == (n,)
     finally:
         primal.release()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs 1, 3, 4, 5 at their own sizes (config 2 and the headline: above)
+# ---------------------------------------------------------------------------------------------------------------
+def test_config1_linear_pg_against_the_reference_fixture():
+    """C1: SVC hinge, linear kernel, ProjectedGradient, n=2000 d=20 — against the reference's own run on the same X, y
+    (tests/golden/cfg1_linear_pg_n2000_d20.npz, tools/gen_golden.py::gen_cfg1): objective history and iterates over the
+    reproducible prefix (projected_gradient.py:76-143), descent and the reference's level afterwards."""
+    from conftest import load_golden
+    from optiml_amd.ml.svm import SVC
+    from optiml_amd.ml.svm.kernels import linear
+    from optiml_amd.ml.svm.losses import hinge
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import ProjectedGradient
+    g = load_golden('cfg1_linear_pg_n2000_d20.npz')
+    X, y = g['X'], g['y']
+    n = len(y)
+    snaps, hist = {}, []
+
+    def cb(o):
+        hist.append(o.f_x)
+        if o.iter in (1, 10, 80, 100):
+            snaps[o.iter] = o.x.copy()
+
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', linear, y=y)
+    opt = ProjectedGradient(quad=quad, ub=np.ones(n), max_iter=120, callback=cb).minimize()
+    ref = g['pg_f_hist']
+    np.testing.assert_allclose(hist[:40], ref[:40], rtol=1e-9)
+    np.testing.assert_allclose(hist[:101], ref[:101], rtol=1e-6)
+    for k, xk in zip(g['pg_x_iters'], g['pg_x_at']):
+        if int(k) <= 100:
+            np.testing.assert_allclose(snaps[int(k)], xk, rtol=1e-6, atol=1e-9, err_msg=f'x at iteration {k}')
+    quad.release()
+    # end to end through SVC.fit: same history over the prefix, monotone afterwards, at least the reference's level
+    est = SVC(loss=hinge, kernel=linear, C=1., reg_intercept=True, dual=True, optimizer=ProjectedGradient,
+              max_iter=1000).fit(X, y)
+    h = np.asarray(est.train_loss_history)
+    assert est.optimizer.status == str(g['pg_status']) and est.optimizer.iter == int(g['pg_iter'])
+    np.testing.assert_allclose(h[:101], ref[:101], rtol=1e-6)
+    assert np.all(np.diff(h) <= 1e-9 * np.maximum(1.0, np.abs(h[:-1])))
+    assert abs(h[-1] - ref[-1]) <= 1e-3 * abs(ref[-1])      # both still far from the optimum, on the same descent curve
+    assert est.score(X, y) > 0.8
+    est.obj.release()
+
+
+def test_config3_interior_point_newton_step_at_full_size():
+    """C3: RBF SVC dual, InteriorPoint, n=50 000 d=128 (interior_point.py:191-267), three iterations.  The Newton system
+    H dx = w, H = Q + diag(lp/(ub-x) + lm/(x-lb)), is checked with an INDEPENDENT device product; the iterate moves by
+    max_t dx; the gap falls; the iterates stay strictly interior."""
+    from optiml_amd import _lib
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import InteriorPoint
+    n, d = 50000, 128
+    X, y = make_blobs(n, d, seed=0)
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
+    ub, lb = np.ones(n), np.zeros(n)
+    rec = []
+
+    def cb(o):   # state callback: x is the point of the record; lp/lm/dx are read from the live solver
+        s = o._solver
+        rec.append(dict(f=o.f_x, p=o.p, gap=o.gap, x=o.x.copy(), lp=s.get(_lib.GET_LP), lm=s.get(_lib.GET_LM),
+                        dx=s.get(_lib.GET_D)))
+
+    opt = InteriorPoint(quad=quad, ub=ub, max_iter=3, callback=cb).minimize()
+    assert opt.status == 'stopped' and opt.iter == 3 and len(rec) == 4
+    dev = quad.device_problem()
+    for k in range(3):
+        r = rec[k]
+        x, lp, lm, dx = r['x'], r['lp'], r['lm'], r['dx']
+        assert np.all(lp > 0) and np.all(lm > 0) and np.all(x > lb) and np.all(x < ub)        # interiority
+        mu = (r['f'] - r['p']) / (4.0 * n * n)
+        umx, xml = ub - x, x - lb
+        w = mu * (ub + lb - 2 * x) / (umx * xml) + lp - lm
+        Hdx = dev.matvec(dx) + (lp / umx + lm / xml) * dx
+        assert np.linalg.norm(Hdx - w) <= 1e-10 * np.linalg.norm(w), f'Newton residual at iteration {k}'
+        # the record's f / p / gap are what the formulas give at the recorded point
+        Qx = dev.matvec(x)
+        np.testing.assert_allclose(r['f'], 0.5 * x @ Qx - x.sum(), rtol=1e-11)
+        np.testing.assert_allclose(r['p'], -(lp @ ub) + lm @ lb - 0.5 * x @ Qx, rtol=1e-11)
+        np.testing.assert_allclose(r['gap'], (r['f'] - r['p']) / max(abs(r['f']), 1), rtol=1e-9)
+        # and the next point lies along dx, a positive step short of the boundary
+        step = rec[k + 1]['x'] - x
+        t = (step @ dx) / (dx @ dx)
+        assert 0 < t and np.linalg.norm(step - t * dx) <= 1e-9 * np.linalg.norm(step)
+    gaps = [r['gap'] for r in rec]
+    assert all(b < a for a, b in zip(gaps, gaps[1:]))
+    quad.release()
+
+
+def test_config3_first_iterations_against_the_oracle_at_n20000():
+    """The same solver against the CPU oracle (dense Q + scipy cho_factor) at the largest size whose factorisations the
+    host finishes in seconds: n=20 000, d=128, the first three iterations."""
+    from oracle import svm_oracle as so, bcqp_oracle as bo
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import InteriorPoint
+    n, d = 20000, 128
+    X, y = make_blobs(n, d, seed=0)
+    Q, q, ub = so.svc_dual(so.gram('rbf', X), y, 1.0)
+    ref = bo.interior_point(Q, q, ub, max_iter=3, keep_x=(1, 2, 3))
+    del Q
+    snaps, hist = {}, []
+
+    def cb(o):
+        hist.append((o.f_x, o.p, o.gap))
+        snaps[o.iter] = o.x.copy()
+
+    quad = KernelQuadratic(X, q, 'svc', gaussian, y=y)
+    opt = InteriorPoint(quad=quad, ub=ub, max_iter=3, callback=cb).minimize()
+    np.testing.assert_allclose([h[0] for h in hist], ref['f_hist'], rtol=1e-9)
+    for k in (1, 2, 3):
+        np.testing.assert_allclose(snaps[k], ref['x_at'][k], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(opt.lp, ref['lp'], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(opt.lm, ref['lm'], rtol=1e-6, atol=1e-12)
+    quad.release()
+
+
+@pytest.fixture(scope='module')
+def config4():
+    from optiml_amd.datasets import make_regression
+    from optiml_amd.ml.svm.kernels import PolyKernel
+    from optiml_amd.opti import KernelQuadratic
+    n, d = 100000, 128                       # C4: SVR eps-insensitive, poly(3, scale, 1), dual dimension 200 000
+    X, y = make_regression(n, d, seed=0)
+    quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', PolyKernel(3, 'scale', 1.0))
+    quad.device_problem()
+    yield n, X, y, quad
+    quad.release()
+
+
+def test_config4_svr_poly_product_spot_rows(config4):
+    """Rows of Q = [[K,-K],[-K,K]] + ee' (svm/_base.py:1098-1100, 1178) with the oracle's polynomial kernel formula
+    (kernels.py:91-95) against the one-panel [s; -s] device product, both halves."""
+    from oracle import svm_oracle as so
+    n, X, y, quad = config4
+    dev = quad.device_problem()
+    v = np.random.RandomState(5).standard_normal(2 * n)
+    Qv = dev.matvec(v)
+    g = so.resolve_gamma('scale', X)
+    diff = v[:n] - v[n:]
+    for i in (0, 255, 256, 31337, 65535, 65536, 99999):
+        Ki = (g * (X @ X[i]) + 1.0) ** 3
+        si = Ki @ diff + diff.sum()
+        scale = np.abs(Ki) @ np.abs(diff)
+        assert abs(Qv[i] - si) <= 1e-12 * scale and abs(Qv[n + i] + si) <= 1e-12 * scale
+    np.testing.assert_array_equal(Qv[:n], -Qv[n:])
+
+
+def test_config4_frank_wolfe_descends_and_carries_its_state(config4):
+    """25 FrankWolfe iterations (frank_wolfe.py:88-165) on the 200 000-dimensional dual: the objective decreases, the
+    iterates stay in the box, the lower bound stays below, and the incrementally carried f / g equal a fresh evaluation."""
+    from optiml_amd.opti.constrained import FrankWolfe
+    n, X, y, quad = config4
+    hist = []
+    cb = lambda o: hist.append((o.iter, o.f_x))
+    cb._bq_needs_state = False
+    opt = FrankWolfe(quad=quad, ub=np.ones(2 * n), max_iter=25, callback=cb).minimize()
+    assert opt.status == 'stopped' and opt.iter == 25 and [k for k, _ in hist] == list(range(26))
+    f = np.array([v for _, v in hist])
+    assert np.all(np.diff(f) <= 0)
+    assert np.all(opt.x >= 0) and np.all(opt.x <= 1)
+    f_chk, g_chk = quad.function_jacobian(opt.x)
+    np.testing.assert_allclose(opt.f_x, f_chk, rtol=1e-10)
+    np.testing.assert_allclose(opt.g_x, g_chk, rtol=1e-8, atol=1e-8 * np.abs(g_chk).max())
+
+
+def test_config4_shape_through_the_two_rank_exchange(tmp_path):
+    """The same SVR / poly / FrankWolfe dual at n=20 000 split over two ranks (tile-row shares of the symmetric panel, one
+    exchange per product): bit-identical to one rank, and the first iterations equal the CPU oracle's."""
+    from test_distributed import _launch
+    from oracle import svm_oracle as so, bcqp_oracle as bo
+    from optiml_amd.datasets import make_regression
+    one = _launch('gpu-host-c4', 1, tmp_path / 'w1', timeout=600)[0]
+    two = _launch('gpu-host-c4', 2, tmp_path / 'w2', timeout=600)
+    for r in two:
+        for key in ('fw_x', 'fw_hist', 'matvec'):
+            assert np.array_equal(r[key], one[key]), key
+    n, d = 20000, 128
+    X, y = make_regression(n, d, seed=0)
+    K = so.gram('poly', X, None, 'scale', 1.0, 3)
+    v = np.random.RandomState(2).standard_normal(2 * n)
+    s = K @ (v[:n] - v[n:]) + (v[:n] - v[n:]).sum()
+    np.testing.assert_allclose(one['matvec'], np.hstack((s, -s)), rtol=1e-10, atol=1e-10 * np.abs(s).max())
+
+
+def test_config5_squared_hinge_active_set_cg_at_full_size():
+    """C5: squared-hinge dual K*yy' + yy' + I/(2C), ub = +inf, x0 = 1, ActiveSet with conjugate-gradient
+    restricted solves, n=250 000 d=256, fp32 panel storage / fp64 accumulation (125 GB on one GPU).  Spot rows including the
+    diagonal shift at fp32 tolerance; three outer iterations (active_set.py:84-230): |L| bookkeeping against the masks, the
+    step is along a direction that solves the restricted system to the inner tolerance (two independent masked products)."""
+    from oracle import svm_oracle as so
+    from optiml_amd import _lib
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import ActiveSetCG
+    n, d, C = 250000, 256, 1.0
+    X, y = make_blobs(n, d, seed=0)
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, diag=1.0 / (2 * C), storage='f32')
+    dev = quad.device_problem()
+    v = np.random.RandomState(11).standard_normal(n)
+    Qv = dev.matvec(v)
+    g = so.resolve_gamma('scale', X)
+    xx = np.einsum('ij,ij->i', X, X)
+    for i in (0, 256, 77777, 131071, 131072, 249999):
+        d2 = np.maximum(-2 * (X @ X[i]) + xx[i] + xx, 0)
+        d2[i] = 0
+        Qi = (np.exp(-g * d2) + 1.0) * y[i] * y
+        ref = Qi @ v + v[i] / (2 * C)
+        assert abs(Qv[i] - ref) <= 2e-7 * (np.abs(Qi) @ np.abs(v)), i      # fp32-rounded entries, fp64 accumulation
+    # the diagonal shift alone: Q e_i picks column i
+    e = np.zeros(n)
+    e[131072] = 1.0
+    col = dev.matvec(e)
+    np.testing.assert_allclose(col[131072], 2.0 + 1.0 / (2 * C), rtol=1e-7)   # K_ii = 1 exactly, + yy' + I/(2C)
+
+    tol = 1e-8
+    rec = []
+
+    class Solver(ActiveSetCG):
+        inner_tol = tol
+
+    def cb(o):   # x: the point of this record (top of iteration k); the masks are read live = after the body of iteration k
+        s = o._solver
+        rec.append(dict(f=o.f_x, nb=o.n_bound, x=o.x.copy(), L=s.get(_lib.GET_MASK_L) > 0, U=s.get(_lib.GET_MASK_U) > 0))
+
+    opt = Solver(quad=quad, ub=np.full(n, np.inf), x=np.ones(n), max_iter=3, callback=cb).minimize()
+    assert opt.iter == 3 and opt.status == 'stopped' and len(rec) == 4 and opt.inner_iters > 0
+    f = [r['f'] for r in rec]
+    assert all(b <= a for a, b in zip(f, f[1:]))
+    none = np.zeros(n, dtype=bool)
+    tops = [none] + [r['L'] for r in rec[:3]]            # bound set at the top of iterations 0..3
+    assert np.array_equal(rec[3]['L'], rec[2]['L'])      # record 3 is the max_iter stop: no body ran
+    for k, r in enumerate(rec):
+        assert not r['U'].any()                                        # ub = +inf: nothing can sit at an upper bound
+        assert r['nb'] == int(tops[k].sum())                           # |L| + |U| of the record = the masks it was taken under
+        assert np.all(r['x'] >= 0) and np.all(r['x'][tops[k]] <= 1e-12)
+    assert rec[1]['nb'] > 0                                            # from x0 = 1 the first ratio step lands on a bound
+    for k in range(3):
+        A = ~tops[k]
+        x = rec[k]['x']
+        step = rec[k + 1]['x'] - x
+        assert np.any(step) and not np.any(step[~A])                  # only free variables move
+        # cand_A = x_A + step_A / t solves Q_AA cand_A = -(q_A + Q_AL lb_L) = 1_A for the t of the ratio test: the residual
+        # as a function of 1/t is affine, so its least-squares minimum bounds the true one from below
+        xa = np.where(A, x, 0.0)
+        QxA = np.where(A, dev.matvec(xa), 0.0)
+        r0 = np.where(A, 1.0, 0.0) - QxA
+        Qs = np.where(A, dev.matvec(np.where(A, step, 0.0)), 0.0)
+        it = (r0 @ Qs) / (Qs @ Qs)
+        assert it >= 1 - 1e-9                                          # t = 1/it in (0, 1]
+        res = np.linalg.norm(r0 - it * Qs)
+        assert res <= 10 * tol * (np.linalg.norm(QxA) + np.sqrt(A.sum())), (k, res)
+    quad.release()

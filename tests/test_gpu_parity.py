@@ -133,7 +133,8 @@ def test_kernel_quadratic_matches_reference_assembly(amd):
 # ---------------------------------------------------------------------------------------------------------
 # solvers against the reference's own unit problems and recorded trajectories
 # ---------------------------------------------------------------------------------------------------------
-PG_STABLE = 80   # iterations over which projected-gradient iterates are reproducible (see below)
+PG_STABLE = 100   # iterations over which projected-gradient iterates are reproducible: the oracle's own perturbation test
+                   # (tests/test_oracle_golden.py::test_pg_is_sensitive_to_rounding) reproduces x to 1e-9 at k = 100
 
 
 def _check_pg_prefix(hist, ref_hist):
@@ -141,9 +142,32 @@ def _check_pg_prefix(hist, ref_hist):
     np.testing.assert_allclose(hist[:PG_STABLE], ref_hist[:PG_STABLE], rtol=1e-6, atol=1e-9)
 
 
+def _pg_residual(Q, q, x, lb, ub):
+    """2-norm of the projected gradient exactly as projected_gradient.py:90,100-102 masks it"""
+    d = -(Q @ x + q)
+    d[(x <= lb + 1e-12) & (d < 0)] = 0
+    d[(x >= ub - 1e-12) & (d > 0)] = 0
+    return np.linalg.norm(d)
+
+
+def _check_pg_solution_bound(x, x_ref, Q, q, lb, ub, eps=1e-6):
+    """Path-independent bound on the converged multipliers.  For a strictly convex box QP (lambda = lambda_min(Q) > 0) any
+    feasible x obeys lambda |x - x*|^2 <= (g(x) - g(x*))'(x - x*) <= -g(x)'(x* - x) <= |d(x)|_2 |x - x*|_2, d the masked
+    projected gradient (x* - x is a feasible direction at x, so the masked-out components only help), i.e.
+    |x - x*|_2 <= |d(x)|_2 / lambda.  The reference stopped at |d| <= eps, hence |x - x_ref|_2 <= (|d(x)|_2 + eps) / lambda
+    whatever path either iteration took."""
+    lam = np.linalg.eigvalsh((Q + Q.T) / 2)
+    if lam[0] <= 1e-12 * lam[-1]:
+        return None   # not strictly convex (linear kernels): no bound
+    assert _pg_residual(Q, q, x_ref, lb, ub) <= eps * (1 + 1e-6)        # the fixture really is a stopped point
+    bound = (_pg_residual(Q, q, x, lb, ub) + eps) / lam[0]
+    assert np.linalg.norm(x - x_ref) <= bound * (1 + 1e-9) + 1e-13
+    return bound
+
+
 def _check_pg_tail(hist, f_x, g, p, key='_f_hist'):
     """Past the reproducible prefix: descent must continue; where the reference converged, the objective reached
-    must agree (the iterate need not: see _check_run)."""
+    must agree (the iterate need not: see _check_run; it obeys the bound of _check_pg_solution_bound)."""
     ref_hist = g[p + key]
     f_ref = float(g[p + '_f_x'])
     assert np.all(np.diff(hist) <= 1e-9 * np.maximum(1.0, np.abs(hist[:-1])))
@@ -152,7 +176,7 @@ def _check_pg_tail(hist, f_x, g, p, key='_f_hist'):
         assert abs(f_x - f_ref) <= 1e-5 * max(1.0, abs(f_ref))
 
 
-def _check_run(opt, g, p, hist, rtol=1e-6, atol=1e-9):
+def _check_run(opt, g, p, hist, rtol=1e-6, atol=1e-9, Q=None):
     """Full-trajectory parity.  ProjectedGradient is the exception: its iteration is chaotic — perturbing the
     REFERENCE's own start by 1e-15 moves its iterates by 1e-3 after ~300 iterations and flips 'optimal at 912'
     into 'stopped at 1000' (tests/test_oracle_golden.py::test_pg_is_sensitive_to_rounding) — so for PG the
@@ -162,6 +186,8 @@ def _check_run(opt, g, p, hist, rtol=1e-6, atol=1e-9):
         _check_pg_prefix(hist, ref_hist)
         _check_pg_tail(np.asarray(hist), opt.f_x, g, p)
         assert np.all(opt.x >= opt.lb - 1e-12) and np.all(opt.x <= opt.ub + 1e-12)
+        if str(g[p + '_status']) == 'optimal' and Q is not None:
+            _check_pg_solution_bound(opt.x, g[p + '_x'], Q, opt.f.q, opt.lb, opt.ub)
         return
     assert opt.status == str(g[p + '_status'])
     assert opt.iter == int(g[p + '_iter'])
@@ -178,7 +204,7 @@ def test_reference_unit_problems(amd, tag, s):
     hist = []
     opt = _solvers()[s](quad=Quadratic(g[f'{tag}_Q'], g[f'{tag}_q']), ub=g[f'{tag}_ub'], lb=g[f'{tag}_lb'],
                         callback=lambda o: hist.append(o.f_x)).minimize()
-    _check_run(opt, g, f'{tag}_{s}', hist)
+    _check_run(opt, g, f'{tag}_{s}', hist, Q=g[f'{tag}_Q'])
     if tag in ('nd2',):  # the reference's own assertion: allclose(x, x*) with x* = (0, 0)
         assert np.allclose(opt.x, 0.0)
 
@@ -196,7 +222,7 @@ def test_trajectory_svc_dense(amd, s, prefix, kw):
             snaps[o.iter] = o.x.copy()
 
     opt = _solvers()[s](quad=Quadratic(g['Q'], g['q']), ub=g['ub'], callback=cb, **kw).minimize()
-    _check_run(opt, g, prefix, hist)
+    _check_run(opt, g, prefix, hist, Q=g['Q'])
     for k, xk in zip(g[prefix + '_x_iters'], g[prefix + '_x_at']):
         if s == 'pg' and int(k) > PG_STABLE:
             continue
@@ -212,7 +238,7 @@ def test_trajectory_lb_and_warm_start(amd, s):
     cb._bq_needs_state = False
     opt = _solvers()[s](quad=Quadratic(g['Q'], g['q']), ub=g['ub'], lb=g['lbx0_lb'], x=g['lbx0_x0'], max_iter=3000,
                         callback=cb).minimize()
-    _check_run(opt, g, 'lbx0_' + s, hist)
+    _check_run(opt, g, 'lbx0_' + s, hist, Q=g['Q'])
 
 
 @pytest.mark.parametrize('s', ['pg', 'fw'])
@@ -226,7 +252,7 @@ def test_trajectory_svr_structured(amd, s):
     cb._bq_needs_state = False
     quad = KernelQuadratic(g['X'], g['q'], 'svr', PolyKernel(3, 'scale', 1.))
     opt = _solvers()[s](quad=quad, ub=g['ub'], callback=cb).minimize()
-    _check_run(opt, g, s, hist, rtol=1e-6, atol=1e-8)
+    _check_run(opt, g, s, hist, rtol=1e-6, atol=1e-8, Q=g['Q'])
 
 
 def test_fp32_storage_tracks_fp64(amd):
@@ -247,6 +273,9 @@ def _check_fit(est, g, p, Xte, tol=1e-6, hist_tol=1e-9):
         ref_hist = g[p + '_loss_hist']
         _check_pg_prefix(est.train_loss_history, ref_hist)
         _check_pg_tail(np.asarray(est.train_loss_history), est.optimizer.f_x, g, p, key='_loss_hist')
+        if str(g[p + '_status']) == 'optimal':   # the converged multipliers obey the path-independent bound
+            o = est.optimizer
+            _check_pg_solution_bound(est.alphas_, g[p + '_alphas'], o.f.Q, o.f.q, o.lb, o.ub)
         return
     assert est.optimizer.status == str(g[p + '_status'])
     assert est.optimizer.iter == int(g[p + '_iter'])

@@ -267,7 +267,7 @@ def test_smo_verbose_and_fp32_panel(amd, capsys):
     assert abs(o32.b - opt.b) <= 1.5e-3 and abs(o32.alphas.sum() - opt.alphas.sum()) <= 0.05
 
 
-@pytest.mark.parametrize('attempt', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('attempt', [0, 1, 2])
 def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch, attempt):
     """Full sweeps take helper workgroups along that form the walker's error sums ahead of it (csrc/bq_smo.hip,
     "Helpers"): the sums are bit-identical to the walker's own, so the run must not depend on how many helpers there
@@ -291,6 +291,12 @@ def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch, attempt):
         quad = KernelQuadratic(Xr, np.hstack((-yr, yr)) + 0.1, 'svr', _kernel('rbf'), rank_one=False)
         r = SMORegression(quad, Xr, yr, None, _kernel('rbf'), 1., 0.1, 1e-3).minimize()
         runs.append((c.iter, c.steps, c.alphas, c.errors, c.b, r.iter, r.steps, r.alphas_p, r.alphas_n, r.b))
+        # the self-checks of the hand-off are assertions, not a safety net: no helper ever read a torn list under a stable
+        # version, no result granule ever arrived torn — and the helpers did deliver sums
+        for st in (c.helper_stats, r.helper_stats):
+            assert st['rejected_list_hash'] == 0 and st['rejected_checksum'] == 0, (h, st)
+            assert st['helpers'] == (48 if h is None else int(h))
+            assert (st['delivered'] > 0) == (st['helpers'] > 0), (h, st)
     assert runs[0][1] > 1000 and runs[0][6] > 1000      # enough pair steps for the list to have been edited often
     for other in runs[1:]:
         for a, b in zip(runs[0], other):

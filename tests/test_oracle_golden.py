@@ -145,6 +145,19 @@ def test_cfg5_squared_hinge_active_set(golden):
     _cmp_run(res, g, 'pg')
 
 
+def test_cfg1_linear_pg_n2000(golden):
+    """BASELINE config 1 (the reference's CPU-runnable case): SVC hinge, linear kernel, ProjectedGradient, n=2000 d=20."""
+    g = golden('cfg1_linear_pg_n2000_d20.npz')
+    X, y = g['X'], g['y']
+    Q, q, ub = so.svc_dual(so.gram('linear', X), y, float(g['C']))
+    res = bo.projected_gradient(Q, q, ub, max_iter=1000, keep_x=(1, 10, 80, 100, 120, 1000))
+    assert res['status'] == str(g['pg_status']) and res['iter'] == int(g['pg_iter'])
+    np.testing.assert_allclose(res['f_hist'], g['pg_f_hist'], rtol=1e-9)
+    for k, xk in zip(g['pg_x_iters'], g['pg_x_at']):
+        np.testing.assert_allclose(res['x_at'][int(k)], xk, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(res['x'], g['pg_alphas'], rtol=1e-7, atol=1e-10)
+
+
 def test_pg_is_sensitive_to_rounding(golden):
     """Evidence for the PG parity policy: the reference formulation itself is chaotic.  A 1e-15 relative
     perturbation of the start changes the iterates by > 1e-6 within 500 iterations (and the stopping iteration),

@@ -294,6 +294,29 @@ def gen_cfg5(out):
     print(f"  cfg5: AS iter={data['as_iter']} status={data['as_status']} f={data['as_f_x']:.10f}")
 
 
+def gen_cfg1(out):
+    # BASELINE config 1: SVC hinge, linear kernel, Wolfe dual via ProjectedGradient, n=2000 d=20 synthetic blobs (SURVEY
+    # 8(d) generator: standardised overlapping blobs, C=1) through the reference's own SVC.fit.  Q (32 MB) is not stored:
+    # it is a function of the stored X, y.  x at a few iterations, the whole objective history, the fitted attributes.
+    n, d = 2000, 20
+    X, y = make_blobs(n, d, seed=0)
+    Xte, _ = make_blobs(32, d, seed=901)
+    keep = (1, 10, 80, 100, 120, 1000)
+    est = SVC(loss=hinge, kernel=linear, C=1., reg_intercept=True, dual=True, optimizer=ProjectedGradient, max_iter=1000)
+    est.fit(X, y)
+    # SVC.fit takes no user callback: the iterates come from the same solver on the same Q (svm/_base.py:552-559, 628-629)
+    K = linear(X)
+    Q = K * np.outer(y, y)
+    Q += np.outer(y, y)
+    run = run_solver(ProjectedGradient, Q, -np.ones(n), np.ones(n), keep=keep, max_iter=1000)
+    assert np.array_equal(run['f_hist'], np.asarray(est.train_loss_history, dtype=float)) and np.array_equal(run['x'], est.alphas_)
+    data = {'X': X, 'y': y, 'Xtest': Xte, 'C': 1.0, 'pg_f_hist': run['f_hist'], 'pg_x_iters': run['x_iters'],
+            'pg_x_at': run['x_at']}
+    data.update(flat('pg', _fit_record(est, Xte)))
+    np.savez_compressed(os.path.join(out, 'cfg1_linear_pg_n2000_d20.npz'), **data)
+    print(f"  cfg1: PG iter={est.optimizer.iter} status={est.optimizer.status} f={est.optimizer.f_x:.10f} nsv={len(est.support_)}")
+
+
 class ALRecorder:
     """Callback for the (augmented-)Lagrangian dual runs: AL value, primal value and x at chosen iterations."""
 
@@ -538,7 +561,7 @@ def main():
     ap.add_argument('--only', default=None, help='run a single generator, e.g. gen_kernels_more')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    for fn in (gen_unit_problems, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5, gen_lagrangian, gen_smo):
+    for fn in (gen_unit_problems, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5, gen_cfg1, gen_lagrangian, gen_smo):
         if args.only and fn.__name__ != args.only:
             continue
         print(fn.__name__)
