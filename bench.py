@@ -468,7 +468,16 @@ def main():
     if world > 1:
         import datetime
         import torch.distributed as dist
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        # gloo announces its connections on stdout (C++ side): keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
         from optiml_amd.dist import TorchComm
         comm = TorchComm()
         # RCCL over xGMI is the data path.  A communicator that cannot be created on EVERY rank ends the run with exit code

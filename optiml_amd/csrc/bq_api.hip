@@ -46,6 +46,7 @@ static int ctx_new(int device, bq_ctx **out) {
     BQ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const char *mode = getenv("BQ_SYM_EXCHANGE");
     c->sym_allreduce = mode != nullptr && strcmp(mode, "allreduce") == 0;
+    bq_ctx_register(c, true);
     *out = c;
     return BQ_OK;
 }
@@ -88,7 +89,12 @@ extern "C" int bq_ctx_create_exchange(int device, int rank, int world, bq_exchan
 
 extern "C" int bq_ctx_destroy(bq_ctx *c) {
     if (c == nullptr) return BQ_OK;
+    if (c->refs > 0) {   // problems still hold this context (and its stream): it goes with the last of them
+        c->zombie = true;
+        return BQ_OK;
+    }
     hipSetDevice(c->device);
+    bq_ctx_register(c, false);
     if (c->stream) hipStreamSynchronize(c->stream);
     bq_comm_destroy(c);
     for (auto &slot : c->prof)
@@ -255,7 +261,7 @@ static int problem_alloc_common(bq_problem *p, const double *q_host) {
     const int64_t slen = bq_round_up(std::max(p->blk * c->world, p->nb * BQ_SYM_TILE), BQ_PAD);
     if (p->symmetric) {
         BQ_HIP(hipMalloc(&p->slab, sizeof(double) * p->nb * p->nb * BQ_SYM_TILE));
-        if (c->world > 1) {   // the gathered segment vectors of every rank
+        if (c->comm_kind != BQ_COMM_NONE) {   // the gathered segment vectors of every rank (also a one-rank communicator)
             const size_t gl = sizeof(double) * (size_t)c->world * p->seg_cmax * p->nb * BQ_SYM_TILE;
             BQ_HIP(hipMalloc(&p->gath, gl));
             BQ_HIP(hipMemsetAsync(p->gath, 0, gl, c->stream));
@@ -307,12 +313,7 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
         c->panel_cache = nullptr;
         c->panel_cache_bytes = 0;
     } else {
-        e = hipMalloc(&p->panel, bytes);
-        if (e != hipSuccess && c->panel_cache) {
-            (void)hipGetLastError();
-            bq_ctx_drop_cache(c);
-            e = hipMalloc(&p->panel, bytes);
-        }
+        e = hipMalloc(&p->panel, bytes);   // bq_device_malloc: drops the cached panel and retries on failure
         p->panel_bytes = bytes;
     }
     if (e != hipSuccess) {
@@ -331,8 +332,21 @@ void bq_ctx_drop_cache(bq_ctx *c) {
     c->panel_cache_bytes = 0;
 }
 
+void bq_problem_unref(bq_problem *p) {
+    if (p == nullptr) return;
+    if (--p->refs <= 0 && p->zombie) {
+        p->refs = 0;
+        p->zombie = false;
+        bq_problem_destroy(p);
+    }
+}
+
 extern "C" int bq_problem_destroy(bq_problem *p) {
     if (p == nullptr) return BQ_OK;
+    if (p->refs > 0) {   // solvers still run on this problem: it goes with the last of them
+        p->zombie = true;
+        return BQ_OK;
+    }
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     if (p->panel && p->panel_bytes >= ((size_t)1 << 30)) {   // keep one large panel for the next problem (see bq_ctx)
@@ -345,7 +359,13 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
                       (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab, (void *)p->gath})
         if (ptr) hipFree(ptr);
     bq_stream_free(p->stream_img);
+    bq_ctx *c = p->ctx;
     delete p;
+    if (--c->refs <= 0 && c->zombie) {
+        c->refs = 0;
+        c->zombie = false;
+        bq_ctx_destroy(c);
+    }
     return BQ_OK;
 }
 
@@ -357,6 +377,7 @@ extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, co
     BQ_HIP(hipSetDevice(c->device));
     bq_problem *p = new bq_problem();
     p->ctx = c;
+    c->refs += 1;
     p->structure = BQ_PLAIN;
     p->storage = storage;
     int rc = problem_layout(p, n, n);
@@ -416,6 +437,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     BQ_HIP(hipSetDevice(c->device));
     bq_problem *p = new bq_problem();
     p->ctx = c;
+    c->refs += 1;
     p->structure = structure;
     p->storage = storage;
     p->kernel = kernel;
@@ -675,7 +697,9 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
             if (ptr) hipFree(ptr);
         delete s->al;
     }
+    bq_problem *p = s->p;
     delete s;
+    bq_problem_unref(p);
     return BQ_OK;
 }
 
@@ -703,6 +727,7 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
     BQ_HIP(hipSetDevice(c->device));
     bq_solver *s = new bq_solver();
     s->p = p;
+    p->refs += 1;
     s->kind = kind;
     s->as_cg = as_cg;
     s->N = p->N;
@@ -798,6 +823,7 @@ extern "C" int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const
     BQ_HIP(hipSetDevice(c->device));
     bq_solver *s = new bq_solver();
     s->p = p;
+    p->refs += 1;
     s->kind = BQ_AL;
     s->N = p->N;
     s->ldN = p->ldN;

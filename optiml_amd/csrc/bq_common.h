@@ -39,6 +39,17 @@ void bq_set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// device allocation: EVERY hipMalloc of the library goes through bq_device_malloc, which on failure gives the panels the
+// live contexts keep cached (bq_ctx.panel_cache) back to the driver and tries once more
+// ---------------------------------------------------------------------------------------------
+hipError_t bq_device_malloc(void **ptr, size_t bytes);
+template <typename T>
+static inline hipError_t bq_device_malloc(T **ptr, size_t bytes) { return bq_device_malloc((void **)ptr, bytes); }
+#ifndef BQ_NO_MALLOC_REDIRECT
+#define hipMalloc(ptr, bytes) bq_device_malloc((ptr), (bytes))
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // layout constants
 // ---------------------------------------------------------------------------------------------
 // Every device vector and every panel row is padded to a multiple of BQ_PAD elements and the pad is
@@ -78,13 +89,19 @@ struct bq_ctx {
     std::vector<hipEvent_t> event_pool;
     // One released panel is kept for the next problem of about the same size: on this platform a 40 GB hipMalloc issued
     // right after a 40 GB hipFree takes 1-2 s instead of 0.04 s (measured), and fits in a loop — multi-class, parameter
-    // sweeps, cross-validation — create panels of the same size over and over.  Dropped when any allocation fails.
+    // sweeps, cross-validation — create panels of the same size over and over.  Dropped when ANY device allocation of the
+    // library fails (bq_device_malloc, which every hipMalloc here is routed through) and with the context.
     void *panel_cache = nullptr;
     size_t panel_cache_bytes = 0;
+    // problems alive on this context; a context destroyed while some are is only marked and goes with the last of them
+    int refs = 0;
+    bool zombie = false;
 };
 
 struct bq_problem {
     bq_ctx *ctx = nullptr;
+    int refs = 0;          // solvers alive on this problem; destroyed while some are: marked, goes with the last of them
+    bool zombie = false;
     int structure = BQ_PLAIN, storage = BQ_F64, kernel = -1;
     bool add_one = false;  // panel holds K and the Hessian entry is +-(K+1)
     int64_t n = 0;         // panel columns (= samples for kernel problems)
@@ -181,6 +198,8 @@ int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0,
 int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count);  // all-reduce(sum) of a replicated-length vector
 // in-place all-gather of equal chunks: buf holds world*chunk doubles, this rank's chunk (at rank*chunk) is fresh on entry
 int bq_exchange_gather(bq_ctx *ctx, double *buf, int64_t chunk);
+void bq_problem_unref(bq_problem *p);   // a solver of p has gone: destroys p if that was pending
+void bq_ctx_register(bq_ctx *c, bool alive);   // bq_alloc.cpp: the contexts whose cached panels a failing allocation may drop
 void bq_ctx_drop_cache(bq_ctx *ctx);   // give the cached panel back to the driver (called before retrying a failed allocation)
 
 // bq_symv.hip: symmetric tile product over tile rows [I0, I1) -> out (nb*256 partial sums)

@@ -1381,7 +1381,9 @@ extern "C" int bq_smo_destroy(bq_smo *s) {
     for (void *ptr : {(void *)s->y, (void *)s->a, (void *)s->am, (void *)s->err, (void *)s->nz, (void *)s->cf, (void *)s->sc,
                       (void *)s->ctl, (void *)s->spec_res})
         if (ptr) hipFree(ptr);
+    bq_problem *p = s->p;
     delete s;
+    bq_problem_unref(p);
     return BQ_OK;
 }
 
@@ -1411,6 +1413,7 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
     BQ_HIP(hipSetDevice(c->device));
     bq_smo *s = new bq_smo();
     s->p = p;
+    p->refs += 1;
     s->task = task;
     s->n = n;
     s->C = C;

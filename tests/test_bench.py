@@ -1,0 +1,76 @@
+"""bench.py's launch logic: `--gpus N` from a plain shell starts N fresh rank processes itself (the parent never touches the
+GPU); a missing RCCL communicator is an error, not a silent host fallback."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, 'bench.py')
+
+
+def _run(args, timeout=600, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=REPO)
+
+
+def test_presets_and_argument_checks():
+    sys.path.insert(0, REPO)
+    import bench
+    a = bench.parse([])
+    assert (a.n, a.d, a.solver, a.task, a.kernel, a.storage, a.gpus) == (100000, 128, 'pg', 'svc', 'rbf', 'f64', 1)
+    a = bench.parse(['--config', 'c5', '--gpus', '8'])
+    assert (a.n, a.d, a.solver, a.storage, a.gpus) == (250000, 256, 'ascg', 'f32', 8)
+    a = bench.parse(['--config', 'c4', '--samples', '20000'])
+    assert (a.n, a.task, a.kernel, a.solver) == (20000, 'svr', 'poly', 'fw')
+    r = _run(['--gpus', '2', '--solver', 'ip'], timeout=120)
+    assert r.returncode != 0 and 'replicas only' in r.stderr
+
+
+def test_self_launch_without_a_gpu_fails_fast_and_loudly():
+    """No GPU in the build container: both spawned ranks fail to create a device context; the parent reports it and returns
+    non-zero within seconds — no hang, no fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a GPU')
+    r = _run(['--gpus', '2', '--samples', '2000', '--features', '8', '--steps', '2', '--warmup', '1', '--no-cpu'], timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ''
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_host_exchange_on_one_gpu():
+    """`python bench.py --gpus 2` from a plain shell: two fresh rank processes (both on GPU 0 of this one-GPU box, host
+    exchange), ONE JSON line from rank 0, same iterates as the single-process run (bit-identical objective)."""
+    common = ['--samples', '6000', '--features', '16', '--steps', '8', '--warmup', '2', '--no-cpu', '--kkt', 'none']
+    one = _run(common + ['--gpus', '1'])
+    assert one.returncode == 0, one.stderr
+    two = _run(common + ['--gpus', '2', '--exchange', 'host'])
+    assert two.returncode == 0, two.stderr
+    lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    a, b = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(lines[0])
+    assert b['n_gpus'] == 2 and b['config']['exchange'] == 'host' and b['config']['sym_exchange'] == 'gather'
+    assert b['config']['rccl_ranks'] == 0 and b['steps_done'] == 8
+    assert a['f_last'] == b['f_last'] and a['kkt_resid_last'] == b['kkt_resid_last']
+    for rec in (a, b):
+        assert rec['roofline']['bound'] == 'hbm' and 0 < rec['roofline']['frac'] < 1.2
+        assert rec['roofline']['frac_survey_8d_bytes'] > rec['roofline']['frac']
+
+
+@pytest.mark.gpu
+def test_rccl_that_cannot_be_created_is_an_error_not_a_fallback():
+    """Two ranks on ONE device cannot form an RCCL communicator: exit code 3, no JSON line; with --allow-host-exchange the
+    run falls back and says so."""
+    common = ['--samples', '4000', '--features', '8', '--steps', '3', '--warmup', '1', '--no-cpu', '--kkt', 'none', '--gpus', '2']
+    env = {'NCCL_DEBUG': 'WARN'}
+    r = _run(common, env=env)
+    assert r.returncode == 3 and r.stdout.strip() == '', (r.returncode, r.stdout, r.stderr[-2000:])
+    assert 'RCCL context unavailable' in r.stderr
+    r = _run(common + ['--allow-host-exchange'], env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['config']['exchange'] == 'host' and rec['config']['rccl_ranks'] == 0

@@ -253,7 +253,7 @@ def test_config1_linear_pg_against_the_reference_fixture():
 def test_config3_interior_point_newton_step_at_full_size():
     """C3: RBF SVC dual, InteriorPoint, n=50 000 d=128 (interior_point.py:191-267), three iterations.  The Newton system
     H dx = w, H = Q + diag(lp/(ub-x) + lm/(x-lb)), is checked with an INDEPENDENT device product; the iterate moves by
-    max_t dx; the gap falls; the iterates stay strictly interior."""
+    max_t dx; the duality gap f - p falls; the iterates stay strictly interior."""
     from optiml_amd import _lib
     from optiml_amd.datasets import make_blobs
     from optiml_amd.ml.svm.kernels import gaussian
@@ -291,8 +291,10 @@ def test_config3_interior_point_newton_step_at_full_size():
         step = rec[k + 1]['x'] - x
         t = (step @ dx) / (dx @ dx)
         assert 0 < t and np.linalg.norm(step - t * dx) <= 1e-9 * np.linalg.norm(step)
-    gaps = [r['gap'] for r in rec]
-    assert all(b < a for a, b in zip(gaps, gaps[1:]))
+    # the duality gap f - p (4 n^2 mu) falls strictly; the RELATIVE gap (f - p) / max(|f|, 1) the stop test looks at does not
+    # in the first iterations of the reference algorithm either, because |f| collapses faster (oracle: 2.0, 5.5, 5.8, 9.3 ...)
+    gaps = [r['f'] - r['p'] for r in rec]
+    assert all(b < a for a, b in zip(gaps, gaps[1:])) and gaps[-1] > 0
     quad.release()
 
 

@@ -3,6 +3,8 @@
 Tolerances (fp64 unless stated): per-kernel outputs rtol 1e-12; solver trajectories / converged alpha rtol 1e-6
 (atol 1e-9), objective rtol 1e-9 — SURVEY.md section 8(d).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -851,3 +853,82 @@ def test_ragged_sizes_kernel_panels(amd, n, monkeypatch):
         assert opt.status == ref['status'] and opt.iter == ref['iter'], (s, n)
         np.testing.assert_allclose(opt.f_x, ref['f_x'], rtol=1e-8, err_msg=f'svr {s} n={n}')
         np.testing.assert_allclose(opt.x, ref['x'], rtol=1e-6, atol=1e-8, err_msg=f'svr {s} n={n}')
+
+
+# ---------------------------------------------------------------------------------------------------------
+# handle lifetimes and the panel cache (run in child processes: they end by tearing everything down)
+# ---------------------------------------------------------------------------------------------------------
+def _run_child(code, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, '-c', code], env=e, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_handles_may_be_destroyed_in_any_order(amd):
+    """Context before problem before solver (what interpreter shutdown can do): the library keeps what is still in use alive
+    (reference counts) instead of writing into freed handles."""
+    out = _run_child('''
+import os
+
+import numpy as np
+from optiml_amd import device, _lib
+from optiml_amd.opti import Quadratic
+from optiml_amd.opti.constrained._base import _DeviceSolver
+rs = np.random.RandomState(0)
+G = rs.standard_normal((300, 320)); Q = G @ G.T / 300
+ctx = device.Context()
+quad = Quadratic(Q, rs.standard_normal(300))
+dev = quad.device_problem(ctx)
+s = _DeviceSolver(dev, _lib.PG, np.zeros(300), np.ones(300), np.full(300, .5), 1e-6, 100)
+s.run(5)
+ctx.close()            # context first ...
+rows, _ = s.run(5)     # ... the solver still runs on it
+assert len(rows) == 5
+dev.close()            # then the problem
+x = s.get(_lib.GET_X_NOW)
+assert np.isfinite(x).all()
+s.close()              # the solver last: everything is released now
+print('ok')
+''')
+    assert 'ok' in out
+
+
+def test_panel_cache_is_reused_and_dropped_when_an_allocation_fails(amd):
+    """A context keeps ONE released panel >= 1 GB for the next problem of about that size (bq_ctx.panel_cache); any failing
+    device allocation of the library drops it and retries (BQ_TEST_ALLOC_FAIL_ABOVE simulates the failure)."""
+    code = '''
+import os
+
+import numpy as np
+from optiml_amd.datasets import make_blobs
+from optiml_amd.ml.svm.kernels import gaussian
+from optiml_amd.opti import KernelQuadratic, Quadratic
+from oracle import svm_oracle as so
+def check(n, seed):
+    X, y = make_blobs(n, 8, seed=seed)
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
+    v = np.random.RandomState(seed).standard_normal(n)
+    Qv = quad.device_problem().matvec(v)
+    g = so.resolve_gamma('scale', X)
+    xx = np.einsum('ij,ij->i', X, X)
+    for i in (0, 255, 256, n - 1):
+        d2 = np.maximum(-2 * (X @ X[i]) + xx[i] + xx, 0); d2[i] = 0
+        np.testing.assert_allclose(Qv[i], ((np.exp(-g * d2) + 1) * y[i] * y) @ v, rtol=1e-9, atol=1e-9)
+    quad.release()
+check(16640, 1)          # 1.1 GB triangle: kept by the context on release
+check(16400, 2)          # slightly smaller: served from the cache (and fully rewritten)
+rs = np.random.RandomState(3)
+G = rs.standard_normal((600, 640)); Q = G @ G.T / 600
+dq = Quadratic(Q, rs.standard_normal(600))   # its 2.9 MB panel "fails" once under the test hook -> cache dropped, retried
+v = rs.standard_normal(600)
+np.testing.assert_allclose(dq.device_problem().matvec(v), Q @ v, rtol=1e-11, atol=1e-11)
+check(16400, 4)          # a fresh allocation again
+print('ok')
+'''
+    assert 'ok' in _run_child(code)
+    assert 'ok' in _run_child(code, {'BQ_TEST_ALLOC_FAIL_ABOVE': str(1 << 20)})
