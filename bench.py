@@ -456,6 +456,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}')
+    # stdout carries ONE JSON line and nothing else: gloo and RCCL (NCCL_DEBUG) write to fd 1 from C++, so fd 1 is pointed at
+    # stderr for the rest of the run and the line goes to a private copy of the original stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
     from optiml_amd import _lib
     from optiml_amd import device
@@ -468,16 +473,7 @@ def main():
     if world > 1:
         import datetime
         import torch.distributed as dist
-        # gloo announces its connections on stdout (C++ side): keep stdout for the ONE JSON line
-        sys.stdout.flush()
-        keep = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
-        finally:
-            sys.stdout.flush()
-            os.dup2(keep, 1)
-            os.close(keep)
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         from optiml_amd.dist import TorchComm
         comm = TorchComm()
         # RCCL over xGMI is the data path.  A communicator that cannot be created on EVERY rank ends the run with exit code
@@ -647,7 +643,7 @@ def main():
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     barrier()
     if comm is not None:
         import torch.distributed as dist

@@ -999,8 +999,11 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
     // iteration and look every time; PG/FW look about every 2 ms of estimated panel streaming time.
     int64_t poll = 1;
     if (s->kind == BQ_PG || s->kind == BQ_FW || s->kind == BQ_AL) {
+        // The interval must be the SAME on every rank (each iteration contains a collective: ranks that stopped enqueueing at
+        // different iterations would leave the others inside it), so it is computed from the mean share n / world, not from
+        // this rank's own rows.
         const double esz = s->p->storage == BQ_F64 ? 8.0 : 4.0;
-        const double rows = (double)(s->p->r1 - s->p->r0);
+        const double rows = (double)s->p->n / (double)c->world;
         const double iter_s = rows * (double)s->p->n * esz * (s->p->symmetric ? 0.5 : 1.0) / 5.0e12 + 30e-6;
         poll = (int64_t)(2.0e-3 / iter_s);
         poll = poll < 1 ? 1 : (poll > 64 ? 64 : poll);

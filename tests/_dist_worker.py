@@ -128,22 +128,33 @@ def gpu_c4(outdir):
     from optiml_amd.ml.svm.kernels import PolyKernel
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.opti.constrained import FrankWolfe
+    import time
+    t0 = time.time()
+    say = lambda what: print(f'[c4 rank {os.environ["RANK"]}] {time.time() - t0:7.2f}s {what}', file=sys.stderr, flush=True)
     comm = make_comm('torch')
+    say('comm up')
     device.init_distributed(comm, exchange='host', device=0)
+    say('context up')
     n, d = 20000, 128
     X, y = make_regression(n, d, seed=0)
     quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', PolyKernel(3, 'scale', 1.0))
+    quad.device_problem()
+    say('panel built')
     res = {'matvec': quad.device_problem().matvec(np.random.RandomState(2).standard_normal(2 * n))}
+    say('panel built, one product done')
     hist = []
     cb = lambda o: hist.append(o.f_x)
     cb._bq_needs_state = False
     opt = FrankWolfe(quad=quad, ub=np.ones(2 * n), max_iter=25, callback=cb).minimize()
     res['fw_x'], res['fw_hist'] = opt.x, np.array(hist)
+    say('25 FrankWolfe iterations done')
     comm.barrier()
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)
 
 
 if __name__ == '__main__':
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=False)   # a stuck rank shows where (its log is printed by the launcher)
     mode, outdir = sys.argv[1], sys.argv[2]
     if mode == 'cpu-torch':
         cpu_mode('torch', outdir)

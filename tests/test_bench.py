@@ -66,7 +66,7 @@ def test_rccl_that_cannot_be_created_is_an_error_not_a_fallback():
     """Two ranks on ONE device cannot form an RCCL communicator: exit code 3, no JSON line; with --allow-host-exchange the
     run falls back and says so."""
     common = ['--samples', '4000', '--features', '8', '--steps', '3', '--warmup', '1', '--no-cpu', '--kkt', 'none', '--gpus', '2']
-    env = {'NCCL_DEBUG': 'WARN'}
+    env = {'NCCL_DEBUG': 'WARN'}     # RCCL's own chatter goes to fd 1: it must not reach the JSON channel either
     r = _run(common, env=env)
     assert r.returncode == 3 and r.stdout.strip() == '', (r.returncode, r.stdout, r.stderr[-2000:])
     assert 'RCCL context unavailable' in r.stderr

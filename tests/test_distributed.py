@@ -25,24 +25,36 @@ def _free_port():
 
 
 def _launch(mode, world, outdir, timeout=300):
+    """One process per rank; each rank's output goes to OUTDIR/rank<r>.log and is shown when a rank fails or hangs."""
+    import time
     port = _free_port()
+    outdir = str(outdir)
     os.makedirs(outdir, exist_ok=True)
-    procs = []
+    procs, logs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
-        procs.append(subprocess.Popen([sys.executable, WORKER, mode, str(outdir)], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
+        logs.append(open(os.path.join(outdir, f'rank{r}.log'), 'w'))
+        procs.append(subprocess.Popen([sys.executable, WORKER, mode, outdir], env=env, stdout=logs[-1],
+                                      stderr=subprocess.STDOUT))
+
+    def tails():
+        for f in logs:
+            f.close()
+        return '\n'.join(f'---- rank {r} ----\n' + open(os.path.join(outdir, f'rank{r}.log')).read()[-3000:] for r in range(world))
+
+    deadline = time.time() + timeout
+    while any(p.poll() is None for p in procs):
+        if time.time() > deadline or any(p.poll() not in (None, 0) for p in procs):
             for q in procs:
-                q.kill()
-            raise
-        outs.append(out)
-    for r, (p, out) in enumerate(zip(procs, outs)):
+                if q.poll() is None:
+                    q.kill()
+            for q in procs:
+                q.wait()
+            raise AssertionError(f'{mode} x{world}: a rank failed or did not finish within {timeout} s\n' + tails())
+        time.sleep(0.05)
+    out = tails()
+    for r, p in enumerate(procs):
         assert p.returncode == 0, f'rank {r} failed:\n{out}'
     return [np.load(os.path.join(outdir, f'rank{r}.npz')) for r in range(world)]
 

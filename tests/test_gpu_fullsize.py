@@ -382,8 +382,8 @@ def test_config4_shape_through_the_two_rank_exchange(tmp_path):
     from test_distributed import _launch
     from oracle import svm_oracle as so, bcqp_oracle as bo
     from optiml_amd.datasets import make_regression
-    one = _launch('gpu-host-c4', 1, tmp_path / 'w1', timeout=600)[0]
-    two = _launch('gpu-host-c4', 2, tmp_path / 'w2', timeout=600)
+    one = _launch('gpu-host-c4', 1, tmp_path / 'w1', timeout=120)[0]
+    two = _launch('gpu-host-c4', 2, tmp_path / 'w2', timeout=120)
     for r in two:
         for key in ('fw_x', 'fw_hist', 'matvec'):
             assert np.array_equal(r[key], one[key]), key
