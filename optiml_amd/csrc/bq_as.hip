@@ -1136,15 +1136,10 @@ int bq_as_iterate(bq_solver *s) {
         // Q[A,A] is not positive definite: the reference's bare `except` switches to scipy's minres on the normal
         // equations (active_set.py:142-151).  Rebuild the (destroyed) restricted Hessian with both triangles, solve,
         // and redo the feasibility test on the minimum-residual candidate.
-        if (nA > 8192) {
-            bq_set_error("restricted Hessian Q[A,A] (|A| = %lld) is not positive definite at pivot %d and too large for "
-                         "the single-workgroup MINRES fallback (limit 8192)", (long long)nA, info);
-            return BQ_ERR_NOT_PD;
-        }
         if (!ws->mr_vec) BQ_HIP(hipMalloc(&ws->mr_vec, sizeof(double) * 10 * ws->cap));
         BQ_TRY(bq_chol_build_h(ws, s->p, w->idx, nA, nullptr, &np, true));
         as_gather_rhs_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->p->q, w->Qz, ws->rhs, np);
-        BQ_TRY(bq_minres_normal(ws, w->ints, ws->cap, ws->mr_vec, w->ints + 7));
+        BQ_TRY(bq_minres_normal(ws, w->ints, nA, np, ws->mr_vec, w->ints + 7));
         as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, ws->rhs, w->z, N, s->lb, s->ub, w->cand);
         BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
         BQ_HIP(hipStreamSynchronize(st));

@@ -14,6 +14,10 @@ struct bq_chol_ws {
     int *info = nullptr;      // 0 = ok, else 1 + index of the first non-positive pivot
     unsigned int *ticket = nullptr;   // last-block ticket of the fused solve kernels
     double *mr_vec = nullptr; // 10 x cap scratch vectors of the MINRES fallback (allocated on first use)
+    void *mr_state = nullptr; // device scalars, partial sums and the pinned done flag of its multi-workgroup form
+    double *mr_part = nullptr;
+    int64_t mr_part_cap = 0;
+    int *mr_flag = nullptr;
     // look-ahead: the narrow work of pass p+1 (diagonal blocks, TRSM, column update) runs on a side stream that owns
     // a few reserved CUs while the wide trailing update of pass p runs on the rest of the chip
     hipStream_t s_main = nullptr, s_side = nullptr;
@@ -27,4 +31,4 @@ constexpr int BQ_H_KPLUS1 = 3;   // internal H-assembly mode: entries K_ij + 1 o
 int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out,
                     bool full = false, int structure_override = -1);
 // bq_minres.hip: x = argmin |H x - q'| via MINRES on H H^T x = H q' (H = ws->H full symmetric, q' = ws->rhs)
-int bq_minres_normal(bq_chol_ws *ws, const int *nA_dev, int64_t np, double *vec, int *iters_dev);
+int bq_minres_normal(bq_chol_ws *ws, const int *nA_dev, int64_t nA, int64_t np, double *vec, int *iters_dev);

@@ -331,8 +331,9 @@ void bq_chol_ws_destroy(bq_chol_ws *ws) {
     if (ws->s_main) hipStreamDestroy(ws->s_main);
     if (ws->s_side) hipStreamDestroy(ws->s_side);
     for (void *p : {(void *)ws->H, (void *)ws->Wt, (void *)ws->LinvT, (void *)ws->rhs, (void *)ws->tmp, (void *)ws->info, (void *)ws->ticket,
-                    (void *)ws->mr_vec})
+                    (void *)ws->mr_vec, (void *)ws->mr_state, (void *)ws->mr_part})
         if (p) hipFree(p);
+    if (ws->mr_flag) hipHostFree(ws->mr_flag);
     delete ws;
 }
 

@@ -8,6 +8,8 @@
 // workgroup with the restricted Hessian resident in L2 avoids ~10 launches and 3 host round-trips per iteration.
 // The operator is applied as H (H v) with the symmetric H = Q[A,A] instead of forming H H^T.
 // Parity can only be loose: the singular case is decided by rounding in the reference as well.
+#include <cstdlib>
+
 #include "bq_chol.h"
 
 constexpr int MT = 1024;   // threads of the persistent workgroup
@@ -167,7 +169,288 @@ __global__ __launch_bounds__(MT) void minres_normal_kernel(const double *__restr
     if (tid == 0 && iters) *iters = itn;
 }
 
-int bq_minres_normal(bq_chol_ws *ws, const int *nA_dev, int64_t np, double *vec, int *iters_dev) {
+// ---------------------------------------------------------------------------------------------------------------
+// The same iteration for restricted systems of ANY size (the reference falls through to minres whatever |A| is,
+// active_set.py:142-151): the two products H (H v) are HBM-streaming row-block kernels over all CUs, the O(n) updates are
+// three fused vector kernels whose last-finishing block carries the scalar recurrences (Lanczos coefficients, Givens
+// rotation, the stopping tests in scipy's order) in a device-resident state, reductions are fixed two-stage trees.  The
+// host enqueues batches of iterations blind and looks at the `done` flag between batches; kernels early-exit on it.
+// ---------------------------------------------------------------------------------------------------------------
+struct mr_state {
+    double beta1, oldb, beta, dbar, epsln, phibar, rhs1, rhs2, tnorm2, gmax, gmin, cs, sn;
+    double alfa, oldeps, delta, denom, phi, root, rtol;
+    long long itn, maxiter;
+    int istop, done;
+    unsigned int ticket[4];
+};
+
+constexpr int MV_T = 256, MV_ITEMS = 4, MV_TILE = MV_T * MV_ITEMS;
+typedef double mr_d2 __attribute__((ext_vector_type(2)));
+
+// y[r] = sum_c H[r][c] x[c], c < np (np a multiple of 128; rows are 16-byte aligned): one workgroup per 4 rows
+__global__ __launch_bounds__(MV_T) void mr_gemv_kernel(const double *__restrict__ H, int64_t ld, int64_t np,
+                                                       const double *__restrict__ x, double *__restrict__ y,
+                                                       const mr_state *st) {
+    if (st->done) return;
+    constexpr int R = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    double acc[R] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t c = 2 * (int64_t)tid; c < np; c += 2 * MV_T) {
+        const mr_d2 xv = *reinterpret_cast<const mr_d2 *>(x + c);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = r0 + r < np ? r0 + r : np - 1;
+            const mr_d2 h = *reinterpret_cast<const mr_d2 *>(H + row * ld + c);
+            acc[r] = fma(h.y, xv.y, fma(h.x, xv.x, acc[r]));
+        }
+    }
+    __shared__ double red[4][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double s = mr_wsum(acc[r]);
+        if (lane == 0) red[wv][r] = s;
+    }
+    __syncthreads();
+    if (tid < R && r0 + tid < np) y[r0 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+// block-wide sum for the 256-thread vector kernels: every thread receives it
+__device__ __forceinline__ double mv_bsum(double v, double *sh) {
+    v = mr_wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+// partial -> part[block]; the block that takes the last ticket gets the total (fixed order), the others NAN-flag false
+__device__ __forceinline__ bool mv_total(double local, double *part, unsigned int *ticket, double *sh, double *total) {
+    const double b = mv_bsum(local, sh);
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = b;
+        __threadfence();   // this block's partial is visible device-wide before the ticket is taken ...
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the compiler may drop the fence's own wait)
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return false;
+    __threadfence();
+    double a = 0.0;
+    for (unsigned int i = threadIdx.x; i < gridDim.x; i += MV_T)
+        a += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *total = mv_bsum(a, sh);
+    if (threadIdx.x == 0) *ticket = 0u;
+    return true;
+}
+
+#define MV_LOOP(i)                                                        \
+    const int64_t _b = (int64_t)blockIdx.x * MV_TILE + threadIdx.x;       \
+    _Pragma("unroll") for (int _j = 0; _j < MV_ITEMS; ++_j)               \
+        for (int64_t i = _b + (int64_t)_j * MV_T, _o = 1; _o && i < np; _o = 0)
+
+// b = H q' is in Ra already: x = 0, w = w2 = 0, |b|^2 -> beta1 and the start values of the recurrences
+__global__ __launch_bounds__(MV_T) void mr_init_kernel(int64_t np, const double *__restrict__ Ra, double *x, double *W0,
+                                                       double *W2, double *part, mr_state *st, long long maxiter, double rtol) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    MV_LOOP(i) {
+        x[i] = 0.0;
+        W0[i] = 0.0;
+        W2[i] = 0.0;
+        s = fma(Ra[i], Ra[i], s);
+    }
+    double tot;
+    if (mv_total(s, part, &st->ticket[0], sh, &tot) && threadIdx.x == 0) {
+        mr_state t;
+        memset(&t, 0, sizeof(t));
+        t.beta1 = tot > 0.0 ? sqrt(tot) : 0.0;
+        t.beta = t.beta1;
+        t.phibar = t.beta1;
+        t.rhs1 = t.beta1;
+        t.gmin = 1.7976931348623157e308;
+        t.cs = -1.0;
+        t.maxiter = maxiter;
+        t.rtol = rtol;
+        t.done = tot > 0.0 ? 0 : 1;   // beta1 == 0: the exact solution is x0 = 0
+        *st = t;
+    }
+}
+
+__global__ __launch_bounds__(MV_T) void mr_scale_kernel(int64_t np, const double *__restrict__ y, double *v, const mr_state *st) {
+    if (st->done) return;
+    const double s = 1.0 / st->beta;
+    MV_LOOP(i) v[i] = s * y[i];
+}
+
+// after ynew = H H v:  [ynew -= (beta / oldb) r1];  alfa = v . ynew
+__global__ __launch_bounds__(MV_T) void mr_alfa_kernel(int64_t np, int sub_r1, const double *__restrict__ v, double *ynew,
+                                                       const double *__restrict__ r1, double *part, mr_state *st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    const double c = sub_r1 ? st->beta / st->oldb : 0.0;
+    double s = 0.0;
+    MV_LOOP(i) {
+        double y = ynew[i];
+        if (sub_r1) {
+            y = y - c * r1[i];
+            ynew[i] = y;
+        }
+        s = fma(v[i], y, s);
+    }
+    double tot;
+    if (mv_total(s, part, &st->ticket[1], sh, &tot) && threadIdx.x == 0) st->alfa = tot;
+}
+
+// ynew -= (alfa / beta) r2;  beta' = |ynew|;  the Givens rotation and everything scalar up to the solution update
+__global__ __launch_bounds__(MV_T) void mr_beta_kernel(int64_t np, long long itn, double *ynew, const double *__restrict__ r2,
+                                                       double *part, mr_state *st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    const double c = st->alfa / st->beta;
+    double s = 0.0;
+    MV_LOOP(i) {
+        const double y = ynew[i] - c * r2[i];
+        ynew[i] = y;
+        s = fma(y, y, s);
+    }
+    double tot;
+    if (mv_total(s, part, &st->ticket[2], sh, &tot) && threadIdx.x == 0) {
+        const double eps = 2.220446049250313e-16;
+        mr_state t = *st;
+        t.oldb = t.beta;
+        t.beta = sqrt(tot);
+        t.tnorm2 += t.alfa * t.alfa + t.oldb * t.oldb + t.beta * t.beta;
+        if (itn == 1 && t.beta / t.beta1 <= 10.0 * eps) t.istop = -1;
+        t.oldeps = t.epsln;
+        t.delta = t.cs * t.dbar + t.sn * t.alfa;
+        const double gbar = t.sn * t.dbar - t.cs * t.alfa;
+        t.epsln = t.sn * t.beta;
+        t.dbar = -t.cs * t.beta;
+        t.root = hypot(gbar, t.dbar);
+        double gamma = hypot(gbar, t.beta);
+        gamma = fmax(gamma, eps);
+        t.cs = gbar / gamma;
+        t.sn = t.beta / gamma;
+        t.phi = t.cs * t.phibar;
+        t.phibar = t.sn * t.phibar;
+        t.denom = 1.0 / gamma;
+        t.gmax = fmax(t.gmax, gamma);
+        t.gmin = fmin(t.gmin, gamma);
+        const double z = t.rhs1 / gamma;
+        t.rhs1 = t.rhs2 - t.delta * z;
+        t.rhs2 = -t.epsln * z;
+        *st = t;
+    }
+}
+
+// w = (v - oldeps w1 - delta w2) / gamma;  x += phi w;  |x| -> the stopping tests;  v <- ynew / beta for the next iteration
+__global__ __launch_bounds__(MV_T) void mr_update_kernel(int64_t np, long long itn, double *v, const double *__restrict__ ynew,
+                                                         double *w, const double *__restrict__ w1, const double *__restrict__ w2,
+                                                         double *x, double *part, mr_state *st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    const double oldeps = st->oldeps, delta = st->delta, denom = st->denom, phi = st->phi, beta = st->beta;
+    const double nexts = beta > 0.0 ? 1.0 / beta : 0.0;
+    double s = 0.0;
+    MV_LOOP(i) {
+        const double wn = (v[i] - oldeps * w1[i] - delta * w2[i]) * denom;
+        w[i] = wn;
+        const double xi = x[i] + phi * wn;
+        x[i] = xi;
+        s = fma(xi, xi, s);
+        v[i] = nexts * ynew[i];
+    }
+    double tot;
+    if (mv_total(s, part, &st->ticket[3], sh, &tot) && threadIdx.x == 0) {
+        const double eps = 2.220446049250313e-16;
+        mr_state t = *st;
+        const double ynorm = sqrt(tot);
+        const double Anorm = sqrt(t.tnorm2);
+        const double epsx = Anorm * ynorm * eps;
+        const double rnorm = t.phibar;
+        const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? INFINITY : rnorm / (Anorm * ynorm);
+        const double test2 = (Anorm == 0.0) ? INFINITY : t.root / Anorm;
+        const double Acond = t.gmax / t.gmin;
+        int istop = t.istop;
+        if (istop == 0) {
+            const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+            if (t2 <= 1.0) istop = 2;
+            if (t1 <= 1.0) istop = 1;
+            if (itn >= t.maxiter) istop = 6;
+            if (Acond >= 0.1 / eps) istop = 4;
+            if (epsx >= t.beta1) istop = 3;
+            if (test2 <= t.rtol) istop = 2;
+            if (test1 <= t.rtol) istop = 1;
+        }
+        st->itn = itn;
+        st->istop = istop;
+        if (istop != 0) {
+            __threadfence();
+            st->done = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(MV_T) void mr_finish_kernel(int64_t np, const int *nA_ptr, const double *__restrict__ x, double *rhs,
+                                                         const mr_state *st, int *iters) {
+    const int n = *nA_ptr;
+    MV_LOOP(i) rhs[i] = i < n ? x[i] : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && iters) *iters = (int)st->itn;
+}
+
+static int minres_normal_big(bq_chol_ws *ws, const int *nA_dev, int64_t nA, int64_t np, double *vec, int *iters_dev) {
+    hipStream_t stm = ws->ctx->stream;
+    const unsigned vb = (unsigned)((np + MV_TILE - 1) / MV_TILE), gb = (unsigned)((np + 3) / 4);
+    if (!ws->mr_state) {
+        BQ_HIP(hipMalloc(&ws->mr_state, 256));
+        BQ_HIP(hipHostMalloc((void **)&ws->mr_flag, 2 * sizeof(int), hipHostMallocDefault));
+    }
+    if (ws->mr_part_cap < (int64_t)vb) {
+        if (ws->mr_part) BQ_HIP(hipFree(ws->mr_part));
+        ws->mr_part = nullptr;
+        BQ_HIP(hipMalloc(&ws->mr_part, sizeof(double) * vb));
+        ws->mr_part_cap = vb;
+    }
+    mr_state *st = (mr_state *)ws->mr_state;
+    static_assert(sizeof(mr_state) <= 256, "mr_state");
+    double *b = vec, *x = vec + np, *R[3] = {vec + 2 * np, vec + 3 * np, vec + 4 * np}, *v = vec + 5 * np,
+           *W[3] = {vec + 6 * np, vec + 7 * np, vec + 8 * np}, *tmp = vec + 9 * np;
+    (void)b;
+    const long long maxiter = 5 * (long long)nA;
+    BQ_HIP(hipMemsetAsync(st, 0, sizeof(mr_state), stm));   // done = 0 for the first product
+    // b = H q' goes straight into R[0] (r1 = b, y = r1)
+    mr_gemv_kernel<<<gb, MV_T, 0, stm>>>(ws->H, ws->ldh, np, ws->rhs, R[0], st);
+    mr_init_kernel<<<vb, MV_T, 0, stm>>>(np, R[0], x, W[0], W[2], ws->mr_part, st, maxiter, 1e-5);
+    mr_scale_kernel<<<vb, MV_T, 0, stm>>>(np, R[0], v, st);
+    long long k = 0;
+    int batch = 8;
+    while (k < maxiter) {
+        BQ_HIP(hipMemcpyAsync(ws->mr_flag, &st->done, sizeof(int), hipMemcpyDeviceToHost, stm));
+        BQ_HIP(hipStreamSynchronize(stm));
+        if (ws->mr_flag[0]) break;
+        for (int q = 0; q < batch && k < maxiter; ++q) {
+            ++k;
+            double *ynew = R[k % 3], *r2 = R[(k + 2) % 3], *r1 = R[(k + 1) % 3];   // (k-1) mod 3, (k-2) mod 3
+            mr_gemv_kernel<<<gb, MV_T, 0, stm>>>(ws->H, ws->ldh, np, v, tmp, st);      // operator = H H^T = H H
+            mr_gemv_kernel<<<gb, MV_T, 0, stm>>>(ws->H, ws->ldh, np, tmp, ynew, st);
+            mr_alfa_kernel<<<vb, MV_T, 0, stm>>>(np, k >= 2 ? 1 : 0, v, ynew, r1, ws->mr_part, st);
+            mr_beta_kernel<<<vb, MV_T, 0, stm>>>(np, k, ynew, r2, ws->mr_part, st);
+            mr_update_kernel<<<vb, MV_T, 0, stm>>>(np, k, v, ynew, W[k % 3], W[(k + 1) % 3], W[(k + 2) % 3], x, ws->mr_part, st);
+        }
+        if (batch < 64) batch *= 2;
+    }
+    mr_finish_kernel<<<vb, MV_T, 0, stm>>>(np, nA_dev, x, ws->rhs, st, iters_dev);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
+// nA: |A| on the host.  Up to BQ_MINRES_BIG_MIN (default 4096) rows the single persistent workgroup is faster (no launches at
+// all); beyond that — and for any size the one workgroup could not hold — the multi-workgroup form.
+int bq_minres_normal(bq_chol_ws *ws, const int *nA_dev, int64_t nA, int64_t np, double *vec, int *iters_dev) {
+    const char *e = getenv("BQ_MINRES_BIG_MIN");   // read per call: tests switch the form inside one process
+    const long long big_min = e ? atoll(e) : 4096ll;
+    if (nA >= big_min) return minres_normal_big(ws, nA_dev, nA, np, vec, iters_dev);
     minres_normal_kernel<<<1, MT, 0, ws->ctx->stream>>>(ws->H, ws->ldh, nA_dev, ws->rhs, vec, np, 1e-5, iters_dev);
     BQ_HIP(hipGetLastError());
     return BQ_OK;

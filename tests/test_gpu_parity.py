@@ -586,6 +586,50 @@ def test_active_set_singular_system_uses_minres(amd, as_factor_mode):
     assert np.all(opt.x >= -1e-9) and np.all(opt.x <= 1 + 1e-9)
 
 
+def test_minres_forms_agree(amd, monkeypatch):
+    """The fallback exists in two forms — one persistent workgroup (small |A|) and the multi-workgroup form that has no
+    size limit: the same Paige-Saunders recurrences, so on the same singular system they give the same trajectory."""
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.kernels import linear
+    g = load_golden('fit_svc_n200.npz')
+    X, y = g['X'], g['y']
+    n = len(y)
+    runs = []
+    for big_min in ('1000000', '0'):
+        monkeypatch.setenv('BQ_MINRES_BIG_MIN', big_min)
+        monkeypatch.setenv('BQ_AS_SCHUR', '0')
+        hist = []
+        cb = lambda o: hist.append(o.f_x)
+        cb._bq_needs_state = False
+        opt = _solvers()['as'](quad=KernelQuadratic(X, -np.ones(n), 'svc', linear, y=y), ub=np.ones(n), max_iter=12,
+                               callback=cb).minimize()
+        runs.append((np.array(hist), opt.x))
+    np.testing.assert_allclose(runs[1][0], runs[0][0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(runs[1][1], runs[0][1], rtol=1e-7, atol=1e-9)
+
+
+def test_active_set_singular_system_at_n10000(amd):
+    """The reference falls through to minres on the normal equations whatever |A| is (active_set.py:142-151); round 1's device
+    fallback stopped at |A| = 8192.  Linear kernel, n = 10 000, d = 20 (rank 21 Hessian): the first iterations against the
+    CPU oracle (scipy's minres on Q_AA Q_AA'), loose by nature: minres stops at rtol 1e-5."""
+    from oracle import svm_oracle as so, bcqp_oracle as bo
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.kernels import linear
+    n, d = 10000, 20
+    X, y = make_blobs(n, d, seed=3)
+    Q, q, ub = so.svc_dual(so.gram('linear', X), y, 1.0)
+    ref = bo.active_set(Q, q, ub, max_iter=3, trace=True)
+    assert all(t['used_minres'] for t in ref['trace'][:3])
+    hist = []
+    cb = lambda o: hist.append(o.f_x)
+    cb._bq_needs_state = False
+    opt = _solvers()['as'](quad=KernelQuadratic(X, q, 'svc', linear, y=y), ub=ub, max_iter=3, callback=cb).minimize()
+    assert opt.status == 'stopped' and opt.iter == 3
+    np.testing.assert_allclose(hist, ref['f_hist'], rtol=2e-3, atol=1e-6)
+    assert np.all(opt.x >= -1e-9) and np.all(opt.x <= 1 + 1e-9)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # API behaviour the reference's callers rely on
 # ---------------------------------------------------------------------------------------------------------
