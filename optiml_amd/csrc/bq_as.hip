@@ -470,12 +470,14 @@ __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__r
 // ---------------------------------------------------------------------------------------------------------------
 // factor re-use: Schur-complement updates of a base factorisation (see the header comment)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int AS_SCHUR_MAX = 512;   // capacity of the update slots
+constexpr int AS_SCHUR_MAX = 1536;   // capacity of the update slots
 // changed indices carried before the base is re-factorised: the larger the factor, the longer it is worth keeping
 // (n^3/3 to rebuild against one more small-system row per carried index)
 static int as_schur_limit(int64_t np0) {
     if (const char *e = getenv("BQ_AS_SCHUR_LIMIT")) return std::max(1, std::min(atoi(e), AS_SCHUR_MAX));   // tests
-    return np0 < 8192 ? 96 : (np0 < 40000 ? 192 : (np0 < 80000 ? 256 : 512));
+    // (re-tuned in round 2 for the two-launches-per-1024-rows sweeps: a solve is ~4x cheaper, so the n^3/3 of a rebuild is
+    // amortised over more iterations: n = 50 000: 0.77 s per rebuild = 3 ms per iteration at 256 carried changes)
+    return np0 < 8192 ? 96 : (np0 < 40000 ? 384 : (np0 < 80000 ? 768 : 1536));
 }
 
 struct as_schur {
@@ -777,6 +779,12 @@ static int as_schur_refresh(bq_solver *s, as_ws *w, int64_t nA, bool *ok) {
         *ok = false;
         return BQ_OK;
     }
+    // this factor is kept for up to hundreds of iterations: make its sweeps short chains of full-chip products
+    static const bool fast_sweeps = [] {
+        const char *e = getenv("BQ_AS_FAST_SWEEPS");
+        return e == nullptr || atoi(e) != 0;
+    }();
+    if (fast_sweeps) BQ_TRY(bq_chol_prepare_sweeps(ws, np0));
     std::fill(c->hpos0.begin(), c->hpos0.end(), -1);
     for (int64_t a = 0; a < nA; ++a) c->hpos0[(size_t)hidx[(size_t)a]] = (int)a;
     c->n0 = nA;

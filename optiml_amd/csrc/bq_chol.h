@@ -18,6 +18,11 @@ struct bq_chol_ws {
     double *mr_part = nullptr;
     int64_t mr_part_cap = 0;
     int *mr_flag = nullptr;
+    // fast sweeps (bq_chol_prepare_sweeps): inverses of the 1024 x 1024 diagonal blocks of the factor and their transposes,
+    // scratch of their construction, the 1024-vector between the two launches of a block step; sweep_np = the factor order
+    // they were prepared for (0: not prepared; bq_chol_solve then walks the 128-row blocks)
+    double *bigM = nullptr, *bigMT = nullptr, *big_scratch = nullptr, *sw_t = nullptr;
+    int64_t big_cap = 0, sweep_np = 0;
     // look-ahead: the narrow work of pass p+1 (diagonal blocks, TRSM, column update) runs on a side stream that owns
     // a few reserved CUs while the wide trailing update of pass p runs on the rest of the chip
     hipStream_t s_main = nullptr, s_side = nullptr;
@@ -27,6 +32,9 @@ struct bq_chol_ws {
 
 int bq_chol_factor(bq_chol_ws *ws, int64_t np);
 int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero = 0);   // rhs[0:first_nonzero) is known to be zero
+// after a successful bq_chol_factor of a factor that will be solved with many times: two launches per 1024 rows and
+// direction instead of one per 128 (writes L^T into the upper triangle of H)
+int bq_chol_prepare_sweeps(bq_chol_ws *ws, int64_t np);
 constexpr int BQ_H_KPLUS1 = 3;   // internal H-assembly mode: entries K_ij + 1 of the n x n panel
 int bq_chol_build_h(bq_chol_ws *ws, bq_problem *p, const int *idx, int64_t m, const double *hd, int64_t *np_out,
                     bool full = false, int structure_override = -1);
