@@ -123,6 +123,10 @@ int bq_ctx_profile_read(bq_ctx *ctx, int which, double *total_ms, int64_t *launc
 /* measured HBM ceilings of this GPU on a scratch buffer of `bytes`: a read-only streaming sweep and a
  * device-to-device copy (read + written bytes), in GB/s — the yardstick beside the nominal 8 TB/s */
 int bq_ctx_probe_bandwidth(bq_ctx *ctx, int64_t bytes, int reps, double *read_gbs, double *copy_gbs);
+/* measured fp64 matrix-core ceiling of this GPU: back-to-back v_mfma_f64_16x16x4_f64 on register operands for about `seconds`
+ * (first half warm-up: the clock settles under the load), in TFLOP/s — the yardstick beside the nominal 78.6 TFLOP/s for
+ * the roofline fraction of the Cholesky (SURVEY 8d asks for nominal-peak and measured fractions) */
+int bq_ctx_probe_mfma_f64(bq_ctx *ctx, double seconds, double *tflops);
 /* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic): equal 128-aligned
  * blocks for dense panels; bq_sym_row_block: the balanced triangular partition (256-aligned) of the symmetric
  * kernel panels, whose ranks stream only the tiles on/below the diagonal */

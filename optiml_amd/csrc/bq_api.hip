@@ -668,6 +668,71 @@ extern "C" int bq_ctx_probe_bandwidth(bq_ctx *c, int64_t bytes, int reps, double
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp64 MFMA probe: what back-to-back v_mfma_f64_16x16x4_f64 with register operands sustain on this GPU at the clock it
+// holds under that load — the yardstick beside the nominal 78.6 TFLOP/s for the Cholesky's roofline fraction
+// ---------------------------------------------------------------------------------------------
+typedef double probe_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void probe_mfma_kernel(double *sink, int iters, double seed) {
+    probe_d4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (probe_d4){0.0, 0.0, 0.0, 0.0};
+    double a = seed + 1e-3 * (double)(threadIdx.x & 15), b = 1.0 - 1e-3 * (double)(threadIdx.x >> 4);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        a = -a;   // keeps the sums bounded without touching the MFMA stream's shape
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    if (s == 12345.678) *sink = s;   // keeps the MFMAs alive, practically never true
+}
+
+extern "C" int bq_ctx_probe_mfma_f64(bq_ctx *c, double seconds, double *tflops) {
+    BQ_ARG(c && tflops, "NULL argument");
+    BQ_ARG(seconds > 0.0 && seconds <= 10.0, "seconds in (0, 10]");
+    BQ_HIP(hipSetDevice(c->device));
+    double *sink = nullptr;
+    BQ_HIP(hipMalloc(&sink, sizeof(double)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const int iters = 4096;
+    const unsigned grid = (unsigned)(c->num_cu * 2);           // 2 workgroups of 4 waves per CU: two waves per SIMD
+    const double flop_per_launch = (double)grid * 4.0 * iters * 16.0 * 2048.0;   // waves x iterations x MFMAs x 2*16*16*4
+    float ms = 0.f;
+    int launches = 0;
+    if (e == hipSuccess) {
+        // warm up for half the requested time so that the clock has settled under the load, then time the other half
+        probe_mfma_kernel<<<grid, 256, 0, c->stream>>>(sink, iters, 0.5);
+        hipEventRecord(e0, c->stream);
+        probe_mfma_kernel<<<grid, 256, 0, c->stream>>>(sink, iters, 0.5);
+        hipEventRecord(e1, c->stream);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        const int per_half = ms > 0.f ? std::max(1, (int)(seconds * 500.0 / ms)) : 1;
+        for (int i = 0; e == hipSuccess && i < per_half; ++i) probe_mfma_kernel<<<grid, 256, 0, c->stream>>>(sink, iters, 0.5);
+        if (e == hipSuccess) {
+            hipEventRecord(e0, c->stream);
+            for (int i = 0; i < per_half; ++i) probe_mfma_kernel<<<grid, 256, 0, c->stream>>>(sink, iters, 0.5);
+            hipEventRecord(e1, c->stream);
+            e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            launches = per_half;
+        }
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(sink);
+    if (e != hipSuccess || ms <= 0.f) {
+        bq_set_error("MFMA probe failed: %s", hipGetErrorString(e));
+        return BQ_ERR_HIP;
+    }
+    *tflops = flop_per_launch * launches / (ms * 1e-3) / 1e12;
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // solvers
 // ---------------------------------------------------------------------------------------------
 static int alloc_vec(bq_solver *s, double **v) {

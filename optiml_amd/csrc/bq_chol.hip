@@ -96,13 +96,19 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(double *__restrict__ H
     bq_tile_store(acc, Ct, ldh);
 }
 
-// the K = 256 update restricted to the first TWO block columns of the trailing matrix starting at r0 (tiles (ti, 0) and
-// (ti >= 1, 1)): the part the next pass's narrow work waits for
-__global__ __launch_bounds__(256, 2) void syrk_head2_kernel(double *__restrict__ H, int64_t ldh, int64_t r0,
-                                                            const double *__restrict__ Wt, int kdim, int64_t T) {
+// the update restricted to the first NC block columns of the trailing matrix starting at r0 (tiles (ti >= c, c), c < NC):
+// the part the next narrow work waits for.  NC = 2 with the K = 256 images of one pass, NC = 4 with the K = 512 images of a
+// super-pass.
+__global__ __launch_bounds__(256, 2) void syrk_head_kernel(double *__restrict__ H, int64_t ldh, int64_t r0,
+                                                           const double *__restrict__ Wt, int kdim, int64_t T, int nc) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    const int64_t b = blockIdx.x;
-    const int64_t ti = b < T ? b : b - T + 1, tj = b < T ? 0 : 1;
+    int64_t b = blockIdx.x, tj = 0;
+    while (tj < nc - 1 && b >= T - tj) {   // column tj holds T - tj tiles
+        b -= T - tj;
+        ++tj;
+    }
+    const int64_t ti = b + tj;
+    if (ti >= T) return;
     const int64_t arow = r0 + ti * NB, bcol = r0 + tj * NB;
     bq_d4 acc[4][4];
     double *Ct = H + arow * ldh + bcol;
@@ -276,7 +282,7 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
         delete ws;
         return BQ_ERR_NOMEM;
     }
-    if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * 4 * NB * ws->ldh);
+    if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * 8 * NB * ws->ldh);   // 2 super-passes x 4 block-column images
     if (e == hipSuccess) e = hipMalloc(&ws->LinvT, sizeof(double) * nblk * NB * NB);
     if (e == hipSuccess) e = hipMalloc(&ws->rhs, sizeof(double) * (ws->cap + NB));
     if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * 4 * NB);   // up to four column slices of a block row
@@ -348,13 +354,17 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_CHOL, &e0, &e1));
     BQ_HIP(hipMemsetAsync(ws->info, 0, sizeof(int), st));
     const int64_t ldh = ws->ldh;
-    // Two block columns per pass p (A_p = 2p*NB, B_p = A_p + NB, trailing start R_p = A_p + 2NB):
-    //   narrow(p): diag(A) ; TRSM(A) ; narrow update of column B ; diag(B) ; TRSM(B)     -> images Wt[p % 2]
-    //   wide(p)  : trailing -= [X_A X_B][X_A X_B]^T in ONE K = 256 pass (half the C-tile traffic of two K = 128 passes),
-    //              split into head (the two block columns pass p+1 factors next) and rest.
-    // With look-ahead narrow(p+1) runs on the side stream (reserved CUs) while wide_rest(p) keeps the rest of the chip
-    // busy; without it everything is issued in order on one stream.
-    auto wimg = [&](int64_t p) { return ws->Wt + (p & 1) * (int64_t)(2 * NB) * ldh; };
+    // Two block columns per pass p (A_p = 2p*NB, B_p = A_p + NB), two passes per SUPER-PASS q (passes 2q, 2q+1):
+    //   narrow(p): diag(A) ; TRSM(A) ; narrow update of column B ; diag(B) ; TRSM(B)        -> images of pass p
+    //   head2(p) : the two block columns pass p+1 factors next  -= [X_A X_B][..]^T           (K = 256, images of pass p)
+    //   wide(q)  : everything behind pass 2q+1 -= X X^T with the FOUR images of passes 2q, 2q+1 in ONE K = 512 pass —
+    //              a C tile is read and written once per 512 columns factored (tools/syrk_probe.hip: the tile update runs at
+    //              0.71 of the MFMA peak with K = 256 and 0.82 with K = 512: its C traffic is not covered by the partner
+    //              workgroup); split into head4 (the four block columns super-pass q+1 factors) and rest.
+    // The images of a super-pass are contiguous in k (pass 2q: rows 0..255, pass 2q+1: rows 256..511), two buffers.
+    // With look-ahead the narrow chain of super-pass q+1 (narrow, head2, narrow — it touches only the four block columns
+    // head4(q) has finished) runs on the side stream while rest(q) keeps the chip busy.
+    auto wimg = [&](int64_t p) { return ws->Wt + ((p >> 1) & 1) * (int64_t)(4 * NB) * ldh + (p & 1) * (int64_t)(2 * NB) * ldh; };
     auto narrow = [&](int64_t p, hipStream_t s) {
         const int64_t a0 = 2 * p * NB;
         if (a0 >= np) return;
@@ -374,42 +384,59 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
         if (b0 + NB >= np) return;
         panel(b0, WtB);
     };
-    auto wide_head = [&](int64_t p, hipStream_t s) {
+    auto head_grid = [](int64_t T, int nc) {
+        int64_t g = 0;
+        for (int c = 0; c < nc && c < T; ++c) g += T - c;
+        return (unsigned)g;
+    };
+    auto head2 = [&](int64_t p, hipStream_t s) {   // K = 256 images of pass p on the two block columns of pass p+1
         const int64_t r0 = 2 * p * NB + 2 * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
-        syrk_head2_kernel<<<(unsigned)(T >= 2 ? 2 * T - 1 : T), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T);
+        syrk_head_kernel<<<head_grid(T, 2), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T, 2);
     };
-    auto wide_rest = [&](int64_t p, hipStream_t s) {
-        const int64_t r0 = 2 * p * NB + 4 * NB;
+    auto wide_head4 = [&](int64_t q, hipStream_t s) {
+        const int64_t r0 = (2 * q + 2) * 2 * NB;
+        if (r0 >= np) return;
+        const int64_t T = (np - r0) / NB;
+        syrk_head_kernel<<<head_grid(T, 4), 256, 0, s>>>(ws->H, ldh, r0, wimg(2 * q), 4 * NB, T, 4);
+    };
+    auto wide_rest4 = [&](int64_t q, hipStream_t s) {
+        const int64_t r0 = (2 * q + 2) * 2 * NB + 4 * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
         const int64_t S = (T + 7) / 8, ntiles = T * (T + 1) / 2;
         // super-tiles pay off once an XCD has many of them; below ~8 rounds of the chip the even split wins
         const int64_t nsuper = ntiles >= 8 * 512 ? S * (S + 1) / 2 : 0;
         const unsigned grid = nsuper ? (unsigned)(((nsuper + 7) / 8) * 8 * 64) : (unsigned)ntiles;
-        syrk_kernel<<<grid, 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T, nsuper);
+        syrk_kernel<<<grid, 256, 0, s>>>(ws->H, ldh, r0, wimg(2 * q), 4 * NB, T, nsuper);
     };
-    const int64_t npass = (np + 2 * NB - 1) / (2 * NB);
+    const int64_t npass = (np + 2 * NB - 1) / (2 * NB), nsup = (npass + 1) / 2;
     if (!ws->lookahead || np < 16 * NB) {
-        for (int64_t p = 0; p < npass; ++p) {
-            narrow(p, st);
-            wide_head(p, st);
-            wide_rest(p, st);
+        for (int64_t q = 0; q < nsup; ++q) {
+            narrow(2 * q, st);
+            head2(2 * q, st);
+            narrow(2 * q + 1, st);
+            wide_head4(q, st);
+            wide_rest4(q, st);
         }
     } else {
         hipStream_t sm = ws->s_main, ss = ws->s_side;
         BQ_HIP(hipEventRecord(ws->ev[0], st));       // everything enqueued so far (H assembly) precedes the factorisation
         BQ_HIP(hipStreamWaitEvent(sm, ws->ev[0], 0));
         narrow(0, sm);
-        for (int64_t p = 0; p < npass; ++p) {
-            hipEvent_t e_head = ws->ev[1 + (p % 3)], e_narrow = ws->ev[4 + (p % 3)];
-            wide_head(p, sm);
+        head2(0, sm);
+        narrow(1, sm);
+        for (int64_t q = 0; q < nsup; ++q) {
+            hipEvent_t e_head = ws->ev[1 + (q % 3)], e_narrow = ws->ev[4 + (q % 3)];
+            wide_head4(q, sm);
             BQ_HIP(hipEventRecord(e_head, sm));
             BQ_HIP(hipStreamWaitEvent(ss, e_head, 0));
-            narrow(p + 1, ss);
+            narrow(2 * q + 2, ss);
+            head2(2 * q + 2, ss);
+            narrow(2 * q + 3, ss);
             BQ_HIP(hipEventRecord(e_narrow, ss));
-            wide_rest(p, sm);
+            wide_rest4(q, sm);
             BQ_HIP(hipStreamWaitEvent(sm, e_narrow, 0));
         }
         BQ_HIP(hipEventRecord(ws->ev[7], sm));

@@ -70,10 +70,15 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
     gload(0);
     lstore(0);
     __syncthreads();
+    // Every global load issued so far (the first chunk, and the caller's accumulator tile if it started from acc = C) has
+    // landed before the loop is entered, and the loop prefetches UNCONDITIONALLY (its last chunk is peeled off below).
+    // Both matter to hipcc's s_waitcnt placement: with a conditional prefetch the loop body joins an "issued" and a
+    // "not issued" path, the pass assumes the smaller outstanding count for the accumulator loads of the prologue and
+    // emits vmcnt(3..0) in front of the chunk's first MFMAs — every wave then sat out the latency of the prefetch it had
+    // just issued (round 1; worth 2 % of the Cholesky once fixed: the co-resident workgroup had been covering most of it).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     const int fr = lane & 15, fk = lane >> 4;
-    for (int64_t c = 0; c < nchunks; ++c) {
-        const int buf = (int)(c & 1);
-        if (c + 1 < nchunks) gload((c + 1) * BQ_GK);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < BQ_GK / 4; ++kk) {
             double a[4], b[4];
@@ -88,11 +93,19 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nchunks) {
-            lstore(buf ^ 1);
-            __syncthreads();
-        }
+    };
+    for (int64_t c = 0; c + 1 < nchunks; ++c) {
+        const int buf = (int)(c & 1);
+        gload((c + 1) * BQ_GK);
+        compute(buf);
+        // nothing of the staging (the NEG_A sign flips wait for the prefetched registers) moves up among the MFMAs: the
+        // prefetch has the whole chunk — 64 MFMAs, 4096 cycles — to land.  (A second register set prefetching TWO chunks
+        // ahead changed nothing, tools/syrk_probe.hip: the staging is bound by the CU's load rate, not by latency.)
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(buf ^ 1);
+        __syncthreads();
     }
+    compute((int)((nchunks - 1) & 1));
 }
 
 // Load / store a whole accumulator tile from / to a row-major matrix (pitch ld): 64 independent 8-byte accesses per lane,

@@ -127,6 +127,12 @@ class Context:
         _lib.check(self._lib.bq_ctx_probe_bandwidth(self.handle, int(nbytes), int(reps), C.byref(r), C.byref(c)))
         return r.value, c.value
 
+    def probe_mfma_f64(self, seconds=1.0):
+        """TFLOP/s that back-to-back fp64 MFMAs on register operands sustain on this GPU (clock under load included)."""
+        t = C.c_double(0)
+        _lib.check(self._lib.bq_ctx_probe_mfma_f64(self.handle, float(seconds), C.byref(t)))
+        return t.value
+
     def close(self):
         if self._h:
             self._lib.bq_ctx_destroy(self._h)
