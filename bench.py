@@ -392,10 +392,15 @@ def kkt_box(solver, n, d, sigma, cpu=True):
     if solver == 'ip' and ch_cnt:
         flops = n ** 3 / 3.0
         tf = flops / (ch_ms / ch_cnt * 1e-3) / 1e12
+        try:   # what back-to-back fp64 MFMAs on register operands sustain on THIS GPU (outside the timed region)
+            probe = ctx.probe_mfma_f64(1.0)
+        except Exception:  # noqa: BLE001
+            probe = None
         rec['roofline'] = {'bound': 'mfma', 'kernel': 'blocked Cholesky of H = Q + diag (syrk/trsm on v_mfma_f64_16x16x4_f64)',
                            'achieved': tf, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TF,
                            'traffic': None, 'flops_per_launch': flops, 'avg_factor_ms': ch_ms / ch_cnt, 'factorisations': ch_cnt,
-                           'factor_share_of_wall': ch_ms * 1e-3 / dt}
+                           'factor_share_of_wall': ch_ms * 1e-3 / dt, 'measured_mfma_f64_TFs': probe,
+                           'frac_of_measured_mfma': (tf / probe) if probe else None}
     elif ch_cnt:
         rec['roofline'] = {'bound': 'mfma', 'kernel': 'base-set Cholesky factorisations (kept across iterations, Schur updates between)',
                            'achieved': None, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None,
