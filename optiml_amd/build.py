@@ -42,8 +42,8 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, obj):
-    extra = os.environ.get('BQ_EXTRA_CXXFLAGS', '').split()   # e.g. -DBQ_DIAG_STAMPS for a diagnostic build
+def _compile(src, obj, extra=()):
+    extra = list(extra) + os.environ.get('BQ_EXTRA_CXXFLAGS', '').split()   # e.g. -DBQ_DIAG_STAMPS for a diagnostic build
     cmd = ['hipcc', '-x', 'hip', '-c', src, '-o', obj] + CXXFLAGS + extra
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -51,24 +51,37 @@ def _compile(src, obj):
     return r.stderr
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJDIR, exist_ok=True)
+SAN_FLAGS = ['-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-g', '-O1']
+
+
+def build(force=False, verbose=False, sanitize=False):
+    """sanitize=True: a second library, lib/asan/libbcqp_hip_asan.so, whose HOST code is instrumented with AddressSanitizer +
+    UndefinedBehaviorSanitizer (the GPU pool offers no device-side sanitizer: XNACK is off).  It is what tests/test_sanitize.py
+    runs the host-only entry points and error paths under; the product library is never built this way."""
+    libdir, objdir, libname = LIBDIR, OBJDIR, LIBNAME
+    if sanitize:
+        libdir = os.path.join(LIBDIR, 'asan')
+        objdir = os.path.join(libdir, 'obj')
+        libname = 'libbcqp_hip_asan.so'
+    os.makedirs(objdir, exist_ok=True)
     hdrs = _headers()
     jobs = []
     objs = []
     for src in _sources():
-        obj = os.path.join(OBJDIR, os.path.basename(src) + '.o')
+        obj = os.path.join(objdir, os.path.basename(src) + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             jobs.append((src, obj))
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
-            for (src, _), warn in zip(jobs, ex.map(lambda a: _compile(*a), jobs)):
+            for (src, _), warn in zip(jobs, ex.map(lambda a: _compile(*a, extra=SAN_FLAGS if sanitize else ()), jobs)):
                 if verbose and warn.strip():
                     print(warn, file=sys.stderr)
-    target = lib_path()
+    target = os.path.join(libdir, libname)
     if jobs or _stale(target, objs):
         cmd = ['hipcc', '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', target] + objs + ['-ldl']
+        if sanitize:
+            cmd += ['-fsanitize=address,undefined']
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
@@ -76,4 +89,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, sanitize='--sanitize' in sys.argv))
