@@ -39,7 +39,7 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
     bq_d2 ra[4], rb[4];
-    auto gload = [&](int64_t kc) {
+    auto gload = [&](int64_t kc) {   // chunk kc / 16 of both operands -> the staging registers
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = tid + 256 * u;
@@ -67,45 +67,108 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
         }
     };
     const int64_t nchunks = kdim / BQ_GK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    // Every global load issued so far (the first chunk, and the caller's accumulator tile if it started from acc = C) has
-    // landed before the loop is entered, and the loop prefetches UNCONDITIONALLY (its last chunk is peeled off below).
-    // Both matter to hipcc's s_waitcnt placement: with a conditional prefetch the loop body joins an "issued" and a
-    // "not issued" path, the pass assumes the smaller outstanding count for the accumulator loads of the prologue and
-    // emits vmcnt(3..0) in front of the chunk's first MFMAs — every wave then sat out the latency of the prefetch it had
-    // just issued (round 1; worth 2 % of the Cholesky once fixed: the co-resident workgroup had been covering most of it).
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     const int fr = lane & 15, fk = lane >> 4;
-    auto compute = [&](int buf) {
+    // fragments of one k-slice of 4 (this lane: 4 A rows, 4 B rows), two register sets so that the reads of slice s+1 are in
+    // flight while the 16 MFMAs of slice s issue
+    double fa[2][4], fb[2][4];
+    auto rd = [&](int set, int buf, int kk) {
 #pragma unroll
-        for (int kk = 0; kk < BQ_GK / 4; ++kk) {
-            double a[4], b[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = sm.A[buf][kk * 4 + fk][wr * 64 + t * 16 + fr];
-                b[t] = sm.B[buf][kk * 4 + fk][wc * 64 + t * 16 + fr];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            fa[set][t] = sm.A[buf][kk * 4 + fk][wr * 64 + t * 16 + fr];
+            fb[set][t] = sm.B[buf][kk * 4 + fk][wc * 64 + t * 16 + fr];
         }
     };
-    for (int64_t c = 0; c + 1 < nchunks; ++c) {
-        const int buf = (int)(c & 1);
-        gload((c + 1) * BQ_GK);
-        compute(buf);
-        // nothing of the staging (the NEG_A sign flips wait for the prefetched registers) moves up among the MFMAs: the
-        // prefetch has the whole chunk — 64 MFMAs, 4096 cycles — to land.  (A second register set prefetching TWO chunks
-        // ahead changed nothing, tools/syrk_probe.hip: the staging is bound by the CU's load rate, not by latency.)
+    auto mm = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    // The chunk loop is software-pipelined ACROSS the chunk boundary so that the matrix pipe always has MFMAs to issue while
+    // the staging happens (tools/syrk_probe.hip: with "64 MFMAs, then stage, barrier, first reads" per chunk the pipe idled
+    // ~10 % — LDS-write completion + barrier + first-read latency at every boundary — and the co-resident workgroup, in
+    // lockstep, did not fill it).  Per chunk c (LDS buffer B = c & 1, O the other):
+    //   slice 0: MFMAs (fragments pre-read at the end of chunk c-1)                    | reads of slice 1
+    //   slice 1: MFMAs | registers (chunk c+1, loaded during chunk c-1) -> LDS O, then the global loads of chunk c+2
+    //   slice 2: MFMAs | reads of slice 3 ; lgkmcnt(0) ; BARRIER — every LDS read of B and every write of O is done
+    //   slice 3: MFMAs (operands in registers)                                          | reads of slice 0 of chunk c+1 from O
+    // One barrier per chunk.  O may be overwritten during chunk c because every wave finished reading it before the barrier
+    // of chunk c-1 (its slice-3 fragments were in registers by then); B may be read in chunk c because its writes preceded
+    // that same barrier.  The global prefetch stays in flight across the barrier (plain loads: the fence of
+    // __syncthreads() waits for LDS only) and has a whole chunk to land.  No load in the steady-state body is conditional
+    // (the last two chunks are peeled): with a conditional prefetch hipcc's s_waitcnt pass joined an "issued" and a "not
+    // issued" path and waited vmcnt(3..0) in front of the chunk's first MFMAs (round 1).
+    gload(0);
+    lstore(0);
+    if (nchunks > 1) gload(BQ_GK);
+    __syncthreads();
+    rd(0, 0, 0);
+    int64_t c = 0;
+    // sched_group_barrier pins the interleave inside each region (masks: MFMA 0x8, VALU 0x2, VMEM read 0x20, DS read 0x100,
+    // DS write 0x200): the next slice's four ds_read2 go out first, the staging is threaded through the MFMAs one
+    // instruction per MFMA — left alone, hipcc put all reads, writes and loads of a region in front of its MFMAs.
+    for (; c + 2 < nchunks; ++c) {
+        const int B = (int)(c & 1), O = B ^ 1;
+        rd(1, B, 1);
+        mm(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 16, 0);
         __builtin_amdgcn_sched_barrier(0);
-        lstore(buf ^ 1);
+        rd(0, B, 2);
+        mm(1);
+        lstore(O);
+        gload((c + 2) * BQ_GK);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1, B, 3);
+        mm(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 16, 0);
+        __builtin_amdgcn_sched_barrier(0);   // the barrier stays BEHIND slice 2's MFMAs: its wait is covered by them
         __syncthreads();
+        rd(0, O, 0);
+        mm(1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 16, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    compute((int)((nchunks - 1) & 1));
+    if (c + 1 < nchunks) {   // second-to-last chunk: its successor waits in the registers, nothing left to prefetch
+        const int B = (int)(c & 1), O = B ^ 1;
+        rd(1, B, 1);
+        mm(0);
+        rd(0, B, 2);
+        mm(1);
+        lstore(O);
+        rd(1, B, 3);
+        mm(0);
+        __syncthreads();
+        rd(0, O, 0);
+        mm(1);
+        ++c;
+    }
+    {   // last chunk
+        const int B = (int)(c & 1);
+        rd(1, B, 1);
+        mm(0);
+        rd(0, B, 2);
+        mm(1);
+        rd(1, B, 3);
+        mm(0);
+        mm(1);
+    }
 }
 
 // Load / store a whole accumulator tile from / to a row-major matrix (pitch ld): 64 independent 8-byte accesses per lane,
