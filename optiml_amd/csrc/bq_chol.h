@@ -7,7 +7,8 @@ struct bq_chol_ws {
     int64_t cap = 0;   // largest padded order the workspace can hold (multiple of 128)
     int64_t ldh = 0;   // row pitch of H
     double *H = nullptr;      // cap x ldh, row-major; lower triangle = matrix, then its Cholesky factor
-    double *Wt = nullptr;     // 2 x (256 x ldh) k-major images of the two block columns of a pass (double-buffered)
+    double *Wt = nullptr;     // 2 x (super_max x 256 x ldh) k-major images of the block columns of a super-pass (double-buffered)
+    int super_max = 2;        // passes per super-pass the image buffers hold
     double *LinvT = nullptr;  // per diagonal block: 128 x 128 image of the inverse triangular factor
     double *rhs = nullptr;    // right-hand side / solution (padded)
     double *tmp = nullptr;    // 128 scratch

@@ -282,7 +282,8 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
         delete ws;
         return BQ_ERR_NOMEM;
     }
-    if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * 8 * NB * ws->ldh);   // 2 super-passes x 4 block-column images
+    ws->super_max = ws->cap >= 24576 ? 4 : 2;   // passes per super-pass the image buffers are sized for
+    if (e == hipSuccess) e = hipMalloc(&ws->Wt, sizeof(double) * 2 * ws->super_max * 2 * NB * ws->ldh);   // 2 super-passes of images
     if (e == hipSuccess) e = hipMalloc(&ws->LinvT, sizeof(double) * nblk * NB * NB);
     if (e == hipSuccess) e = hipMalloc(&ws->rhs, sizeof(double) * (ws->cap + NB));
     if (e == hipSuccess) e = hipMalloc(&ws->tmp, sizeof(double) * 4 * NB);   // up to four column slices of a block row
@@ -356,15 +357,24 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     const int64_t ldh = ws->ldh;
     // Two block columns per pass p (A_p = 2p*NB, B_p = A_p + NB), two passes per SUPER-PASS q (passes 2q, 2q+1):
     //   narrow(p): diag(A) ; TRSM(A) ; narrow update of column B ; diag(B) ; TRSM(B)        -> images of pass p
-    //   head2(p) : the two block columns pass p+1 factors next  -= [X_A X_B][..]^T           (K = 256, images of pass p)
-    //   wide(q)  : everything behind pass 2q+1 -= X X^T with the FOUR images of passes 2q, 2q+1 in ONE K = 512 pass —
-    //              a C tile is read and written once per 512 columns factored (tools/syrk_probe.hip: the tile update runs at
-    //              0.71 of the MFMA peak with K = 256 and 0.82 with K = 512: its C traffic is not covered by the partner
-    //              workgroup); split into head4 (the four block columns super-pass q+1 factors) and rest.
-    // The images of a super-pass are contiguous in k (pass 2q: rows 0..255, pass 2q+1: rows 256..511), two buffers.
-    // With look-ahead the narrow chain of super-pass q+1 (narrow, head2, narrow — it touches only the four block columns
-    // head4(q) has finished) runs on the side stream while rest(q) keeps the chip busy.
-    auto wimg = [&](int64_t p) { return ws->Wt + ((p >> 1) & 1) * (int64_t)(4 * NB) * ldh + (p & 1) * (int64_t)(2 * NB) * ldh; };
+    //   head_in(p): the two block columns pass p+1 factors next  -= the images of the super-pass so far
+    //   wide(q)  : everything behind the super-pass -= X X^T with ALL its images in ONE K = P * 256 pass — a C tile is read
+    //              and written once per P * 256 columns factored (tools/syrk_probe.hip: the tile update runs at 0.71 of the
+    //              MFMA peak with K = 256, 0.83 with K = 512: its C traffic and prologue are not covered by the partner
+    //              workgroup); split into head (the 2P block columns the next chain works on) and rest.
+    // The images of a super-pass are contiguous in k, two buffers.
+    // With look-ahead the narrow chain of super-pass q+1 (it touches only the 2P block columns head(q) has finished) runs on
+    // the high-priority side stream while rest(q) keeps the chip busy.
+    // P passes per super-pass (env BQ_CHOL_SUPER, default by size): the wide update then has K = P * 256.  A larger P cuts the C
+    // traffic and the per-tile prologue per flop further but lengthens the narrow chain between two wide updates.
+    const int P = [&] {
+        const char *e = getenv("BQ_CHOL_SUPER");
+        int v = e ? atoi(e) : (np >= 65536 ? 4 : (np >= 24576 ? 3 : 2));   // measured: n=50k 674 / 674 / 688 ms, n=100k 5.17 / 5.11 / 5.06 s for P = 2 / 3 / 4
+        return v < 1 ? 1 : (v > ws->super_max ? ws->super_max : v);
+    }();
+    auto wimg = [&](int64_t p) {   // images of a super-pass are contiguous in k; two buffers
+        return ws->Wt + ((p / P) & 1) * (int64_t)(P * 2 * NB) * ldh + (p % P) * (int64_t)(2 * NB) * ldh;
+    };
     auto narrow = [&](int64_t p, hipStream_t s) {
         const int64_t a0 = 2 * p * NB;
         if (a0 >= np) return;
@@ -389,54 +399,59 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
         for (int c = 0; c < nc && c < T; ++c) g += T - c;
         return (unsigned)g;
     };
-    auto head2 = [&](int64_t p, hipStream_t s) {   // K = 256 images of pass p on the two block columns of pass p+1
+    // the two block columns pass p+1 factors  -=  the images of ALL passes of p's super-pass so far (K = 256 .. (P-1) 256)
+    auto head_in = [&](int64_t p, hipStream_t s) {
         const int64_t r0 = 2 * p * NB + 2 * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
-        syrk_head_kernel<<<head_grid(T, 2), 256, 0, s>>>(ws->H, ldh, r0, wimg(p), 2 * NB, T, 2);
+        const int64_t first = p / P * P;
+        syrk_head_kernel<<<head_grid(T, 2), 256, 0, s>>>(ws->H, ldh, r0, wimg(first), (int)((p - first + 1) * 2 * NB), T, 2);
     };
-    auto wide_head4 = [&](int64_t q, hipStream_t s) {
-        const int64_t r0 = (2 * q + 2) * 2 * NB;
+    // the narrow chain of super-pass q: narrow, head_in, narrow, ..., narrow
+    auto chain = [&](int64_t q, hipStream_t s) {
+        for (int j = 0; j < P; ++j) {
+            narrow(q * P + j, s);
+            if (j + 1 < P) head_in(q * P + j, s);
+        }
+    };
+    // everything behind super-pass q  -=  X X^T with its 2P images in one K = P * 256 pass: first the 2P block columns the next
+    // chain works on, then the rest
+    auto wide_head = [&](int64_t q, hipStream_t s) {
+        const int64_t r0 = (q + 1) * P * 2 * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
-        syrk_head_kernel<<<head_grid(T, 4), 256, 0, s>>>(ws->H, ldh, r0, wimg(2 * q), 4 * NB, T, 4);
+        syrk_head_kernel<<<head_grid(T, 2 * P), 256, 0, s>>>(ws->H, ldh, r0, wimg(q * P), P * 2 * NB, T, 2 * P);
     };
-    auto wide_rest4 = [&](int64_t q, hipStream_t s) {
-        const int64_t r0 = (2 * q + 2) * 2 * NB + 4 * NB;
+    auto wide_rest = [&](int64_t q, hipStream_t s) {
+        const int64_t r0 = (q + 1) * P * 2 * NB + 2 * P * NB;
         if (r0 >= np) return;
         const int64_t T = (np - r0) / NB;
         const int64_t S = (T + 7) / 8, ntiles = T * (T + 1) / 2;
         // super-tiles pay off once an XCD has many of them; below ~8 rounds of the chip the even split wins
         const int64_t nsuper = ntiles >= 8 * 512 ? S * (S + 1) / 2 : 0;
         const unsigned grid = nsuper ? (unsigned)(((nsuper + 7) / 8) * 8 * 64) : (unsigned)ntiles;
-        syrk_kernel<<<grid, 256, 0, s>>>(ws->H, ldh, r0, wimg(2 * q), 4 * NB, T, nsuper);
+        syrk_kernel<<<grid, 256, 0, s>>>(ws->H, ldh, r0, wimg(q * P), P * 2 * NB, T, nsuper);
     };
-    const int64_t npass = (np + 2 * NB - 1) / (2 * NB), nsup = (npass + 1) / 2;
+    const int64_t npass = (np + 2 * NB - 1) / (2 * NB), nsup = (npass + P - 1) / P;
     if (!ws->lookahead || np < 16 * NB) {
         for (int64_t q = 0; q < nsup; ++q) {
-            narrow(2 * q, st);
-            head2(2 * q, st);
-            narrow(2 * q + 1, st);
-            wide_head4(q, st);
-            wide_rest4(q, st);
+            chain(q, st);
+            wide_head(q, st);
+            wide_rest(q, st);
         }
     } else {
         hipStream_t sm = ws->s_main, ss = ws->s_side;
         BQ_HIP(hipEventRecord(ws->ev[0], st));       // everything enqueued so far (H assembly) precedes the factorisation
         BQ_HIP(hipStreamWaitEvent(sm, ws->ev[0], 0));
-        narrow(0, sm);
-        head2(0, sm);
-        narrow(1, sm);
+        chain(0, sm);
         for (int64_t q = 0; q < nsup; ++q) {
             hipEvent_t e_head = ws->ev[1 + (q % 3)], e_narrow = ws->ev[4 + (q % 3)];
-            wide_head4(q, sm);
+            wide_head(q, sm);
             BQ_HIP(hipEventRecord(e_head, sm));
             BQ_HIP(hipStreamWaitEvent(ss, e_head, 0));
-            narrow(2 * q + 2, ss);
-            head2(2 * q + 2, ss);
-            narrow(2 * q + 3, ss);
+            chain(q + 1, ss);
             BQ_HIP(hipEventRecord(e_narrow, ss));
-            wide_rest4(q, sm);
+            wide_rest(q, sm);
             BQ_HIP(hipStreamWaitEvent(sm, e_narrow, 0));
         }
         BQ_HIP(hipEventRecord(ws->ev[7], sm));
