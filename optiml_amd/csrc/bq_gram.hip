@@ -397,6 +397,11 @@ int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, i
 // share a row block through LDS, and the chunk's 128 row sums go to S[chunk][row]; stream_reduce_kernel adds the chunks
 // in order.  No symmetry credit (each tile is computed where it is used): 2 n^2 d flop per product.
 // ---------------------------------------------------------------------------------------------------------------
+// exp / pow chains kept in flight per lane in the streamed product's epilogue (a chain is ~40 dependent fp64 instructions: one
+// at a time left the VALU idle; measured 62.5 / 60.4 / 59.8 ms per n=100k product for 1 / 2 / 4)
+#ifndef STREAM_EXP_ILP
+#define STREAM_EXP_ILP 4
+#endif
 struct bq_stream_images {
     gram_images img;
     double *S = nullptr;       // nchunk x rows_pad partial products
@@ -460,8 +465,8 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
                     }
                     if (add_one) kv += 1.0;
                     part = fma(kv, w[gj], part);   // w is zero beyond n (padded to the panel pitch)
-                    if (KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY)
-                        __builtin_amdgcn_sched_barrier(0);   // one exp / pow chain at a time (register pressure)
+                    if ((KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY) && ((j + 1) % STREAM_EXP_ILP == 0))
+                        __builtin_amdgcn_sched_barrier(0);   // STREAM_EXP_ILP exp / pow chains in flight (register pressure)
                 }
                 part += __shfl_xor(part, 1, 64);
                 part += __shfl_xor(part, 2, 64);
