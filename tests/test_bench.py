@@ -74,3 +74,23 @@ def test_rccl_that_cannot_be_created_is_an_error_not_a_fallback():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec['config']['exchange'] == 'host' and rec['config']['rccl_ranks'] == 0
+
+
+@pytest.mark.gpu
+def test_launched_by_torch_distributed_run_like_the_driver():
+    """The driver's N > 1 command: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...  (two ranks on GPU 0 of this box, host exchange): ONE JSON line on stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), BENCH, '--gpus', '2', '--exchange', 'host', '--samples', '5000', '--features', '16',
+           '--steps', '6', '--warmup', '2', '--no-cpu', '--kkt', 'none']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps_done'] == 6 and rec['config']['exchange'] == 'host'
