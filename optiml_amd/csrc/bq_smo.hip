@@ -162,10 +162,10 @@ __device__ __forceinline__ void st_rel(unsigned int *p, unsigned int v) {
     __hip_atomic_store((smo_gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void fence_acq() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-// Ordering (MI355X_MICROARCH.md, inter-workgroup visibility).  Walker -> helpers: the list is edited with plain stores by all
-// sixteen waves; EVERY wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier, then thread 0 issues the
-// agent-scope release (L2 write-back), waits for it, stores the control words write-through, waits again, and only then
-// the new even version.  (Round 1 had a workgroup-scope fence in front of the barrier: it compiles to nothing another CU
+// Ordering (MI355X_MICROARCH.md, inter-workgroup visibility).  Walker -> helpers: the list is edited with WRITE-THROUGH
+// (sc1) stores by all sixteen waves; EVERY wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier, then
+// thread 0 stores the control words write-through, waits again, and only then the new even version — the "sc1 payload,
+// drained, one lane's sc1 flag" form, which needs no L2 write-back per pair step.  (Round 1 had a workgroup-scope fence in front of the barrier: it compiles to nothing another CU
 // can observe, so fifteen waves' list stores could still be in flight when the version appeared — a helper then formed a
 // sum from old entries under the new version: the 1-in-3-runs path change with 240+ helpers.)  Helpers: wave 0 polls
 // the version relaxed and runs ONE agent-scope acquire when it moves; every consuming wave runs its own acquire when it
@@ -289,7 +289,8 @@ __device__ __forceinline__ void smo_rebuild(int64_t n, int *__restrict__ nz, Smo
     int total;
     int pos = smo_bscan(cnt, S.scan, &total);
     for (int64_t j = lo; j < hi; ++j)
-        if (nonzero(j)) nz[pos++] = (int)j;
+        if (nonzero(j))   // write-through like every store to the global list (see sup_put)
+            __hip_atomic_store((__attribute__((address_space(1))) int *)&nz[pos++], (int)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) S.nnz = total;
     __syncthreads();
 }
@@ -312,9 +313,13 @@ struct SupGlobal {
 };
 __device__ __forceinline__ int sup_idx(const SupList &L, const SupGlobal &G, int q) { return q < SMO_CAP ? L.nz[q] : G.nz[q]; }
 __device__ __forceinline__ double sup_cf(const SupList &L, const SupGlobal &G, int q) { return q < SMO_CAP ? L.cf[q] : G.cf[q]; }
+// the global copy is what the helper workgroups read: WRITE-THROUGH (sc1) stores, so that publishing an edit needs no L2
+// write-back (MI355X_MICROARCH.md, visibility: payload stored sc1 + every storing wave drained + flag = a valid hand-off for
+// sc1 loads; the release fence it replaces cost a buffer_wbl2 per pair step)
 __device__ __forceinline__ void sup_put(SupList &L, const SupGlobal &G, int q, int idx, double c) {
-    G.nz[q] = idx;
-    G.cf[q] = c;
+    __hip_atomic_store((__attribute__((address_space(1))) int *)&G.nz[q], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((__attribute__((address_space(1))) long long *)&G.cf[q], __double_as_longlong(c), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
     if (q < SMO_CAP) {
         L.nz[q] = idx;
         L.cf[q] = c;
@@ -425,11 +430,9 @@ __device__ __forceinline__ void spec_begin(const SmoSpec &P, SmoShared &S) {
 }
 __device__ __forceinline__ void spec_end(const SmoSpec &P, SmoShared &S, long long at) {
     if (P.helpers == 0) return;
-    SMO_DRAIN();   // EVERY wave: its list stores have reached the L2
+    SMO_DRAIN();   // EVERY wave: its write-through list stores have left the CU and are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // write the XCD's dirty lines back device-wide ...
-        SMO_DRAIN();                                         // ... and wait for it (the compiler may drop the fence's own wait)
         S.ver += 2u;
         S.win = (unsigned int)P.helpers;   // one sample for wave 0 of every helper workgroup
         st_rlx(&P.ctl[SPEC_NNZ], (unsigned int)S.nnz);
