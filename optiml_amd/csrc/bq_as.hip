@@ -40,6 +40,7 @@
 #include "bq_qelem.h"
 
 #define ACT_TOL 1e-12
+constexpr int AS_SCHUR_MAX = 1536;   // capacity of the update slots
 
 #define VEC_LOOP(i)                                                             \
     const int64_t _base = (int64_t)blockIdx.x * BQ_VEC_TILE + threadIdx.x;      \
@@ -85,35 +86,6 @@ __device__ __forceinline__ double as_wmin(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
     return v;
-}
-
-// idx = ascending indices of the free set A = !(L | U); ints[0] = |A|, ints[1] = |L| + |U|
-__global__ __launch_bounds__(256) void as_compact_kernel(int64_t N, const unsigned char *__restrict__ mL,
-                                                         const unsigned char *__restrict__ mU, int *__restrict__ idx,
-                                                         int *__restrict__ ints) {
-    __shared__ int wtot[4];
-    __shared__ int base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (int64_t c0 = 0; c0 < N; c0 += 256) {
-        const int64_t i = c0 + tid;
-        const int flag = (i < N) && !(mL[i] | mU[i]);
-        const unsigned long long bal = __ballot(flag);
-        const int within = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wtot[wv] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wv; ++w) off += wtot[w];
-        if (flag) idx[off + within] = (int)i;
-        __syncthreads();
-        if (tid == 0) base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        ints[0] = base;
-        ints[1] = (int)N - base;
-    }
 }
 
 __global__ void as_top_kernel(bq_scal *sc, const int *__restrict__ ints, bq_iter_stat *stats) {
@@ -230,81 +202,210 @@ __global__ __launch_bounds__(256) void as_release_kernel(int64_t N, const double
     }
 }
 
-// ratio step towards the candidate on the free set:  x += max_t (cand - x)     (single block)
-__global__ __launch_bounds__(256) void as_step_kernel(int64_t N, const unsigned char *__restrict__ mL,
-                                                      const unsigned char *__restrict__ mU, const double *__restrict__ cand,
-                                                      const double *__restrict__ lb, const double *__restrict__ ub,
-                                                      double *__restrict__ x, bq_scal *sc) {
+// ---------------------------------------------------------------------------------------------------------------
+// The per-iteration O(N) steps, multi-block (round 2).  Their single-block predecessors walked N elements with 256
+// threads: 35-110 us each at n = 20 000, four of them per iteration = 16 % of an ActiveSet iteration once the triangular
+// sweeps were fixed.  Same arithmetic, same results (minima, counts and index lists do not depend on the block order);
+// the last-finishing block of a launch closes the step (fixed-order final reduction over the per-block partials).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool as_last_block_mb(unsigned int *ticket) {
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();   // this block's partials are visible device-wide before the ticket is taken
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        if (threadIdx.x == 0) *ticket = 0u;
+    }
+    return last != 0;
+}
+
+// free-set compaction, pass 1: part[b] = number of free indices in block b's 1024 elements; the last block turns the counts
+// into exclusive offsets (in place) and writes ints[0] = |A|, ints[1] = |L| + |U|
+__global__ __launch_bounds__(256) void as_count_free_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                            const unsigned char *__restrict__ mU, int *__restrict__ cnt,
+                                                            int *__restrict__ ints, unsigned int *ticket) {
+    __shared__ int wt[4];
+    int c = 0;
+    VEC_LOOP(i) c += (i < N && !(mL[i] | mU[i])) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&cnt[blockIdx.x], wt[0] + wt[1] + wt[2] + wt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (as_last_block_mb(ticket) && threadIdx.x == 0) {
+        int run = 0;
+        for (unsigned int b = 0; b < gridDim.x; ++b) {
+            const int v = __hip_atomic_load(&cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cnt[b] = run;
+            run += v;
+        }
+        ints[0] = run;
+        ints[1] = (int)N - run;
+    }
+}
+// pass 2: idx[offset of the block + rank inside the block] = i, ascending (element j of thread t: index b*1024 + j*256 + t)
+__global__ __launch_bounds__(256) void as_write_free_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                            const unsigned char *__restrict__ mU, const int *__restrict__ cnt,
+                                                            int *__restrict__ idx) {
+    __shared__ int wt[BQ_VEC_ITEMS][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int flag[BQ_VEC_ITEMS], within[BQ_VEC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        const int64_t i = (int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x;
+        flag[j] = (i < N && !(mL[i] | mU[i])) ? 1 : 0;
+        const unsigned long long bal = __ballot(flag[j]);
+        within[j] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wt[j][wv] = __popcll(bal);
+    }
+    __syncthreads();
+    int off = cnt[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        int o = off;
+        for (int w = 0; w < wv; ++w) o += wt[j][w];
+        if (flag[j]) idx[o + within[j]] = (int)((int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x);
+        off += wt[j][0] + wt[j][1] + wt[j][2] + wt[j][3];
+    }
+}
+
+// ratio test of the step towards the candidate: sc->step = min over the free set (active_set.py:166-173), partial minima per
+// block, the last block takes the minimum over them
+__global__ __launch_bounds__(256) void as_step_min_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                          const unsigned char *__restrict__ mU, const double *__restrict__ cand,
+                                                          const double *__restrict__ lb, const double *__restrict__ ub,
+                                                          const double *__restrict__ x, double *part, bq_scal *sc) {
     __shared__ double sh[4];
     double rmin = INFINITY;
-    for (int64_t i = threadIdx.x; i < N; i += 256) {
-        if (mL[i] | mU[i]) continue;
-        const double d = cand[i] - x[i];
-        if (d > 0.0) rmin = fmin(rmin, (ub[i] - x[i]) / d);
-        if (d < 0.0) rmin = fmin(rmin, (lb[i] - x[i]) / d);
+    VEC_LOOP(i) {
+        if (i < N && !(mL[i] | mU[i])) {
+            const double d = cand[i] - x[i];
+            if (d > 0.0) rmin = fmin(rmin, (ub[i] - x[i]) / d);
+            if (d < 0.0) rmin = fmin(rmin, (lb[i] - x[i]) / d);
+        }
     }
     rmin = as_wmin(rmin);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rmin;
     __syncthreads();
-    const double t = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
-    for (int64_t i = threadIdx.x; i < N; i += 256) {
-        if (mL[i] | mU[i]) continue;
-        const double d = cand[i] - x[i];
-        x[i] = x[i] + __dmul_rn(t, d);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&part[blockIdx.x], fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (as_last_block_mb(&sc->ticket[0])) {
+        double m = INFINITY;
+        for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256)
+            m = fmin(m, __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        m = as_wmin(m);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) sc->step = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
     }
-    if (threadIdx.x == 0) sc->step = t;
+}
+__global__ void as_step_apply_kernel(int64_t N, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                     const double *__restrict__ cand, double *__restrict__ x, const bq_scal *sc) {
+    const double t = sc->step;
+    VEC_LOOP(i) {
+        if (i < N && !(mL[i] | mU[i])) x[i] = x[i] + __dmul_rn(t, cand[i] - x[i]);
+    }
 }
 
-// move free variables that reached a bound into L / U (L first, as the reference), count them, advance iter
-__global__ __launch_bounds__(256) void as_absorb_kernel(int64_t N, unsigned char *__restrict__ mL,
-                                                        unsigned char *__restrict__ mU, const double *__restrict__ x,
-                                                        const double *__restrict__ lb, const double *__restrict__ ub,
-                                                        bq_scal *sc, int *__restrict__ ints, bq_iter_stat *stats) {
-    __shared__ int cl[256], cu[256];
-    __shared__ int rec;
-    if (threadIdx.x == 0) rec = 0;
-    __syncthreads();
+// free variables that reached a bound move into L / U (L first, as the reference); ints[5], ints[6] = how many, ints[8] = the
+// total, ints[9 ..] = up to 16 of their indices (the host sorts them); the last block closes the iteration.
+// ints[26] is the slot counter of this launch (zeroed by the last block for the next one; ints[7] belongs to MINRES).
+__global__ __launch_bounds__(256) void as_absorb_mb_kernel(int64_t N, unsigned char *__restrict__ mL, unsigned char *__restrict__ mU,
+                                                           const double *__restrict__ x, const double *__restrict__ lb,
+                                                           const double *__restrict__ ub, bq_scal *sc, int *__restrict__ ints,
+                                                           int *__restrict__ cnt, bq_iter_stat *stats) {
+    __shared__ int wl[4], wu[4];
     int nl = 0, nu = 0;
-    for (int64_t i = threadIdx.x; i < N; i += 256) {
-        if (mL[i] | mU[i]) continue;
-        bool hit = false;
-        if (x[i] <= lb[i] + ACT_TOL) {
-            mL[i] = 1;
-            ++nl;
-            hit = true;
-        } else if (x[i] >= ub[i] - ACT_TOL) {
-            mU[i] = 1;
-            ++nu;
-            hit = true;
-        }
-        if (hit) {   // the first 16 absorbed indices, for the factor re-use (ints[8] = how many there were)
-            const int slot = atomicAdd(&rec, 1);
-            if (slot < 16) ints[9 + slot] = (int)i;
+    VEC_LOOP(i) {
+        if (i < N && !(mL[i] | mU[i])) {
+            bool hit = false;
+            if (x[i] <= lb[i] + ACT_TOL) {
+                mL[i] = 1;
+                ++nl;
+                hit = true;
+            } else if (x[i] >= ub[i] - ACT_TOL) {
+                mU[i] = 1;
+                ++nu;
+                hit = true;
+            }
+            if (hit) {
+                const int slot = atomicAdd(&ints[26], 1);
+                if (slot < 16) ints[9 + slot] = (int)i;
+            }
         }
     }
-    cl[threadIdx.x] = nl;
-    cu[threadIdx.x] = nu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        nl += __shfl_down(nl, off, 64);
+        nu += __shfl_down(nu, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wl[threadIdx.x >> 6] = nl;
+        wu[threadIdx.x >> 6] = nu;
+    }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            cl[threadIdx.x] += cl[threadIdx.x + s];
-            cu[threadIdx.x] += cu[threadIdx.x + s];
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        ints[5] = cl[0];
-        ints[6] = cu[0];
-        ints[8] = rec;
+        __hip_atomic_store(&cnt[2 * blockIdx.x], wl[0] + wl[1] + wl[2] + wl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cnt[2 * blockIdx.x + 1], wu[0] + wu[1] + wu[2] + wu[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (as_last_block_mb(&sc->ticket[1]) && threadIdx.x == 0) {
+        int tl = 0, tu = 0;
+        for (unsigned int b = 0; b < gridDim.x; ++b) {
+            tl += __hip_atomic_load(&cnt[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tu += __hip_atomic_load(&cnt[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ints[5] = tl;
+        ints[6] = tu;
+        ints[8] = __hip_atomic_load(&ints[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ints[26], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long row = sc->iter - sc->stat_base;
         if (row >= 0 && row < sc->stat_cap) {
             stats[row].r2 = 0.0;
-            stats[row].r3 = (double)(((long long)cl[0] << 32) | (long long)cu[0]);
+            stats[row].r3 = (double)(((long long)tl << 32) | (long long)tu);
         }
         sc->iter += 1;
     }
 }
 
+// the kept-factor candidate in two multi-block steps: cand = bound values / 0 everywhere (+ the feasibility flag raised), then
+// the base variables that are still free and the freed ones scatter their values and lower the flag where a value leaves the box
+__global__ void as_cand_fill_kernel(int64_t N, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                    const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ cand,
+                                    int *__restrict__ ints) {
+    VEC_LOOP(i) {
+        if (i < N) cand[i] = mU[i] ? ub[i] : (mL[i] ? lb[i] : 0.0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ints[2] = 1;
+}
+__global__ void as_cand_scatter_kernel(int64_t n0, int m, const int *__restrict__ idx0, const int *__restrict__ meta,
+                                       const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                       const double *__restrict__ lb, const double *__restrict__ ub,
+                                       const double *__restrict__ y, const double *__restrict__ coef,
+                                       double *__restrict__ cand, int *__restrict__ ints) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (a < n0) {
+        const int i = idx0[a];
+        if (!(mL[i] | mU[i])) {
+            const double v = y[a];
+            cand[i] = v;
+            bad = !(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL);
+        }
+    }
+    if (a < m && meta[a] == 1) {
+        const int i = meta[AS_SCHUR_MAX + a];
+        const double v = coef[a];
+        cand[i] = v;
+        bad = bad || !(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL);
+    }
+    if (bad) ints[2] = 0;   // benign race: every writer stores 0
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // conjugate gradients on Q[A,A] (BQ_AS_CG).  Vectors are full length and zero outside A.
@@ -470,7 +571,6 @@ __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__r
 // ---------------------------------------------------------------------------------------------------------------
 // factor re-use: Schur-complement updates of a base factorisation (see the header comment)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int AS_SCHUR_MAX = 1536;   // capacity of the update slots
 // changed indices carried before the base is re-factorised: the larger the factor, the longer it is worth keeping
 // (n^3/3 to rebuild against one more small-system row per carried index)
 static int as_schur_limit(int64_t np0) {
@@ -581,40 +681,6 @@ __global__ void as_schur_combine_kernel(int64_t np0, int m, const double *__rest
     y[a] = v;
 }
 
-// cand = bound values on L and U, y on the base variables that are still free, the bordered unknowns on the freed
-// ones; ints[2] = every free coordinate inside [lb - tol, ub + tol]   (single block)
-__global__ __launch_bounds__(256) void as_schur_candidate_kernel(int64_t N, int64_t n0, int m, const int *__restrict__ idx0,
-                                                                 const int *__restrict__ meta,
-                                                                 const unsigned char *__restrict__ mL,
-                                                                 const unsigned char *__restrict__ mU,
-                                                                 const double *__restrict__ lb, const double *__restrict__ ub,
-                                                                 const double *__restrict__ y, const double *__restrict__ coef,
-                                                                 double *__restrict__ cand, int *__restrict__ ints) {
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
-    __syncthreads();
-    for (int64_t i = threadIdx.x; i < N; i += 256) cand[i] = mU[i] ? ub[i] : (mL[i] ? lb[i] : 0.0);
-    __syncthreads();
-    int mybad = 0;
-    for (int64_t a = threadIdx.x; a < n0; a += 256) {
-        const int i = idx0[a];
-        if (mL[i] | mU[i]) continue;
-        const double v = y[a];
-        cand[i] = v;
-        if (!(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL)) mybad = 1;
-    }
-    for (int k = threadIdx.x; k < m; k += 256) {
-        if (meta[k] != 1) continue;
-        const int i = meta[AS_SCHUR_MAX + k];
-        const double v = coef[k];
-        cand[i] = v;
-        if (!(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL)) mybad = 1;
-    }
-    if (mybad) bad = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) ints[2] = bad ? 0 : 1;
-}
-
 // C = L D L' of the m x m Schur complement, kept on the host and grown by one row per new slot (O(m^2)); C is symmetric
 // quasi-definite — minus a positive definite block for the pinned variables, a positive definite one for the freed —
 // so it factorises without pivoting in any order.  as_ldl_solve checks the residual; on failure the caller falls back
@@ -707,6 +773,22 @@ static bool as_small_solve(int m, const std::vector<double> &C, const double *t,
 }
 
 static as_ws *get_ws(bq_solver *s) { return reinterpret_cast<as_ws *>(s->as_ws); }
+
+// launches of the multi-block per-iteration steps; their per-block partials live in three disjoint slices of s->partials
+static_assert(BQ_MAX_PARTIAL_Q >= 3, "as_launch_*: three slices of the partials buffer");
+static void as_launch_compact(bq_solver *s, as_ws *w, hipStream_t st) {
+    int *cnt = reinterpret_cast<int *>(s->partials + s->nblk);
+    as_count_free_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, cnt, w->ints, &s->sc->pad1[0]);
+    as_write_free_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, cnt, w->idx);
+}
+static void as_launch_step(bq_solver *s, as_ws *w, hipStream_t st) {
+    as_step_min_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, w->cand, s->lb, s->ub, s->x, s->partials, s->sc);
+    as_step_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, w->cand, s->x, s->sc);
+}
+static void as_launch_absorb(bq_solver *s, as_ws *w, hipStream_t st) {
+    int *cnt = reinterpret_cast<int *>(s->partials + 2 * s->nblk);
+    as_absorb_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, s->x, s->lb, s->ub, s->sc, w->ints, cnt, s->stats);
+}
 
 static int eval_f(bq_solver *s, double *g_out) {
     // Qd = Q x ; f = 1/2 x'Qx + q'x -> sc->f ; optionally g = Qx + q
@@ -936,8 +1018,12 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         BQ_HIP(hipStreamSynchronize(st));   // coef is on this stack frame
     }
     as_schur_combine_kernel<<<gb, 256, 0, st>>>(np0, m, c->y0, c->W, c->cap, c->small + AS_SCHUR_MAX, c->y);
-    as_schur_candidate_kernel<<<1, 256, 0, st>>>(N, n0, m, c->idx0, c->meta, s->mL, s->mU, s->lb, s->ub, c->y,
-                                                 c->small + AS_SCHUR_MAX, w->cand, w->ints);
+    as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
+    {
+        const int64_t span = n0 > m ? (n0 > 0 ? n0 : 1) : (int64_t)m;
+        as_cand_scatter_kernel<<<dim3((unsigned)((span + 255) / 256)), 256, 0, st>>>(n0, m, c->idx0, c->meta, s->mL, s->mU, s->lb, s->ub,
+                                                                                  c->y, c->small + AS_SCHUR_MAX, w->cand, w->ints);
+    }
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     BQ_HIP(hipGetLastError());
@@ -1084,7 +1170,7 @@ int bq_as_iterate(bq_solver *s) {
     bq_chol_ws *ws = s->chol;
     const int64_t N = s->N;
 
-    as_compact_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, w->idx, w->ints);
+    as_launch_compact(s, w, st);
     as_top_kernel<<<1, 1, 0, st>>>(s->sc, w->ints, s->stats);
     if (!s->host.done) {  // snapshot of the point this record describes
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->x, w->x_eval);
@@ -1104,9 +1190,9 @@ int bq_as_iterate(bq_solver *s) {
             BQ_TRY(eval_f(s, s->g));
             as_release_kernel<<<1, 256, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
         } else {
-            as_step_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, w->cand, s->lb, s->ub, s->x, s->sc);
+            as_launch_step(s, w, st);
             BQ_TRY(eval_f(s, nullptr));
-            as_absorb_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, s->x, s->lb, s->ub, s->sc, w->ints, s->stats);
+            as_launch_absorb(s, w, st);
         }
         BQ_HIP(hipGetLastError());
         return BQ_OK;
@@ -1121,9 +1207,9 @@ int bq_as_iterate(bq_solver *s) {
             BQ_TRY(eval_f(s, s->g));
             as_release_kernel<<<1, 256, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
         } else {
-            as_step_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, w->cand, s->lb, s->ub, s->x, s->sc);
+            as_launch_step(s, w, st);
             BQ_TRY(eval_f(s, nullptr));
-            as_absorb_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, s->x, s->lb, s->ub, s->sc, w->ints, s->stats);
+            as_launch_absorb(s, w, st);
         }
         BQ_HIP(hipGetLastError());
         return BQ_OK;
@@ -1159,9 +1245,9 @@ int bq_as_iterate(bq_solver *s) {
         BQ_TRY(eval_f(s, s->g));
         as_release_kernel<<<1, 256, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
     } else {
-        as_step_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, w->cand, s->lb, s->ub, s->x, s->sc);
+        as_launch_step(s, w, st);
         BQ_TRY(eval_f(s, nullptr));
-        as_absorb_kernel<<<1, 256, 0, st>>>(N, s->mL, s->mU, s->x, s->lb, s->ub, s->sc, w->ints, s->stats);
+        as_launch_absorb(s, w, st);
     }
     BQ_HIP(hipGetLastError());
     return BQ_OK;
