@@ -15,6 +15,8 @@
 
 #include "bq_mfma_tile.h"
 
+#include <type_traits>
+
 constexpr int GT = BQ_GT;
 constexpr int GK = BQ_GK;
 
@@ -49,6 +51,36 @@ __global__ void row_norms_kernel(const double *__restrict__ X, int64_t n, int64_
 template <typename T> __device__ __forceinline__ void store_elem(T *p, double v);
 template <> __device__ __forceinline__ void store_elem<double>(double *p, double v) { __builtin_nontemporal_store(v, p); }
 template <> __device__ __forceinline__ void store_elem<float>(float *p, double v) { __builtin_nontemporal_store((float)v, p); }
+
+// exp for the kernel maps (arguments <= 0 for gamma > 0; correct up to the overflow threshold all the same).  18 vector
+// instructions against ~25 of the device library's exp: round-to-nearest of x log2(e) by the 1.5 * 2^52 trick (the integer
+// is the low word of the sum: no rndne / cvt), two-term Cody-Waite reduction, degree-11 polynomial with the Chebyshev-node
+// coefficients of (exp(r) - 1 - r) / r^2 on |r| <= ln(2) / 2 (tools/exp_fit.py: 1.7e-17 relative), one ldexp that also
+// produces the subnormal results; the clamp at -746 replaces the library's range selects.  <= 1 ulp from glibc's exp on
+// 4e7 points of [-746, 0] (tools/exp_check.c), exp(0) = 1 exactly.  Matters because on gfx950 vector instructions and
+// fp64 MFMAs exclude each other (bq_mfma_tile.h): every instruction of the epilogue is taken from the matrix pipe's time.
+// A NaN argument gives 0 (v_max drops it), like the fmax(dist, 0) in front of it.
+__device__ __forceinline__ double bq_exp(double x) {
+    x = fmax(x, -746.0);
+    const double magic = 6755399441055744.0;   // 1.5 * 2^52
+    const double t = fma(x, 1.4426950408889634074, magic);
+    const double n = t - magic;
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 0x1.af3a57ea0843fp-26;
+    p = fma(p, r, 0x1.2891a1928aa16p-22);
+    p = fma(p, r, 0x1.71de0c9540aa2p-19);
+    p = fma(p, r, 0x1.a019b8f77d16ep-16);
+    p = fma(p, r, 0x1.a01a01a8454fcp-13);
+    p = fma(p, r, 0x1.6c16c1789064ap-10);
+    p = fma(p, r, 0x1.1111111110834p-7);
+    p = fma(p, r, 0x1.5555555553d5ep-5);
+    p = fma(p, r, 0x1.5555555555556p-3);
+    p = fma(p, r, 0x1.0000000000001p-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, __double2loint(t));
+}
 
 struct gram_params {
     const double *At, *Bt;   // k-major padded images: At[dp][mp], Bt[dp][np]
@@ -94,39 +126,46 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
         // the MFMA loop (32+ VGPRs) and spill.  An opaque zero makes them per-iteration values.
         int64_t opaque = 0;
         asm volatile("" : "+s"(opaque));
-        // epilogue, row by row: one (packed or pitched) row base per accumulator row, then the kernel map per element
+        // epilogue, row by row: one (packed or pitched) row base per accumulator row, then the kernel map per element.  Two
+        // instances: only the tile on the diagonal of a symmetric build pays for the "exact zero distance at i == j" test
+        auto epilogue = [&](auto on_diag) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int64_t gi = opaque + arow + wr * 64 + i * 16 + crow + 4 * v;
-                if (gi >= P.arow1) continue;
-                T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
-                const double ai = rowsq[wv][i * 16 + crow + 4 * v];
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t gi = opaque + arow + bq_acc_row(i, v);
+                    if (gi >= P.arow1) continue;
+                    T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
+                    const double ai = rowsq[wv][bq_acc_row64(i, v)];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
-                    if (gj >= P.n) continue;
-                    const double dot = acc[i][j][v];
-                    double kv;
-                    if (KIND == BQ_KERNEL_RBF) {
-                        double dist = -2.0 * dot;
-                        dist += ai;
-                        dist += P.b2[gj];
-                        dist = fmax(dist, 0.0);
-                        if (P.same && gi == gj) dist = 0.0;
-                        kv = exp(-P.gamma * dist);
-                    } else if (KIND == BQ_KERNEL_POLY) {
-                        kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
-                    } else if (KIND == BQ_KERNEL_SIGMOID) {
-                        kv = tanh(P.gamma * dot + P.coef0);
-                    } else {
-                        kv = dot;
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t gj = bcol + bq_acc_col(j);
+                        if (gj >= P.n) continue;
+                        const double dot = acc[i][j][v];
+                        double kv;
+                        if (KIND == BQ_KERNEL_RBF) {
+                            double dist = -2.0 * dot;
+                            dist += ai;
+                            dist += P.b2[gj];
+                            dist = fmax(dist, 0.0);
+                            if (decltype(on_diag)::value && gi == gj) dist = 0.0;
+                            kv = bq_exp(-P.gamma * dist);
+                        } else if (KIND == BQ_KERNEL_POLY) {
+                            kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                        } else if (KIND == BQ_KERNEL_SIGMOID) {
+                            kv = tanh(P.gamma * dot + P.coef0);
+                        } else {
+                            kv = dot;
+                        }
+                        store_elem<T>(rowp + gj, kv);
                     }
-                    store_elem<T>(rowp + gj, kv);
                 }
             }
-        }
+        };
+        if (KIND == BQ_KERNEL_RBF && P.same && arow == bcol)
+            epilogue(std::true_type{});
+        else
+            epilogue(std::false_type{});
         __syncthreads();   // the next tile's prologue refills the LDS buffers
     }
 }
@@ -178,7 +217,7 @@ __global__ __launch_bounds__(256) void gram_l1_kernel(gram_params P, T *__restri
             const int64_t gi = arow + 4 * tr + u, gj = bcol + 4 * tc + v;
             if (gi < P.arow1 && gj < P.n)
                 store_elem<T>(out + (P.lower_only ? bq_sym_addr(gi, gj, P.arow0 / BQ_SYM_TILE) : (gi - P.arow0) * P.ld + gj),
-                              exp(-P.gamma * acc[u][v]));
+                              bq_exp(-P.gamma * acc[u][v]));
         }
 }
 
@@ -409,6 +448,16 @@ struct bq_stream_images {
     int nchunk = 1;
 };
 
+#ifdef BQ_DIAG_STAMPS   // diagnostic build only: per-wave phase stamps of four workgroups of the third product -> stderr
+__device__ long long bq_stream_stamps[4][4][1 + 3 * 8];
+#define STREAM_STAMP(slot)                                                                                         \
+    do {                                                                                                           \
+        if (sblk >= 0 && (J - j0) < 8 && lane == 0) bq_stream_stamps[sblk][wv][1 + 3 * (J - j0) + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define STREAM_STAMP(slot) do { } while (0)
+#endif
+
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, const double *__restrict__ w, int add_one,
                                                              int64_t tiles_per_chunk, double *__restrict__ S,
@@ -426,55 +475,76 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
     const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
     rowsum[wv][lane] = 0.0;
     rowsq[wv][lane] = P.a2[arow + (wv >> 1) * 64 + lane];
+#ifdef BQ_DIAG_STAMPS
+    const int sblk = (blockIdx.y == 1 && (blockIdx.x == 0 || blockIdx.x == 1 || blockIdx.x == 256 || blockIdx.x == 257))
+                         ? (int)(blockIdx.x & 1) + 2 * (int)(blockIdx.x >> 8) : -1;
+    if (sblk >= 0 && lane == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        bq_stream_stamps[sblk][wv][0] = ((long long)xcc << 32) | hw;
+    }
+#endif
     for (int64_t J = j0; J < j1; ++J) {
         const int64_t bcol = J * GT;
         bq_d4 acc[4][4];
         bq_tile_zero(acc);
+        STREAM_STAMP(0);
         bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
+        STREAM_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's loads (w, norms) below the MFMA loop: hoisted above it
                                              // they stay live across it and spill
         int64_t opaque = 0;                  // ... and keep the J-invariant row indices per-iteration values (same reason)
         asm volatile("" : "+s"(opaque));
         // epilogue: kernel map, contraction with this tile's slice of w, fold over the 16 lanes that share a row; the
-        // running row sums live in LDS so that no accumulator stays in registers across the MFMA loop
+        // running row sums live in LDS so that no accumulator stays in registers across the MFMA loop.  Two instances: only
+        // the tile on the diagonal pays for the "exact zero distance at i == j" test
+        auto epilogue = [&](auto on_diag) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int64_t gi = opaque + arow + wr * 64 + i * 16 + crow + 4 * v;
-                const double ai = KIND == BQ_KERNEL_RBF ? rowsq[wv][i * 16 + crow + 4 * v] : 0.0;
-                double part = 0.0;
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t gi = opaque + arow + bq_acc_row(i, v);
+                    const double ai = KIND == BQ_KERNEL_RBF ? rowsq[wv][bq_acc_row64(i, v)] : 0.0;
+                    double part = 0.0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int64_t gj = bcol + wc * 64 + j * 16 + ccol;
-                    const double dot = acc[i][j][v];
-                    double kv;
-                    if (KIND == BQ_KERNEL_RBF) {
-                        double dist = -2.0 * dot;
-                        dist += ai;
-                        dist += P.b2[gj];
-                        dist = fmax(dist, 0.0);
-                        if (gi == gj) dist = 0.0;
-                        kv = exp(-P.gamma * dist);
-                    } else if (KIND == BQ_KERNEL_POLY) {
-                        kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
-                    } else if (KIND == BQ_KERNEL_SIGMOID) {
-                        kv = tanh(P.gamma * dot + P.coef0);
-                    } else {
-                        kv = dot;
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t gj = bcol + bq_acc_col(j);
+                        const double dot = acc[i][j][v];
+                        double kv;
+                        if (KIND == BQ_KERNEL_RBF) {
+                            double dist = -2.0 * dot;
+                            dist += ai;
+                            dist += P.b2[gj];
+                            dist = fmax(dist, 0.0);
+                            if (decltype(on_diag)::value && gi == gj) dist = 0.0;
+                            kv = bq_exp(-P.gamma * dist);
+                        } else if (KIND == BQ_KERNEL_POLY) {
+                            kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                        } else if (KIND == BQ_KERNEL_SIGMOID) {
+                            kv = tanh(P.gamma * dot + P.coef0);
+                        } else {
+                            kv = dot;
+                        }
+                        if (add_one) kv += 1.0;
+                        part = fma(kv, w[gj], part);   // w is zero beyond n (padded to the panel pitch)
+                        if ((KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY) && ((j + 1) % STREAM_EXP_ILP == 0))
+                            __builtin_amdgcn_sched_barrier(0);   // STREAM_EXP_ILP exp / pow chains in flight (register pressure)
                     }
-                    if (add_one) kv += 1.0;
-                    part = fma(kv, w[gj], part);   // w is zero beyond n (padded to the panel pitch)
-                    if ((KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY) && ((j + 1) % STREAM_EXP_ILP == 0))
-                        __builtin_amdgcn_sched_barrier(0);   // STREAM_EXP_ILP exp / pow chains in flight (register pressure)
+                    part += __shfl_xor(part, 1, 64);
+                    part += __shfl_xor(part, 2, 64);
+                    part += __shfl_xor(part, 4, 64);
+                    part += __shfl_xor(part, 8, 64);
+                    if (ccol == 0) rowsum[wv][bq_acc_row64(i, v)] += part;
                 }
-                part += __shfl_xor(part, 1, 64);
-                part += __shfl_xor(part, 2, 64);
-                part += __shfl_xor(part, 4, 64);
-                part += __shfl_xor(part, 8, 64);
-                if (ccol == 0) rowsum[wv][i * 16 + crow + 4 * v] += part;
             }
-        }
+        };
+        if (KIND == BQ_KERNEL_RBF && arow == bcol)
+            epilogue(std::true_type{});
+        else
+            epilogue(std::false_type{});
+        STREAM_STAMP(2);
         __syncthreads();   // the next tile's prologue refills the LDS buffers
     }
     __syncthreads();
@@ -503,9 +573,10 @@ int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int
     }
     const int64_t tiles_m = (r1 - r0 + GT - 1) / GT, tiles_n = (n + GT - 1) / GT;
     st->rows_pad = (tiles_m > 0 ? tiles_m : 1) * GT;
-    // enough workgroups to fill the chip a few times over, but never more chunks than column tiles
-    int nchunk = (int)((4 * (int64_t)ctx->num_cu * 2 + tiles_m - 1) / (tiles_m > 0 ? tiles_m : 1));
-    nchunk = nchunk < 1 ? 1 : (nchunk > 16 ? 16 : nchunk);
+    // ~24 rounds of workgroups over the chip's 2 x num_cu slots (all workgroups last the same: with 4.6 rounds — three chunks
+    // at n = 100 000 — the fifth, half-empty round cost 9 %), but never more chunks than column tiles
+    int nchunk = (int)((24 * (int64_t)ctx->num_cu * 2 + tiles_m - 1) / (tiles_m > 0 ? tiles_m : 1));
+    nchunk = nchunk < 1 ? 1 : (nchunk > 32 ? 32 : nchunk);
     if (nchunk > tiles_n) nchunk = (int)tiles_n;
     st->nchunk = nchunk;
     if (hipMalloc(&st->S, sizeof(double) * st->rows_pad * nchunk) != hipSuccess) {
@@ -573,6 +644,26 @@ int bq_stream_product(bq_ctx *ctx, void *h, int64_t n, int64_t r0, int64_t r1, i
     stream_reduce_kernel<<<(unsigned)((P.m + 255) / 256), 256, 0, ctx->stream>>>(st->S, P.m, st->rows_pad, st->nchunk,
                                                                                  out_rows, done);
     BQ_HIP(hipGetLastError());
+#ifdef BQ_DIAG_STAMPS
+    {
+        static int calls = 0;
+        if (++calls == 3) {
+            static long long h[4][4][25];
+            hipStreamSynchronize(ctx->stream);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(bq_stream_stamps), sizeof(h));
+            for (int b = 0; b < 4; ++b)
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    fprintf(stderr, "stamps blk %d wave %d xcc %lld hw_id 0x%llx t0 %lld:", b, w4, h[b][w4][0] >> 32,
+                            h[b][w4][0] & 0xffffffffll, h[b][w4][1]);
+                    for (int j = 0; j < 8; ++j)
+                        fprintf(stderr, "  [mfma %.2f epi %.2f gap %.2f]", (h[b][w4][2 + 3 * j] - h[b][w4][1 + 3 * j]) / 100.0,
+                                (h[b][w4][3 + 3 * j] - h[b][w4][2 + 3 * j]) / 100.0,
+                                j < 7 ? (h[b][w4][4 + 3 * j] - h[b][w4][3 + 3 * j]) / 100.0 : 0.0);
+                    fprintf(stderr, "\n");
+                }
+        }
+    }
+#endif
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
     return BQ_OK;
 }

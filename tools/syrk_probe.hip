@@ -23,14 +23,18 @@ __global__ __launch_bounds__(256, 2) void syrk_var(double *__restrict__ H, int64
     if (VAR == 0 || VAR == 3) bq_tile_load(acc, Ct, ldh); else bq_tile_zero(acc);
     if (VAR == 2) {   // no global traffic in the loop: stage one chunk, then run the same number of MFMA chunks on it
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1, fr = lane & 15, fk = lane >> 4;
-        for (int e = tid; e < 16 * 144; e += 256) { (&sm.A[0][0][0])[e] = 1e-3 * e; (&sm.B[0][0][0])[e] = 1e-3; }
+        for (int e = tid; e < 16 * BQ_GP; e += 256) { (&sm.A[0][0][0])[e] = 1e-3 * e; (&sm.B[0][0][0])[e] = 1e-3; }
         __syncthreads();
         for (int c = 0; c < kdim / 16; ++c) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 double a[4], b[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { a[t] = sm.A[0][kk * 4 + fk][wr * 64 + t * 16 + fr]; b[t] = sm.B[0][kk * 4 + fk][wc * 64 + t * 16 + fr]; }
+                for (int tp = 0; tp < 2; ++tp) {
+                    const bq_d2 va = *reinterpret_cast<const bq_d2 *>(&sm.A[0][kk * 4 + fk][wr * 64 + tp * 32 + 2 * fr]);
+                    const bq_d2 vb = *reinterpret_cast<const bq_d2 *>(&sm.B[0][kk * 4 + fk][wc * 64 + tp * 32 + 2 * fr]);
+                    a[2 * tp] = va.x; a[2 * tp + 1] = va.y; b[2 * tp] = vb.x; b[2 * tp + 1] = vb.y;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
