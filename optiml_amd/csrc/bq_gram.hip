@@ -51,6 +51,20 @@ __global__ void row_norms_kernel(const double *__restrict__ X, int64_t n, int64_
 template <typename T> __device__ __forceinline__ void store_elem(T *p, double v);
 template <> __device__ __forceinline__ void store_elem<double>(double *p, double v) { __builtin_nontemporal_store(v, p); }
 template <> __device__ __forceinline__ void store_elem<float>(float *p, double v) { __builtin_nontemporal_store((float)v, p); }
+// two adjacent elements (p 16-byte aligned for double, 8-byte for float): one store instruction
+__device__ __forceinline__ void store_pair(double *p, double a, double b) {
+    bq_d2 v;
+    v.x = a;
+    v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<bq_d2 *>(p));
+}
+__device__ __forceinline__ void store_pair(float *p, double a, double b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v;
+    v.x = (float)a;
+    v.y = (float)b;
+    __builtin_nontemporal_store(v, reinterpret_cast<f2 *>(p));
+}
 
 // exp for the kernel maps (arguments <= 0 for gamma > 0; correct up to the overflow threshold all the same).  18 vector
 // instructions against ~25 of the device library's exp: round-to-nearest of x log2(e) by the 1.5 * 2^52 trick (the integer
@@ -126,46 +140,60 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
         // the MFMA loop (32+ VGPRs) and spill.  An opaque zero makes them per-iteration values.
         int64_t opaque = 0;
         asm volatile("" : "+s"(opaque));
-        // epilogue, row by row: one (packed or pitched) row base per accumulator row, then the kernel map per element.  Two
-        // instances: only the tile on the diagonal of a symmetric build pays for the "exact zero distance at i == j" test
-        auto epilogue = [&](auto on_diag) {
+        // epilogue, row by row: the kernel map per element, two adjacent columns per store.  Instances: only the tile on the
+        // diagonal of a symmetric build pays for the "exact zero distance at i == j" test, only tiles that stick out of the
+        // matrix for the bounds tests (their branches also cut the rows into separate blocks: two exp chains in flight
+        // instead of four).  A row's address is this lane's base (once per tile) + a uniform multiple of the pitch.
+        const int64_t pitch = P.lower_only ? bq_sym_pitch(arow / BQ_SYM_TILE) : P.ld;
+        const int64_t tile0 = P.lower_only ? bq_sym_addr(arow, 0, I0) : (arow - P.arow0) * P.ld;   // uniform
+        T *const lane_base = out + tile0 + (int64_t)(wr * 64 + 2 * crow) * pitch + bcol + wc * 64 + 2 * ccol;
+        auto epilogue = [&](auto on_diag, auto on_edge) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int64_t gi = opaque + arow + bq_acc_row(i, v);
-                    if (gi >= P.arow1) continue;
-                    T *rowp = out + (P.lower_only ? bq_sym_addr(gi, 0, I0) : (gi - P.arow0) * P.ld);
+                    if (decltype(on_edge)::value && gi >= P.arow1) continue;
+                    T *rowp = lane_base + (opaque + (i >> 1) * 32 + 8 * v + (i & 1)) * pitch;
                     const double ai = rowsq[wv][bq_acc_row64(i, v)];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int64_t gj = bcol + bq_acc_col(j);
-                        if (gj >= P.n) continue;
-                        const double dot = acc[i][j][v];
-                        double kv;
-                        if (KIND == BQ_KERNEL_RBF) {
-                            double dist = -2.0 * dot;
-                            dist += ai;
-                            dist += P.b2[gj];
-                            dist = fmax(dist, 0.0);
-                            if (decltype(on_diag)::value && gi == gj) dist = 0.0;
-                            kv = bq_exp(-P.gamma * dist);
-                        } else if (KIND == BQ_KERNEL_POLY) {
-                            kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
-                        } else if (KIND == BQ_KERNEL_SIGMOID) {
-                            kv = tanh(P.gamma * dot + P.coef0);
-                        } else {
-                            kv = dot;
+                    for (int jp = 0; jp < 2; ++jp) {   // columns j = 2 jp and 2 jp + 1 of this lane are adjacent (even, odd)
+                        const int64_t gj = bcol + bq_acc_col(2 * jp);
+                        if (decltype(on_edge)::value && gj >= P.n) continue;
+                        double kv[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const double dot = acc[i][2 * jp + h][v];
+                            if (KIND == BQ_KERNEL_RBF) {
+                                double dist = -2.0 * dot;
+                                dist += ai;
+                                dist += P.b2[gj + h];   // padded to the image pitch
+                                dist = fmax(dist, 0.0);
+                                if (decltype(on_diag)::value && P.same && gi == gj + h) dist = 0.0;
+                                kv[h] = bq_exp(-P.gamma * dist);
+                            } else if (KIND == BQ_KERNEL_POLY) {
+                                kv[h] = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                            } else if (KIND == BQ_KERNEL_SIGMOID) {
+                                kv[h] = tanh(P.gamma * dot + P.coef0);
+                            } else {
+                                kv[h] = dot;
+                            }
                         }
-                        store_elem<T>(rowp + gj, kv);
+                        if (!decltype(on_edge)::value || gj + 1 < P.n)
+                            store_pair(rowp + jp * 32, kv[0], kv[1]);
+                        else
+                            store_elem<T>(rowp + jp * 32, kv[0]);
                     }
+                    if (KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY) __builtin_amdgcn_sched_barrier(0);   // four chains in flight
                 }
             }
         };
-        if (KIND == BQ_KERNEL_RBF && P.same && arow == bcol)
-            epilogue(std::true_type{});
+        if (arow + GT > P.arow1 || bcol + GT > P.n)
+            epilogue(std::true_type{}, std::true_type{});   // rare: the test for the diagonal rides along
+        else if (KIND == BQ_KERNEL_RBF && P.same && arow == bcol)
+            epilogue(std::true_type{}, std::false_type{});
         else
-            epilogue(std::false_type{});
+            epilogue(std::false_type{}, std::false_type{});
         __syncthreads();   // the next tile's prologue refills the LDS buffers
     }
 }
@@ -500,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
         // epilogue: kernel map, contraction with this tile's slice of w, fold over the 16 lanes that share a row; the
         // running row sums live in LDS so that no accumulator stays in registers across the MFMA loop.  Two instances: only
         // the tile on the diagonal pays for the "exact zero distance at i == j" test
+        const double one = add_one ? 1.0 : 0.0;   // K + 1 without a select per element (x + 0.0 == x for every x the maps produce)
         auto epilogue = [&](auto on_diag) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -527,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
                         } else {
                             kv = dot;
                         }
-                        if (add_one) kv += 1.0;
+                        kv += one;
                         part = fma(kv, w[gj], part);   // w is zero beyond n (padded to the panel pitch)
                         if ((KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY) && ((j + 1) % STREAM_EXP_ILP == 0))
                             __builtin_amdgcn_sched_barrier(0);   // STREAM_EXP_ILP exp / pow chains in flight (register pressure)

@@ -50,13 +50,14 @@ __device__ __forceinline__ int bq_acc_col(int j) { return (int)((threadIdx.x >> 
 // A_ROWS: the A operand is NOT an image but the row-major matrix itself, element (arow + r, k) at At[(arow + r) * lda + k]
 // (16 contiguous doubles per row and chunk); it is transposed on its way into LDS.  Saves the transposing pre-pass for
 // operands that are consumed once (the TRSM input).
-// Address arithmetic stays off the vector ALU inside the chunk loop: on gfx950 an fp64 MFMA runs ON the SIMD's 16 fp64 lanes
-// (64 cycles for 1024 FMAs = the vector rate), and while one is in flight no VALU instruction of ANY wave of that SIMD
-// issues (tools/coissue_probe.hip: a co-resident wave's fp64 / fp32 / int32 chains got ~0.1 % of their stand-alone rate, with
-// or without s_setprio).  Every v_add / v_lshl_add in the loop is therefore taken 1:1 from the MFMA cycles — the round-2
-// loop spent 40 VALU instructions per 64 MFMAs (5 %) on the global and LDS addresses of the staging.  Here the operands are
-// fetched with raw buffer loads (per-lane offset fixed for the whole tile, the chunk advance is a scalar add on the
-// resource's base) and the loop is unrolled over the two LDS buffers so that every LDS address is base + immediate.
+// Address arithmetic stays off the vector ALU inside the chunk loop.  Vector instructions are paid for in matrix-pipe time
+// on this part (tools/coissue_probe.hip): a wave with independent MFMAs queued back to back leaves a co-resident wave of
+// its SIMD ~0.1 % of its stand-alone vector issue rate (fp64 / fp32 / int32 chains alike, with or without s_setprio), and
+// k vector instructions placed after each MFMA of the same wave lengthen its 65-cycle period by ~13 + 5 (k - 1) cycles.
+// The round-2a loop spent 40 vector instructions per 64 MFMAs on the global and LDS addresses of the staging (5-7 % of the
+// tile rate, tools/syrk_probe.hip).  Here the operands are fetched with raw buffer loads (per-lane offset fixed for the
+// whole tile, the chunk advance is a scalar add on the resource's base) and the loop is unrolled over the two LDS buffers so
+// that every LDS address is base + immediate: 2 vector instructions per 128 MFMAs in the steady state.
 __device__ __forceinline__ const double *bq_uniform(const double *p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
