@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(double *__restrict__ H, in
     const int64_t arow = i0 + ti * NB, bcol = i0 + tj * NB;
     bq_d4 acc[4][4];
     double *Ct = H + arow * ldh + bcol;
-    bq_tile_load(acc, Ct, ldh);   // acc = C, then acc -= X_i X_j^T, then plain stores
-    bq_mfma_tile_128<true>(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
-    bq_tile_store(acc, Ct, ldh);
+    bq_tile_zero(acc);   // acc = X_i X_j^T, then C -= acc: the C tile is read after the loop (bq_tile_sub_store)
+    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
+    bq_tile_sub_store(acc, Ct, ldh);
 }
 
 // the same update restricted to the first block column of the trailing matrix (tiles (ti, 0)): makes the next block
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(double *__restrict__ H
     const int64_t arow = i0 + (int64_t)blockIdx.x * NB;
     bq_d4 acc[4][4];
     double *Ct = H + arow * ldh + i0;
-    bq_tile_load(acc, Ct, ldh);   // acc = C, then acc -= X_i X_j^T, then plain stores
-    bq_mfma_tile_128<true>(Wt, ldh, arow, Wt, ldh, i0, NB, sm, acc);
-    bq_tile_store(acc, Ct, ldh);
+    bq_tile_zero(acc);   // acc = X_i X_j^T, then C -= acc
+    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, i0, NB, sm, acc);
+    bq_tile_sub_store(acc, Ct, ldh);
 }
 
 // the update restricted to the first NC block columns of the trailing matrix starting at r0 (tiles (ti >= c, c), c < NC):
@@ -112,9 +112,9 @@ __global__ __launch_bounds__(256, 2) void syrk_head_kernel(double *__restrict__ 
     const int64_t arow = r0 + ti * NB, bcol = r0 + tj * NB;
     bq_d4 acc[4][4];
     double *Ct = H + arow * ldh + bcol;
-    bq_tile_load(acc, Ct, ldh);   // acc = C, then acc -= X_i X_j^T, then plain stores
-    bq_mfma_tile_128<true>(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
-    bq_tile_store(acc, Ct, ldh);
+    bq_tile_zero(acc);   // acc = X_i X_j^T, then C -= acc: the C tile is read after the loop (bq_tile_sub_store)
+    bq_mfma_tile_128(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
+    bq_tile_sub_store(acc, Ct, ldh);
 }
 
 // ---------------------------------------------------------------------------------------------

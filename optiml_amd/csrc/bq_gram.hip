@@ -66,35 +66,9 @@ __device__ __forceinline__ void store_pair(float *p, double a, double b) {
     __builtin_nontemporal_store(v, reinterpret_cast<f2 *>(p));
 }
 
-// exp for the kernel maps (arguments <= 0 for gamma > 0; correct up to the overflow threshold all the same).  18 vector
-// instructions against ~25 of the device library's exp: round-to-nearest of x log2(e) by the 1.5 * 2^52 trick (the integer
-// is the low word of the sum: no rndne / cvt), two-term Cody-Waite reduction, degree-11 polynomial with the Chebyshev-node
-// coefficients of (exp(r) - 1 - r) / r^2 on |r| <= ln(2) / 2 (tools/exp_fit.py: 1.7e-17 relative), one ldexp that also
-// produces the subnormal results; the clamp at -746 replaces the library's range selects.  <= 1 ulp from glibc's exp on
-// 4e7 points of [-746, 0] (tools/exp_check.c), exp(0) = 1 exactly.  Matters because on gfx950 vector instructions and
-// fp64 MFMAs exclude each other (bq_mfma_tile.h): every instruction of the epilogue is taken from the matrix pipe's time.
-// A NaN argument gives 0 (v_max drops it), like the fmax(dist, 0) in front of it.
-__device__ __forceinline__ double bq_exp(double x) {
-    x = fmax(x, -746.0);
-    const double magic = 6755399441055744.0;   // 1.5 * 2^52
-    const double t = fma(x, 1.4426950408889634074, magic);
-    const double n = t - magic;
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 0x1.af3a57ea0843fp-26;
-    p = fma(p, r, 0x1.2891a1928aa16p-22);
-    p = fma(p, r, 0x1.71de0c9540aa2p-19);
-    p = fma(p, r, 0x1.a019b8f77d16ep-16);
-    p = fma(p, r, 0x1.a01a01a8454fcp-13);
-    p = fma(p, r, 0x1.6c16c1789064ap-10);
-    p = fma(p, r, 0x1.1111111110834p-7);
-    p = fma(p, r, 0x1.5555555553d5ep-5);
-    p = fma(p, r, 0x1.5555555555556p-3);
-    p = fma(p, r, 0x1.0000000000001p-1);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, __double2loint(t));
-}
+#define BQ_EXP_ATTR __device__ __forceinline__
+#define BQ_EXP_LOINT(t) __double2loint(t)
+#include "bq_exp.h"
 
 struct gram_params {
     const double *At, *Bt;   // k-major padded images: At[dp][mp], Bt[dp][np]
@@ -500,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
     const int64_t arow = P.arow0 + tm * GT;
     const int64_t j0 = chunk * tiles_per_chunk, j1 = (j0 + tiles_per_chunk < tiles_n) ? j0 + tiles_per_chunk : tiles_n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
+    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15;
     rowsum[wv][lane] = 0.0;
     rowsq[wv][lane] = P.a2[arow + (wv >> 1) * 64 + lane];
 #ifdef BQ_DIAG_STAMPS

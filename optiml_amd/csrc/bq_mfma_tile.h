@@ -252,6 +252,31 @@ __device__ __forceinline__ void bq_tile_store(const bq_d4 (&acc)[4][4], double *
             }
 }
 
+// C -= acc (the accumulators hold the product X_i X_j^T: no negation while staging): the tile is read AFTER the K loop,
+// 8 rows at a time.  tools/syrk_probe.hip: "acc = C, loop, store" ran the tile update at 65.0 / 69.0 / 70.1 TFLOP/s for
+// K = 512 / 768 / 1024, this form at 69.5 / 73.6 / 74.3 = the rate without any C traffic — the 32 strided C loads (one
+// page per row) no longer sit in front of the first operand loads of the tile.  Warming the tile's lines with scratch loads
+// under the MFMAs on top of it was 1-3 % slower and is not kept.
+__device__ __forceinline__ void bq_tile_sub_store(const bq_d4 (&acc)[4][4], double *__restrict__ C, int64_t ld) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bq_d2 c[4][2];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+                c[v][jp] = *reinterpret_cast<const bq_d2 *>(C + (int64_t)bq_acc_row(i, v) * ld + bq_acc_col(2 * jp));
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                c[v][jp].x -= acc[i][2 * jp][v];
+                c[v][jp].y -= acc[i][2 * jp + 1][v];
+                *reinterpret_cast<bq_d2 *>(C + (int64_t)bq_acc_row(i, v) * ld + bq_acc_col(2 * jp)) = c[v][jp];
+            }
+    }
+}
+
 // Visit every accumulator element of this lane: f(row_in_tile, col_in_tile, value)
 template <typename F>
 __device__ __forceinline__ void bq_tile_foreach(bq_d4 (&acc)[4][4], F &&f) {

@@ -768,6 +768,36 @@ def test_laplacian_and_sigmoid_kernels(amd):
     _check_fit(est, g, 'laplacian_ip', g['fit_Xtest'], tol=1e-5)
 
 
+def test_kernel_map_exp_on_the_device_matches_numpy_over_its_whole_range(amd):
+    """bq_exp (csrc/bq_exp.h) as the device runs it: one feature, gamma = 1, so that the distance -2xy + x^2 + y^2 is formed
+    from exactly representable pieces in the reference's order and only the exp differs.  Arguments from 0 down to the
+    underflow threshold, through the panel build (packed, same = True, diagonal instance) and the rectangular build (edge
+    instance): <= 2 ulp of numpy's exp, subnormal results included, and exactly 1 on the diagonal."""
+    from optiml_amd.ml.svm.kernels import GaussianKernel
+    rs = np.random.RandomState(5)
+    x = np.concatenate((np.linspace(0.0, 27.4, 300), rs.uniform(0, 27.4, 213)))   # (x - y)^2 up to 750
+    x = np.round(x * 1024) / 1024      # 10 fractional bits: products and squares are exact in fp64
+    X = x[:, None]
+    k = GaussianKernel(1.0)
+    K = k(X)
+    xx = x * x
+    dist = np.maximum((-2.0 * np.outer(x, x) + xx[:, None]) + xx[None, :], 0.0)
+    np.fill_diagonal(dist, 0.0)
+    want = np.exp(-dist)
+    assert np.all(np.diag(K) == 1.0)
+    big = want > 1e-300
+    assert np.max(np.abs(K[big] - want[big]) / want[big]) <= 2 * np.finfo(float).eps
+    assert np.max(np.abs(K[~big] - want[~big])) <= 2 * np.maximum(np.spacing(want[~big]), 5e-324).max()
+    assert (want == 0).any() and np.all(K[want == 0] == 0)          # underflow reaches exact zero
+    Y = X[::3] + 0.5
+    KY = k(Y, X)
+    y = Y[:, 0]
+    dY = np.maximum((-2.0 * np.outer(y, x) + (y * y)[:, None]) + xx[None, :], 0.0)
+    wy = np.exp(-dY)
+    ok = wy > 1e-300
+    assert np.max(np.abs(KY[ok] - wy[ok]) / wy[ok]) <= 2 * np.finfo(float).eps
+
+
 def test_svr_ip_full_2n_system_matches_the_reduced_default(amd, tmp_path):
     """SVR + InteriorPoint factorises the n x n system in u = dx+ - dx- by default (symmetric elimination, bq_ip.hip);
     BQ_IP_SVR_REDUCED=0 selects the reference's own 2n x 2n factorisation (interior_point.py:235).  Both must follow

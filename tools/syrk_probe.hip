@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, 2) void syrk_var(double *__restrict__ H, int64
     const int64_t arow = ti * NB, bcol = tj * NB;
     bq_d4 acc[4][4];
     double *Ct = H + arow * ldh + bcol;
-    if (VAR == 0 || VAR == 3) bq_tile_load(acc, Ct, ldh); else bq_tile_zero(acc);
+    if (VAR == 0 || VAR == 3) bq_tile_load(acc, Ct, ldh); else bq_tile_zero(acc);   // VAR 5: C is read after the loop (the shipped form)
     if (VAR == 2) {   // no global traffic in the loop: stage one chunk, then run the same number of MFMA chunks on it
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1, fr = lane & 15, fk = lane >> 4;
         for (int e = tid; e < 16 * BQ_GP; e += 256) { (&sm.A[0][0][0])[e] = 1e-3 * e; (&sm.B[0][0][0])[e] = 1e-3; }
@@ -42,10 +42,13 @@ __global__ __launch_bounds__(256, 2) void syrk_var(double *__restrict__ H, int64
             }
             __syncthreads();
         }
+    } else if (VAR == 5) {
+        bq_mfma_tile_128<false>(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
     } else {
         bq_mfma_tile_128<true>(Wt, ldh, arow, Wt, ldh, bcol, kdim, sm, acc);
     }
-    if (VAR == 0 || VAR == 3) bq_tile_store(acc, Ct, ldh);
+    if (VAR == 5) bq_tile_sub_store(acc, Ct, ldh);
+    else if (VAR == 0 || VAR == 3) bq_tile_store(acc, Ct, ldh);
     else {
         double sum = 0.0;
 #pragma unroll
@@ -73,17 +76,18 @@ int main(int argc, char **argv) {
     const int64_t n = T * NB, ldh = n;
     double *H, *Wt;
     hipMalloc(&H, sizeof(double) * n * ldh);
-    hipMalloc(&Wt, sizeof(double) * 512 * ldh);
+    hipMalloc(&Wt, sizeof(double) * 1024 * ldh);
     hipMemset(H, 0, sizeof(double) * n * ldh);
-    std::vector<double> w((size_t)512 * ldh);
+    std::vector<double> w((size_t)1024 * ldh);
     for (size_t i = 0; i < w.size(); ++i) w[i] = 1e-3 * (double)((i * 2654435761u) % 1000) - 0.5;
     hipMemcpy(Wt, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice);
-    for (int kdim : {256, 512}) {
-        run<0>("full tile update (C load, K loop, C store)", H, ldh, Wt, kdim, T);
+    for (int kdim : {512, 768, 1024}) {
+        run<0>("acc = C, K loop with negated A, C store (rounds 1-2a)", H, ldh, Wt, kdim, T);
         run<1>("no C traffic (acc = 0, no store)", H, ldh, Wt, kdim, T);
         run<2>("no global traffic at all (LDS reads + MFMA + barriers)", H, ldh, Wt, kdim, T);
         run<3>("full, ONE workgroup per CU", H, ldh, Wt, kdim, T);
         run<4>("no C traffic, ONE workgroup per CU", H, ldh, Wt, kdim, T);
+        run<5>("C read after the loop (C -= acc, no negation in the loop)", H, ldh, Wt, kdim, T);
     }
     return 0;
 }
