@@ -147,6 +147,8 @@ __device__ __forceinline__ void bq_mfma_tile_128(const double *__restrict__ At, 
     // sched_group_barrier pins the interleave inside each region (masks: MFMA 0x8, VALU 0x2, VMEM read 0x20, DS read 0x100,
     // DS write 0x200): the next slice's four ds_read2 go out first, the staging is threaded through the MFMAs one
     // instruction per MFMA — left alone, hipcc put all reads, writes and loads of a region in front of its MFMAs.
+    // (Requesting chunk 0 of the NEXT tile before the epilogue of the current one — a kernel walking a strip of d = 128 tiles has
+    // only 8 chunks per tile — was measured too: panel build unchanged, streamed RBF product 44.5 -> 48.2 ms.  Not kept.)
     auto steady = [&](int B, int O, int64_t c) {   // B, O are literals at every call site: LDS addresses fold to immediates
         rd(1, B, 1);
         mm(0);
