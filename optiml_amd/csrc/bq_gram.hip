@@ -66,6 +66,14 @@ __device__ __forceinline__ void store_pair(float *p, double a, double b) {
     __builtin_nontemporal_store(v, reinterpret_cast<f2 *>(p));
 }
 
+// (gamma <x, y> + coef0)^degree: degrees 2 and 3 (the reference's default) by multiplication — pow() is ~150 vector
+// instructions per element, x * x * x two; <= 1 ulp from the reference's pow(x, 3.0).  DEG = 0: any degree, pow().
+template <int DEG>
+__device__ __forceinline__ double bq_poly_map(double x, int degree) {
+    if (DEG == 2) return x * x;
+    if (DEG == 3) return x * x * x;
+    return pow(x, (double)degree);
+}
 #define BQ_EXP_ATTR __device__ __forceinline__
 #define BQ_EXP_LOINT(t) __double2loint(t)
 #include "bq_exp.h"
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
         const int64_t pitch = P.lower_only ? bq_sym_pitch(arow / BQ_SYM_TILE) : P.ld;
         const int64_t tile0 = P.lower_only ? bq_sym_addr(arow, 0, I0) : (arow - P.arow0) * P.ld;   // uniform
         T *const lane_base = out + tile0 + (int64_t)(wr * 64 + 2 * crow) * pitch + bcol + wc * 64 + 2 * ccol;
-        auto epilogue = [&](auto on_diag, auto on_edge) {
+        auto epilogue = [&](auto on_diag, auto on_edge, auto deg) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
                                 if (decltype(on_diag)::value && P.same && gi == gj + h) dist = 0.0;
                                 kv[h] = bq_exp(-P.gamma * dist);
                             } else if (KIND == BQ_KERNEL_POLY) {
-                                kv[h] = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                                kv[h] = bq_poly_map<decltype(deg)::value>(P.gamma * dot + P.coef0, P.degree);
                             } else if (KIND == BQ_KERNEL_SIGMOID) {
                                 kv[h] = tanh(P.gamma * dot + P.coef0);
                             } else {
@@ -162,12 +170,19 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
                 }
             }
         };
+        typedef std::integral_constant<int, 0> deg_any;
+        typedef std::integral_constant<int, 2> deg_2;
+        typedef std::integral_constant<int, 3> deg_3;
         if (arow + GT > P.arow1 || bcol + GT > P.n)
-            epilogue(std::true_type{}, std::true_type{});   // rare: the test for the diagonal rides along
+            epilogue(std::true_type{}, std::true_type{}, deg_any{});   // rare: the test for the diagonal rides along
         else if (KIND == BQ_KERNEL_RBF && P.same && arow == bcol)
-            epilogue(std::true_type{}, std::false_type{});
+            epilogue(std::true_type{}, std::false_type{}, deg_any{});
+        else if (KIND == BQ_KERNEL_POLY && P.degree == 3)
+            epilogue(std::false_type{}, std::false_type{}, deg_3{});
+        else if (KIND == BQ_KERNEL_POLY && P.degree == 2)
+            epilogue(std::false_type{}, std::false_type{}, deg_2{});
         else
-            epilogue(std::false_type{}, std::false_type{});
+            epilogue(std::false_type{}, std::false_type{}, deg_any{});
         __syncthreads();   // the next tile's prologue refills the LDS buffers
     }
 }
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
         // running row sums live in LDS so that no accumulator stays in registers across the MFMA loop.  Two instances: only
         // the tile on the diagonal pays for the "exact zero distance at i == j" test
         const double one = add_one ? 1.0 : 0.0;   // K + 1 without a select per element (x + 0.0 == x for every x the maps produce)
-        auto epilogue = [&](auto on_diag) {
+        auto epilogue = [&](auto on_diag, auto deg) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
                             if (decltype(on_diag)::value && gi == gj) dist = 0.0;
                             kv = bq_exp(-P.gamma * dist);
                         } else if (KIND == BQ_KERNEL_POLY) {
-                            kv = pow(P.gamma * dot + P.coef0, (double)P.degree);
+                            kv = bq_poly_map<decltype(deg)::value>(P.gamma * dot + P.coef0, P.degree);
                         } else if (KIND == BQ_KERNEL_SIGMOID) {
                             kv = tanh(P.gamma * dot + P.coef0);
                         } else {
@@ -544,9 +559,13 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
             }
         };
         if (KIND == BQ_KERNEL_RBF && arow == bcol)
-            epilogue(std::true_type{});
+            epilogue(std::true_type{}, std::integral_constant<int, 0>{});
+        else if (KIND == BQ_KERNEL_POLY && P.degree == 3)
+            epilogue(std::false_type{}, std::integral_constant<int, 3>{});
+        else if (KIND == BQ_KERNEL_POLY && P.degree == 2)
+            epilogue(std::false_type{}, std::integral_constant<int, 2>{});
         else
-            epilogue(std::false_type{});
+            epilogue(std::false_type{}, std::integral_constant<int, 0>{});
         STREAM_STAMP(2);
         __syncthreads();   // the next tile's prologue refills the LDS buffers
     }
