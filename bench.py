@@ -380,9 +380,20 @@ def kkt_box(solver, n, d, sigma, cpu=True):
     cls = InteriorPoint if solver == 'ip' else ActiveSet
     ctx.profile(True)
     ctx.profile_read(_lib.PROF_CHOL, reset=True)
+    import threading
+    stop = threading.Event()
+
+    def heartbeat():   # long fits (n=100 000 InteriorPoint: 6 min) must not look hung to whoever watches stderr
+        while not stop.wait(60.0):
+            print(f'[bench] {cls.__name__} n={n}: {time.perf_counter() - t0:.0f} s', file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls, max_iter=10 ** 7).fit(X, y)
-    dt = time.perf_counter() - t0
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
+    try:
+        est = SVC(loss=hinge, kernel=gaussian, C=1., reg_intercept=True, dual=True, optimizer=cls, max_iter=10 ** 7).fit(X, y)
+    finally:
+        dt = time.perf_counter() - t0
+        stop.set()
     o = est.optimizer
     ch_ms, ch_cnt = ctx.profile_read(_lib.PROF_CHOL, reset=True)
     rec = {'route': f'SVC.fit(optimizer={cls.__name__})', 'n': n, 'd': d, 'value': dt, 'unit': 's', 'iterations': int(o.iter),
@@ -623,11 +634,19 @@ def main():
             out['roofline']['traffic_source'] = traffic['source']
             out['roofline']['traffic_note'] = 'PMC pass (FETCH_SIZE x2 per the gfx950 note, + WRITE_SIZE) of this command, committed file'
         if args.storage == 'stream':   # no panel: the product is the fused Gram-tile x vector kernel, MFMA-bound
-            flops = 2.0 * (-(-(r1 - r0) // 128) * 128) * (-(-n // 128) * 128) * (-(-d // 16) * 16)
+            dp = -(-d // 16) * 16
+            full = 2.0 * (-(-(r1 - r0) // 128) * 128) * (-(-n // 128) * 128) * dp
+            t0, t1 = r0 // 128, -(-r1 // 128)   # every lower-triangle tile of this rank's tile rows once, used for rows and columns
+            flops = 2.0 * ((t1 * (t1 + 1) - t0 * (t0 + 1)) // 2) * 128 * 128 * dp
             tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gram_stream_kernel (Gram tiles recomputed, fused with the product)',
+            out['roofline'] = {'bound': 'mfma',
+                               'kernel': 'gram_stream_sym_kernel (lower-triangle Gram tiles recomputed, each used for its rows and its '
+                                         'columns, fused with the product)',
                                'achieved': tf, 'peak': FP64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TF, 'traffic': None,
-                               'avg_launch_ms': avg_ms, 'launches': mv_cnt, 'flops_per_launch': flops}
+                               'avg_launch_ms': avg_ms, 'launches': mv_cnt, 'flops_per_launch': flops,
+                               'row_block_equivalent_TFs': full / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                               'note': 'frac counts the MFMA flops actually issued (the tiles on/below the diagonal in this rank\'s tile rows); '
+                                       'row_block_equivalent_TFs prices the launch at 2 rows n d, which is not what runs'}
     barrier()
     solver.close()
     quad.release()

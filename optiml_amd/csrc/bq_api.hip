@@ -260,7 +260,7 @@ static int problem_alloc_common(bq_problem *p, const double *q_host) {
     BQ_HIP(hipMemsetAsync(p->w, 0, sizeof(double) * p->ld, c->stream));
     const int64_t slen = bq_round_up(std::max(p->blk * c->world, p->nb * BQ_SYM_TILE), BQ_PAD);
     if (p->symmetric) {
-        BQ_HIP(hipMalloc(&p->slab, sizeof(double) * p->nb * p->nb * BQ_SYM_TILE));
+        if (!p->streamed) BQ_HIP(hipMalloc(&p->slab, sizeof(double) * p->nb * p->nb * BQ_SYM_TILE));   // streamed: its own scratch
         if (c->comm_kind != BQ_COMM_NONE) {   // the gathered segment vectors of every rank (also a one-rank communicator)
             const size_t gl = sizeof(double) * (size_t)c->world * p->seg_cmax * p->nb * BQ_SYM_TILE;
             BQ_HIP(hipMalloc(&p->gath, gl));
@@ -448,8 +448,9 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     p->diag_add = diag_add;
     p->d = d;
     p->streamed = storage == BQ_STREAM;
-    p->symmetric = !p->streamed && !full_panel;  // Gram panels are symmetric: store and stream only the tiles on/below the
-                                                 // diagonal, unless the caller asked for whole rows (BQ_FULL_PANEL)
+    // Gram panels are symmetric: store and stream only the tiles on/below the diagonal, unless the caller asked for whole rows
+    // (BQ_FULL_PANEL).  Streamed problems take the same segment partition of the tile rows and form each lower-triangle tile once.
+    p->symmetric = p->streamed || !full_panel;
     int rc = problem_layout(p, n, structure == BQ_SVR ? 2 * n : n);
     if (rc == BQ_OK) rc = problem_alloc_common(p, q);
     if (rc != BQ_OK) {
@@ -470,7 +471,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
         if ((e = hipMemcpyAsync(p->sgn, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(e);
     }
     if (p->streamed)
-        rc = bq_stream_prepare(c, p->X, n, d, p->r0, p->r1, &p->stream_img);
+        rc = bq_stream_prepare(c, p->X, n, d, p->I0 * BQ_SYM_TILE, p->I1 * BQ_SYM_TILE, &p->stream_img);
     else
         rc = bq_launch_gram(c, p->X, n, d, p->r0, p->r1, kernel, gamma, coef0, degree, p->panel, storage, p->ld, p->symmetric);
     if (rc != BQ_OK) {
@@ -584,8 +585,8 @@ extern "C" int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms) 
     if (p->symmetric) bq_sym_seg_table(p, &tab);
     auto local = [&]() {
         if (p->streamed)
-            return bq_stream_product(c, p->stream_img, p->n, p->r0, p->r1, p->kernel, p->gamma, p->coef0, p->degree,
-                                     p->add_one, p->w, p->s + p->r0, nullptr);
+            return bq_stream_sym_product(c, p->stream_img, p->n, p->nb, tab, p->kernel, p->gamma, p->coef0, p->degree, p->add_one, p->w,
+                                         p->s, 0, nullptr);
         return p->symmetric ? bq_launch_symv(c, p->panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr)
                             : bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w,
                                              p->s + p->r0, nullptr);

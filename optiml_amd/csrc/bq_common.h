@@ -252,10 +252,13 @@ int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int 
                        double *out);
 
 // streamed mode (bq_gram.hip): persistent k-major image of X + the fused Gram-tile x vector product
+// rows [r0, r1): this rank's 256-row tile rows (whole canonical segments; r1 may exceed n)
 int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int64_t r0, int64_t r1, void **out);
+// the streamed product: segments / slots as for bq_launch_symv (mode 0: summed over this rank's segments into out; mode 1: per
+// segment into the gathered buffer)
+int bq_stream_sym_product(bq_ctx *ctx, void *h, int64_t n, int64_t nb, const bq_seg_table &tab, int kernel, double gamma, double coef0,
+                          int degree, bool add_one, const double *w, double *out, int mode, const int *done);
 void bq_stream_free(void *h);
-int bq_stream_product(bq_ctx *ctx, void *h, int64_t n, int64_t r0, int64_t r1, int kernel, double gamma, double coef0,
-                      int degree, bool add_one, const double *w, double *out_rows, const int *done);
 
 int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                           const double *A, int64_t t, const double *B, double *out);

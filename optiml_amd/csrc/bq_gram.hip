@@ -16,6 +16,7 @@
 #include "bq_mfma_tile.h"
 
 #include <type_traits>
+#include <vector>
 
 constexpr int GT = BQ_GT;
 constexpr int GK = BQ_GK;
@@ -447,85 +448,74 @@ int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, i
 // ---------------------------------------------------------------------------------------------------------------
 // Streamed mode (BQ_STREAM): no resident panel — every product recomputes the Gram tiles on the MFMA and contracts them
 // with the input vector inside the same kernel (the fallback when n^2 s does not fit in HBM).
-// One workgroup owns a 128-row tile of this rank's row block and a chunk of column tiles: per column tile the shared
-// tile kernel yields the 128 x 128 dot products, the kernel map turns them into K (or K + 1) and each lane folds its 64
-// values into 16 per-row sums.  At the end the 16 lanes that share a row are combined with shuffles, the two waves that
-// share a row block through LDS, and the chunk's 128 row sums go to S[chunk][row]; stream_reduce_kernel adds the chunks
-// in order.  No symmetry credit (each tile is computed where it is used): 2 n^2 d flop per product.
 // ---------------------------------------------------------------------------------------------------------------
-// exp / pow chains kept in flight per lane in the streamed product's epilogue (a chain is ~40 dependent fp64 instructions: one
-// at a time left the VALU idle; measured 62.5 / 60.4 / 59.8 ms per n=100k product for 1 / 2 / 4)
-#ifndef STREAM_EXP_ILP
-#define STREAM_EXP_ILP 4
+// exp / pow chains kept in flight per lane in the epilogue (a chain is ~20-40 dependent fp64 instructions: one at a time left
+// the vector ALU idle)
+#ifndef STREAM_SYM_EXP_ILP
+#define STREAM_SYM_EXP_ILP 2
 #endif
 struct bq_stream_images {
     gram_images img;
-    double *S = nullptr;       // nchunk x rows_pad partial products
-    int64_t rows_pad = 0;
-    int nchunk = 1;
+    // this rank owns the 128-row tiles [t0, t1) (whole canonical segments) and forms every tile (I, J), J <= I, of those rows
+    // once; work units = (row tile, range of U column tiles)
+    int64_t T = 0, t0 = 0, t1 = 0, nunits = 0;
+    int64_t U = 1, kmax = 1;    // column tiles per unit (a function of n only: sums associate the same for any rank count), ranges per row
+    int *unit = nullptr;        // nunits x 4: row tile, first column tile, end column tile, slot in SU ((row - t0) * kmax + range)
+    double *SU = nullptr;       // (t1 - t0) x kmax x 128: row sums of the units
+    double *slab = nullptr;     // column sums of the off-diagonal tile (I, J), I in [t0, t1), at (I (I - 1) - t0 (t0 - 1)) / 2 + J
 };
 
-#ifdef BQ_DIAG_STAMPS   // diagnostic build only: per-wave phase stamps of four workgroups of the third product -> stderr
-__device__ long long bq_stream_stamps[4][4][1 + 3 * 8];
-#define STREAM_STAMP(slot)                                                                                         \
-    do {                                                                                                           \
-        if (sblk >= 0 && (J - j0) < 8 && lane == 0) bq_stream_stamps[sblk][wv][1 + 3 * (J - j0) + (slot)] = wall_clock64(); \
-    } while (0)
-#else
-#define STREAM_STAMP(slot) do { } while (0)
-#endif
-
+// ---------------------------------------------------------------------------------------------------------------
+// K is symmetric, so a tile (I, J), J < I, is formed ONCE and used twice: its row sums K_IJ w_J go to y_I, its column sums
+// K_IJ^T w_I to y_J — half the MFMAs and half the kernel-map evaluations of a row-block form (rounds 1-2a: every rank formed all
+// tiles of its rows; n = 100 000 RBF 44.6 ms per product against 24.1 ms now).
+// Ranks own whole canonical segments of tile rows, exactly as for the resident symmetric panels (bq_sym_segments): a rank
+// forms the tiles (I, J <= I) of its rows.  A workgroup owns a unit = (row tile I, a range of U column tiles): row sums
+// accumulate in LDS over the unit and land in SU[unit]; the 128 column sums of every off-diagonal tile land in the slab (each
+// lane folds its 16 rows per column, the four lane groups of a wave meet through shuffles, the two waves of a column half
+// through LDS).  The reduce kernels then form, per segment s and output tile t, y_s[t] = (the units of row t in range order, if
+// t lies in s) + (the column sums of the tiles (I, t), I in s, I > t, ascending), and add the segment vectors in segment order
+// — on one rank in the same kernel, across ranks after the all-gather (bq_launch_symv_segsum).  U depends on n only, so every
+// sum associates the same way for any rank count: streamed products are bit-identical for 1 / 2 / 4 / 8 ranks like the
+// resident ones.  No atomics.
+// ---------------------------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, const double *__restrict__ w, int add_one,
-                                                             int64_t tiles_per_chunk, double *__restrict__ S,
-                                                             int64_t rows_pad, const int *done) {
+__global__ __launch_bounds__(256, 2) void gram_stream_sym_kernel(gram_params P, const double *__restrict__ w, int add_one,
+                                                                 const int *__restrict__ unit, double *__restrict__ SU,
+                                                                 double *__restrict__ slab, int64_t t0, const int *done) {
     if (done != nullptr && *done) return;
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    __shared__ double rowsum[4][64];   // per wave: running sums of its 64 rows over its 64 columns of every tile so far
-    __shared__ double rowsq[4][64];    // per wave: squared norms of its 64 rows (kept out of the registers on purpose: as
-                                       // loop invariants they would stay live across the MFMA loop and force spills)
-    const int64_t tiles_n = (P.n + GT - 1) / GT;
-    const int64_t tm = blockIdx.x, chunk = blockIdx.y;
-    const int64_t arow = P.arow0 + tm * GT;
-    const int64_t j0 = chunk * tiles_per_chunk, j1 = (j0 + tiles_per_chunk < tiles_n) ? j0 + tiles_per_chunk : tiles_n;
+    __shared__ double rowsum[4][64];
+    __shared__ double rowsq[4][64];
+    __shared__ double wrow[4][64];      // w over the unit's rows, per wave like rowsq
+    __shared__ double colsum[2][128];   // per row half: column sums of the current tile
+    const int I = unit[4 * blockIdx.x], j0 = unit[4 * blockIdx.x + 1], j1 = unit[4 * blockIdx.x + 2], slot = unit[4 * blockIdx.x + 3];
+    const int64_t arow = (int64_t)I * GT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15;
+    const int wr = wv >> 1, wc = wv & 1, ccol = lane & 15, crow = lane >> 4;
     rowsum[wv][lane] = 0.0;
-    rowsq[wv][lane] = P.a2[arow + (wv >> 1) * 64 + lane];
-#ifdef BQ_DIAG_STAMPS
-    const int sblk = (blockIdx.y == 1 && (blockIdx.x == 0 || blockIdx.x == 1 || blockIdx.x == 256 || blockIdx.x == 257))
-                         ? (int)(blockIdx.x & 1) + 2 * (int)(blockIdx.x >> 8) : -1;
-    if (sblk >= 0 && lane == 0) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        bq_stream_stamps[sblk][wv][0] = ((long long)xcc << 32) | hw;
-    }
-#endif
-    for (int64_t J = j0; J < j1; ++J) {
-        const int64_t bcol = J * GT;
+    rowsq[wv][lane] = P.a2[arow + wr * 64 + lane];
+    wrow[wv][lane] = w[arow + wr * 64 + lane];
+    for (int J = j0; J < j1; ++J) {
+        const int64_t bcol = (int64_t)J * GT;
         bq_d4 acc[4][4];
         bq_tile_zero(acc);
-        STREAM_STAMP(0);
         bq_mfma_tile_128(P.At, P.mp, arow, P.Bt, P.np, bcol, P.dp, sm, acc);
-        STREAM_STAMP(1);
-        __builtin_amdgcn_sched_barrier(0);   // keep the epilogue's loads (w, norms) below the MFMA loop: hoisted above it
-                                             // they stay live across it and spill
-        int64_t opaque = 0;                  // ... and keep the J-invariant row indices per-iteration values (same reason)
+        __builtin_amdgcn_sched_barrier(0);
+        int64_t opaque = 0;
         asm volatile("" : "+s"(opaque));
-        // epilogue: kernel map, contraction with this tile's slice of w, fold over the 16 lanes that share a row; the
-        // running row sums live in LDS so that no accumulator stays in registers across the MFMA loop.  Two instances: only
-        // the tile on the diagonal pays for the "exact zero distance at i == j" test
-        const double one = add_one ? 1.0 : 0.0;   // K + 1 without a select per element (x + 0.0 == x for every x the maps produce)
+        const double one = add_one ? 1.0 : 0.0;
         auto epilogue = [&](auto on_diag, auto deg) {
+            double col[4] = {0.0, 0.0, 0.0, 0.0};
+            double part[16];   // one per accumulator row of this lane; folded over the 16 lanes of a row after the maps
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int64_t gi = opaque + arow + bq_acc_row(i, v);
                     const double ai = KIND == BQ_KERNEL_RBF ? rowsq[wv][bq_acc_row64(i, v)] : 0.0;
-                    double part = 0.0;
+                    const double wi = wrow[wv][bq_acc_row64(i, v)];   // zero beyond n
+                    double pr = 0.0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int64_t gj = bcol + bq_acc_col(j);
@@ -546,19 +536,43 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
                             kv = dot;
                         }
                         kv += one;
-                        part = fma(kv, w[gj], part);   // w is zero beyond n (padded to the panel pitch)
-                        if ((KIND == BQ_KERNEL_RBF || KIND == BQ_KERNEL_POLY) && ((j + 1) % STREAM_EXP_ILP == 0))
-                            __builtin_amdgcn_sched_barrier(0);   // STREAM_EXP_ILP exp / pow chains in flight (register pressure)
+                        pr = fma(kv, w[gj], pr);   // w is zero beyond n (padded to the panel pitch)
+                        if (!decltype(on_diag)::value) col[j] = fma(kv, wi, col[j]);   // the diagonal tile is used once
+                        if ((KIND == BQ_KERNEL_RBF || (KIND == BQ_KERNEL_POLY && decltype(deg)::value == 0)) && ((j + 1) % STREAM_SYM_EXP_ILP == 0))
+                            __builtin_amdgcn_sched_barrier(0);
                     }
-                    part += __shfl_xor(part, 1, 64);
-                    part += __shfl_xor(part, 2, 64);
-                    part += __shfl_xor(part, 4, 64);
-                    part += __shfl_xor(part, 8, 64);
-                    if (ccol == 0) rowsum[wv][bq_acc_row64(i, v)] += part;
+                    part[4 * i + v] = pr;
                 }
             }
+            // one straight block up to here (a branch per row cut it into 16, with values carried — and spilled — between them)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double q = part[r];
+                q += __shfl_xor(q, 1, 64);
+                q += __shfl_xor(q, 2, 64);
+                q += __shfl_xor(q, 4, 64);
+                q += __shfl_xor(q, 8, 64);
+                part[r] = q;
+            }
+            if (!decltype(on_diag)::value) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double c = col[j];
+                    c += __shfl_xor(c, 16, 64);
+                    c += __shfl_xor(c, 32, 64);
+                    col[j] = c;
+                }
+            }
+            if (ccol == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rowsum[wv][bq_acc_row64(r >> 2, r & 3)] += part[r];
+            }
+            if (!decltype(on_diag)::value && crow == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) colsum[wr][wc * 64 + bq_acc_col64(j)] = col[j];
+            }
         };
-        if (KIND == BQ_KERNEL_RBF && arow == bcol)
+        if (I == J)
             epilogue(std::true_type{}, std::integral_constant<int, 0>{});
         else if (KIND == BQ_KERNEL_POLY && P.degree == 3)
             epilogue(std::false_type{}, std::integral_constant<int, 3>{});
@@ -566,24 +580,52 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(gram_params P, cons
             epilogue(std::false_type{}, std::integral_constant<int, 2>{});
         else
             epilogue(std::false_type{}, std::integral_constant<int, 0>{});
-        STREAM_STAMP(2);
-        __syncthreads();   // the next tile's prologue refills the LDS buffers
+        __syncthreads();   // colsum complete; the next tile's prologue may refill the operand buffers
+        if (I != J && threadIdx.x < 128)
+            slab[(((int64_t)I * (I - 1) - t0 * (t0 - 1)) / 2 + J) * 128 + threadIdx.x] = colsum[0][threadIdx.x] + colsum[1][threadIdx.x];
     }
     __syncthreads();
-    if (wc == 0) {   // the two waves of a row block (column halves) are combined in a fixed order
-        const int64_t gi = arow + wr * 64 + lane;
-        S[chunk * rows_pad + (gi - P.arow0)] = gi < P.arow1 ? rowsum[wv][lane] + rowsum[wv + 1][lane] : 0.0;
-    }
+    if (wc == 0) SU[(int64_t)slot * 128 + wr * 64 + lane] = rowsum[wv][lane] + rowsum[wv + 1][lane];
 }
 
-__global__ void stream_reduce_kernel(const double *__restrict__ S, int64_t rows, int64_t rows_pad, int nchunk,
-                                     double *__restrict__ out, const int *done) {
-    if (done != nullptr && *done) return;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
+// y_s over output tile t, element e: the units of row t in range order (if t lies in the segment's 128-row tiles [lo, hi)),
+// then the column sums of the tiles (I, t), I in [lo, hi), I > t, ascending
+struct stream_sym_geom {
+    int64_t T, t0, U, kmax, n, len;
+};
+__device__ __forceinline__ double stream_seg_partial(const double *__restrict__ SU, const double *__restrict__ slab,
+                                                     const stream_sym_geom &g, int64_t t, int e, int64_t lo, int64_t hi) {
     double a = 0.0;
-    for (int c = 0; c < nchunk; ++c) a += S[(int64_t)c * rows_pad + i];
-    out[i] = a;
+    if (t >= lo && t < hi)
+        for (int64_t k = 0; k * g.U <= t; ++k) a += SU[((t - g.t0) * g.kmax + k) * 128 + e];
+    for (int64_t I = (t + 1 > lo ? t + 1 : lo); I < hi; ++I) a += slab[((I * (I - 1) - g.t0 * (g.t0 - 1)) / 2 + t) * 128 + e];
+    return a;
+}
+// one rank: the segment vectors are added in segment order right here
+__global__ __launch_bounds__(128) void stream_sym_reduce_kernel(const double *__restrict__ SU, const double *__restrict__ slab,
+                                                                stream_sym_geom g, bq_seg_table tab, double *__restrict__ out,
+                                                                const int *done) {
+    if (done != nullptr && *done) return;
+    const int64_t t = blockIdx.x;
+    const int e = threadIdx.x;
+    double acc = 0.0;
+    for (int s = tab.lo; s < tab.hi; ++s) {
+        const int64_t lo = 2 * tab.cut[s], hi = 2 * tab.cut[s + 1] < g.T ? 2 * tab.cut[s + 1] : g.T;
+        acc += stream_seg_partial(SU, slab, g, t, e, lo, hi);
+    }
+    out[t * GT + e] = t * GT + e < g.n ? acc : 0.0;
+}
+// several ranks: this rank's segment vectors, each to its slot of the gathered buffer
+__global__ __launch_bounds__(128) void stream_sym_reduce_seg_kernel(const double *__restrict__ SU, const double *__restrict__ slab,
+                                                                    stream_sym_geom g, bq_seg_table tab, double *__restrict__ gath,
+                                                                    const int *done) {
+    if (done != nullptr && *done) return;
+    const int64_t t = blockIdx.x;
+    const int s = tab.lo + (int)blockIdx.y;
+    const int e = threadIdx.x;
+    const int64_t lo = 2 * tab.cut[s], hi = 2 * tab.cut[s + 1] < g.T ? 2 * tab.cut[s + 1] : g.T;
+    const double v = stream_seg_partial(SU, slab, g, t, e, lo, hi);
+    gath[(int64_t)tab.slot[s] * g.len + t * GT + e] = t * GT + e < g.n ? v : 0.0;
 }
 
 int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int64_t r0, int64_t r1, void **out) {
@@ -593,19 +635,43 @@ int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int
         delete st;
         return rc;
     }
-    const int64_t tiles_m = (r1 - r0 + GT - 1) / GT, tiles_n = (n + GT - 1) / GT;
-    st->rows_pad = (tiles_m > 0 ? tiles_m : 1) * GT;
-    // ~24 rounds of workgroups over the chip's 2 x num_cu slots (all workgroups last the same: with 4.6 rounds — three chunks
-    // at n = 100 000 — the fifth, half-empty round cost 9 %), but never more chunks than column tiles
-    int nchunk = (int)((24 * (int64_t)ctx->num_cu * 2 + tiles_m - 1) / (tiles_m > 0 ? tiles_m : 1));
-    nchunk = nchunk < 1 ? 1 : (nchunk > 32 ? 32 : nchunk);
-    if (nchunk > tiles_n) nchunk = (int)tiles_n;
-    st->nchunk = nchunk;
-    if (hipMalloc(&st->S, sizeof(double) * st->rows_pad * nchunk) != hipSuccess) {
-        bq_set_error("cannot allocate the streamed-product scratch");
-        free_image(&st->img);
-        delete st;
-        return BQ_ERR_NOMEM;
+    const int64_t tiles_n = (n + GT - 1) / GT;
+    {   // rows [r0, r1) are whole 256-row tile rows of canonical segments (r1 may exceed n)
+        const int64_t T = tiles_n, total = T * (T + 1) / 2;
+        const int64_t t0 = r0 / GT, t1 = (r1 + GT - 1) / GT < T ? (r1 + GT - 1) / GT : T;
+        // units sized for ~24 rounds of workgroups on each of 8 ranks, from n alone (the association of the row sums must not
+        // depend on the rank count)
+        const int64_t target = 24 * 512 * 8;
+        const int64_t U = total / target > 0 ? (total + target - 1) / target : 1;
+        const int64_t kmax = (T + U - 1) / U;
+        // launch order: column range by column range, rows descending inside a range — the workgroups in flight walk the SAME
+        // column tiles at about the same time, like the row-block form (measured equal to row-major unit order at n = 100 000:
+        // the operand images live in the last-level cache either way)
+        std::vector<int> unit;
+        for (int64_t k = 0; k < kmax; ++k)
+            for (int64_t t = t1 - 1; t >= t0 && t >= k * U; --t) {
+                unit.push_back((int)t);
+                unit.push_back((int)(k * U));
+                unit.push_back((int)(k * U + U < t + 1 ? k * U + U : t + 1));
+                unit.push_back((int)((t - t0) * kmax + k));
+            }
+        st->T = T;
+        st->t0 = t0;
+        st->t1 = t1;
+        st->U = U;
+        st->kmax = kmax;
+        st->nunits = (int64_t)unit.size() / 4;
+        const int64_t rows = t1 > t0 ? t1 - t0 : 0;
+        const int64_t nslab = rows > 0 ? (t1 * (t1 - 1) - t0 * (t0 - 1)) / 2 : 0;
+        hipError_t e = hipMalloc(&st->unit, sizeof(int) * (unit.size() + 4));
+        if (e == hipSuccess) e = hipMalloc(&st->SU, sizeof(double) * (rows * kmax + 1) * 128);
+        if (e == hipSuccess) e = hipMalloc(&st->slab, sizeof(double) * (nslab + 1) * 128);
+        if (e == hipSuccess && !unit.empty()) e = hipMemcpy(st->unit, unit.data(), sizeof(int) * unit.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            bq_set_error("cannot allocate the symmetric streamed-product scratch: %s", hipGetErrorString(e));
+            bq_stream_free(st);
+            return BQ_ERR_NOMEM;
+        }
     }
     *out = st;
     return BQ_OK;
@@ -615,26 +681,28 @@ void bq_stream_free(void *h) {
     if (!h) return;
     bq_stream_images *st = (bq_stream_images *)h;
     free_image(&st->img);
-    if (st->S) hipFree(st->S);
+    if (st->unit) hipFree(st->unit);
+    if (st->SU) hipFree(st->SU);
+    if (st->slab) hipFree(st->slab);
     delete st;
 }
 
-// out_rows[0 : r1 - r0) = (K or K + 1)[r0:r1, :] w
-int bq_stream_product(bq_ctx *ctx, void *h, int64_t n, int64_t r0, int64_t r1, int kernel, double gamma, double coef0,
-                      int degree, bool add_one, const double *w, double *out_rows, const int *done) {
-    if (r1 <= r0) return BQ_OK;
+// mode 0: out (nb * 256) = the sum of this rank's segment vectors in segment order; mode 1: each of this
+// rank's segment vectors to its slot of the gathered buffer `out` (slots of nb * 256)
+int bq_stream_sym_product(bq_ctx *ctx, void *h, int64_t n, int64_t nb, const bq_seg_table &tab, int kernel, double gamma, double coef0,
+                          int degree, bool add_one, const double *w, double *out, int mode, const int *done) {
     bq_stream_images *st = (bq_stream_images *)h;
     BQ_ARG(kernel != BQ_KERNEL_LAPLACIAN, "the streamed mode is built for the inner-product kernels (linear, poly, rbf, sigmoid)");
     gram_params P;
     P.lower_only = 0;
     P.At = P.Bt = st->img.At;
     P.a2 = P.b2 = st->img.a2;
-    P.m = r1 - r0;
+    P.m = n;
     P.n = n;
     P.mp = P.np = st->img.mp;
     P.dp = st->img.dp;
-    P.arow0 = r0;
-    P.arow1 = r1;
+    P.arow0 = 0;
+    P.arow1 = n;
     P.same = 1;
     P.kernel = kernel;
     P.degree = degree;
@@ -642,50 +710,32 @@ int bq_stream_product(bq_ctx *ctx, void *h, int64_t n, int64_t r0, int64_t r1, i
     P.coef0 = coef0;
     P.ld = 0;
     P.ntiles = 0;
-    const int64_t tiles_m = (P.m + GT - 1) / GT, tiles_n = (n + GT - 1) / GT;
-    BQ_ARG(r0 % GT == 0, "row block must be tile aligned");
-    const int64_t per = (tiles_n + st->nchunk - 1) / st->nchunk;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
-    dim3 grid((unsigned)tiles_m, (unsigned)st->nchunk);
-    // one instantiation per kernel map: with all of exp / pow / tanh inlined in the 64-element epilogue the kernel spilled
-    switch (kernel) {
-        case BQ_KERNEL_RBF:
-            gram_stream_kernel<BQ_KERNEL_RBF><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
-            break;
-        case BQ_KERNEL_POLY:
-            gram_stream_kernel<BQ_KERNEL_POLY><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
-            break;
-        case BQ_KERNEL_SIGMOID:
-            gram_stream_kernel<BQ_KERNEL_SIGMOID><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
-            break;
-        default:
-            gram_stream_kernel<BQ_KERNEL_LINEAR><<<grid, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, per, st->S, st->rows_pad, done);
-            break;
-    }
-    stream_reduce_kernel<<<(unsigned)((P.m + 255) / 256), 256, 0, ctx->stream>>>(st->S, P.m, st->rows_pad, st->nchunk,
-                                                                                 out_rows, done);
-    BQ_HIP(hipGetLastError());
-#ifdef BQ_DIAG_STAMPS
-    {
-        static int calls = 0;
-        if (++calls == 3) {
-            static long long h[4][4][25];
-            hipStreamSynchronize(ctx->stream);
-            hipMemcpyFromSymbol(h, HIP_SYMBOL(bq_stream_stamps), sizeof(h));
-            for (int b = 0; b < 4; ++b)
-                for (int w4 = 0; w4 < 4; ++w4) {
-                    fprintf(stderr, "stamps blk %d wave %d xcc %lld hw_id 0x%llx t0 %lld:", b, w4, h[b][w4][0] >> 32,
-                            h[b][w4][0] & 0xffffffffll, h[b][w4][1]);
-                    for (int j = 0; j < 8; ++j)
-                        fprintf(stderr, "  [mfma %.2f epi %.2f gap %.2f]", (h[b][w4][2 + 3 * j] - h[b][w4][1 + 3 * j]) / 100.0,
-                                (h[b][w4][3 + 3 * j] - h[b][w4][2 + 3 * j]) / 100.0,
-                                j < 7 ? (h[b][w4][4 + 3 * j] - h[b][w4][3 + 3 * j]) / 100.0 : 0.0);
-                    fprintf(stderr, "\n");
-                }
+    const unsigned nu = (unsigned)st->nunits;
+    if (nu > 0) {
+        switch (kernel) {
+            case BQ_KERNEL_RBF:
+                gram_stream_sym_kernel<BQ_KERNEL_RBF><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                break;
+            case BQ_KERNEL_POLY:
+                gram_stream_sym_kernel<BQ_KERNEL_POLY><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                break;
+            case BQ_KERNEL_SIGMOID:
+                gram_stream_sym_kernel<BQ_KERNEL_SIGMOID><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                break;
+            default:
+                gram_stream_sym_kernel<BQ_KERNEL_LINEAR><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                break;
         }
     }
-#endif
+    BQ_HIP(hipGetLastError());
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
+    stream_sym_geom g{st->T, st->t0, st->U, st->kmax, n, nb * BQ_SYM_TILE};
+    if (mode == 0)
+        stream_sym_reduce_kernel<<<(unsigned)st->T, 128, 0, ctx->stream>>>(st->SU, st->slab, g, tab, out, done);
+    else if (tab.hi > tab.lo)
+        stream_sym_reduce_seg_kernel<<<dim3((unsigned)st->T, (unsigned)(tab.hi - tab.lo)), 128, 0, ctx->stream>>>(st->SU, st->slab, g, tab, out, done);
+    BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

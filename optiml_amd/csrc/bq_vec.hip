@@ -98,10 +98,25 @@ __global__ void finish_kernel(int structure, int64_t n, int64_t N, double diag_a
 // all-gather of the segment vectors + their sum in segment order (or, BQ_SYM_EXCHANGE=allreduce, one all-reduce(sum)).
 int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done) {
     bq_ctx *ctx = p->ctx;
-    if (p->streamed) {   // no panel: Gram tiles recomputed inside the product (bq_gram.hip), row blocks + all-gather
-        BQ_TRY(bq_stream_product(ctx, p->stream_img, p->n, p->r0, p->r1, p->kernel, p->gamma, p->coef0, p->degree, add_one,
-                                 w, p->s + p->r0, done));
-        return bq_exchange_rows(ctx, p->s, p->n, p->blk, p->r0, p->r1);
+    if (p->streamed) {   // no panel: the lower-triangle Gram tiles of this rank's segments recomputed inside the product, each
+                         // used for its rows and its columns; exchange exactly as for the resident symmetric panels
+        bq_seg_table tab;
+        bq_sym_seg_table(p, &tab);
+        auto prod = [&](double *out, int mode) {
+            return bq_stream_sym_product(ctx, p->stream_img, p->n, p->nb, tab, p->kernel, p->gamma, p->coef0, p->degree, add_one, w, out,
+                                         mode, done);
+        };
+        if (ctx->comm_kind == BQ_COMM_NONE) {
+            BQ_TRY(prod(p->s, 0));
+        } else if (ctx->sym_allreduce) {
+            BQ_TRY(prod(p->s, 0));
+            BQ_TRY(bq_exchange_sum(ctx, p->s, p->nb * BQ_SYM_TILE));
+        } else {
+            BQ_TRY(prod(p->gath, 1));
+            BQ_TRY(bq_exchange_gather(ctx, p->gath, (int64_t)p->seg_cmax * p->nb * BQ_SYM_TILE));
+            BQ_TRY(bq_launch_symv_segsum(ctx, p->nb, tab, p->gath, p->s, done));
+        }
+        return BQ_OK;
     }
     if (p->symmetric) {
         bq_seg_table tab;

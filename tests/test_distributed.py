@@ -73,7 +73,9 @@ def test_two_rank_row_block_exchange_cpu(tmp_path, kind):
 
 SYM_KEYS = ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_dual', 'al_f', 'ascg_kernel_x',
             'ascg_kernel_f')
-ROW_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'stream_matvec', 'stream_fw_x', 'ascg_x', 'ascg_iter', 'ascg_inner')
+ROW_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'ascg_x', 'ascg_iter', 'ascg_inner')
+# streamed kernel problems use the symmetric segment exchange since round 2b (every lower-triangle tile formed once)
+SYM_KEYS = SYM_KEYS + ('stream_matvec', 'stream_fw_x')
 
 
 @pytest.fixture(scope='module')
@@ -89,8 +91,8 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path, one_rank):
     assert tuple(two[0]['rows']) == (0, 512) and tuple(two[1]['rows']) == (512, 700)
     # dense panels: equal 128-aligned row blocks
     assert tuple(two[0]['dense_rows']) == (0, 256) and tuple(two[1]['dense_rows']) == (256, 500)
-    # streamed kernel problems: the same equal 128-aligned row blocks (700 rows -> 384 + 316), all-gather
-    assert tuple(two[0]['stream_rows']) == (0, 384) and tuple(two[1]['stream_rows']) == (384, 700)
+    # streamed kernel problems: the segment partition of the tile rows, like the resident symmetric panels
+    assert tuple(two[0]['stream_rows']) == (0, 512) and tuple(two[1]['stream_rows']) == (512, 700)
     np.testing.assert_allclose(one['stream_matvec'], one['matvec'], rtol=1e-11, atol=1e-11)
     for r in two:
         assert str(r['sym_exchange']) == 'gather'
@@ -134,9 +136,9 @@ def test_allreduce_variant_of_the_symmetric_exchange(tmp_path, one_rank):
         assert str(r['sym_exchange']) == 'allreduce'
         for key in ROW_KEYS:
             assert np.array_equal(r[key], one_rank[key]), key
-        for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f'):
+        for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f', 'stream_matvec'):
             np.testing.assert_allclose(r[key], one_rank[key], rtol=1e-12, atol=1e-12, err_msg=key)
-        for key in ('pg_x', 'fw_x', 'al_x', 'al_dual'):
+        for key in ('pg_x', 'fw_x', 'al_x', 'al_dual', 'stream_fw_x'):
             np.testing.assert_allclose(r[key], one_rank[key], rtol=1e-9, atol=1e-11, err_msg=key)
     for key in ('matvec', 'pg_x', 'fw_x'):
         assert np.array_equal(two[0][key], two[1][key]), key

@@ -17,7 +17,7 @@ for which in before after; do
     rocprofv3 --pmc $pass1 --kernel-trace --output-format csv -d "$out/${which}_p1" -- "${prog[@]}" "${args[@]}" > /dev/null 2> "$out/${which}_p1.err" || { tail -5 "$out/${which}_p1.err"; exit 1; }
     rocprofv3 --pmc $pass2 --kernel-trace --output-format csv -d "$out/${which}_p2" -- "${prog[@]}" "${args[@]}" > /dev/null 2> "$out/${which}_p2.err" || { tail -5 "$out/${which}_p2.err"; exit 1; }
     python3 tools/pmc_table.py $(find "$out/${which}_p1" "$out/${which}_p2" -name '*counter_collection.csv') > "$out/${which}_pmc_all.txt"
-    awk '/^[^ ]/{keep = ($0 ~ /gram_stream_kernel/)} keep' "$out/${which}_pmc_all.txt" > "$out/${which}_pmc.txt"
+        awk '/^[^ ]/{keep = ($0 ~ /gram_stream/)} keep' "$out/${which}_pmc_all.txt" > "$out/${which}_pmc.txt"
     cat "$out/${which}_pmc.txt"
     rm -rf "$out/${which}_p1" "$out/${which}_p2"
 done
