@@ -685,19 +685,34 @@ __global__ void as_schur_combine_kernel(int64_t np0, int m, const double *__rest
 // quasi-definite — minus a positive definite block for the pinned variables, a positive definite one for the freed —
 // so it factorises without pivoting in any order.  as_ldl_solve checks the residual; on failure the caller falls back
 // to the pivoted elimination below (and from there to a fresh base factor).
+// sum_j a[j] * b[j] with four independent partial sums (the host compiler does not re-associate a scalar reduction: this is
+// the difference between ~1 and ~4 flop per cycle on the m^2 loops below, which sit on every iteration's critical path)
+static inline double as_dot4(const double *a, const double *b, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        s0 += a[j] * b[j];
+        s1 += a[j + 1] * b[j + 1];
+        s2 += a[j + 2] * b[j + 2];
+        s3 += a[j + 3] * b[j + 3];
+    }
+    for (; j < n; ++j) s0 += a[j] * b[j];
+    return (s0 + s1) + (s2 + s3);
+}
+
 static bool as_ldl_extend(as_schur *c, int m) {
     const size_t ld = AS_SCHUR_MAX;
+    std::vector<double> z;
     for (int k = c->ldl_n; k < m; ++k) {
         double *lk = &c->Lc[(size_t)k * ld];
         // L z = C[0:k, k]  (forward), l = z / D, d = C[k][k] - sum l z
+        z.assign((size_t)k + 1, 0.0);
         for (int i = 0; i < k; ++i) {
-            double v = c->C[(size_t)i * ld + k];
-            const double *li = &c->Lc[(size_t)i * ld];
-            for (int j = 0; j < i; ++j) v -= li[j] * lk[j] * c->Dc[j];   // lk[j] already holds l_j
+            const double v = c->C[(size_t)i * ld + k] - as_dot4(&c->Lc[(size_t)i * ld], z.data(), i);
+            z[i] = v;
             lk[i] = v / c->Dc[i];
         }
-        double d = c->C[(size_t)k * ld + k];
-        for (int j = 0; j < k; ++j) d -= lk[j] * lk[j] * c->Dc[j];
+        const double d = c->C[(size_t)k * ld + k] - as_dot4(lk, z.data(), k);
         if (!std::isfinite(d) || d == 0.0) return false;
         c->Dc[k] = d;
         lk[k] = 1.0;
@@ -710,29 +725,31 @@ static bool as_ldl_solve(as_schur *c, int m, const double *t, double *w) {
     if (!as_ldl_extend(c, m)) return false;
     const size_t ld = AS_SCHUR_MAX;
     std::vector<double> y(t, t + m);
-    for (int i = 0; i < m; ++i) {
-        const double *li = &c->Lc[(size_t)i * ld];
-        double v = y[i];
-        for (int j = 0; j < i; ++j) v -= li[j] * y[j];
-        y[i] = v;
-    }
+    for (int i = 0; i < m; ++i) y[i] -= as_dot4(&c->Lc[(size_t)i * ld], y.data(), i);   // L y = t, rows of L contiguous
     for (int i = 0; i < m; ++i) y[i] /= c->Dc[i];
+    // L' w = y by columns of L' = rows of L: once w[i] is final it is eliminated from the unknowns above it (contiguous row i;
+    // the dot-product form walked a COLUMN of the 1536-pitch factor per unknown: one cache line per element)
     for (int i = m - 1; i >= 0; --i) {
-        double v = y[i];
-        for (int j = i + 1; j < m; ++j) v -= c->Lc[(size_t)j * ld + i] * w[j];
-        w[i] = v;
+        const double wi = y[i];
+        w[i] = wi;
+        const double *li = &c->Lc[(size_t)i * ld];
+        for (int j = 0; j < i; ++j) y[j] -= li[j] * wi;
     }
     // residual against the stored C
     double worst = 0.0, scale = 0.0;
     for (int i = 0; i < m; ++i) {
-        double r = t[i], s = std::fabs(t[i]);
-        for (int j = 0; j < m; ++j) {
-            r -= c->C[(size_t)i * ld + j] * w[j];
-            s += std::fabs(c->C[(size_t)i * ld + j] * w[j]);
+        const double *ci = &c->C[(size_t)i * ld];
+        const double r = t[i] - as_dot4(ci, w, m);
+        double s0 = 0.0, s1 = 0.0;
+        int j = 0;
+        for (; j + 2 <= m; j += 2) {
+            s0 += std::fabs(ci[j] * w[j]);
+            s1 += std::fabs(ci[j + 1] * w[j + 1]);
         }
+        for (; j < m; ++j) s0 += std::fabs(ci[j] * w[j]);
         if (!std::isfinite(r)) return false;
         worst = std::max(worst, std::fabs(r));
-        scale = std::max(scale, s);
+        scale = std::max(scale, std::fabs(t[i]) + s0 + s1);
     }
     return worst <= 1e-11 * scale;
 }
