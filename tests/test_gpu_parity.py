@@ -101,7 +101,8 @@ def test_gram_against_reference_fixture(amd):
     assert np.all(np.diag(gaussian(X)) == 1.0)
 
 
-@pytest.mark.parametrize('n,d', [(130, 3), (300, 20), (777, 64), (1100, 129)])
+# d -> k-chunks of 16 in the MFMA tile loop: 1, 2, 3, 4, 5, 6, 7 and 9 (the loop runs chunk pairs and has a 1-3 chunk tail)
+@pytest.mark.parametrize('n,d', [(130, 3), (300, 20), (260, 40), (777, 64), (200, 70), (385, 90), (150, 100), (1100, 129)])
 @pytest.mark.parametrize('kind', ['linear', 'poly', 'rbf'])
 def test_gram_against_oracle(amd, n, d, kind):
     from oracle import svm_oracle as so
