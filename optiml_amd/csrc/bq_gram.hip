@@ -642,7 +642,8 @@ int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int
         // units sized for ~24 rounds of workgroups on each of 8 ranks, from n alone (the association of the row sums must not
         // depend on the rank count)
         const int64_t target = 24 * 512 * 8;
-        const int64_t U = total / target > 0 ? (total + target - 1) / target : 1;
+        int64_t U = total / target > 0 ? (total + target - 1) / target : 1;
+        if (const char *e = getenv("BQ_STREAM_UNIT")) U = atoll(e) > 0 ? atoll(e) : U;   // tests: several tiles per unit at small n
         const int64_t kmax = (T + U - 1) / U;
         // launch order: column range by column range, rows descending inside a range — the workgroups in flight walk the SAME
         // column tiles at about the same time, like the row-block form (measured equal to row-major unit order at n = 100 000:

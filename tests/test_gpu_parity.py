@@ -859,6 +859,29 @@ def test_streamed_product_matches_the_resident_panel(amd, structure, kname, n):
         b.gram()          # nothing is resident
 
 
+@pytest.mark.parametrize('unit', ['2', '3', '5'])
+def test_streamed_product_with_several_tiles_per_unit(amd, monkeypatch, unit):
+    """At test sizes a work unit of the streamed product is one tile; BQ_STREAM_UNIT forces the shape of the large-n case (a unit
+    = several column tiles whose row sums accumulate in LDS, truncated units next to the diagonal, several units per row)."""
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    rs = np.random.RandomState(11)
+    n, d = 1411, 24                                   # 12 tile rows, ragged last tile
+    X = rs.standard_normal((n, d))
+    y = np.where(rs.standard_normal(n) > 0, 1., -1.)
+    q = -np.ones(n)
+    a = KernelQuadratic(X, q, 'svc', gaussian, y=y)
+    monkeypatch.setenv('BQ_STREAM_UNIT', unit)
+    b = KernelQuadratic(X, q, 'svc', gaussian, y=y, storage='stream')
+    try:
+        for seed in (0, 1):
+            v = np.random.RandomState(seed).standard_normal(n)
+            np.testing.assert_allclose(b.device_problem().matvec(v), a.device_problem().matvec(v), rtol=1e-11, atol=1e-11)
+    finally:
+        a.release()
+        b.release()
+
+
 def test_streamed_fit_follows_the_reference(amd):
     """SVC.fit with storage='stream': FrankWolfe trajectory of the fixture (stable solver) to the usual tolerance; the
     factorising solvers refuse the mode."""
