@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Coefficients of the kernel maps' exp (optiml_amd/csrc/bq_exp.h): (exp(r) - 1 - r) / r^2 interpolated at the Chebyshev nodes of
+|r| <= ln(2) / 2 (degree 9, extended precision, iterative refinement), printed as C hex floats with the error of the assembled
+1 + r + r^2 q(r).    python tools/exp_fit.py"""
 import numpy as np
 from numpy.polynomial import chebyshev as C, polynomial as P
 L = np.longdouble

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Diagnostic (run from the repo root on a GPU box): SVR + InteriorPoint on the two SVR fixtures, default reduced n x n system;
+prints the distance of the multipliers from the reference's (the test of the same name in tests/test_gpu_parity.py asserts it)."""
 import sys, os, json, numpy as np
 sys.path.insert(0, os.getcwd())
 from optiml_amd.ml.svm import SVR
