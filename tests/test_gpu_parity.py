@@ -835,7 +835,7 @@ print(json.dumps({'iter': est.optimizer.iter, 'status': est.optimizer.status, 'f
 # streamed mode (BQ_STREAM): no resident panel, Gram tiles recomputed inside every product (SURVEY 8(d) fallback)
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('structure,kname', [('svc', 'rbf'), ('svr', 'poly'), ('svc', 'linear'), ('plain', 'sigmoid')])
-@pytest.mark.parametrize('n', [300, 1300])
+@pytest.mark.parametrize('n', [50, 129, 300, 1300])   # one tile, two tiles with a one-row second, ragged, 11 tile rows
 def test_streamed_product_matches_the_resident_panel(amd, structure, kname, n):
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.ml.svm import kernels as kk
