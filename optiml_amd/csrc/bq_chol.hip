@@ -359,9 +359,9 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     //   narrow(p): diag(A) ; TRSM(A) ; narrow update of column B ; diag(B) ; TRSM(B)        -> images of pass p
     //   head_in(p): the two block columns pass p+1 factors next  -= the images of the super-pass so far
     //   wide(q)  : everything behind the super-pass -= X X^T with ALL its images in ONE K = P * 256 pass — a C tile is read
-    //              and written once per P * 256 columns factored (tools/syrk_probe.hip: the tile update runs at 0.71 of the
-    //              MFMA peak with K = 256, 0.83 with K = 512: its C traffic and prologue are not covered by the partner
-    //              workgroup); split into head (the 2P block columns the next chain works on) and rest.
+    //              and written once per P * 256 columns factored (tools/syrk_probe.hip, final tile kernel: 69.5 / 73.6 /
+    //              74.3 TFLOP/s at K = 512 / 768 / 1024; with the round-1 kernel it was 0.71 of the MFMA peak at K = 256);
+    //              split into head (the 2P block columns the next chain works on) and rest.
     // The images of a super-pass are contiguous in k, two buffers.
     // With look-ahead the narrow chain of super-pass q+1 (it touches only the 2P block columns head(q) has finished) runs on
     // the high-priority side stream while rest(q) keeps the chip busy.
@@ -369,7 +369,7 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     // traffic and the per-tile prologue per flop further but lengthens the narrow chain between two wide updates.
     const int P = [&] {
         const char *e = getenv("BQ_CHOL_SUPER");
-        int v = e ? atoi(e) : (np >= 65536 ? 4 : (np >= 24576 ? 3 : 2));   // measured: n=50k 674 / 674 / 688 ms, n=100k 5.17 / 5.11 / 5.06 s for P = 2 / 3 / 4
+        int v = e ? atoi(e) : (np >= 65536 ? 4 : (np >= 24576 ? 3 : 2));   // measured (final kernel): n=50k 622 / 608 / 621 ms, n=32k 192 / 190 / 194 ms for P = 2 / 3 / 4
         return v < 1 ? 1 : (v > ws->super_max ? ws->super_max : v);
     }();
     auto wimg = [&](int64_t p) {   // images of a super-pass are contiguous in k; two buffers
