@@ -117,6 +117,28 @@ def test_gram_against_oracle(amd, n, d, kind):
         assert np.all(np.diag(out) == 1.0)
 
 
+@pytest.mark.parametrize('degree', [1, 2, 3, 4, 5])
+def test_polynomial_map_degrees(amd, degree):
+    """Degrees 2 and 3 run by multiplication (<= 1 ulp from pow), every other degree through pow(): all against NumPy's `**`
+    (kernels.py:95), on the panel build, the rectangular build and the streamed product."""
+    from optiml_amd.ml.svm.kernels import PolyKernel
+    from optiml_amd.opti import KernelQuadratic
+    rs = np.random.RandomState(degree)
+    X, Y = rs.standard_normal((333, 17)), rs.standard_normal((45, 17))
+    gamma, c0 = 0.21, 0.7
+    k = PolyKernel(degree, gamma, c0)
+    want = (gamma * X @ X.T + c0) ** degree
+    np.testing.assert_allclose(k(X), want, rtol=1e-12, atol=1e-13 * np.abs(want).max())
+    wy = (gamma * Y @ X.T + c0) ** degree
+    np.testing.assert_allclose(k(Y, X), wy, rtol=1e-12, atol=1e-13 * np.abs(wy).max())
+    q = KernelQuadratic(X, np.zeros(333), 'plain', k, storage='stream')
+    try:
+        v = rs.standard_normal(333)
+        np.testing.assert_allclose(q.device_problem().matvec(v), want @ v, rtol=1e-11, atol=1e-11 * np.abs(want @ v).max())
+    finally:
+        q.release()
+
+
 def test_kernel_quadratic_matches_reference_assembly(amd):
     """Q v through the structured device operator == the reference's materialised Q (svc and svr forms)."""
     from optiml_amd.opti import KernelQuadratic
