@@ -128,6 +128,17 @@ def test_three_ranks_uneven_partitions(tmp_path, one_rank):
 
 
 @pytest.mark.gpu
+def test_four_ranks_two_segments_each(tmp_path, one_rank):
+    """World size 4 — the C4 rank count: two canonical segments per rank; 700 rows = 3 tile rows -> tile rows 2 + 0 + 1 + 0
+    (two ranks own no tile row and contribute zero vectors).  Still bit-identical to one rank."""
+    four = _launch('gpu-host', 4, tmp_path / 'w4')
+    assert [tuple(r['rows']) for r in four] == [(0, 512), (512, 512), (512, 700), (700, 700)]
+    for r in four:
+        for key in ROW_KEYS + SYM_KEYS:
+            assert np.array_equal(r[key], one_rank[key]), key
+
+
+@pytest.mark.gpu
 def test_allreduce_variant_of_the_symmetric_exchange(tmp_path, one_rank):
     """sym_exchange='allreduce' (rank partials added by the transport, the collective BASELINE's north star names): the
     same values up to the association of the rank sum."""
