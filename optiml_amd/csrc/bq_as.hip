@@ -594,6 +594,10 @@ struct as_schur {
     double *y0 = nullptr, *y = nullptr;  // device: cap
     double *small = nullptr;          // device: AS_SCHUR_MAX results / coefficients
     int *meta = nullptr;              // device: kind[], var[] of the slots (2 x AS_SCHUR_MAX)
+    // pinned staging of the per-iteration transfers (slot table up, dot products down, coefficients up): asynchronous copies
+    // from / to pageable stack arrays needed a stream synchronisation each just to keep the array alive
+    int *meta_pin = nullptr;
+    double *small_pin = nullptr, *coef_pin = nullptr;
     long long refreshes = 0, reused = 0;
     bool y0_valid = false;   // y0 = Q00^-1 b0 is current: b0 only moves when a variable OUTSIDE the base changes sides
 };
@@ -831,6 +835,8 @@ static void as_schur_free(as_ws *w) {
     for (void *ptr : {(void *)c->idx0, (void *)c->pos0, (void *)c->U, (void *)c->W, (void *)c->y0, (void *)c->y,
                       (void *)c->small, (void *)c->meta})
         if (ptr) hipFree(ptr);
+    for (void *ptr : {(void *)c->meta_pin, (void *)c->small_pin, (void *)c->coef_pin})
+        if (ptr) hipHostFree(ptr);
     delete c;
     w->sch = nullptr;
 }
@@ -848,6 +854,10 @@ static int as_schur_setup(bq_solver *s, as_ws *w) {
     BQ_HIP(hipMalloc(&c->y, sizeof(double) * c->cap));
     BQ_HIP(hipMalloc(&c->small, sizeof(double) * 2 * AS_SCHUR_MAX));
     BQ_HIP(hipMalloc(&c->meta, sizeof(int) * 2 * AS_SCHUR_MAX));
+    BQ_HIP(hipHostMalloc(&c->meta_pin, sizeof(int) * 2 * AS_SCHUR_MAX));
+    BQ_HIP(hipHostMalloc(&c->small_pin, sizeof(double) * AS_SCHUR_MAX));
+    BQ_HIP(hipHostMalloc(&c->coef_pin, sizeof(double) * AS_SCHUR_MAX));
+    memset(c->meta_pin, 0, sizeof(int) * 2 * AS_SCHUR_MAX);
     c->hpos0.assign((size_t)s->N, -1);
     c->C.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
     c->Lc.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
@@ -987,13 +997,12 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
     const int m = (int)c->kind.size();
     const unsigned gb = (unsigned)((np0 + 255) / 256);
     *good = false;
-    int hmeta[2 * AS_SCHUR_MAX] = {0};
+    int *hmeta = c->meta_pin;   // the previous iteration's copy is long complete (every pass through here ends in a synchronisation)
     for (int k = 0; k < m; ++k) {
         hmeta[k] = c->kind[k];
         hmeta[AS_SCHUR_MAX + k] = c->var[k];
     }
-    BQ_HIP(hipMemcpyAsync(c->meta, hmeta, sizeof(hmeta), hipMemcpyHostToDevice, st));
-    BQ_HIP(hipStreamSynchronize(st));   // hmeta is on this stack frame
+    BQ_HIP(hipMemcpyAsync(c->meta, hmeta, sizeof(int) * 2 * AS_SCHUR_MAX, hipMemcpyHostToDevice, st));
     if (!c->y0_valid) {   // while only base variables reach bounds, b0 and Q00^-1 b0 stay what they were
         as_schur_z_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, c->pos0, w->z);
         BQ_TRY(bq_problem_apply(p, w->z, w->Qz, nullptr));
@@ -1002,7 +1011,7 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         BQ_HIP(hipMemcpyAsync(c->y0, ws->rhs, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
         c->y0_valid = true;
     }
-    double host_small[AS_SCHUR_MAX];
+    double *host_small = c->small_pin;
     for (int k = computed; k < m; ++k) {   // the columns of the new slots and their rows of C
         double *uk = c->U + (int64_t)k * c->cap, *wk = c->W + (int64_t)k * c->cap;
         as_schur_col_kernel<T><<<gb, 256, 0, st>>>(c->kind[k], c->var[k], c->kind[k] == 0 ? c->hpos0[(size_t)c->var[k]] : -1, n0,
@@ -1021,7 +1030,7 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
             c->C[(size_t)k * AS_SCHUR_MAX + i] = host_small[i];
         }
     }
-    double coef[AS_SCHUR_MAX] = {0};
+    double *coef = c->coef_pin;
     if (m > 0) {
         as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
                                                   s->ub, p->q, w->Qz, c->small);
@@ -1032,7 +1041,6 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
             if (!as_small_solve(m, c->C, host_small, coef)) return BQ_OK;
         }
         BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
-        BQ_HIP(hipStreamSynchronize(st));   // coef is on this stack frame
     }
     as_schur_combine_kernel<<<gb, 256, 0, st>>>(np0, m, c->y0, c->W, c->cap, c->small + AS_SCHUR_MAX, c->y);
     as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
