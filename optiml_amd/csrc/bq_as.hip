@@ -852,10 +852,10 @@ static int as_schur_setup(bq_solver *s, as_ws *w) {
     BQ_HIP(hipMalloc(&c->W, sizeof(double) * AS_SCHUR_MAX * c->cap));
     BQ_HIP(hipMalloc(&c->y0, sizeof(double) * c->cap));
     BQ_HIP(hipMalloc(&c->y, sizeof(double) * c->cap));
-    BQ_HIP(hipMalloc(&c->small, sizeof(double) * 2 * AS_SCHUR_MAX));
+    BQ_HIP(hipMalloc(&c->small, sizeof(double) * 3 * AS_SCHUR_MAX));   // dots of a new column | coefficients | dots with y0
     BQ_HIP(hipMalloc(&c->meta, sizeof(int) * 2 * AS_SCHUR_MAX));
     BQ_HIP(hipHostMalloc(&c->meta_pin, sizeof(int) * 2 * AS_SCHUR_MAX));
-    BQ_HIP(hipHostMalloc(&c->small_pin, sizeof(double) * AS_SCHUR_MAX));
+    BQ_HIP(hipHostMalloc(&c->small_pin, sizeof(double) * 2 * AS_SCHUR_MAX));
     BQ_HIP(hipHostMalloc(&c->coef_pin, sizeof(double) * AS_SCHUR_MAX));
     memset(c->meta_pin, 0, sizeof(int) * 2 * AS_SCHUR_MAX);
     c->hpos0.assign((size_t)s->N, -1);
@@ -1011,7 +1011,8 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         BQ_HIP(hipMemcpyAsync(c->y0, ws->rhs, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
         c->y0_valid = true;
     }
-    double *host_small = c->small_pin;
+    double *host_small = c->small_pin, *host_t = c->small_pin + AS_SCHUR_MAX;
+    bool have_t = false;
     for (int k = computed; k < m; ++k) {   // the columns of the new slots and their rows of C
         double *uk = c->U + (int64_t)k * c->cap, *wk = c->W + (int64_t)k * c->cap;
         as_schur_col_kernel<T><<<gb, 256, 0, st>>>(c->kind[k], c->var[k], c->kind[k] == 0 ? c->hpos0[(size_t)c->var[k]] : -1, n0,
@@ -1023,6 +1024,12 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         as_schur_dots_kernel<T><<<k + 1, 256, 0, st>>>(0, k, c->U, wk, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
                                                       s->ub, p->q, w->Qz, c->small);
         BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
+        if (k == m - 1) {   // the right-hand side of the small system needs nothing from the host: same round trip
+            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                      s->ub, p->q, w->Qz, c->small + 2 * AS_SCHUR_MAX);
+            BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+            have_t = true;
+        }
         BQ_HIP(hipStreamSynchronize(st));
         for (int i = 0; i <= k; ++i) {
             if (!std::isfinite(host_small[i])) return BQ_OK;
@@ -1032,13 +1039,15 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
     }
     double *coef = c->coef_pin;
     if (m > 0) {
-        as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
-                                                  s->ub, p->q, w->Qz, c->small);
-        BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * m, hipMemcpyDeviceToHost, st));
-        BQ_HIP(hipStreamSynchronize(st));
-        if (!as_ldl_solve(c, m, host_small, coef)) {   // incremental factorisation first, pivoted elimination as the fallback
+        if (!have_t) {
+            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                      s->ub, p->q, w->Qz, c->small + 2 * AS_SCHUR_MAX);
+            BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+            BQ_HIP(hipStreamSynchronize(st));
+        }
+        if (!as_ldl_solve(c, m, host_t, coef)) {   // incremental factorisation first, pivoted elimination as the fallback
             c->ldl_n = 0;
-            if (!as_small_solve(m, c->C, host_small, coef)) return BQ_OK;
+            if (!as_small_solve(m, c->C, host_t, coef)) return BQ_OK;
         }
         BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
     }
