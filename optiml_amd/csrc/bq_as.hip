@@ -88,7 +88,9 @@ __device__ __forceinline__ double as_wmin(double v) {
     return v;
 }
 
-__global__ void as_top_kernel(bq_scal *sc, const int *__restrict__ ints, bq_iter_stat *stats) {
+__global__ void as_top_kernel(bq_scal *sc, int *__restrict__ ints, bq_iter_stat *stats, int n_all) {
+    ints[27] = n_all;   // as_release_mb_kernel: running minima of the candidate indices
+    ints[28] = n_all;
     if (sc->done) return;
     const long long row = sc->iter - sc->stat_base;
     if (row >= 0 && row < sc->stat_cap) {
@@ -150,55 +152,6 @@ __global__ __launch_bounds__(256) void as_candidate_kernel(const int *__restrict
 __global__ void as_copy_kernel(int64_t N, const double *__restrict__ src, double *__restrict__ dst) {
     VEC_LOOP(i) {
         if (i < N) dst[i] = src[i];
-    }
-}
-
-// first index of L with g < -tol (ints[3]) and of U with g > tol (ints[4]); N if none.  Single block.
-__global__ __launch_bounds__(256) void as_release_kernel(int64_t N, const double *__restrict__ g,
-                                                         unsigned char *__restrict__ mL, unsigned char *__restrict__ mU,
-                                                         bq_scal *sc, int *__restrict__ ints, bq_iter_stat *stats) {
-    __shared__ long long sl[256], su[256];
-    long long hl = N, hu = N;
-    for (int64_t i = threadIdx.x; i < N; i += 256) {
-        if (mL[i] && g[i] < -ACT_TOL && i < hl) hl = i;
-        if (mU[i] && g[i] > ACT_TOL && i < hu) hu = i;
-    }
-    sl[threadIdx.x] = hl;
-    su[threadIdx.x] = hu;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            sl[threadIdx.x] = sl[threadIdx.x] < sl[threadIdx.x + s] ? sl[threadIdx.x] : sl[threadIdx.x + s];
-            su[threadIdx.x] = su[threadIdx.x] < su[threadIdx.x + s] ? su[threadIdx.x] : su[threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        hl = sl[0];
-        hu = su[0];
-        ints[3] = (int)hl;
-        ints[4] = (int)hu;
-        const long long row = sc->iter - sc->stat_base;
-        const bool rec = row >= 0 && row < sc->stat_cap;
-        if (hl < N) {
-            mL[hl] = 0;
-            if (rec) {
-                stats[row].r2 = 1.0;
-                stats[row].r3 = (double)hl;
-            }
-            sc->iter += 1;
-        } else if (hu < N) {
-            mU[hu] = 0;
-            if (rec) {
-                stats[row].r2 = 2.0;
-                stats[row].r3 = (double)hu;
-            }
-            sc->iter += 1;
-        } else {
-            if (rec) stats[row].r2 = 3.0;
-            sc->status = BQ_STATUS_OPTIMAL;
-            sc->done = 1;
-        }
     }
 }
 
@@ -370,6 +323,65 @@ __global__ __launch_bounds__(256) void as_absorb_mb_kernel(int64_t N, unsigned c
             stats[row].r3 = (double)(((long long)tl << 32) | (long long)tu);
         }
         sc->iter += 1;
+    }
+}
+
+// first index of L with g < -tol and of U with g > tol (Bland's rule, active_set.py:178-199): block minima meet in two atomic
+// minima (ints[27], ints[28], reset by as_top_kernel); the last block releases the variable, writes the record and closes the
+// iteration — or declares the point optimal
+__global__ __launch_bounds__(256) void as_release_mb_kernel(int64_t N, const double *__restrict__ g, unsigned char *__restrict__ mL,
+                                                            unsigned char *__restrict__ mU, bq_scal *sc, int *__restrict__ ints,
+                                                            bq_iter_stat *stats) {
+    __shared__ int sl[4], su[4];
+    int hl = (int)N, hu = (int)N;
+    VEC_LOOP(i) {
+        if (i < N) {
+            if (mL[i] && g[i] < -ACT_TOL && (int)i < hl) hl = (int)i;
+            if (mU[i] && g[i] > ACT_TOL && (int)i < hu) hu = (int)i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        hl = min(hl, __shfl_down(hl, off, 64));
+        hu = min(hu, __shfl_down(hu, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sl[threadIdx.x >> 6] = hl;
+        su[threadIdx.x >> 6] = hu;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        hl = min(min(sl[0], sl[1]), min(sl[2], sl[3]));
+        hu = min(min(su[0], su[1]), min(su[2], su[3]));
+        if (hl < (int)N) atomicMin(&ints[27], hl);
+        if (hu < (int)N) atomicMin(&ints[28], hu);
+    }
+    if (as_last_block_mb(&sc->pad1[1]) && threadIdx.x == 0) {
+        const long long ghl = __hip_atomic_load(&ints[27], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long ghu = __hip_atomic_load(&ints[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ints[3] = (int)ghl;
+        ints[4] = (int)ghu;
+        const long long row = sc->iter - sc->stat_base;
+        const bool rec = row >= 0 && row < sc->stat_cap;
+        if (ghl < N) {
+            mL[ghl] = 0;
+            if (rec) {
+                stats[row].r2 = 1.0;
+                stats[row].r3 = (double)ghl;
+            }
+            sc->iter += 1;
+        } else if (ghu < N) {
+            mU[ghu] = 0;
+            if (rec) {
+                stats[row].r2 = 2.0;
+                stats[row].r3 = (double)ghu;
+            }
+            sc->iter += 1;
+        } else {
+            if (rec) stats[row].r2 = 3.0;
+            sc->status = BQ_STATUS_OPTIMAL;
+            sc->done = 1;
+        }
     }
 }
 
@@ -1205,7 +1217,7 @@ int bq_as_iterate(bq_solver *s) {
     const int64_t N = s->N;
 
     as_launch_compact(s, w, st);
-    as_top_kernel<<<1, 1, 0, st>>>(s->sc, w->ints, s->stats);
+    as_top_kernel<<<1, 1, 0, st>>>(s->sc, w->ints, s->stats, (int)N);
     if (!s->host.done) {  // snapshot of the point this record describes
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->x, w->x_eval);
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, w->g_eval);
@@ -1222,7 +1234,7 @@ int bq_as_iterate(bq_solver *s) {
         if (w->host_ints[2]) {
             as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
             BQ_TRY(eval_f(s, s->g));
-            as_release_kernel<<<1, 256, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
+            as_release_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
         } else {
             as_launch_step(s, w, st);
             BQ_TRY(eval_f(s, nullptr));
@@ -1239,7 +1251,7 @@ int bq_as_iterate(bq_solver *s) {
         if (w->host_ints[2]) {
             as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
             BQ_TRY(eval_f(s, s->g));
-            as_release_kernel<<<1, 256, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
+            as_release_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
         } else {
             as_launch_step(s, w, st);
             BQ_TRY(eval_f(s, nullptr));
@@ -1277,7 +1289,7 @@ int bq_as_iterate(bq_solver *s) {
     if (w->host_ints[2]) {
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
         BQ_TRY(eval_f(s, s->g));
-        as_release_kernel<<<1, 256, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
+        as_release_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
     } else {
         as_launch_step(s, w, st);
         BQ_TRY(eval_f(s, nullptr));
