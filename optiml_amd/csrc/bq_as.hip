@@ -125,30 +125,6 @@ __global__ void as_gather_rhs_kernel(const int *__restrict__ ints, const int *__
     rhs[a] = (a < nA) ? -(q[idx[a]] + Qz[idx[a]]) : 0.0;
 }
 
-// cand = z on the bounds, solution on A; ints[2] = every free coordinate inside [lb - tol, ub + tol]
-__global__ __launch_bounds__(256) void as_candidate_kernel(const int *__restrict__ idx, int *__restrict__ ints,
-                                                           const double *__restrict__ sol, const double *__restrict__ z,
-                                                           int64_t N, const double *__restrict__ lb,
-                                                           const double *__restrict__ ub, double *__restrict__ cand) {
-    // single block: N is swept twice, the feasibility flag needs no atomics
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
-    __syncthreads();
-    for (int64_t i = threadIdx.x; i < N; i += 256) cand[i] = z[i];
-    __syncthreads();
-    const int nA = ints[0];
-    int mybad = 0;
-    for (int a = threadIdx.x; a < nA; a += 256) {
-        const int i = idx[a];
-        const double v = sol[a];
-        cand[i] = v;
-        if (!(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL)) mybad = 1;
-    }
-    if (mybad) bad = 1;  // benign race: every writer stores 1
-    __syncthreads();
-    if (threadIdx.x == 0) ints[2] = bad ? 0 : 1;
-}
-
 __global__ void as_copy_kernel(int64_t N, const double *__restrict__ src, double *__restrict__ dst) {
     VEC_LOOP(i) {
         if (i < N) dst[i] = src[i];
@@ -394,6 +370,16 @@ __global__ void as_cand_fill_kernel(int64_t N, const unsigned char *__restrict__
         if (i < N) cand[i] = mU[i] ? ub[i] : (mL[i] ? lb[i] : 0.0);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) ints[2] = 1;
+}
+// ... and the plain restricted solve: the solution on the compacted free set (ints[0] entries of idx) scatters the same way
+__global__ void as_cand_scatter_idx_kernel(const int *__restrict__ idx, int *__restrict__ ints, const double *__restrict__ sol,
+                                           const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ cand) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= ints[0]) return;
+    const int i = idx[a];
+    const double v = sol[a];
+    cand[i] = v;
+    if (!(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL)) ints[2] = 0;   // benign race: every writer stores 0
 }
 __global__ void as_cand_scatter_kernel(int64_t n0, int m, const int *__restrict__ idx0, const int *__restrict__ meta,
                                        const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
@@ -1150,7 +1136,8 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
         return BQ_ERR_NOT_PD;
     }
     as_cg_gather_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->x, w->dlt, w->sol, N);
-    as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, w->sol, w->z, N, s->lb, s->ub, w->cand);
+    as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
+    as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, w->sol, s->lb, s->ub, w->cand);
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     return BQ_OK;
@@ -1267,7 +1254,8 @@ int bq_as_iterate(bq_solver *s) {
     as_gather_rhs_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->p->q, w->Qz, ws->rhs, np);
     BQ_TRY(bq_chol_factor(ws, np));
     BQ_TRY(bq_chol_solve(ws, np));
-    as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, ws->rhs, w->z, N, s->lb, s->ub, w->cand);
+    as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
+    as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, ws->rhs, s->lb, s->ub, w->cand);
     int info = 0;
     BQ_HIP(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
@@ -1280,7 +1268,8 @@ int bq_as_iterate(bq_solver *s) {
         BQ_TRY(bq_chol_build_h(ws, s->p, w->idx, nA, nullptr, &np, true));
         as_gather_rhs_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->p->q, w->Qz, ws->rhs, np);
         BQ_TRY(bq_minres_normal(ws, w->ints, nA, np, ws->mr_vec, w->ints + 7));
-        as_candidate_kernel<<<1, 256, 0, st>>>(w->idx, w->ints, ws->rhs, w->z, N, s->lb, s->ub, w->cand);
+        as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
+        as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, ws->rhs, s->lb, s->ub, w->cand);
         BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
         BQ_HIP(hipStreamSynchronize(st));
         w->minres_calls += 1;
