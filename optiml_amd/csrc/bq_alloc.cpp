@@ -49,7 +49,11 @@ hipError_t bq_device_malloc(void **ptr, size_t bytes) {
                 dropped = true;
             }
     }
-    if (!dropped) return e;
+    // a failed hipMalloc leaves its error pending: the next hipGetLastError() of an unrelated call would report "out of
+    // memory" (seen: after a panel that does not fit, the next — small — problem failed once).  The caller gets the code.
     (void)hipGetLastError();
-    return hipMalloc(ptr, bytes);
+    if (!dropped) return e;
+    e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
 }

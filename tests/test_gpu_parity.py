@@ -904,6 +904,33 @@ def test_streamed_product_with_several_tiles_per_unit(amd, monkeypatch, unit):
         b.release()
 
 
+def test_a_panel_that_does_not_fit_is_a_clean_error(amd):
+    """n = 290 000 fp64: 337 GB of panel on a 288 GB device.  The create call reports BQ_ERR_NOMEM (-6) with the size in the
+    message, nothing stays pending in the runtime (the next, small problem must work — a failed hipMalloc used to leave its
+    error for the next hipGetLastError()), and the same n runs in the streamed mode."""
+    from optiml_amd import _lib
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    n = 290000
+    X, y = make_blobs(n, 4, seed=0)
+    big = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
+    with pytest.raises(_lib.BcqpError) as err:
+        big.device_problem()
+    assert err.value.code == -6 and 'panel' in str(err.value)
+    X2, y2 = make_blobs(1500, 4, seed=1)
+    small = KernelQuadratic(X2, -np.ones(1500), 'svc', gaussian, y=y2)
+    st = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, storage='stream')
+    try:
+        v = np.random.RandomState(0).standard_normal(1500)
+        np.testing.assert_allclose(small.device_problem().matvec(v), small.Q @ v, rtol=1e-11, atol=1e-9)
+        out = st.device_problem().matvec(np.ones(n))
+        assert out.shape == (n,) and np.all(np.isfinite(out))
+    finally:
+        small.release()
+        st.release()
+
+
 def test_streamed_fit_follows_the_reference(amd):
     """SVC.fit with storage='stream': FrankWolfe trajectory of the fixture (stable solver) to the usual tolerance; the
     factorising solvers refuse the mode."""
