@@ -1144,6 +1144,10 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
 }
 
 int bq_as_start(bq_solver *s) {
+    if (s->chol) {   // a numerically singular Q_AA must take the minres branch, not the sign of its rounding noise (bq_chol.h)
+        const char *e = getenv("BQ_AS_PIVOT_REL");
+        s->chol->pivot_rel = e ? atof(e) : 1e-13;
+    }
     bq_ctx *ctx = s->p->ctx;
     as_ws *w = new as_ws();
     s->as_ws = w;

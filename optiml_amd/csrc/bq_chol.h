@@ -29,6 +29,11 @@ struct bq_chol_ws {
     hipStream_t s_main = nullptr, s_side = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool lookahead = false;
+    // pivot_rel > 0: a pivot <= pivot_rel * (the diagonal entry of the matrix as given) counts as non-positive.  LAPACK's test is
+    // "<= 0", which on a numerically singular matrix is decided by the sign of rounding noise; ActiveSet sets 1e-13 so that a
+    // singular Q_AA reliably takes the reference's minres branch (active_set.py:142-151).  0: LAPACK's test (InteriorPoint, linalg).
+    double pivot_rel = 0.0;
+    double *pivot_thr = nullptr;   // cap thresholds, filled at the start of a factorisation when pivot_rel > 0
 };
 
 int bq_chol_factor(bq_chol_ws *ws, int64_t np);

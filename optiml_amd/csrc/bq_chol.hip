@@ -23,7 +23,7 @@
 constexpr int NB = 128;
 // 1. diagonal block (factor + invert): bq_potrf_diag.hip
 int bq_potrf_diag_setup();
-void bq_launch_potrf_diag(hipStream_t st, double *H, int64_t ldh, int64_t k0, double *LinvT, int *info);
+void bq_launch_potrf_diag(hipStream_t st, double *H, int64_t ldh, int64_t k0, double *LinvT, int *info, const double *thr);
 
 // ---------------------------------------------------------------------------------------------
 // 2./3. block column: TRSM as GEMM (which also leaves the k-major image of its result), SYRK on the trailing triangle
@@ -339,10 +339,15 @@ void bq_chol_ws_destroy(bq_chol_ws *ws) {
     if (ws->s_side) hipStreamDestroy(ws->s_side);
     for (void *p : {(void *)ws->H, (void *)ws->Wt, (void *)ws->LinvT, (void *)ws->rhs, (void *)ws->tmp, (void *)ws->info, (void *)ws->ticket,
                     (void *)ws->mr_vec, (void *)ws->mr_state, (void *)ws->mr_part, (void *)ws->bigM, (void *)ws->bigMT,
-                    (void *)ws->big_scratch, (void *)ws->sw_t})
+                    (void *)ws->big_scratch, (void *)ws->sw_t, (void *)ws->pivot_thr})
         if (p) hipFree(p);
     if (ws->mr_flag) hipHostFree(ws->mr_flag);
     delete ws;
+}
+
+__global__ void pivot_thr_kernel(const double *__restrict__ H, int64_t ldh, int64_t np, double rel, double *__restrict__ thr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) thr[i] = rel * fabs(H[i * ldh + i]);
 }
 
 // factor the leading np x np block of ws->H (np multiple of 128, lower triangle valid) in place
@@ -355,6 +360,12 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_CHOL, &e0, &e1));
     BQ_HIP(hipMemsetAsync(ws->info, 0, sizeof(int), st));
     const int64_t ldh = ws->ldh;
+    const double *thr = nullptr;
+    if (ws->pivot_rel > 0.0) {   // thresholds from the diagonal as given, before any update touches it
+        if (!ws->pivot_thr) BQ_HIP(hipMalloc(&ws->pivot_thr, sizeof(double) * ws->cap));
+        pivot_thr_kernel<<<(unsigned)((np + 255) / 256), 256, 0, st>>>(ws->H, ldh, np, ws->pivot_rel, ws->pivot_thr);
+        thr = ws->pivot_thr;
+    }
     // Two block columns per pass p (A_p = 2p*NB, B_p = A_p + NB), two passes per SUPER-PASS q (passes 2q, 2q+1):
     //   narrow(p): diag(A) ; TRSM(A) ; narrow update of column B ; diag(B) ; TRSM(B)        -> images of pass p
     //   head_in(p): the two block columns pass p+1 factors next  -= the images of the super-pass so far
@@ -385,12 +396,12 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
             const double *LinvT = ws->LinvT + (k0 / NB) * NB * NB;
             trsm_gemm_kernel<<<(unsigned)T, 256, 0, s>>>(ws->H, ldh, k0, i0, Wimg, LinvT);
         };
-        bq_launch_potrf_diag(s, ws->H, ldh, a0, ws->LinvT + (a0 / NB) * NB * NB, ws->info);
+        bq_launch_potrf_diag(s, ws->H, ldh, a0, ws->LinvT + (a0 / NB) * NB * NB, ws->info, thr);
         const int64_t b0 = a0 + NB;
         if (b0 >= np) return;
         panel(a0, WtA);
         syrk_col_kernel<<<(unsigned)((np - b0) / NB), 256, 0, s>>>(ws->H, ldh, b0, WtA);
-        bq_launch_potrf_diag(s, ws->H, ldh, b0, ws->LinvT + (b0 / NB) * NB * NB, ws->info);
+        bq_launch_potrf_diag(s, ws->H, ldh, b0, ws->LinvT + (b0 / NB) * NB * NB, ws->info, thr);
         if (b0 + NB >= np) return;
         panel(b0, WtB);
     };

@@ -64,7 +64,8 @@ __device__ __forceinline__ pd_d4 wave_tile16(int K, FA A, FB B) {
 }
 
 __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ H, int64_t ldh, int64_t k0,
-                                                           double *__restrict__ LinvT, int *__restrict__ info, long long *stamps) {
+                                                           double *__restrict__ LinvT, int *__restrict__ info, long long *stamps,
+                                                           const double *__restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *M = smem;
     double *dinv = M + PB * PL;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
             const int i = lane & 31;
             int bad = 0;
             double myri = 1.0;   // 1 / L[i][i]
+            const double mythr = thr ? thr[k0 + o + i] : 0.0;   // smallest acceptable pivot of this lane's row (0: LAPACK's test)
             auto panel = [&](auto tag) {
                 constexpr int c0 = decltype(tag)::value;
                 double a[8];
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(PT) void potrf_diag128_kernel(double *__restrict__ 
                 for (int jj = 0; jj < 8; ++jj) {
                     const int j = c0 + jj;
                     double d = rdlane(a[jj], j);
-                    if (!(d > 0.0)) {   // uniform
+                    if (!(d > rdlane(mythr, j))) {   // uniform
                         if (bad == 0) bad = o + j + 1;
                         d = 1.0;
                     }
@@ -329,12 +331,12 @@ int bq_potrf_diag_setup() {
     return BQ_OK;
 }
 
-void bq_launch_potrf_diag(hipStream_t st, double *H, int64_t ldh, int64_t k0, double *LinvT, int *info) {
+void bq_launch_potrf_diag(hipStream_t st, double *H, int64_t ldh, int64_t k0, double *LinvT, int *info, const double *thr) {
 #ifdef BQ_DIAG_STAMPS
     static long long *dstamps = nullptr;
     static int calls = 0;
     if (!dstamps) hipMalloc(&dstamps, 64 * sizeof(long long));
-    potrf_diag128_kernel<<<1, PT, POTRF_LDS, st>>>(H, ldh, k0, LinvT, info, calls == 3 ? dstamps : nullptr);
+    potrf_diag128_kernel<<<1, PT, POTRF_LDS, st>>>(H, ldh, k0, LinvT, info, calls == 3 ? dstamps : nullptr, thr);
     if (calls == 3) {
         long long h[64];
         hipStreamSynchronize(st);
@@ -343,6 +345,6 @@ void bq_launch_potrf_diag(hipStream_t st, double *H, int64_t ldh, int64_t k0, do
     }
     ++calls;
 #else
-    potrf_diag128_kernel<<<1, PT, POTRF_LDS, st>>>(H, ldh, k0, LinvT, info, nullptr);
+    potrf_diag128_kernel<<<1, PT, POTRF_LDS, st>>>(H, ldh, k0, LinvT, info, nullptr, thr);
 #endif
 }

@@ -631,6 +631,30 @@ def test_minres_forms_agree(amd, monkeypatch):
     np.testing.assert_allclose(runs[1][1], runs[0][1], rtol=1e-7, atol=1e-9)
 
 
+def test_active_set_on_a_rank_deficient_problem_follows_the_oracle_to_the_end(amd):
+    """17 points in 3 dimensions, linear kernel: Q has rank 4.  While the free set is larger than the rank, Q_AA is singular and
+    the reference takes its minres branch (active_set.py:142-151) — if its Cholesky fails, which with LAPACK's `pivot <= 0` test
+    is decided by the sign of rounding noise.  The device factorisation calls a pivot below 1e-13 of the original diagonal
+    non-positive (bq_chol.h: pivot_rel), so it takes that branch reliably; with LAPACK's test it factored the singular 7 x 7 system
+    of iteration 10 "successfully", left the reference's path there and ended in a zero-step cycle.  Now: the oracle's 48
+    iterations, the same status and the same point."""
+    from oracle import svm_oracle as so, bcqp_oracle as bo
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import ActiveSet
+    rs = np.random.RandomState(0)
+    for n in (2, 3, 5, 17):                      # the draw that exposed it
+        X = rs.standard_normal((n, 3))
+        y = np.array([1., -1.] * n)[:n]
+    Q, q, ub = so.svc_dual(so.gram('linear', X), y, 1.0)
+    assert np.linalg.matrix_rank(Q) == 4
+    ref = bo.active_set(Q, q, ub, max_iter=200, trace=True)
+    assert ref['status'] == 'optimal' and sum(e['used_minres'] for e in ref['trace']) >= 10
+    got = ActiveSet(quad=Quadratic(Q, q), ub=ub, max_iter=200).minimize()
+    assert got.status == 'optimal' and got.iter == ref['iter']
+    np.testing.assert_allclose(got.x, ref['x'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got.f_x, ref['f_x'], rtol=1e-10)
+
+
 def test_active_set_singular_system_at_n10000(amd):
     """The reference falls through to minres on the normal equations whatever |A| is (active_set.py:142-151); round 1's device
     fallback stopped at |A| = 8192.  Linear kernel, n = 10 000, d = 20 (rank 21 Hessian): the first iterations against the
