@@ -1235,7 +1235,8 @@ int bq_as_iterate(bq_solver *s) {
         return BQ_OK;
     }
     bool solved = false;
-    if (as_schur_enabled() && nA >= as_schur_min()) BQ_TRY(as_schur_step(s, w, nA, &solved));
+    // (an empty free set has nothing to keep: with BQ_AS_SCHUR_MIN=0 it reached the kept-factor path and launched empty grids)
+    if (as_schur_enabled() && nA > 0 && nA >= as_schur_min()) BQ_TRY(as_schur_step(s, w, nA, &solved));
     if (!solved && w->sch) w->sch->valid = false;   // the classic path below overwrites the kept factor
     if (solved) {
         w->last_branch = w->host_ints[2] ? 1 : 0;
