@@ -61,7 +61,7 @@ def gpu_mode(exchange, outdir, sym_exchange=None):
     assert ctx.exchange == (exchange if (comm.world_size > 1 or exchange == 'rccl') else 'none')
     info = ctx.comm_info()
     res = {'rccl_ranks': np.array(info['rccl_ranks']), 'sym_exchange': np.array(info['sym_exchange'])}
-    n = 700
+    n = int(os.environ.get('BQ_TEST_DIST_N', '700'))   # 700 = 3 tile rows of 256; the tests also run 257 and 2100
     X, y = make_blobs(n, 12, seed=5)
     quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
     dev = quad.device_problem()
@@ -85,7 +85,7 @@ def gpu_mode(exchange, outdir, sym_exchange=None):
     Qd = G @ G.T / 500
     dq = Quadratic(Qd, rs.standard_normal(500))
     res['dense_rows'] = np.array(dq.device_problem().dims()[2:])
-    res['dense_matvec'] = dq.device_problem().matvec(v[:500])
+    res['dense_matvec'] = dq.device_problem().matvec(np.random.RandomState(12).standard_normal(500))
     opt = ProjectedGradient(quad=dq, ub=np.ones(500), max_iter=40).minimize()
     res['dense_pg_x'] = opt.x
     # augmented-Lagrangian dual: same sharded product, everything else replicated

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(mode, world, outdir, timeout=300):
+def _launch(mode, world, outdir, timeout=300, extra_env=None):
     """One process per rank; each rank's output goes to OUTDIR/rank<r>.log and is shown when a rank fails or hangs."""
     import time
     port = _free_port()
@@ -33,7 +33,7 @@ def _launch(mode, world, outdir, timeout=300):
     procs, logs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2', **(extra_env or {}))
         logs.append(open(os.path.join(outdir, f'rank{r}.log'), 'w'))
         procs.append(subprocess.Popen([sys.executable, WORKER, mode, outdir], env=env, stdout=logs[-1],
                                       stderr=subprocess.STDOUT))
@@ -136,6 +136,20 @@ def test_four_ranks_two_segments_each(tmp_path, one_rank):
     for r in four:
         for key in ROW_KEYS + SYM_KEYS:
             assert np.array_equal(r[key], one_rank[key]), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [257, 2100])
+def test_other_sizes_split_the_same_way(tmp_path, n):
+    """257 rows = two tile rows, the second with ONE row (two ranks: 1 + 1 tile rows; three ranks: one of them owns nothing);
+    2100 rows = nine tile rows (segments of 3 / 1 / 1 / 1 / 1 / 1 / 1 / 0 tile rows — an empty canonical segment).  Symmetric,
+    streamed and row-block products and every solve on them: one rank = two ranks = three ranks, bit for bit."""
+    env = {'BQ_TEST_DIST_N': str(n)}
+    one = _launch('gpu-host', 1, tmp_path / 'w1', extra_env=env)[0]
+    for world in (2, 3):
+        for r in _launch('gpu-host', world, tmp_path / f'w{world}', extra_env=env):
+            for key in ROW_KEYS + SYM_KEYS:
+                assert np.array_equal(r[key], one[key]), (world, key)
 
 
 @pytest.mark.gpu
