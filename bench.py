@@ -81,6 +81,14 @@ def parse(argv=None):
                          'n (tol 1e-3), ip = InteriorPoint at BASELINE config 3 shape n=50000 d=128 (gap 1e-10, ~50 s)')
     ap.add_argument('--sigma', type=float, default=8.0, help='blob spread of the synthetic data (SURVEY 8d: 8 overlapping, 3 separable)')
     ap.add_argument('--inner-tol', type=float, default=1e-8, help='ascg: relative residual of the inner conjugate gradients')
+    ap.add_argument('--emulate-shares', default=None, metavar='G[,G...]',
+                    help='ONE GPU, one process: for every rank k of a G-way partition build only that rank\'s share of the panel '
+                         '(bq_ctx_create_share: every per-rank kernel of the iteration, collectives are no-ops) and time it; prints '
+                         'one JSON record with per-share kernel time / GB/s / fixed cost and the iteration rate they predict for '
+                         'G GPUs (e.g. --emulate-shares 1,2,4,8)')
+    ap.add_argument('--exchange-us', type=float, default=50.0,
+                    help='--emulate-shares: ASSUMED duration of the one collective per product (not measurable on one GPU); the '
+                         'prediction is printed with it and with 0')
     ap.add_argument('--cpu-study', action='store_true',
                     help='CPU only (SURVEY 8d): the oracle timed at three sizes to check the n^2 (PG) / n^3 (Cholesky) laws '
                          'behind the extrapolated baseline, plus a blocked Gram-streaming product at the full n')
@@ -457,10 +465,89 @@ def bench_kkt_line(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# what the 1 -> 8 GPU curve will look like, measured on ONE GPU: every rank's share of the partition, one at a time
+# ---------------------------------------------------------------------------------------------------------------------
+def share_timing(args):
+    """For every G in --emulate-shares and every rank k < G: a share context (rank k of G, no transport), the rank's part of
+    the Gram panel, and --steps solver iterations of exactly the kernels that rank runs in a G-GPU job (tile product over its
+    canonical segments, per-segment reduction, ordered segment sum, the fused O(n) kernels) — everything but the collective,
+    which moves nothing here.  The iterates are meaningless (partial products); the TIMES are the rank's.  Prediction:
+    G-GPU iteration time = the slowest share + the assumed collective (--exchange-us), stated with and without it."""
+    from optiml_amd import _lib, device
+    from optiml_amd.datasets import make_blobs, make_regression
+    from optiml_amd.ml.svm.kernels import PolyKernel, gaussian, linear
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained._base import _DeviceSolver
+    n, d = args.n, args.d
+    kern = {'rbf': gaussian, 'poly': PolyKernel(3, 'scale', 1.0), 'linear': linear}[args.kernel]
+    if args.task == 'svc':
+        X, y = make_blobs(n, d, seed=0, sigma=args.sigma)
+        q, yy, struct = -np.ones(n), y, 'svc'
+    else:
+        X, y = make_regression(n, d, seed=0)
+        q, yy, struct = np.hstack((-y, y)) + 0.1, None, 'svr'
+    N = len(q)
+    esz = 8 if args.storage == 'f64' else 4
+    kind = _lib.FW if args.solver == 'fw' else _lib.PG
+    T = 256
+    out = {'what': 'share_timing', 'metric': 'dual_qp_iterations_per_sec (predicted from single-GPU share timings)',
+           'config': {'workload': f'{args.task}_{args.kernel}_{args.solver}_dual_n{n}_d{d}', 'n': n, 'd': d, 'storage': args.storage,
+                      'steps': args.steps, 'warmup': args.warmup},
+           'assumed_exchange_us': args.exchange_us, 'partitions': []}
+    name = None
+    for G in [int(g) for g in args.emulate_shares.split(',') if g]:
+        shares = []
+        for k in range(G):
+            ctx = device.Context(share=(k, G)) if G > 1 else device.Context()
+            name = name or ctx.name
+            quad = KernelQuadratic(X, q, struct, kern, y=yy, storage=args.storage)
+            ctx.profile(True)
+            dev = quad.device_problem(ctx)
+            gram_ms, _ = ctx.profile_read(_lib.PROF_GRAM, reset=True)
+            _, _, r0, r1 = dev.dims()
+            solver = _DeviceSolver(dev, kind, np.zeros(N), np.ones(N), np.ones(N) / 2, 1e-6, 10 ** 9)
+            solver.run(max(args.warmup, 1))
+            ctx.profile_read(_lib.PROF_MATVEC, reset=True)
+            t0 = time.perf_counter()
+            rows, _ = solver.run(args.steps)
+            dt = time.perf_counter() - t0
+            mv_ms, mv_cnt = ctx.profile_read(_lib.PROF_MATVEC, reset=True)
+            i0, i1 = r0 // T, -(-r1 // T)
+            tiles = i1 * (i1 + 1) // 2 - i0 * (i0 + 1) // 2
+            alg = tiles * (T * T * esz + T * 8) + (tiles // 8 + i1 - i0) * T * 8 + 2 * n * 8
+            avg = mv_ms / max(mv_cnt, 1)
+            step_ms = 1e3 * dt / max(len(rows), 1)
+            shares.append({'rank': k, 'tile_rows': [i0, i1], 'rows': r1 - r0, 'tiles': tiles, 'strips': sum(I // 8 + 1 for I in range(i0, i1)),
+                           'panel_GB': tiles * T * T * esz / 1e9, 'gram_build_ms': gram_ms, 'steps_done': len(rows),
+                           'symv_tiles_ms': avg, 'symv_GBs': alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
+                           'symv_frac_of_8TBs': alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0,
+                           'ms_per_step': step_ms, 'fixed_cost_ms': step_ms - avg})
+            print(f'[share] G={G} k={k}: tiles {tiles}, symv {avg:.3f} ms ({shares[-1]["symv_GBs"]:.0f} GB/s), step {step_ms:.3f} ms',
+                  file=sys.stderr, flush=True)
+            solver.close()
+            quad.release()
+            ctx.close()
+        worst = max(s['ms_per_step'] for s in shares)
+        out['partitions'].append({
+            'G': G, 'shares': shares, 'slowest_share_ms_per_step': worst,
+            'predicted_iter_per_s_no_exchange': 1e3 / worst,
+            'predicted_iter_per_s': 1e3 / (worst + (args.exchange_us * 1e-3 if G > 1 else 0.0)),
+            'min_symv_frac_of_8TBs': min(s['symv_frac_of_8TBs'] for s in shares)})
+    base = next((p for p in out['partitions'] if p['G'] == 1), None)
+    if base:
+        for p in out['partitions']:
+            p['predicted_speedup_vs_1'] = p['predicted_iter_per_s'] / base['predicted_iter_per_s']
+    out['config']['device'] = name
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if args.cpu_study:
         return cpu_study(args)
+    if args.emulate_shares:
+        return share_timing(args)
     if args.solver in ('ip', 'as', 'smo'):
         if args.gpus != 1:
             raise SystemExit('InteriorPoint / ActiveSet factorise on one GPU and SMO walks the samples sequentially '
@@ -487,11 +574,10 @@ def main():
 
     comm = None
     if world > 1:
-        import datetime
-        import torch.distributed as dist
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
-        from optiml_amd.dist import TorchComm
-        comm = TorchComm()
+        # rendezvous / barrier / max-over-ranks: torch.distributed (gloo) when torch is importable, else the package's own
+        # TCP communicator (BQ_RENDEZVOUS=socket forces it) — the data path is RCCL either way
+        from optiml_amd.dist import from_env
+        comm = from_env(timeout=600.0)
         # RCCL over xGMI is the data path.  A communicator that cannot be created on EVERY rank ends the run with exit code
         # 3 — a scaling number must never silently be a host-transport number — unless --allow-host-exchange asks for the
         # gloo fallback (reported in config.exchange).
@@ -506,7 +592,7 @@ def main():
                 if ctx is not None:
                     ctx.close()
                 if not args.allow_host_exchange:
-                    dist.destroy_process_group()
+                    comm.close()
                     raise SystemExit(3)
                 print(f'[bench] rank {rank}: --allow-host-exchange: using the host (gloo) exchange', file=sys.stderr, flush=True)
                 ctx, exchange = None, 'host'
@@ -564,13 +650,23 @@ def main():
     rows, status = solver.run(args.steps)                # device-resident; returns after the stream has drained
     t1 = time.perf_counter()
     barrier()
-    elapsed = t1 - t0
+    own_elapsed = elapsed = t1 - t0
     if comm is not None:
         elapsed = comm.max_float(elapsed)
     done = len(rows)
     mv_ms, mv_cnt = ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     ex_ms, ex_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
     inner = (solver.inner_iters() - inner0) if ascg else 0
+    per_rank = None
+    if comm is not None:   # every rank's share and timings in the one line rank 0 prints
+        cols = [comm.allgather_float(v) for v in (own_elapsed * 1e3 / max(done, 1), mv_ms / max(mv_cnt, 1),
+                                                  (ex_ms / ex_cnt) if ex_cnt else 0.0)]
+        per_rank = []
+        for k in range(world):
+            b, e = device.row_block(n, k, world, symmetric=True)
+            j0, j1 = b // 256, -(-e // 256)
+            per_rank.append({'rank': k, 'rows': e - b, 'tile_rows': [j0, j1], 'tiles': j1 * (j1 + 1) // 2 - j0 * (j0 + 1) // 2,
+                             'ms_per_step': cols[0][k], 'symv_tiles_ms': cols[1][k], 'exchange_ms_per_product': cols[2][k]})
 
     esz = 8 if args.storage == 'f64' else 4
     probe = (0.0, 0.0)
@@ -624,6 +720,8 @@ def main():
             'exchange_ms_per_step': (ex_ms / max(done, 1)) if ex_cnt else 0.0,
             'exchange_ms_per_product': (ex_ms / ex_cnt) if ex_cnt else 0.0,
         }
+        if per_rank is not None:
+            out['per_rank'] = per_rank
         if ascg:
             out['inner_products_per_step'] = inner / max(done, 1)
             out['inner_tol'] = args.inner_tol
@@ -670,8 +768,7 @@ def main():
         print(json.dumps(out), file=json_out, flush=True)
     barrier()
     if comm is not None:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        comm.close()
 
 
 def measured_traffic(workload, world):

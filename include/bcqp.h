@@ -107,9 +107,13 @@ int bq_ctx_create(int device, bq_ctx **out);
 int bq_comm_unique_id(void *uid128);
 int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_ctx **out);
 int bq_ctx_create_exchange(int device, int rank, int world, bq_exchange_fn fn, void *user, bq_ctx **out);
+/* ONE rank's share of a `world`-way partition with no transport behind it: panels, segments and every kernel of the
+ * per-rank iteration are exactly those of rank `rank` of `world`, every collective is a no-op — so products hold this rank's
+ * contributions only.  For timing and inspecting a share on a single GPU (bench.py --emulate-shares); never a solver. */
+int bq_ctx_create_share(int device, int rank, int world, bq_ctx **out);
 int bq_ctx_destroy(bq_ctx *ctx);
 int bq_ctx_info(const bq_ctx *ctx, int *device, int *rank, int *world, char *name, size_t name_cap);
-/* the exchange behind a multi-rank context: kind 0 none / 1 RCCL / 2 callback; comm_ranks = ncclCommCount of the live
+/* the exchange behind a multi-rank context: kind 0 none / 1 RCCL / 2 callback / 3 share (bq_ctx_create_share); comm_ranks = ncclCommCount of the live
  * communicator (0 without RCCL); sym_allreduce = 1 when symmetric products end in an all-reduce (BQ_SYM_EXCHANGE=allreduce)
  * instead of the default all-gather of segment partials summed in a fixed order (bit-identical for any rank count) */
 int bq_ctx_comm_info(const bq_ctx *ctx, int *kind, int *comm_ranks, int *sym_allreduce);
@@ -156,6 +160,12 @@ int bq_problem_dims(const bq_problem *p, int64_t *n_dual, int64_t *n_rows, int64
 int bq_problem_matvec(bq_problem *p, const double *v, double *out);
 /* f = 1/2 x'Qx + q'x and (optionally, g != NULL) g = Qx + q   optiml/opti/_base.py:282, 291 */
 int bq_problem_eval(bq_problem *p, const double *x, double *f, double *g);
+/* x_out = argmin 1/2 x'Qx + q'x without the box: Quadratic.x_star(), optiml/opti/_base.py:259-269 —
+ * cho_solve(cho_factor(Q), -q) on the device (H assembled from the resident panel, blocked MFMA Cholesky); when a pivot
+ * is <= 0 (scipy: LinAlgError) the reference's fallback scipy.sparse.linalg.minres(Q, -q)[0] with its defaults (rtol 1e-5,
+ * 5 N iterations), one panel product per iteration.  *method: 0 Cholesky, 1 MINRES; *minres_iters: its iteration count.
+ * Single-rank contexts, resident panels. */
+int bq_problem_x_star(bq_problem *p, double *x_out, int *method, int64_t *minres_iters);
 /* out = K w with the raw Gram panel (kernel problems only; n-vectors)  svm/_base.py:877-880 */
 int bq_problem_gram_matvec(bq_problem *p, const double *w, double *out);
 /* copy rows [row0,row0+nrows) of this rank's resident panel (n columns each) to the host as fp64 */

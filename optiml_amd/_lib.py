@@ -57,6 +57,7 @@ PROTOTYPES = {
     'bq_comm_unique_id': (C.c_int, [_vp]),
     'bq_ctx_create_rccl': (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     'bq_ctx_create_exchange': (C.c_int, [C.c_int, C.c_int, C.c_int, EXCHANGE_FN, _vp, C.POINTER(_vp)]),
+    'bq_ctx_create_share': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     'bq_ctx_destroy': (C.c_int, [_vp]),
     'bq_ctx_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     'bq_ctx_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -74,6 +75,7 @@ PROTOTYPES = {
     'bq_problem_dims': (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_problem_matvec': (C.c_int, [_vp, _dp, _dp]),
     'bq_problem_eval': (C.c_int, [_vp, _dp, _dp, _dp]),
+    'bq_problem_x_star': (C.c_int, [_vp, _dp, C.POINTER(C.c_int), C.POINTER(_i64)]),
     'bq_problem_gram_matvec': (C.c_int, [_vp, _dp, _dp]),
     'bq_problem_panel_rows': (C.c_int, [_vp, _i64, _i64, _dp]),
     'bq_problem_time_matvec': (C.c_int, [_vp, C.c_int, _dp]),

@@ -18,6 +18,44 @@ void bq_ctx_register(bq_ctx *c, bool alive) {
     if (!alive && it != g_live.end()) g_live.erase(it);
 }
 
+// The cached panel of a context is touched from three places — a new problem taking it, a destroyed problem leaving its
+// panel, a failing allocation (of ANY context, on any thread) dropping it — so every access goes through g_mu.
+static void drop_cache_locked(bq_ctx *c) {
+    if (c->panel_cache) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipSetDevice(c->device);
+        hipFree(c->panel_cache);
+        hipSetDevice(dev);
+    }
+    c->panel_cache = nullptr;
+    c->panel_cache_bytes = 0;
+}
+
+void bq_ctx_drop_cache(bq_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drop_cache_locked(c);
+}
+
+// the cached panel if it holds `bytes` with at most 25 % to spare; the caller owns it afterwards
+void *bq_ctx_cache_take(bq_ctx *c, size_t bytes, size_t *cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!c->panel_cache || c->panel_cache_bytes < bytes || c->panel_cache_bytes - bytes > bytes / 4) return nullptr;
+    void *p = c->panel_cache;
+    *cap = c->panel_cache_bytes;
+    c->panel_cache = nullptr;
+    c->panel_cache_bytes = 0;
+    return p;
+}
+
+// a released panel becomes the context's cached one (whatever was cached before goes back to the driver)
+void bq_ctx_cache_put(bq_ctx *c, void *panel, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drop_cache_locked(c);
+    c->panel_cache = panel;
+    c->panel_cache_bytes = bytes;
+}
+
 hipError_t bq_device_malloc(void **ptr, size_t bytes) {
     // BQ_TEST_ALLOC_FAIL_ABOVE=<bytes>: test hook — requests above the threshold fail ONCE per request while a cached
     // panel exists, so that the drop-and-retry path is exercised without exhausting a 288 GB device
@@ -41,11 +79,7 @@ hipError_t bq_device_malloc(void **ptr, size_t bytes) {
         std::lock_guard<std::mutex> lk(g_mu);
         for (bq_ctx *c : g_live)
             if (c->panel_cache) {
-                int dev = 0;
-                hipGetDevice(&dev);
-                hipSetDevice(c->device);
-                bq_ctx_drop_cache(c);
-                hipSetDevice(dev);
+                drop_cache_locked(c);
                 dropped = true;
             }
     }

@@ -57,8 +57,12 @@ int bq_comm_init_rccl(bq_ctx *ctx, const void *uid128);  // bq_comm.cpp
 void bq_comm_destroy(bq_ctx *ctx);
 int bq_comm_size(const bq_ctx *ctx);
 
+// the segment table (bq_seg_table) is a fixed-size struct passed to kernels by value: 8 * ceil(world / 8) segments must fit
+#define BQ_ARG_WORLD(world) BQ_ARG(bq_sym_segments(world) <= BQ_SYM_SEG_MAX, "world is limited to 64 ranks (BQ_SYM_SEG_MAX canonical segments)")
+
 extern "C" int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_ctx **out) {
     BQ_ARG(world >= 1 && rank >= 0 && rank < world, "rank/world");
+    BQ_ARG_WORLD(world);
     BQ_ARG(uid128 != nullptr, "uid is NULL");
     bq_ctx *c = nullptr;
     BQ_TRY(ctx_new(device, &c));
@@ -76,6 +80,7 @@ extern "C" int bq_ctx_create_rccl(int device, int rank, int world, const void *u
 extern "C" int bq_ctx_create_exchange(int device, int rank, int world, bq_exchange_fn fn, void *user, bq_ctx **out) {
     BQ_ARG(world >= 1 && rank >= 0 && rank < world, "rank/world");
     BQ_ARG(fn != nullptr || world == 1, "exchange callback is NULL");
+    BQ_ARG_WORLD(world);
     bq_ctx *c = nullptr;
     BQ_TRY(ctx_new(device, &c));
     c->rank = rank;
@@ -83,6 +88,18 @@ extern "C" int bq_ctx_create_exchange(int device, int rank, int world, bq_exchan
     c->comm_kind = world > 1 ? BQ_COMM_CALLBACK : BQ_COMM_NONE;
     c->exch_fn = fn;
     c->exch_user = user;
+    *out = c;
+    return BQ_OK;
+}
+
+extern "C" int bq_ctx_create_share(int device, int rank, int world, bq_ctx **out) {
+    BQ_ARG(world >= 1 && rank >= 0 && rank < world, "rank/world");
+    BQ_ARG_WORLD(world);
+    bq_ctx *c = nullptr;
+    BQ_TRY(ctx_new(device, &c));
+    c->rank = rank;
+    c->world = world;
+    c->comm_kind = BQ_COMM_SHARE;
     *out = c;
     return BQ_OK;
 }
@@ -218,7 +235,7 @@ static void sym_tile_rows(int64_t nb, int rank, int world, int64_t *I0, int64_t 
 }
 
 void bq_sym_seg_table(const bq_problem *p, bq_seg_table *tab) {
-    const int world = p->ctx->world;
+    const int world = p->ctx->world;   // <= 64: checked where a multi-rank context is created (BQ_ARG_WORLD)
     tab->count = p->seg_count;
     tab->lo = p->seg_lo;
     tab->hi = p->seg_hi;
@@ -307,11 +324,10 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
                                       : (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld;
     const size_t bytes = (elems > 0 ? elems : 1) * esz;
     hipError_t e = hipSuccess;
-    if (c->panel_cache && c->panel_cache_bytes >= bytes && c->panel_cache_bytes - bytes <= bytes / 4) {
-        p->panel = c->panel_cache;   // the panel a destroyed problem left behind
-        p->panel_bytes = c->panel_cache_bytes;
-        c->panel_cache = nullptr;
-        c->panel_cache_bytes = 0;
+    size_t cached = 0;
+    if (void *kept = bq_ctx_cache_take(c, bytes, &cached)) {
+        p->panel = kept;   // the panel a destroyed problem left behind
+        p->panel_bytes = cached;
     } else {
         e = hipMalloc(&p->panel, bytes);   // bq_device_malloc: drops the cached panel and retries on failure
         p->panel_bytes = bytes;
@@ -324,12 +340,6 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
     }
     BQ_HIP(hipMemsetAsync(p->panel, 0, bytes, c->stream));
     return BQ_OK;
-}
-
-void bq_ctx_drop_cache(bq_ctx *c) {
-    if (c->panel_cache) hipFree(c->panel_cache);
-    c->panel_cache = nullptr;
-    c->panel_cache_bytes = 0;
 }
 
 void bq_problem_unref(bq_problem *p) {
@@ -350,9 +360,7 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     if (p->panel && p->panel_bytes >= ((size_t)1 << 30)) {   // keep one large panel for the next problem (see bq_ctx)
-        bq_ctx_drop_cache(p->ctx);
-        p->ctx->panel_cache = p->panel;
-        p->ctx->panel_cache_bytes = p->panel_bytes;
+        bq_ctx_cache_put(p->ctx, p->panel, p->panel_bytes);
         p->panel = nullptr;
     }
     for (void *ptr : {(void *)p->panel, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,

@@ -270,12 +270,8 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
     ws->cap = bq_round_up(n, NB);
     ws->ldh = ws->cap;
     const int64_t nblk = ws->cap / NB;
+    // bq_device_malloc: a panel kept for re-use that is in the way is dropped and the allocation retried
     hipError_t e = hipMalloc(&ws->H, sizeof(double) * ws->ldh * ws->cap);
-    if (e != hipSuccess && ctx->panel_cache) {   // a panel kept for re-use may be what is in the way
-        (void)hipGetLastError();
-        bq_ctx_drop_cache(ctx);
-        e = hipMalloc(&ws->H, sizeof(double) * ws->ldh * ws->cap);
-    }
     if (e != hipSuccess) {
         bq_set_error("cannot allocate the %lld x %lld factorisation workspace (%.1f GB): %s", (long long)ws->cap,
                      (long long)ws->cap, 8e-9 * ws->ldh * ws->cap, hipGetErrorString(e));

@@ -139,7 +139,7 @@ void bq_comm_destroy(bq_ctx *ctx) {
 
 // buf holds world*chunk doubles; this rank's chunk (at rank*chunk) is fresh on entry, all chunks on return
 int bq_exchange_gather(bq_ctx *ctx, double *buf, int64_t chunk) {
-    if (ctx->comm_kind == BQ_COMM_NONE) return BQ_OK;
+    if (ctx->comm_kind == BQ_COMM_NONE || ctx->comm_kind == BQ_COMM_SHARE) return BQ_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_EXCH, &e0, &e1));
     if (ctx->comm_kind == BQ_COMM_RCCL) {
@@ -158,7 +158,7 @@ int bq_exchange_gather(bq_ctx *ctx, double *buf, int64_t chunk) {
 
 // s holds world*blk doubles; rows [r0,r1) (this rank's block, r0 == rank*blk, clipped to n) are fresh on entry
 int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0, int64_t r1) {
-    if (ctx->comm_kind == BQ_COMM_NONE) return BQ_OK;
+    if (ctx->comm_kind == BQ_COMM_NONE || ctx->comm_kind == BQ_COMM_SHARE) return BQ_OK;
     if (ctx->comm_kind != BQ_COMM_CALLBACK) return bq_exchange_gather(ctx, s, blk);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_EXCH, &e0, &e1));
@@ -169,7 +169,7 @@ int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0,
 
 // in-place all-reduce(sum) of v[0:count) — BQ_SYM_EXCHANGE=allreduce: every rank holds partial sums for every output block
 int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count) {
-    if (ctx->comm_kind == BQ_COMM_NONE) return BQ_OK;
+    if (ctx->comm_kind == BQ_COMM_NONE || ctx->comm_kind == BQ_COMM_SHARE) return BQ_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_EXCH, &e0, &e1));
     if (ctx->comm_kind == BQ_COMM_RCCL) {

@@ -63,7 +63,9 @@ constexpr int BQ_MAX_PARTIAL_Q = 8;               // reduced quantities per kern
 static inline int64_t bq_round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
 
 enum { BQ_PROF_MATVEC = 0, BQ_PROF_GRAM = 1, BQ_PROF_CHOL = 2, BQ_PROF_EXCH = 3, BQ_PROF_COUNT = 4 };
-enum { BQ_COMM_NONE = 0, BQ_COMM_RCCL = 1, BQ_COMM_CALLBACK = 2 };
+// BQ_COMM_SHARE: one rank's share of a `world`-way partition with NO transport behind it — every collective is a no-op, so the
+// products hold this rank's contributions only.  It exists to time and inspect a share on a single GPU (bq_ctx_create_share).
+enum { BQ_COMM_NONE = 0, BQ_COMM_RCCL = 1, BQ_COMM_CALLBACK = 2, BQ_COMM_SHARE = 3 };
 
 struct bq_prof_slot {
     double total_ms = 0.0;
@@ -200,7 +202,10 @@ int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count);  // all-reduce(sum) 
 int bq_exchange_gather(bq_ctx *ctx, double *buf, int64_t chunk);
 void bq_problem_unref(bq_problem *p);   // a solver of p has gone: destroys p if that was pending
 void bq_ctx_register(bq_ctx *c, bool alive);   // bq_alloc.cpp: the contexts whose cached panels a failing allocation may drop
-void bq_ctx_drop_cache(bq_ctx *ctx);   // give the cached panel back to the driver (called before retrying a failed allocation)
+// bq_alloc.cpp: the cached panel of a context, every access under one mutex (a failing allocation on another thread may drop it)
+void bq_ctx_drop_cache(bq_ctx *ctx);   // give the cached panel back to the driver
+void *bq_ctx_cache_take(bq_ctx *ctx, size_t bytes, size_t *cap);   // the cached panel if it fits `bytes` (<= 25 % spare), else null
+void bq_ctx_cache_put(bq_ctx *ctx, void *panel, size_t bytes);
 
 // bq_symv.hip: symmetric tile product over tile rows [I0, I1) -> out (nb*256 partial sums)
 constexpr int64_t BQ_SYM_TILE = 256;

@@ -33,28 +33,68 @@ def row_block(n, rank, world, symmetric=False):
     return b.value, e.value
 
 
+def _agree(comm, failure, what):
+    """Every rank learns whether ANY rank failed `what`, and then all of them raise — a rank that gave up alone would leave
+    the others waiting inside the next collective (RCCL's communicator bootstrap has no timeout of its own)."""
+    if comm.max_float(0.0 if failure is None else 1.0) > 0.0:
+        if failure is not None:
+            raise failure
+        raise RuntimeError(f'{what} failed on another rank')
+
+
 class Context:
-    def __init__(self, device=None, comm=None, exchange='rccl', sym_exchange=None):
+    def __init__(self, device=None, comm=None, exchange='rccl', sym_exchange=None, share=None):
         """exchange: 'rccl' (RCCL over xGMI) or 'host' (the communicator's host collectives; tests).  sym_exchange: how the
         products of symmetric kernel panels are closed — 'gather' (default: all-gather of the per-segment partial vectors,
         added in segment order on every rank, bit-identical iterates for any rank count) or 'allreduce' (one all-reduce(sum);
-        the association of the rank sum then belongs to the transport).  None: the BQ_SYM_EXCHANGE environment variable."""
+        the association of the rank sum then belongs to the transport).  None: the BQ_SYM_EXCHANGE environment variable.
+        share=(k, G): rank k's share of a G-way partition with no transport (collectives are no-ops, products are partial) —
+        for timing one share on one GPU, never for solving.
+
+        device=None: LOCAL_RANK.  An RCCL rank needs a device of its own: LOCAL_RANK >= the visible device count is an
+        error there (agreed on by all ranks before the communicator is created); ranks of the host exchange may share a
+        device (LOCAL_RANK modulo the device count: the multi-process tests on a one-GPU box)."""
         lib = _lib.load()
         self._lib = lib
         self._h = C.c_void_p()
         self._cb = None
         self.comm = comm
+        rccl = share is None and comm is not None and exchange == 'rccl'
+        failure = None
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', '0'))
-            ndev = device_count()
-            if ndev > 0:
+            try:
+                ndev = device_count()
+            except _lib.BcqpError as err:
+                if not rccl:
+                    raise
+                ndev, failure = 0, err
+            if rccl:
+                if failure is None and device >= ndev:
+                    failure = RuntimeError(f'LOCAL_RANK={device} but only {ndev} device(s) are visible: an RCCL rank needs a '
+                                           f'device of its own (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES too narrow?)')
+            elif ndev > 0:
                 device %= ndev
         self.device = device
-        if comm is None or (comm.world_size == 1 and exchange != 'rccl'):
+        if share is not None:
+            k, g = share
+            self.rank, self.world, self.exchange = int(k), int(g), 'share'
+            _lib.check(lib.bq_ctx_create_share(device, int(k), int(g), C.byref(self._h)))
+        elif comm is None or (comm.world_size == 1 and exchange != 'rccl'):
             self.rank, self.world, self.exchange = 0, 1, 'none'
             _lib.check(lib.bq_ctx_create(device, C.byref(self._h)))
         elif exchange == 'rccl':
             self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'rccl'
+            # pre-flight, agreed on by every rank BEFORE anyone enters ncclCommInitRank: this rank's device exists, can be
+            # selected and can hold a stream (a plain context is created and destroyed)
+            if failure is None:
+                try:
+                    probe = C.c_void_p()
+                    _lib.check(lib.bq_ctx_create(device, C.byref(probe)))
+                    lib.bq_ctx_destroy(probe)
+                except _lib.BcqpError as err:
+                    failure = err
+            _agree(comm, failure, 'the device pre-flight of the RCCL context')
             uid = C.create_string_buffer(128)
             failure = None
             if comm.rank == 0:
@@ -84,6 +124,8 @@ class Context:
                     return 1
 
             self._cb = _lib.EXCHANGE_FN(_exchange)
+            # the native context can outlive this object (it goes with the last problem built on it): the trampoline must too
+            _CALLBACKS.append(self._cb)
             _lib.check(lib.bq_ctx_create_exchange(device, comm.rank, comm.world_size, self._cb, None, C.byref(self._h)))
         else:
             raise ValueError(f"unknown exchange '{exchange}' (use 'rccl' or 'host')")
@@ -105,11 +147,11 @@ class Context:
         return buf.value.decode()
 
     def comm_info(self):
-        """{'kind': 'none'|'rccl'|'callback', 'rccl_ranks': ncclCommCount of the live communicator (0 without RCCL),
+        """{'kind': 'none'|'rccl'|'callback'|'share', 'rccl_ranks': ncclCommCount of the live communicator (0 without RCCL),
         'sym_exchange': 'gather'|'allreduce'}"""
         kind, ranks, ar = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.check(self._lib.bq_ctx_comm_info(self.handle, C.byref(kind), C.byref(ranks), C.byref(ar)))
-        return {'kind': ('none', 'rccl', 'callback')[kind.value], 'rccl_ranks': ranks.value,
+        return {'kind': ('none', 'rccl', 'callback', 'share')[kind.value], 'rccl_ranks': ranks.value,
                 'sym_exchange': 'allreduce' if ar.value else 'gather'}
 
     def profile(self, enable=True):
@@ -145,6 +187,7 @@ class Context:
             pass
 
 
+_CALLBACKS = []   # ctypes trampolines of host-exchange contexts, kept for the life of the process (a few bytes each)
 _default = None
 
 

@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-__all__ = ['TorchComm', 'SocketComm', 'from_env', 'block_size']
+__all__ = ['TorchComm', 'SocketComm', 'ThreadComm', 'from_env', 'block_size']
 
 
 def block_size(n, world):
@@ -32,6 +32,13 @@ class _Base:
         r = self.rank if rank is None else rank
         b = min(n, r * blk)
         return b, min(n, b + blk)
+
+    def close(self):
+        pass
+
+    def allgather_float(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank (control plane: one max per rank)."""
+        return [self.max_float(float(x) if self.rank == k else float('-inf')) for k in range(self.world_size)]
 
 
 class TorchComm(_Base):
@@ -81,6 +88,11 @@ class TorchComm(_Base):
         t = torch.tensor([float(x)], dtype=torch.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
+
+    def close(self):
+        if getattr(self, '_owns_group', False) and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+            self._owns_group = False
 
 
 # Wire format of SocketComm: a fixed 16-byte header (magic, kind, payload length) followed by raw bytes — byte strings and
@@ -245,20 +257,81 @@ class SocketComm(_Base):
             self._sock.close()
 
 
-def from_env(prefer_torch=True):
-    """Communicator for the current launcher environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+class ThreadComm(_Base):
+    """Ranks as THREADS of one process (one context and one HIP stream each, on one or several devices): the partition, the
+    per-rank kernels and the exchange protocol of a G-rank run inside a single process — how the full-size 4- and 8-way
+    partitions are checked on a one-GPU box, where at most a handful of processes may hold the device.  Create the G
+    members with ThreadComm.group(G) and hand member k to thread k."""
+
+    def __init__(self, rank, shared):
+        self.rank, self.world_size, self._s = rank, shared['world'], shared
+
+    @classmethod
+    def group(cls, world, timeout=600.0):
+        import threading
+        shared = {'world': world, 'barrier': threading.Barrier(world, timeout=timeout), 'slots': [None] * world}
+        return [cls(r, shared) for r in range(world)]
+
+    def _exchange(self, mine):
+        """every member's object, in rank order"""
+        s = self._s
+        s['slots'][self.rank] = mine
+        s['barrier'].wait()
+        out = list(s['slots'])
+        s['barrier'].wait()   # nobody overwrites a slot before everybody has read them
+        return out
+
+    def broadcast_bytes(self, data, src=0):
+        return self._exchange(bytes(data) if self.rank == src else None)[src]
+
+    def allgather_rows(self, buf, r0, r1):
+        for b, e, part in self._exchange((r0, r1, np.array(buf[r0:r1], copy=True))):
+            if e > b:
+                buf[b:e] = part
+
+    def allreduce_sum(self, buf):
+        parts = self._exchange(np.array(buf, copy=True))
+        acc = parts[0].copy()
+        for p in parts[1:]:      # fixed rank order -> deterministic
+            acc += p
+        buf[:] = acc
+
+    def barrier(self):
+        self._exchange(None)
+
+    def max_float(self, x):
+        return max(self._exchange(float(x)))
+
+    def abort(self):
+        """a member that failed wakes the others (they raise BrokenBarrierError instead of waiting for it)"""
+        self._s['barrier'].abort()
+
+
+def from_env(prefer_torch=True, timeout=600.0):
+    """Communicator for the current launcher environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT): torch.distributed
+    (gloo) when torch is importable, otherwise — or with BQ_RENDEZVOUS=socket — the dependency-free SocketComm on
+    MASTER_PORT + 33.  BQ_RENDEZVOUS=torch insists on torch."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world == 1:
         return SocketComm(0, 1)
-    if prefer_torch:
+    mode = os.environ.get('BQ_RENDEZVOUS', '')
+    if mode not in ('', 'torch', 'socket'):
+        raise ValueError(f"BQ_RENDEZVOUS='{mode}' (use 'torch' or 'socket')")
+    if (prefer_torch and mode != 'socket') or mode == 'torch':
         try:
+            import datetime
             import torch.distributed as dist
-            if not dist.is_initialized():
-                dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-            return TorchComm()
+            owns = not dist.is_initialized()
+            if owns:
+                dist.init_process_group(backend='gloo', rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=timeout))
+            comm = TorchComm()
+            comm._owns_group = owns
+            return comm
         except ImportError:
-            pass
+            if mode == 'torch':
+                raise
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(os.environ.get('MASTER_PORT', '29500')) + 33
-    return SocketComm(rank, world, addr, port)
+    return SocketComm(rank, world, addr, port, timeout=timeout)

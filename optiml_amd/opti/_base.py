@@ -77,6 +77,15 @@ class _DeviceProblem:
         _lib.check(self._lib.bq_problem_eval(self._h, _lib.ptr(x), C.byref(f), _lib.ptr(g)))
         return f.value, g
 
+    def x_star(self):
+        """(x, method, minres_iterations): the unconstrained minimiser by Cholesky ('cholesky') or, when Q is not positive
+        definite, scipy's default MINRES ('minres') — optiml/opti/_base.py:259-269."""
+        N = self.dims()[0]
+        x = np.empty(N)
+        method, iters = C.c_int(0), C.c_int64(0)
+        _lib.check(self._lib.bq_problem_x_star(self._h, _lib.ptr(x), C.byref(method), C.byref(iters)))
+        return x, ('cholesky', 'minres')[method.value], iters.value
+
     def gram_matvec(self, w):
         n = self.dims()[1]
         w = _lib.as_f64(w, n, 'w')
@@ -153,6 +162,16 @@ class Quadratic(OptimizationFunction):
             self._dev = None
 
     # -- reference interface ------------------------------------------------------------------
+    def x_star(self):
+        """optiml/opti/_base.py:259-269: cho_solve(cho_factor(Q), -q), or minres(Q, -q)[0] when Q is not positive definite —
+        both on the device (blocked MFMA Cholesky of the resident Hessian; MINRES on the panel product)."""
+        if not hasattr(self, 'x_opt'):
+            self.x_opt, self.x_opt_method, self.x_opt_iters = self.device_problem().x_star()
+        return self.x_opt
+
+    def f_star(self):
+        return self.function(self.x_star())   # optiml/opti/_base.py:271-272
+
     def function(self, x):
         return self.device_problem().eval(x, want_grad=False)[0]
 

@@ -36,6 +36,14 @@ def qp_grad(Q, q, x):
     return Q @ x + q                        # opti/_base.py:291
 
 
+def x_star(Q, q):
+    """Unconstrained minimiser, opti/_base.py:259-269: Cholesky when Q is positive definite, else scipy's default minres."""
+    try:
+        return cho_solve(cho_factor(Q), -q), 'cholesky'
+    except np.linalg.LinAlgError:
+        return minres(Q, -q)[0], 'minres'
+
+
 def _box(ub, lb, x0):
     ub = np.asarray(ub, dtype=float)
     lb = np.zeros_like(ub) if lb is None else np.asarray(lb, dtype=float)

@@ -93,6 +93,23 @@ def test_bad_arguments_are_reported_not_crashed(lib):
         _lib.check(lib.bq_problem_matvec(None, None, None))
 
 
+def test_more_ranks_than_the_segment_table_holds_are_refused(lib):
+    """bq_seg_table (passed to kernels by value) holds 64 canonical segments = 64 ranks: a larger world is a bad argument in
+    every multi-rank constructor, before any device is touched (it used to write past the struct)."""
+    import ctypes as C
+    from optiml_amd import _lib
+    h = C.c_void_p()
+    uid = C.create_string_buffer(128)
+    cb = _lib.EXCHANGE_FN(lambda *a: 0)
+    for world in (65, 72, 1000):
+        assert lib.bq_ctx_create_rccl(0, 0, world, uid, C.byref(h)) == _lib.ERR_BADARG
+        assert b'64 ranks' in lib.bq_last_error()
+        assert lib.bq_ctx_create_exchange(0, 0, world, cb, None, C.byref(h)) == _lib.ERR_BADARG
+        assert lib.bq_ctx_create_share(0, 0, world, C.byref(h)) == _lib.ERR_BADARG
+    assert lib.bq_ctx_create_share(0, 3, 2, C.byref(h)) == _lib.ERR_BADARG and b'rank' in lib.bq_last_error()
+    assert not h
+
+
 def test_python_surface_matches_reference_names():
     import optiml_amd.opti as opti
     import optiml_amd.opti.constrained as con

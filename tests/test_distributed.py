@@ -71,6 +71,63 @@ def test_two_rank_row_block_exchange_cpu(tmp_path, kind):
         assert np.array_equal(res[0][f'gathered_{n}'], res[1][f'gathered_{n}'])
 
 
+def run_thread_ranks(world, body, timeout=600.0):
+    """body(member) on `world` threads of THIS process, one ThreadComm member each; results in rank order.  A rank that raises
+    aborts the group's barrier so that the others fail too instead of waiting for it."""
+    import threading
+    from optiml_amd.dist import ThreadComm
+    members = ThreadComm.group(world, timeout=timeout)
+    res, err = [None] * world, []
+
+    def run(k):
+        try:
+            res[k] = body(members[k])
+        except BaseException as exc:  # noqa: BLE001
+            err.append((k, exc))
+            members[k].abort()
+
+    threads = [threading.Thread(target=run, args=(k,), name=f'rank{k}') for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if err:
+        first = [e for e in err if not isinstance(e[1], threading.BrokenBarrierError)] or err
+        raise AssertionError(f'rank {first[0][0]} of {world} failed: {first[0][1]!r}') from first[0][1]
+    return res
+
+
+def test_thread_ranks_primitives():
+    """ThreadComm: the communicator contract with the ranks as threads of one process (what the full-size 4- and 8-way
+    partition tests run on a one-GPU box)."""
+    def body(c):
+        assert c.broadcast_bytes(b'abc' if c.rank == 0 else b'', src=0) == b'abc'
+        n = 1000
+        r0, r1 = c.rows_of(n)
+        buf = np.zeros(n)
+        buf[r0:r1] = np.arange(r0, r1) + 0.5
+        c.allgather_rows(buf, r0, r1)
+        assert np.array_equal(buf, np.arange(n) + 0.5)
+        v = np.full(7, float(c.rank + 1))
+        c.allreduce_sum(v)
+        assert np.array_equal(v, np.full(7, sum(range(1, c.world_size + 1))))
+        c.barrier()
+        assert c.max_float(c.rank * 1.5) == 1.5 * (c.world_size - 1)
+        assert c.allgather_float(10.0 + c.rank) == [10.0 + k for k in range(c.world_size)]
+        return c.rank
+
+    for world in (1, 4, 8):
+        assert run_thread_ranks(world, body, timeout=30.0) == list(range(world))
+
+    def bad(c):
+        if c.rank == 2:
+            raise ValueError('boom')
+        c.barrier()
+
+    with pytest.raises(AssertionError, match='rank 2 of 4 failed.*boom'):
+        run_thread_ranks(4, bad, timeout=30.0)
+
+
 SYM_KEYS = ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_dual', 'al_f', 'ascg_kernel_x',
             'ascg_kernel_f')
 ROW_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'ascg_x', 'ascg_iter', 'ascg_inner')
@@ -167,3 +224,37 @@ def test_allreduce_variant_of_the_symmetric_exchange(tmp_path, one_rank):
             np.testing.assert_allclose(r[key], one_rank[key], rtol=1e-9, atol=1e-11, err_msg=key)
     for key in ('matvec', 'pg_x', 'fw_x'):
         assert np.array_equal(two[0][key], two[1][key]), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_share_contexts_hold_one_ranks_part_of_the_product(world):
+    """bq_ctx_create_share: rank k's share of a `world`-way partition with no transport (what bench.py --emulate-shares times).
+    Its product is that rank's contribution alone: the shares of all ranks add up to the one-rank product (to rounding — the
+    sum over shares is not the canonical segment order), every share owns the rows bq_sym_row_block names, and a share of a
+    one-way partition is the plain context."""
+    from optiml_amd import device
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    n, d = 3000, 16
+    X, y = make_blobs(n, d, seed=5)
+    v = np.random.RandomState(1).standard_normal(n)
+    ctx = device.Context(device=0)
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
+    full = quad.device_problem(ctx).matvec(v)
+    quad.release()
+    ctx.close()
+    acc = np.zeros(n)
+    for k in range(world):
+        ctx = device.Context(device=0, share=(k, world))
+        assert (ctx.rank, ctx.world, ctx.exchange) == (k, world, 'share') and ctx.comm_info()['kind'] == 'share'
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
+        dev = quad.device_problem(ctx)
+        assert dev.dims()[2:] == device.row_block(n, k, world, symmetric=True)
+        part = dev.matvec(v)
+        assert np.array_equal(part, dev.matvec(v))
+        acc += part
+        quad.release()
+        ctx.close()
+    np.testing.assert_allclose(acc, full, rtol=1e-12, atol=1e-12 * np.abs(full).max())

@@ -464,3 +464,84 @@ def test_config5_squared_hinge_active_set_cg_at_full_size():
         res = np.linalg.norm(r0 - it * Qs)
         assert res <= 10 * tol * (np.linalg.norm(QxA) + np.sqrt(A.sum())), (k, res)
     quad.release()
+
+
+def _partition_body(make_quad, make_solver, v, steps):
+    """One rank of a host-exchange partition inside this process: its share of the panel, one product, `steps` iterations."""
+    def body(comm):
+        from optiml_amd import _lib, device
+        ctx = device.Context(device=0, comm=comm, exchange='host')
+        quad = make_quad()
+        try:
+            dev = quad.device_problem(ctx)
+            res = {'rows': dev.dims()[2:], 'matvec': dev.matvec(v)}
+            solver = make_solver(dev)
+            rows, _ = solver.run(steps)
+            res.update(f=rows['f'].copy(), r1=rows['r1'].copy(), x=solver.get(_lib.GET_X_NOW), inner=solver.inner_iters())
+            solver.close()
+        finally:
+            quad.release()
+            ctx.close()
+        return res
+    return body
+
+
+def _assert_partition_equals_one_rank(one, many, n, world):
+    from optiml_amd import device
+    for k, r in enumerate(many):
+        assert r['rows'] == device.row_block(n, k, world, symmetric=True)
+        for key in ('matvec', 'f', 'r1', 'x'):
+            assert np.array_equal(r[key], one[key]), (k, key)
+        assert r['inner'] == one['inner']
+
+
+def test_config4_full_size_over_four_ranks():
+    """C4 at its own size and rank count: SVR / poly(3) / FrankWolfe, n = 100 000 (dual dimension 200 000), the packed panel
+    split over FOUR ranks (balanced triangular shares, 40 GB in all) — the ranks are threads of this process on the one GPU,
+    one context and stream each, exchanging through the host callback (all-gather of the per-segment partial vectors).
+    Product and three solver iterations are bit-identical to one rank."""
+    from test_distributed import run_thread_ranks
+    from optiml_amd import _lib
+    from optiml_amd.datasets import make_regression
+    from optiml_amd.ml.svm.kernels import PolyKernel
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained._base import _DeviceSolver
+    n, d = 100000, 128
+    X, y = make_regression(n, d, seed=0)
+    q = np.hstack((-y, y)) + 0.1
+    v = np.random.RandomState(3).standard_normal(2 * n)
+    make_quad = lambda: KernelQuadratic(X, q, 'svr', PolyKernel(3, 'scale', 1.0))
+    make_solver = lambda dev: _DeviceSolver(dev, _lib.FW, np.zeros(2 * n), np.ones(2 * n), np.ones(2 * n) / 2, 1e-6, 10 ** 9)
+    body = _partition_body(make_quad, make_solver, v, 3)
+    one = run_thread_ranks(1, body)[0]
+    assert np.all(np.diff(one['f']) < 0) and np.array_equal(one['matvec'][:n], -one['matvec'][n:])
+    four = run_thread_ranks(4, body)
+    _assert_partition_equals_one_rank(one, four, n, 4)
+
+
+def test_config5_full_size_over_eight_ranks():
+    """C5 at its own size and rank count: squared-hinge RBF dual, ActiveSet with conjugate-gradient restricted solves,
+    n = 250 000, d = 256, fp32 panel (125 GB in all) split over EIGHT ranks = eight threads / contexts / streams of this
+    process on the one GPU (the box allows six processes on the card), host-callback exchange.  One product and two outer
+    iterations (each tens of masked panel products + one collective each) are bit-identical to one rank."""
+    from test_distributed import run_thread_ranks
+    from optiml_amd import _lib
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained._base import _DeviceSolver
+    n, d = 250000, 256
+    X, y = make_blobs(n, d, seed=0)
+    v = np.random.RandomState(4).standard_normal(n)
+    make_quad = lambda: KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, diag=0.5, storage='f32')
+
+    def make_solver(dev):
+        s = _DeviceSolver(dev, _lib.AS_CG, np.zeros(n), np.full(n, np.inf), np.ones(n), 1e-6, 10 ** 9)
+        s.set_inner(1e-8, 0)
+        return s
+
+    body = _partition_body(make_quad, make_solver, v, 2)
+    one = run_thread_ranks(1, body)[0]
+    assert one['inner'] > 0 and one['f'][1] < one['f'][0]
+    eight = run_thread_ranks(8, body)
+    _assert_partition_equals_one_rank(one, eight, n, 8)

@@ -68,6 +68,62 @@ def test_dense_matvec_and_eval(amd, n, storage):
     quad.release()
 
 
+X_STAR_CASES = ['nd2', 'nd5', 'nd64', 'rbf_svc200', 'lin_svc80', 'rbf_svr40', 'indef48']
+
+
+@pytest.mark.parametrize('tag', X_STAR_CASES)
+def test_quadratic_x_star_and_f_star(amd, tag):
+    """Quadratic.x_star() / f_star() (opti/_base.py:259-273) against the reference's own values: device Cholesky where scipy's
+    cho_factor succeeds (x rtol 1e-9), the restated MINRES with scipy's iteration count where it raises (held to the level its
+    own stop test determines an iterate to)."""
+    from optiml_amd.opti import Quadratic
+    g = load_golden('x_star.npz')
+    Q, q, xr, fr = g[f'{tag}_Q'], g[f'{tag}_q'], g[f'{tag}_x_star'], float(g[f'{tag}_f_star'])
+    quad = Quadratic(Q, q)
+    x = quad.x_star()
+    assert quad.x_opt_method == str(g[f'{tag}_method'])
+    assert x is quad.x_star()                       # cached like the reference's x_opt
+    if quad.x_opt_method == 'cholesky':
+        np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-12 * np.abs(xr).max())
+        np.testing.assert_allclose(quad.f_star(), fr, rtol=1e-11)
+    else:
+        # MINRES stops at |r| <= 1e-5 |Q| |x| (scipy's default rtol): an iterate is determined to that residual level, and its
+        # components along (near-)null directions of Q are rounding noise in the reference too (rbf_svr40: q has a component
+        # along the null vector [1; 1]; lin_svc80: the 6th step of a rank-6 problem returns |x| ~ 6e9 of noise; indef48 runs
+        # all 48 Lanczos steps).  What is reproducible: the branch, the iteration count, the image Q x to the stop level, f*.
+        assert quad.x_opt_iters == int(g[f'{tag}_minres_iters'])
+        level = 2e-5 * np.linalg.norm(Q, 2) * max(np.linalg.norm(x), np.linalg.norm(xr))
+        assert np.linalg.norm(Q @ (x - xr)) <= level
+        assert np.linalg.norm(Q @ x + q) <= np.linalg.norm(Q @ xr + q) + level
+        if tag != 'lin_svc80':
+            np.testing.assert_allclose(quad.f_star(), fr, rtol=1e-3)
+    quad.release()
+
+
+def test_kernel_quadratic_x_star_from_the_packed_panel(amd):
+    """x_star on the lazy SVM duals: H is assembled on the device from the packed Gram tiles (SVC signs and rank-one term,
+    SVR 2n x 2n block structure) — the same fixtures as above, built from X instead of a dense Q."""
+    from optiml_amd.datasets import make_blobs, make_regression
+    from optiml_amd.ml.svm.kernels import gaussian, linear
+    from optiml_amd.opti import KernelQuadratic
+    g = load_golden('x_star.npz')
+    X, y = make_blobs(200, 8, seed=3)
+    quad = KernelQuadratic(X, -np.ones(200), 'svc', gaussian, y=y)
+    np.testing.assert_allclose(quad.x_star(), g['rbf_svc200_x_star'], rtol=1e-7, atol=1e-9 * np.abs(g['rbf_svc200_x_star']).max())
+    assert quad.x_opt_method == 'cholesky'
+    np.testing.assert_allclose(quad.f_star(), float(g['rbf_svc200_f_star']), rtol=1e-10)
+    quad.release()
+    X, t = make_regression(40, 6, seed=5)
+    quad = KernelQuadratic(X, np.hstack((-t, t)) + 0.1, 'svr', gaussian)
+    xr = g['rbf_svr40_x_star']
+    x = quad.x_star()
+    assert quad.x_opt_method == 'minres' and abs(quad.x_opt_iters - int(g['rbf_svr40_minres_iters'])) <= 1
+    Q = g['rbf_svr40_Q']
+    assert np.linalg.norm(Q @ (x - xr)) <= 2e-5 * np.linalg.norm(Q, 2) * np.linalg.norm(xr)   # see the test above
+    np.testing.assert_allclose(quad.f_star(), float(g['rbf_svr40_f_star']), rtol=1e-3)
+    quad.release()
+
+
 def test_matvec_is_deterministic(amd):
     from optiml_amd.opti import Quadratic
     rs = np.random.RandomState(1)

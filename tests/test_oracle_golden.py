@@ -30,6 +30,20 @@ def test_reference_unit_problems(golden, tag, s):
     _cmp_run(res, g, f'{tag}_{s}')
 
 
+X_STAR_CASES = ['nd2', 'nd5', 'nd64', 'rbf_svc200', 'lin_svc80', 'rbf_svr40', 'indef48']
+
+
+@pytest.mark.parametrize('tag', X_STAR_CASES)
+def test_reference_x_star(golden, tag):
+    """Quadratic.x_star() / f_star() of the reference (opti/_base.py:259-273), both branches."""
+    g = golden('x_star.npz')
+    Q, q = g[f'{tag}_Q'], g[f'{tag}_q']
+    x, method = bo.x_star(Q, q)
+    assert method == str(g[f'{tag}_method'])
+    np.testing.assert_allclose(x, g[f'{tag}_x_star'], rtol=1e-12, atol=1e-12 * np.abs(g[f'{tag}_x_star']).max())
+    np.testing.assert_allclose(bo.qp_value(Q, q, x), float(g[f'{tag}_f_star']), rtol=1e-12)
+
+
 def test_reference_nd5_known_optimum(golden):
     # SURVEY section 4: x* and f* of the ndim=5, seed=7, lb=ub/4 problem
     g = golden('unit_problems.npz')

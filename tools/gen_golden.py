@@ -6,8 +6,9 @@ the committed outputs are plain data: inputs and the reference's outputs on them
 
 The reference's box-constrained solvers / SVC / SVR need only numpy + scipy + sklearn, but the
 package import chain also pulls `autograd`, `qpsolvers`, `wurlitzer`, `cvxpy`, `casadi`, which are
-not installed here and are never exercised on this path (`Quadratic` overrides jacobian/hessian,
-`x_star()` is not called).  They are satisfied by empty in-memory modules below; `autograd.numpy`
+not installed here and are never exercised on this path (`Quadratic` overrides jacobian/hessian;
+its own `x_star()` is scipy's cho_solve / minres — only the box-constrained optimizers' `x_star`, which is never called,
+would need qpsolvers).  They are satisfied by empty in-memory modules below; `autograd.numpy`
 is a namespace view of the real numpy, so every arithmetic operation is numpy's own.
 Nothing is written to /root/reference and no reference source is copied.
 
@@ -140,6 +141,52 @@ def gen_unit_problems(out):
     for s, cls in SOLVERS.items():
         data.update(flat('nd64_' + s, run_solver(cls, Q, q, ub, keep=(1, 2, 5, 10, 50, 100))))
     np.savez_compressed(os.path.join(out, 'unit_problems.npz'), **data)
+
+
+def gen_x_star(out):
+    """Quadratic.x_star() / f_star() of the reference (optiml/opti/_base.py:259-273): the Cholesky branch on the strictly convex
+    generator problems and an RBF SVC dual, the minres branch on Hessians that are singular by construction (linear-kernel SVC
+    dual: rank <= d + 1; SVR dual [[K,-K],[-K,K]] + ee': rank <= n + 1) and on an indefinite one (deterministic failure)."""
+    from scipy.linalg import cho_factor
+    from scipy.sparse.linalg import minres
+    cases = {}
+    for tag, kw in (('nd2', dict(ndim=2)), ('nd5', dict(ndim=5, seed=7)), ('nd64', dict(ndim=64, seed=11))):
+        Q, q, _ = generate_box_constrained_quadratic(**kw)
+        cases[tag] = (Q, q)
+    X, y = make_blobs(200, 8, seed=3)
+    K = GaussianKernel(gamma='scale')(X)
+    cases['rbf_svc200'] = (K * np.outer(y, y) + np.outer(y, y), -np.ones(200))
+    X, y = make_blobs(80, 5, seed=4)
+    K = LinearKernel()(X)
+    cases['lin_svc80'] = (K * np.outer(y, y) + np.outer(y, y), -np.ones(80))
+    X, t = make_regression(40, 6, seed=5)
+    K = GaussianKernel(gamma='scale')(X)
+    e = np.hstack((np.ones(40), -np.ones(40)))
+    cases['rbf_svr40'] = (np.vstack((np.hstack((K, -K)), np.hstack((-K, K)))) + np.outer(e, e), np.hstack((-t, t)) + 0.1)
+    rs = np.random.RandomState(6)
+    A = rs.standard_normal((48, 48))
+    w = np.linspace(-1.0, 3.0, 48)
+    U, _ = np.linalg.qr(A)
+    Qi = (U * w) @ U.T
+    cases['indef48'] = ((Qi + Qi.T) / 2, rs.standard_normal(48))
+    data = {}
+    for tag, (Q, q) in cases.items():
+        quad = Quadratic(Q, q)
+        x = np.array(quad.x_star(), dtype=float)
+        f = float(quad.f_star())
+        try:
+            cho_factor(Q)
+            method = 'cholesky'
+            its = 0
+        except np.linalg.LinAlgError:
+            method = 'minres'
+            cnt = [0]
+            minres(Q, -q, callback=lambda xk: cnt.__setitem__(0, cnt[0] + 1))
+            its = cnt[0]
+        data.update({f'{tag}_Q': Q, f'{tag}_q': q, f'{tag}_x_star': x, f'{tag}_f_star': f, f'{tag}_method': method,
+                     f'{tag}_minres_iters': its})
+        print(f'  {tag}: {method} ({its} minres iterations), f* = {f:.12g}, |Qx+q| = {np.linalg.norm(Q @ x + q):.3e}')
+    np.savez_compressed(os.path.join(out, 'x_star.npz'), **data)
 
 
 def gen_kernels(out):
@@ -561,7 +608,7 @@ def main():
     ap.add_argument('--only', default=None, help='run a single generator, e.g. gen_kernels_more')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    for fn in (gen_unit_problems, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5, gen_cfg1, gen_lagrangian, gen_smo):
+    for fn in (gen_unit_problems, gen_x_star, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5, gen_cfg1, gen_lagrangian, gen_smo):
         if args.only and fn.__name__ != args.only:
             continue
         print(fn.__name__)
