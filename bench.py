@@ -86,6 +86,9 @@ def parse(argv=None):
                          '(bq_ctx_create_share: every per-rank kernel of the iteration, collectives are no-ops) and time it; prints '
                          'one JSON record with per-share kernel time / GB/s / fixed cost and the iteration rate they predict for '
                          'G GPUs (e.g. --emulate-shares 1,2,4,8)')
+    ap.add_argument('--probe-gib', default='', metavar='GiB[,GiB...]',
+                    help='--emulate-shares: also run the bare streaming-read / copy probe on scratch buffers of these sizes (is the '
+                         'read rate a function of the footprint?)')
     ap.add_argument('--exchange-us', type=float, default=50.0,
                     help='--emulate-shares: ASSUMED duration of the one collective per product (not measurable on one GPU); the '
                          'prediction is printed with it and with 0')
@@ -533,6 +536,14 @@ def share_timing(args):
             'predicted_iter_per_s_no_exchange': 1e3 / worst,
             'predicted_iter_per_s': 1e3 / (worst + (args.exchange_us * 1e-3 if G > 1 else 0.0)),
             'min_symv_frac_of_8TBs': min(s['symv_frac_of_8TBs'] for s in shares)})
+    if args.probe_gib:
+        ctx = device.Context()
+        out['probe'] = []
+        for gib in [float(x) for x in args.probe_gib.split(',') if x]:
+            r, c = ctx.probe_bandwidth(int(gib * (1 << 30)), 5)
+            out['probe'].append({'GiB': gib, 'read_GBs': r, 'copy_GBs': c})
+            print(f'[share] probe {gib} GiB: read {r:.0f} GB/s, copy {c:.0f} GB/s', file=sys.stderr, flush=True)
+        ctx.close()
     base = next((p for p in out['partitions'] if p['G'] == 1), None)
     if base:
         for p in out['partitions']:
@@ -725,6 +736,9 @@ def main():
         if ascg:
             out['inner_products_per_step'] = inner / max(done, 1)
             out['inner_tol'] = args.inner_tol
+            out['inner_preconditioner'] = 'none (BQ_AS_CG_PC=0)' if os.environ.get('BQ_AS_CG_PC') == '0' else \
+                'diagonal + first-order Taylor features of the RBF kernel (d + 2 columns), Woodbury'
+            out['inner_warm_start'] = os.environ.get('BQ_AS_CG_WARM') != '0'
             out['products_per_sec'] = mv_cnt / elapsed
         traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
         if traffic:

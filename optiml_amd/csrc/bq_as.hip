@@ -29,7 +29,9 @@
 // restricted system is solved by conjugate gradients on the masked panel operator v -> m.(Q (m.v)), m = indicator of
 // A — no H, no factorisation, one panel product per inner iteration, so it runs on sharded, fp32-stored and streamed
 // panels and on any number of ranks (the vectors and scalar recurrences are replicated, reductions fixed-order).  The
-// iteration starts from the current point (delta = 0), which after a one-index change of A is already close.
+// iteration starts from the candidate of the previous outer iteration (the free set has moved by one index since) and, on
+// RBF / linear panels, is preconditioned by a diagonal + low-rank model of Q[A,A] built from explicit features (struct
+// as_pc): at BASELINE config 5 that takes the inner iterations per outer iteration from ~80 to ~30 (round 3).
 #include <cmath>
 
 #include <algorithm>
@@ -55,6 +57,25 @@ struct as_cg_scal {
     long long iters, max_iters;
     int done, info;
     unsigned int ticket[2];
+    double rz;   // preconditioned runs: r'z (alpha = rz / p'Qp, beta = rz_new / rz)
+    int pc, pad;
+};
+
+// Preconditioner of the inner conjugate gradients: P = D + Phi Phi' restricted to the free set, Phi (N x m, m << N) an
+// explicit low-rank factor of the smooth part of the Hessian and D the diagonal left over.  Applied through Woodbury:
+//   P_AA^-1 r = D^-1 r - D^-1 Phi_A G^-1 Phi_A' D^-1 r,   G = I + Phi_A' D_A^-1 Phi_A  (m x m, factorised once per outer iteration).
+// RBF panels: the first-order Taylor features of exp(-g|x-x'|^2) = e^{-g|x|^2} e^{-g|x'|^2} (1 + 2g x.x' + ...), i.e.
+// Phi_i = y_i e^{-g|x_i|^2} [1, sqrt(2g) x_i] (+ the y_i column of the rank-one term): the d + 1 directions whose eigenvalues
+// grow like n.  Linear panels: Phi = y o [X, 1] is exact.  The other kernels run unpreconditioned.
+struct as_pc {
+    int m = 0;               // features
+    int64_t mp = 0;          // m padded to the factorisation block
+    double *Phi = nullptr;   // m x ldN, feature-major (a column of the N x m matrix is contiguous)
+    double *dinv = nullptr;  // ldN: 1 / D_i
+    double *z = nullptr;     // ldN: preconditioned residual
+    double *Gpart = nullptr; // slices x mp x mp partial Gram sums
+    double *cls = nullptr;   // class statistics (as_pc_class_kernel), BQ_SVC + RBF only
+    bq_chol_ws *ws = nullptr;
 };
 
 struct as_ws {
@@ -74,6 +95,9 @@ struct as_ws {
     as_cg_scal *cg = nullptr;
     int *cg_flag_host = nullptr;   // pinned: {done, info}
     long long cg_iters = 0;
+    as_pc *pc = nullptr;           // null: plain conjugate gradients
+    bool have_cand = false;        // w->cand holds the candidate of the previous outer iteration (the warm start)
+    bool warm = true;              // BQ_AS_CG_WARM=0: start every inner solve from the current point
 };
 
 
@@ -447,10 +471,13 @@ __global__ void as_make_xt_kernel(int64_t N, const unsigned char *__restrict__ m
 }
 
 // r = p = -(Q xt + q) on A, 0 elsewhere; delta = 0; the stop level is rtol * (|(Q xt)_A| + |q_A|)
+// (Qlevel: the product the stop level is taken from — Q x of the CURRENT point when the iteration starts somewhere else, so
+// that a warm start does not change what "solved to rtol" means)
 __global__ void as_cg_init_kernel(int64_t N, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
-                                  const double *__restrict__ Qxt, const double *__restrict__ q, double *__restrict__ dlt,
+                                  const double *__restrict__ Qxt, const double *__restrict__ Qlevel,
+                                  const double *__restrict__ q, double *__restrict__ dlt,
                                   double *__restrict__ r, double *__restrict__ pv, double *part, int64_t nblk,
-                                  as_cg_scal *cg, double rtol, long long max_iters) {
+                                  as_cg_scal *cg, double rtol, long long max_iters, int pc) {
     __shared__ double sh[4];
     double srr = 0.0, sqx = 0.0, sq = 0.0;
     VEC_LOOP(i) {
@@ -463,7 +490,8 @@ __global__ void as_cg_init_kernel(int64_t N, const unsigned char *__restrict__ m
             dlt[i] = 0.0;
             srr += __dmul_rn(ri, ri);
             if (fr) {
-                sqx += __dmul_rn(a, a);
+                const double al = Qlevel[i];
+                sqx += __dmul_rn(al, al);
                 sq += __dmul_rn(b, b);
             }
         }
@@ -489,6 +517,8 @@ __global__ void as_cg_init_kernel(int64_t N, const unsigned char *__restrict__ m
             cg->iters = 0;
             cg->max_iters = max_iters;
             cg->info = 0;
+            cg->pc = pc;
+            cg->rz = rr;
             cg->done = (rr <= cg->tol2) ? 1 : 0;
         }
     }
@@ -513,7 +543,7 @@ __global__ void as_cg_pap_kernel(int64_t N, const double *__restrict__ pv, const
                 cg->info = 1;
                 cg->alpha = 0.0;
             } else {
-                cg->alpha = cg->rr / pAp;
+                cg->alpha = (cg->pc ? cg->rz : cg->rr) / pAp;
             }
         }
     }
@@ -541,7 +571,7 @@ __global__ void as_cg_update_kernel(int64_t N, const unsigned char *__restrict__
         const double rr = as_final_sum(part, nblk, sh);
         if (threadIdx.x == 0) {
             cg->ticket[1] = 0;
-            cg->beta = cg->rr > 0.0 ? rr / cg->rr : 0.0;
+            if (!cg->pc) cg->beta = cg->rr > 0.0 ? rr / cg->rr : 0.0;   // preconditioned: beta = rz_new / rz (as_pc_apply_kernel)
             cg->rr = rr;
             cg->iters += 1;
             if (cg->info || rr <= cg->tol2 || cg->iters >= cg->max_iters || !isfinite(rr)) cg->done = 1;
@@ -558,12 +588,235 @@ __global__ void as_cg_dir_kernel(int64_t N, const double *__restrict__ r, double
     }
 }
 
-// sol[a] = x[idx[a]] + delta[idx[a]]: the restricted solution in the compact order as_candidate_kernel reads
+// sol[a] = x[idx[a]] + delta[idx[a]] (x: the point the iteration started from): the restricted solution in the compact order
+// as_candidate_kernel reads
 __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__restrict__ idx,
                                     const double *__restrict__ x, const double *__restrict__ dlt,
                                     double *__restrict__ sol, int64_t N) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a < ints[0] && a < N) sol[a] = x[idx[a]] + dlt[idx[a]];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the diagonal + low-rank preconditioner of the inner iteration (struct as_pc)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PC_MAX_M = 1024;   // features the apply kernel keeps in LDS
+constexpr int PC_T = 32, PC_C = 64, PC_SLICES = 8;
+
+// class statistics of the samples (BQ_SVC panels): cls[k] = a_k = (mean_+ - mean_-)_k / 2, cls[d + k] = m0_k = (mean_+ + mean_-)_k / 2,
+// cls[2d] = |a|.  One workgroup per feature column for the sums, the last one to finish closes.
+__global__ __launch_bounds__(256) void as_pc_class_kernel(int64_t n, int64_t d, const double *__restrict__ X,
+                                                          const double *__restrict__ sgn, double *__restrict__ cls,
+                                                          unsigned int *ticket) {
+    __shared__ double sh[4];
+    const int64_t k = blockIdx.x;
+    double sp = 0.0, sm = 0.0, cp = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double v = X[i * d + k];
+        if (sgn[i] > 0.0) {
+            sp += v;
+            cp += 1.0;
+        } else {
+            sm += v;
+        }
+    }
+    sp = as_block_sum(sp, sh);
+    sm = as_block_sum(sm, sh);
+    cp = as_block_sum(cp, sh);
+    if (threadIdx.x == 0) {
+        const double cm = (double)n - cp;
+        const double mp = cp > 0.0 ? sp / cp : 0.0, mm = cm > 0.0 ? sm / cm : 0.0;
+        cls[k] = (cp > 0.0 && cm > 0.0) ? 0.5 * (mp - mm) : 0.0;
+        cls[d + k] = (cp > 0.0 && cm > 0.0) ? 0.5 * (mp + mm) : (cp > 0.0 ? mp : mm);
+    }
+    if (as_last_block(ticket)) {
+        double s2 = 0.0;
+        for (int64_t j = threadIdx.x; j < d; j += 256) s2 += cls[j] * cls[j];
+        s2 = as_block_sum(s2, sh);
+        if (threadIdx.x == 0) {
+            cls[2 * d] = sqrt(s2);
+            *ticket = 0;
+        }
+    }
+}
+
+// Phi (feature-major) and 1 / D_i, D_i = Q_ii - |Phi_i|^2 (floored at 1e-8 Q_ii: P only has to be positive definite).
+// One thread per sample.  RBF:
+//   family 1 (d + 1 columns): y e^{-g|x|^2} [1, sqrt(2g) x]                    the order-0/1 terms of e^{2g x.x'}
+//   family 2 (d columns, BQ_SVC): 2g |a| e^{-g|x|^2} (x - m0 - y a)               the cross term 2 (y y' |a|^2)(e.e') of the order-2
+//       term (2g x.x')^2 / 2 with x = m0 + y a + e split into class means and deviation: d more directions whose eigenvalues
+//       grow like n (at BASELINE config 5 they sit at ~0.4 of family 1's)
+__global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t ld, const double *__restrict__ X,
+                                      const double *__restrict__ sgn, const double *__restrict__ cls, double gamma,
+                                      int add_one, double diag_add, int m, double *__restrict__ Phi, double *__restrict__ dinv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ld) return;
+    if (i >= n) {
+        for (int j = 0; j < m; ++j) Phi[(int64_t)j * ld + i] = 0.0;
+        dinv[i] = 0.0;
+        return;
+    }
+    const double y = sgn ? sgn[i] : 1.0;
+    const double *x = X + i * d;
+    double sq = 0.0;
+    for (int64_t k = 0; k < d; ++k) sq = fma(x[k], x[k], sq);
+    double s = 0.0, qii;
+    int col = 0;
+    if (kernel == BQ_KERNEL_RBF) {
+        const double e = exp(-gamma * sq);
+        const double c0 = y * e, c1 = c0 * sqrt(2.0 * gamma);
+        Phi[i] = c0;
+        s = c0 * c0;
+        for (int64_t k = 0; k < d; ++k) {
+            const double v = c1 * x[k];
+            Phi[(1 + k) * ld + i] = v;
+            s = fma(v, v, s);
+        }
+        col = (int)d + 1;
+        if (cls != nullptr) {
+            const double c2 = 2.0 * gamma * cls[2 * d] * e;
+            for (int64_t k = 0; k < d; ++k) {
+                const double v = c2 * (x[k] - cls[d + k] - y * cls[k]);
+                Phi[(col + k) * ld + i] = v;
+                s = fma(v, v, s);
+            }
+            col += (int)d;
+        }
+        qii = 1.0;
+    } else {   // linear: exact features
+        for (int64_t k = 0; k < d; ++k) {
+            const double v = y * x[k];
+            Phi[k * ld + i] = v;
+            s = fma(v, v, s);
+        }
+        col = (int)d;
+        qii = sq;
+    }
+    if (add_one) {
+        Phi[(int64_t)col * ld + i] = y;
+        s += 1.0;
+        qii += 1.0;
+    }
+    qii += diag_add;
+    dinv[i] = 1.0 / fmax(qii - s, 1e-8 * qii);
+}
+
+// Gpart[slice][a][b] = sum over the slice's FREE samples of Phi[a][i] Phi[b][i] / D_i, lower tiles (b-tile <= a-tile)
+__global__ __launch_bounds__(256) void as_pc_gram_kernel(int m, int64_t mp, int64_t N, int64_t ld, const double *__restrict__ Phi,
+                                                         const double *__restrict__ dinv, const unsigned char *__restrict__ mL,
+                                                         const unsigned char *__restrict__ mU, double *__restrict__ Gpart) {
+    __shared__ double As[PC_T][PC_C + 1], Bs[PC_T][PC_C + 1];
+    // (ta, tb) from the linear lower-triangle tile index
+    int ta = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((ta + 1) * (ta + 2) / 2 <= (int)blockIdx.x) ++ta;
+    while (ta * (ta + 1) / 2 > (int)blockIdx.x) --ta;
+    const int tb = (int)blockIdx.x - ta * (ta + 1) / 2;
+    const int a0 = ta * PC_T, b0 = tb * PC_T;
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    const int64_t per = ((N + PC_SLICES - 1) / PC_SLICES + PC_C - 1) / PC_C * PC_C;
+    const int64_t i0 = (int64_t)blockIdx.y * per, i1 = i0 + per < N ? i0 + per : N;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t c = i0; c < i1; c += PC_C) {
+#pragma unroll
+        for (int k = 0; k < (PC_T * PC_C) / 256; ++k) {
+            const int e = t + k * 256, row = e / PC_C, cc = e % PC_C;
+            const int64_t i = c + cc;
+            double wgt = 0.0;
+            if (i < i1 && !(mL[i] | mU[i])) wgt = dinv[i];
+            As[row][cc] = (a0 + row < m && wgt != 0.0) ? Phi[(int64_t)(a0 + row) * ld + i] * wgt : 0.0;
+            Bs[row][cc] = (b0 + row < m && i < i1) ? Phi[(int64_t)(b0 + row) * ld + i] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < PC_C; ++k) {
+            const double bv = Bs[tx][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fma(As[ty * 4 + j][k], bv, acc[j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        Gpart[((int64_t)blockIdx.y * mp + a0 + ty * 4 + j) * mp + b0 + tx] = acc[j];
+}
+
+// H = I + the slices of Gpart added in slice order (lower triangle; identity on the pad rows)
+__global__ void as_pc_gram_reduce_kernel(int m, int64_t mp, const double *__restrict__ Gpart, double *__restrict__ H, int64_t ldh) {
+    const int64_t a = blockIdx.y, b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b > a || b >= mp) return;
+    double v = (a == b) ? 1.0 : 0.0;
+    if (a < m)
+        for (int sidx = 0; sidx < PC_SLICES; ++sidx) v += Gpart[((int64_t)sidx * mp + a) * mp + b];
+    H[a * ldh + b] = v;
+}
+
+// t[j] = sum_i Phi[j][i] r_i / D_i   (r vanishes outside the free set); one workgroup per feature, fixed order
+__global__ __launch_bounds__(256) void as_pc_tphi_kernel(int m, int64_t N, int64_t ld, const double *__restrict__ Phi,
+                                                         const double *__restrict__ dinv, const double *__restrict__ r,
+                                                         double *__restrict__ tvec, const as_cg_scal *cg) {
+    if (cg->done) return;
+    __shared__ double sh[4];
+    const int j = blockIdx.x;
+    if (j >= m) {
+        if (threadIdx.x == 0) tvec[j] = 0.0;
+        return;
+    }
+    const double *col = Phi + (int64_t)j * ld;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 768 < N; i += 1024) {
+        s0 = fma(col[i], r[i] * dinv[i], s0);
+        s1 = fma(col[i + 256], r[i + 256] * dinv[i + 256], s1);
+        s2 = fma(col[i + 512], r[i + 512] * dinv[i + 512], s2);
+        s3 = fma(col[i + 768], r[i + 768] * dinv[i + 768], s3);
+    }
+    for (; i < N; i += 256) s0 = fma(col[i], r[i] * dinv[i], s0);
+    const double s = as_block_sum((s0 + s1) + (s2 + s3), sh);
+    if (threadIdx.x == 0) tvec[j] = s;
+}
+
+// z = P^-1 r on the free set: z_i = (r_i - Phi_i . u) / D_i, u = G^-1 t;  rz = r'z;  beta = rz / rz_old (first: 0)
+__global__ void as_pc_apply_kernel(int m, int64_t N, int64_t ld, const double *__restrict__ Phi, const double *__restrict__ dinv,
+                                   const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                   const double *__restrict__ r, const double *__restrict__ u, double *__restrict__ z,
+                                   double *part, int64_t nblk, as_cg_scal *cg, int first) {
+    if (cg->done) return;
+    __shared__ double us[PC_MAX_M];
+    __shared__ double sh[4];
+    for (int j = threadIdx.x; j < m; j += BQ_VEC_BLOCK) us[j] = u[j];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + threadIdx.x;
+    double acc[BQ_VEC_ITEMS];
+#pragma unroll
+    for (int k = 0; k < BQ_VEC_ITEMS; ++k) acc[k] = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const double *col = Phi + (int64_t)j * ld + base;   // ld is a multiple of the tile: always in range
+        const double uj = us[j];
+#pragma unroll
+        for (int k = 0; k < BQ_VEC_ITEMS; ++k) acc[k] = fma(col[k * BQ_VEC_BLOCK], uj, acc[k]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < BQ_VEC_ITEMS; ++k) {
+        const int64_t i = base + (int64_t)k * BQ_VEC_BLOCK;
+        double zi = 0.0;
+        if (i < N && !(mL[i] | mU[i])) {
+            zi = dinv[i] * (r[i] - acc[k]);
+            s += __dmul_rn(r[i], zi);
+        }
+        z[i] = zi;
+    }
+    s = as_block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (as_last_block(&cg->ticket[0])) {
+        const double rz = as_final_sum(part, nblk, sh);
+        if (threadIdx.x == 0) {
+            cg->ticket[0] = 0;
+            cg->beta = (first || !(cg->rz > 0.0)) ? 0.0 : rz / cg->rz;
+            cg->rz = rz;
+            if (!(rz > 0.0) || !isfinite(rz)) cg->info = 2;   // P is positive definite: r'z <= 0 means r = 0 or a broken factor
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1094,8 +1347,84 @@ static int as_schur_step(bq_solver *s, as_ws *w, int64_t nA, bool *solved) {
     return BQ_OK;
 }
 
+static bool as_env_on(const char *name) {
+    const char *e = getenv(name);
+    return !(e && atoi(e) == 0);
+}
+
+// build the preconditioner's features once per solver (null: the panel's kernel has none, or BQ_AS_CG_PC=0)
+static int as_pc_create(bq_solver *s, as_pc **out) {
+    *out = nullptr;
+    bq_problem *p = s->p;
+    if (!as_env_on("BQ_AS_CG_PC")) return BQ_OK;
+    if (p->X == nullptr || (p->structure != BQ_PLAIN && p->structure != BQ_SVC)) return BQ_OK;
+    int m;
+    const bool classes = p->kernel == BQ_KERNEL_RBF && p->structure == BQ_SVC && as_env_on("BQ_AS_CG_PC_CLASS");
+    if (p->kernel == BQ_KERNEL_RBF)
+        m = (int)p->d + 1 + (classes ? (int)p->d : 0);
+    else if (p->kernel == BQ_KERNEL_LINEAR && p->diag_add > 0.0)
+        m = (int)p->d;
+    else
+        return BQ_OK;
+    if (p->add_one) m += 1;
+    if (m > PC_MAX_M || p->d > PC_MAX_M) return BQ_OK;
+    bq_ctx *ctx = p->ctx;
+    as_pc *pc = new as_pc();
+    pc->m = m;
+    pc->mp = bq_round_up(m, 128);
+    int rc = bq_chol_ws_create(ctx, pc->mp, &pc->ws);
+    hipError_t e = hipSuccess;
+    if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(double) * (size_t)m * s->ldN);
+    if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->dinv, sizeof(double) * s->ldN);
+    if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->z, sizeof(double) * s->ldN);
+    if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gpart, sizeof(double) * PC_SLICES * pc->mp * pc->mp);
+    if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->Gpart, 0, sizeof(double) * PC_SLICES * pc->mp * pc->mp, ctx->stream);
+    if (rc != BQ_OK || e != hipSuccess) {   // no room for the features: run unpreconditioned rather than fail
+        if (pc->ws) bq_chol_ws_destroy(pc->ws);
+        for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart})
+            if (ptr) hipFree(ptr);
+        delete pc;
+        (void)hipGetLastError();
+        return BQ_OK;
+    }
+    if (classes) {
+        BQ_HIP(hipMalloc(&pc->cls, sizeof(double) * (2 * p->d + 2)));
+        BQ_HIP(hipMemsetAsync(pc->cls, 0, sizeof(double) * (2 * p->d + 2), ctx->stream));
+        unsigned int *ticket = (unsigned int *)(pc->cls + 2 * p->d + 1);   // the spare slot, zeroed above
+        as_pc_class_kernel<<<(unsigned)p->d, 256, 0, ctx->stream>>>(p->n, p->d, p->X, p->sgn, pc->cls, ticket);
+    }
+    as_pc_features_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->kernel, p->n, p->d, s->ldN, p->X, p->sgn, pc->cls,
+                                                                             p->gamma, p->add_one ? 1 : 0, p->diag_add, m, pc->Phi,
+                                                                             pc->dinv);
+    BQ_HIP(hipGetLastError());
+    *out = pc;
+    return BQ_OK;
+}
+
+static void as_pc_free(as_pc *pc) {
+    if (!pc) return;
+    if (pc->ws) bq_chol_ws_destroy(pc->ws);
+    for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls})
+        if (ptr) hipFree(ptr);
+    delete pc;
+}
+
+// z = P_AA^-1 r (+ r'z and beta on the device)
+static int as_pc_apply(bq_solver *s, as_ws *w, int first) {
+    as_pc *pc = w->pc;
+    hipStream_t st = s->p->ctx->stream;
+    as_pc_tphi_kernel<<<(unsigned)pc->mp, 256, 0, st>>>(pc->m, s->N, s->ldN, pc->Phi, pc->dinv, w->r, pc->ws->rhs, w->cg);
+    BQ_TRY(bq_chol_solve(pc->ws, pc->mp));
+    as_pc_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(pc->m, s->N, s->ldN, pc->Phi, pc->dinv, s->mL, s->mU, w->r,
+                                                               pc->ws->rhs, pc->z, s->partials, s->nblk, w->cg, first);
+    return BQ_OK;
+}
+
 // the restricted solve of one outer iteration by conjugate gradients; leaves the candidate in w->cand and the
-// feasibility flag in w->host_ints[2]
+// feasibility flag in w->host_ints[2].
+//   start: the candidate of the previous outer iteration (the free set has moved by one index since, so it solves the new
+//   system up to one column of Q), else the current point;  BQ_AS_CG_WARM=0: always the current point
+//   preconditioner: struct as_pc (RBF and linear panels);   BQ_AS_CG_PC=0: none
 static int as_cg_solve(bq_solver *s, as_ws *w) {
     bq_ctx *ctx = s->p->ctx;
     hipStream_t st = ctx->stream;
@@ -1103,10 +1432,26 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
     const int64_t nA = w->host_ints[0];
     const dim3 grid = vgrid(s->ldN);
     const long long cap = s->inner_max > 0 ? s->inner_max : 2 * (long long)nA + 50;
-    as_make_xt_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, s->x, w->z);
+    as_pc *pc = w->pc;
+    const double *start = (w->warm && w->have_cand) ? w->cand : s->x;
+    as_make_xt_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, start, w->z);
     BQ_TRY(bq_problem_apply(s->p, w->z, w->Qz, nullptr));
-    as_cg_init_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->Qz, s->p->q, w->dlt, w->r, w->pv, s->partials,
-                                                     nblk, w->cg, s->inner_rtol, cap);
+    // s->Qd = Q x of the current point (eval_f at the end of the previous outer iteration, or of bq_as_start)
+    as_cg_init_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->Qz, start == s->x ? w->Qz : s->Qd, s->p->q, w->dlt, w->r,
+                                                     w->pv, s->partials, nblk, w->cg, s->inner_rtol, cap, pc ? 1 : 0);
+    const double *zr = w->r;   // what the next direction is built from: the residual, or the preconditioned residual
+    if (pc) {
+        // G = I + Phi_A' D_A^-1 Phi_A for the free set of this outer iteration, factorised once
+        const int tiles = (int)(pc->mp / PC_T);
+        as_pc_gram_kernel<<<dim3((unsigned)(tiles * (tiles + 1) / 2), PC_SLICES), 256, 0, st>>>(pc->m, pc->mp, N, s->ldN, pc->Phi, pc->dinv,
+                                                                                               s->mL, s->mU, pc->Gpart);
+        as_pc_gram_reduce_kernel<<<dim3((unsigned)((pc->mp + 255) / 256), (unsigned)pc->mp), 256, 0, st>>>(pc->m, pc->mp, pc->Gpart,
+                                                                                                         pc->ws->H, pc->ws->ldh);
+        BQ_TRY(bq_chol_factor(pc->ws, pc->mp));
+        BQ_TRY(as_pc_apply(s, w, 1));
+        as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, pc->z, w->pv, w->cg);   // beta = 0: p = z
+        zr = pc->z;
+    }
     // batches of inner iterations between looks at the done flag; after it is set the vector kernels return at once
     // and only the products of the rest of the batch are wasted, so batches start small
     int batch = 4;
@@ -1120,24 +1465,33 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
             as_cg_pap_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, w->pv, w->Qp, s->partials, nblk, w->cg);
             as_cg_update_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->dlt, w->r, w->pv, w->Qp, s->partials,
                                                                nblk, w->cg);
-            as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, w->r, w->pv, w->cg);
+            if (pc) BQ_TRY(as_pc_apply(s, w, 0));
+            as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, zr, w->pv, w->cg);
         }
         queued += batch;
         if (batch < 32) batch *= 2;
     }
     as_cg_scal h;
     BQ_HIP(hipMemcpyAsync(&h, w->cg, sizeof(as_cg_scal), hipMemcpyDeviceToHost, st));
+    int pc_info = 0;
+    if (pc) BQ_HIP(hipMemcpyAsync(&pc_info, pc->ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     w->cg_iters += h.iters;
+    if (pc_info != 0 || h.info == 2) {
+        bq_set_error("the preconditioner of the inner conjugate gradients is not positive definite (pivot %d, |A| = %lld): "
+                     "BQ_AS_CG_PC=0 runs without it", pc_info, (long long)nA);
+        return BQ_ERR_NOT_PD;
+    }
     if (h.info != 0 || !std::isfinite(h.rr)) {
         bq_set_error("conjugate gradients on the restricted Hessian Q[A,A] (|A| = %lld) met a direction of non-positive "
                      "curvature after %lld iterations: the system is not positive definite",
                      (long long)nA, (long long)h.iters);
         return BQ_ERR_NOT_PD;
     }
-    as_cg_gather_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(w->ints, w->idx, s->x, w->dlt, w->sol, N);
+    as_cg_gather_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(w->ints, w->idx, w->z, w->dlt, w->sol, N);
     as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
     as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, w->sol, s->lb, s->ub, w->cand);
+    w->have_cand = true;
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     return BQ_OK;
@@ -1167,6 +1521,8 @@ int bq_as_start(bq_solver *s) {
         BQ_HIP(hipMalloc(&w->cg, sizeof(as_cg_scal)));
         BQ_HIP(hipMemsetAsync(w->cg, 0, sizeof(as_cg_scal), ctx->stream));
         BQ_HIP(hipHostMalloc(&w->cg_flag_host, 2 * sizeof(int)));
+        w->warm = as_env_on("BQ_AS_CG_WARM");
+        BQ_TRY(as_pc_create(s, &w->pc));
     }
     BQ_HIP(hipMalloc(&s->mL, (size_t)s->ldN));
     BQ_HIP(hipMalloc(&s->mU, (size_t)s->ldN));
@@ -1183,6 +1539,7 @@ void bq_as_free(bq_solver *s) {
                     (void *)w->cg})
         if (p) hipFree(p);
     if (w->cg_flag_host) hipHostFree(w->cg_flag_host);
+    as_pc_free(w->pc);
     as_schur_free(w);
     delete w;
     s->as_ws = nullptr;
