@@ -76,9 +76,13 @@ def parse(argv=None):
     ap.add_argument('--cpu-sizes', default='20000,30000', help='sample sizes of the CPU baseline leg (SURVEY 8d)')
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='timed seconds per CPU sample size')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--kkt', default='all', choices=['none', 'smo', 'ip', 'all'],
+    ap.add_argument('--cpu-stream-iters', type=int, default=0,
+                    help='also time a blocked Gram-streaming CPU product at the FULL n this many times (~35 s each at n=100000): a '
+                         'measured CPU bound beside the extrapolated reference-formulation figure (SURVEY 8d)')
+    ap.add_argument('--kkt', default='all', choices=['none', 'smo', 'ip', 'all', 'ip100k'],
                     help="time_to_kkt sub-records of the default line (N=1): smo = SVC.fit(optimizer='smo') at the workload's "
-                         'n (tol 1e-3), ip = InteriorPoint at BASELINE config 3 shape n=50000 d=128 (gap 1e-10, ~50 s)')
+                         'n (tol 1e-3), ip = InteriorPoint at BASELINE config 3 shape n=50000 d=128 (gap 1e-10, ~50 s); ip100k = all of '
+                         'these + InteriorPoint at the HEADLINE size n=100000 d=128 (~6.5 min: not in the default line)')
     ap.add_argument('--sigma', type=float, default=8.0, help='blob spread of the synthetic data (SURVEY 8d: 8 overlapping, 3 separable)')
     ap.add_argument('--inner-tol', type=float, default=1e-8, help='ascg: relative residual of the inner conjugate gradients')
     ap.add_argument('--emulate-shares', default=None, metavar='G[,G...]',
@@ -143,12 +147,39 @@ def spawn_ranks(n):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU legs (the oracle is imported HERE only: it is the thing timed beside the device path, never part of it)
 # ---------------------------------------------------------------------------------------------------------------------
-def _cpu_info():
+def _blas_threads():
+    """(threads the BLAS behind numpy's `@` actually runs, how that was found out).  threadpoolctl when importable; otherwise the
+    OpenBLAS that numpy loaded is asked directly (openblas_get_num_threads through ctypes on the library in /proc/self/maps) —
+    os.cpu_count() is NOT the answer on a 256-thread host where OpenBLAS was built for 64."""
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        threads = os.cpu_count() or 1
+        pools = [p for p in threadpool_info() if p.get('user_api') == 'blas'] or threadpool_info()
+        if pools:
+            return max(p.get('num_threads', 1) for p in pools), 'threadpoolctl'
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        import ctypes
+        np.dot(np.ones(4), np.ones(4))   # make sure the BLAS is loaded
+        libs = sorted({line.split()[-1] for line in open('/proc/self/maps') if 'openblas' in line.lower() and '.so' in line})
+        for path in libs:
+            lib = ctypes.CDLL(path)
+            for sym in ('openblas_get_num_threads', 'openblas_get_num_threads64_', 'scipy_openblas_get_num_threads64_',
+                        'scipy_openblas_get_num_threads'):
+                fn = getattr(lib, sym, None)
+                if fn is not None:
+                    fn.restype = ctypes.c_int
+                    return int(fn()), f'{sym} of {os.path.basename(path)}'
+    except Exception:  # noqa: BLE001
+        pass
+    env = os.environ.get('OPENBLAS_NUM_THREADS') or os.environ.get('OMP_NUM_THREADS')
+    if env and env.isdigit():
+        return int(env), 'environment'
+    return os.cpu_count() or 1, 'os.cpu_count() (BLAS not identified)'
+
+
+def _cpu_info():
+    threads, how = _blas_threads()
     model = ''
     try:
         for line in open('/proc/cpuinfo'):
@@ -157,7 +188,7 @@ def _cpu_info():
                 break
     except OSError:
         pass
-    return {'cores': int(threads), 'cpu_model': model, 'os_cpu_count': os.cpu_count(),
+    return {'cores': int(threads), 'cores_source': how, 'cpu_model': model, 'os_cpu_count': os.cpu_count(),
             'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS'), 'OPENBLAS_NUM_THREADS': os.environ.get('OPENBLAS_NUM_THREADS')}
 
 
@@ -204,14 +235,47 @@ def cpu_baseline(args):
         expo = 2.0
     fitted = 1.0 / (last['s_per_iter'] * (args.n / last['n']) ** expo) if args.n > last['n'] else 1.0 / last['s_per_iter']
     desc = ', '.join(f"n={s['n']}: {s['iters']} it, {1e3 * s['s_per_iter']:.1f} ms/it ({s['GBs_of_Q']:.0f} GB/s of Q)" for s in samples)
-    out = {'value': fitted, 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': args.n > last['n'],
-           'fitted_exponent': expo, 'value_n2_law': n2,
+    out = {'value': n2, 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': args.n > last['n'],
+           'law': 'n^2 (three dense n x n products per iteration)', 'fitted_exponent': expo, 'value_fitted_exponent': fitted,
            'sample': f'oracle {args.solver.upper()} (reference formulation: dense fp64 Q on host, 3 products/iter), d={args.d}: {desc}; '
-                     f'value = rate at n={last["n"]} scaled to n={args.n} with the fitted exponent {expo:.2f} '
-                     f'(value_n2_law: with exponent 2); Gram+Q assembly excluded',
+                     f'value = rate at n={last["n"]} scaled to n={args.n} by (n_s/n)^2, the law of a bandwidth-bound dense product '
+                     f'(value_fitted_exponent: with the exponent {expo:.2f} fitted between the samples — two points on a shared '
+                     f'host, it moves from run to run); Gram+Q assembly excluded',
            'samples': samples}
+    if args.cpu_stream_iters > 0 and args.task == 'svc' and args.kernel == 'rbf':
+        out['streamed_product_full_n'] = cpu_streamed_product(args.n, args.d, args.cpu_stream_iters)
     out.update(info)
     return out
+
+
+def cpu_streamed_product(n, d, iters, blk=2000):
+    """SURVEY 8(d)'s measured bound that needs no extrapolation: ONE product Q v at the FULL n on the host cores with K never
+    materialised — row blocks of the RBF Gram matrix formed (BLAS GEMM + exp) and applied at once.  The cheapest thing a CPU
+    can do per iteration (the reference formulation does three products on a resident Q it could not hold)."""
+    from oracle import svm_oracle as so
+    from optiml_amd.datasets import make_blobs
+    X, y = make_blobs(n, d, seed=0)
+    gamma = so.resolve_gamma('scale', X)
+    sq = np.einsum('ij,ij->i', X, X)
+    v = np.random.RandomState(0).uniform(size=n) * y
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        o = np.empty(n)
+        for r0 in range(0, n, blk):
+            r1 = min(n, r0 + blk)
+            D = X[r0:r1] @ X.T
+            D *= -2.0
+            D += sq[r0:r1, None]
+            D += sq[None, :]
+            np.maximum(D, 0.0, out=D)
+            D *= -gamma
+            np.exp(D, out=D)
+            o[r0:r1] = D @ v + v.sum()
+        times.append(time.perf_counter() - t0)
+        print(f'[bench] CPU streamed product n={n}: {times[-1]:.2f} s', file=sys.stderr, flush=True)
+    return {'n': n, 'block_rows': blk, 's_per_product': times, 'iter_per_s_at_one_product_per_iteration': 1.0 / min(times),
+            'kind': 'measured at full n (not the reference formulation: K recomputed per product, one product per iteration)'}
 
 
 def cpu_baseline_as(args, info):
@@ -337,7 +401,7 @@ def cpu_study(args):
 # ---------------------------------------------------------------------------------------------------------------------
 # time-to-KKT-tol records (BASELINE.json's second metric): the routes that reach a stop test
 # ---------------------------------------------------------------------------------------------------------------------
-def kkt_smo(n, d, sigma, X=None, y=None, cpu=True, cpu_n=3000):
+def kkt_smo(n, d, sigma, X=None, y=None, cpu=True, cpu_n=12000):
     """SVC.fit(optimizer='smo') end to end (Gram build + sweeps, tol 1e-3) on one GPU; CPU: the oracle's SMO sweeps at a
     bounded n, reported AT that n and scaled (pair steps grow ~linearly with n and each costs O(n): n^2), labelled."""
     from optiml_amd import device
@@ -362,17 +426,23 @@ def kkt_smo(n, d, sigma, X=None, y=None, cpu=True, cpu_n=3000):
     est.obj.release()
     if cpu:
         from oracle import smo_oracle as smo, svm_oracle as so
-        ns = min(cpu_n, n)
-        K = so.gram('rbf', X[:ns])
-        yb = np.where(y[:ns] == np.unique(y)[-1], 1., -1.)
-        t0 = time.perf_counter()
-        r = smo.smo_svc(K, yb, 1., 1e-3)
-        dtc = time.perf_counter() - t0
-        rec['cpu_baseline'] = {'value': dtc * (n / ns) ** 2, 'unit': 's', 'kind': 'port (extrapolated)', 'extrapolated': n > ns,
-                               'cores': 1, 'measured_s_at_sample': dtc, 'sample_n': ns,
-                               'sample': f'oracle SMO sweeps (reference algorithm in NumPy, dense K on host, Gram build excluded) at '
-                                         f'n={ns}: {r["iter"]} outer iterations, {r["steps"]} pair steps in {dtc:.2f} s; value scaled '
-                                         f'by (n/n_s)^2 to n={n}'}
+        samples = []
+        for ns in sorted({min(cpu_n // 2, n), min(cpu_n, n)}):
+            K = so.gram('rbf', X[:ns])
+            yb = np.where(y[:ns] == np.unique(y)[-1], 1., -1.)
+            t0 = time.perf_counter()
+            r = smo.smo_svc(K, yb, 1., 1e-3)
+            samples.append({'n': ns, 's': time.perf_counter() - t0, 'outer_iterations': int(r['iter']), 'pair_steps': int(r['steps'])})
+        last = samples[-1]
+        expo = float(np.polyfit(np.log([v['n'] for v in samples]), np.log([v['s'] for v in samples]), 1)[0]) if len(samples) > 1 else 2.0
+        rec['cpu_baseline'] = {'value': last['s'] * (n / last['n']) ** 2, 'unit': 's', 'kind': 'port (extrapolated)', 'extrapolated': n > last['n'],
+                               'cores': 1, 'cores_note': 'SMO is a sequential chain of pair steps: one core is the algorithm\'s nature, not a choice',
+                               'law': 'n^2 (pair steps grow ~linearly with n and each costs O(n))', 'fitted_exponent': expo,
+                               'value_fitted_exponent': last['s'] * (n / last['n']) ** expo,
+                               'measured_s_at_sample': last['s'], 'sample_n': last['n'], 'samples': samples,
+                               'sample': 'oracle SMO sweeps (reference algorithm in NumPy, dense K on host, Gram build excluded) at '
+                                         + ', '.join(f"n={v['n']}: {v['pair_steps']} pair steps in {v['s']:.2f} s" for v in samples)
+                                         + f'; value = the larger sample scaled by (n/n_s)^2 to n={n}'}
     return rec
 
 
@@ -433,18 +503,30 @@ def kkt_box(solver, n, d, sigma, cpu=True):
     est.obj.release()
     if cpu:
         from oracle import bcqp_oracle as bo, svm_oracle as so
-        ns = min(n, 6000 if solver == 'ip' else 2500)
-        Q, q, ub = so.svc_dual(so.gram('rbf', X[:ns]), y[:ns], 1.0)
         fn = bo.interior_point if solver == 'ip' else bo.active_set
-        k = 4 if solver == 'ip' else 12
-        t0 = time.perf_counter()
-        r = fn(Q, q, ub, max_iter=k)
-        per = (time.perf_counter() - t0) / max(r['iter'], 1)
-        rec['cpu_baseline'] = {'value': per * (n / ns) ** 3 * o.iter, 'unit': 's', 'kind': 'port (extrapolated)', 'extrapolated': n > ns,
-                               'cores': _cpu_info()['cores'], 'measured_s_per_iteration_at_sample': per, 'sample_n': ns,
-                               'sample': f'oracle {solver.upper()} (reference algorithm in NumPy/SciPy: cho_factor per iteration, dense Q on '
-                                         f'host) at n={ns}: {per:.3f} s/iteration over {r["iter"]} iterations; value = that x (n/n_s)^3 x '
-                                         f'the {o.iter} iterations the device run needed at n={n}; Gram and Q assembly excluded'}
+        sizes = (6000, 12000) if solver == 'ip' else (2000, 4000)
+        k = 3 if solver == 'ip' else 12
+        samples = []
+        for ns in sorted({min(v, n) for v in sizes}):
+            Q, q, ub = so.svc_dual(so.gram('rbf', X[:ns]), y[:ns], 1.0)
+            t0 = time.perf_counter()
+            r = fn(Q, q, ub, max_iter=k)
+            samples.append({'n': ns, 's_per_iteration': (time.perf_counter() - t0) / max(r['iter'], 1), 'iterations': int(r['iter'])})
+            del Q
+        last = samples[-1]
+        expo = float(np.polyfit(np.log([v['n'] for v in samples]), np.log([v['s_per_iteration'] for v in samples]), 1)[0]) \
+            if len(samples) > 1 else 3.0
+        info = _cpu_info()
+        rec['cpu_baseline'] = {'value': last['s_per_iteration'] * (n / last['n']) ** expo * o.iter, 'unit': 's',
+                               'kind': 'port (extrapolated)', 'extrapolated': n > last['n'], 'cores': info['cores'],
+                               'cores_source': info['cores_source'], 'fitted_exponent': expo,
+                               'law': 'fitted exponent between the two samples (a threaded dpotrf is not at its n^3 asymptote at these sizes)',
+                               'value_n3_law': last['s_per_iteration'] * (n / last['n']) ** 3 * o.iter,
+                               'measured_s_per_iteration_at_sample': last['s_per_iteration'], 'sample_n': last['n'], 'samples': samples,
+                               'sample': f'oracle {solver.upper()} (reference algorithm in NumPy/SciPy: cho_factor per iteration, dense Q on host): '
+                                         + ', '.join(f"n={v['n']}: {v['s_per_iteration']:.3f} s/iteration" for v in samples)
+                                         + f'; value = the larger sample x (n/n_s)^{expo:.2f} (fitted) x the {o.iter} iterations the device run '
+                                           f'needed at n={n} (value_n3_law: with exponent 3); Gram and Q assembly excluded'}
     return rec
 
 
@@ -767,10 +849,12 @@ def main():
             # BASELINE's second metric in the same line: the routes that reach a KKT tolerance
             kk = {}
             try:
-                if args.kkt in ('smo', 'all'):
+                if args.kkt in ('smo', 'all', 'ip100k'):
                     kk['smo'] = kkt_smo(n, d, args.sigma, X=X, y=y, cpu=not args.no_cpu)
-                if args.kkt in ('ip', 'all'):
+                if args.kkt in ('ip', 'all', 'ip100k'):
                     kk['ip_config3'] = kkt_box('ip', 50000, 128, args.sigma, cpu=not args.no_cpu)
+                if args.kkt == 'ip100k':
+                    kk['ip_headline'] = kkt_box('ip', n, d, args.sigma, cpu=False)
             except Exception as exc:  # noqa: BLE001 — the headline number must survive a failing side record
                 kk['error'] = repr(exc)
             out['time_to_kkt'] = kk

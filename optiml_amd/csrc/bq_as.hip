@@ -1452,16 +1452,16 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
         as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, pc->z, w->pv, w->cg);   // beta = 0: p = z
         zr = pc->z;
     }
-    // batches of inner iterations between looks at the done flag; after it is set the vector kernels return at once
-    // and only the products of the rest of the batch are wasted, so batches start small
-    int batch = 4;
+    // batches of inner iterations between looks at the done flag; after it is set every kernel of the rest of the batch —
+    // the panel product included — returns at once, so an over-long batch costs launches, not products
+    int batch = 8;
     long long queued = 0;
     while (true) {
         BQ_HIP(hipMemcpyAsync(w->cg_flag_host, &w->cg->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         BQ_HIP(hipStreamSynchronize(st));
         if (w->cg_flag_host[0] || queued >= cap) break;
         for (int b = 0; b < batch; ++b) {
-            BQ_TRY(bq_problem_apply(s->p, w->pv, w->Qp, nullptr));
+            BQ_TRY(bq_problem_apply(s->p, w->pv, w->Qp, &w->cg->done));
             as_cg_pap_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, w->pv, w->Qp, s->partials, nblk, w->cg);
             as_cg_update_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->dlt, w->r, w->pv, w->Qp, s->partials,
                                                                nblk, w->cg);

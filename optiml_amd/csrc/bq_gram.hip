@@ -91,22 +91,40 @@ struct gram_params {
     double gamma, coef0;
     int64_t ld;              // output pitch (elements)
     int64_t ntiles;          // tiles of this launch (XCD-aware remap bound)
+    int rect_rb, rect_sb;    // > 0: 1-D grid walked in XCD-local rectangles of GRAM_RECT_R tile rows x GRAM_RECT_S strips
+    int tiles_m, strips;
 };
 
 // One workgroup owns a 128-row tile row and a strip of GRAM_STRIP consecutive 128-column tiles (blockIdx.y): looping over
 // the strip keeps the row slice of the image hot and amortises the workgroup start over several tiles (one tile per
 // workgroup ran at 36 % MFMA-pipe utilisation: `profiles/r01/pmc_mfma_ip_n50000.txt`).
 constexpr int GRAM_STRIP = 8;
+// Workgroup order.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, MI355X_MICROARCH.md), each XCD
+// has its own 4 MiB L2 and keeps 64 workgroups in flight.  The 64 consecutive work items of ONE XCD form a rectangle of
+// GRAM_RECT_R tile rows x GRAM_RECT_S column strips: its 16 row slices of the image (2 MiB) stay in that L2 while every
+// column tile streams through once for 16 consumers, instead of every workgroup re-fetching its row slice for each of its
+// 8 column tiles (round 2: 44 GB of L2 fills per n = 100 000 build for a 0.1 GB operand).  Speed only: any placement is correct.
+constexpr int GRAM_RECT_R = 16, GRAM_RECT_S = 4;
 template <typename T, int KIND>
 __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    const int64_t arow = P.arow0 + (int64_t)blockIdx.x * GT;
+    int64_t bx = blockIdx.x, by = blockIdx.y;
+    if (P.rect_rb > 0) {
+        const int64_t b = blockIdx.x;
+        const int64_t xcd = b & 7, slot = b >> 3;
+        const int64_t rect = (slot / (GRAM_RECT_R * GRAM_RECT_S)) * 8 + xcd, idx = slot % (GRAM_RECT_R * GRAM_RECT_S);
+        if (rect >= (int64_t)P.rect_rb * P.rect_sb) return;
+        bx = (rect % P.rect_rb) * GRAM_RECT_R + idx % GRAM_RECT_R;
+        by = (rect / P.rect_rb) * GRAM_RECT_S + idx / GRAM_RECT_R;
+        if (bx >= P.tiles_m || by >= P.strips) return;
+    }
+    const int64_t arow = P.arow0 + bx * GT;
     int64_t tiles_n = (P.n + GT - 1) / GT;
     if (P.lower_only) {   // symmetric panel: columns up to the end of this row's 256-tile on the diagonal
         const int64_t lim = ((arow / BQ_SYM_TILE) + 1) * (BQ_SYM_TILE / GT);
         tiles_n = lim < tiles_n ? lim : tiles_n;
     }
-    const int64_t j0 = (int64_t)blockIdx.y * GRAM_STRIP;
+    const int64_t j0 = by * GRAM_STRIP;
     const int64_t j1 = j0 + GRAM_STRIP < tiles_n ? j0 + GRAM_STRIP : tiles_n;
     if (j0 >= j1) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -266,6 +284,7 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
                     int64_t n, bool same, int kernel, double gamma, double coef0, int degree, void *out,
                     int storage, int64_t ld, bool lower_only = false) {
     gram_params P;
+    P.rect_rb = P.rect_sb = P.tiles_m = P.strips = 0;
     P.lower_only = lower_only ? 1 : 0;
     P.At = A.At;
     P.Bt = B.At;
@@ -301,7 +320,21 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
             gram_l1_kernel<float><<<lgrid, 256, 0, ctx->stream>>>(P, reinterpret_cast<float *>(out));
     } else {
         P.ntiles = tiles_m * tiles_n;
-        dim3 grid((unsigned)tiles_m, (unsigned)((tiles_n + GRAM_STRIP - 1) / GRAM_STRIP));
+        const int64_t strips = (tiles_n + GRAM_STRIP - 1) / GRAM_STRIP;
+        dim3 grid((unsigned)tiles_m, (unsigned)strips);
+        P.rect_rb = P.rect_sb = 0;
+        P.tiles_m = (int)tiles_m;
+        P.strips = (int)strips;
+        static const bool rect_order = [] {
+            const char *e = getenv("BQ_GRAM_ORDER");   // 0: the plain 2-D grid (tile rows fastest)
+            return !(e && atoi(e) == 0);
+        }();
+        if (rect_order && tiles_m * strips >= 8 * GRAM_RECT_R * GRAM_RECT_S) {
+            P.rect_rb = (int)((tiles_m + GRAM_RECT_R - 1) / GRAM_RECT_R);
+            P.rect_sb = (int)((strips + GRAM_RECT_S - 1) / GRAM_RECT_S);
+            const int64_t nrect = (int64_t)P.rect_rb * P.rect_sb;
+            grid = dim3((unsigned)(((nrect + 7) / 8) * 8 * GRAM_RECT_R * GRAM_RECT_S), 1);
+        }
         // one instantiation per kernel map (all of exp / pow / tanh inlined in the 64-element epilogue costs registers)
 #define BQ_GRAM_LAUNCH(KIND)                                                                                           \
     do {                                                                                                               \
@@ -711,6 +744,7 @@ int bq_stream_sym_product(bq_ctx *ctx, void *h, int64_t n, int64_t nb, const bq_
     P.coef0 = coef0;
     P.ld = 0;
     P.ntiles = 0;
+    P.rect_rb = P.rect_sb = P.tiles_m = P.strips = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
     const unsigned nu = (unsigned)st->nunits;
