@@ -648,12 +648,14 @@ __global__ __launch_bounds__(256) void as_pc_class_kernel(int64_t n, int64_t d, 
 //       grow like n (at BASELINE config 5 they sit at ~0.4 of family 1's)
 __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t ld, const double *__restrict__ X,
                                       const double *__restrict__ sgn, const double *__restrict__ cls, double gamma,
-                                      int add_one, double diag_add, int m, double *__restrict__ Phi, double *__restrict__ dinv) {
+                                      int add_one, double diag_add, int m, double *__restrict__ Phi, double *__restrict__ dinv,
+                                      double *__restrict__ share) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ld) return;
     if (i >= n) {
         for (int j = 0; j < m; ++j) Phi[(int64_t)j * ld + i] = 0.0;
         dinv[i] = 0.0;
+        share[i] = 1.0;
         return;
     }
     const double y = sgn ? sgn[i] : 1.0;
@@ -699,6 +701,7 @@ __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t 
     }
     qii += diag_add;
     dinv[i] = 1.0 / fmax(qii - s, 1e-8 * qii);
+    share[i] = (qii - s) / qii;   // what the features leave of the diagonal: the host refuses a model that leaves too little
 }
 
 // Gpart[slice][a][b] = sum over the slice's FREE samples of Phi[a][i] Phi[b][i] / D_i, lower tiles (b-tile <= a-tile)
@@ -1352,52 +1355,68 @@ static bool as_env_on(const char *name) {
     return !(e && atoi(e) == 0);
 }
 
-// build the preconditioner's features once per solver (null: the panel's kernel has none, or BQ_AS_CG_PC=0)
+static void as_pc_free(as_pc *pc);
+
+// The model P = D + Phi Phi' is only used when it leaves every sample a diagonal share D_i / Q_ii of at least this much: a
+// feature set that explains (or over-explains: D_i <= 0) the whole diagonal of some sample is a Taylor expansion outside its
+// range (2 g |x|^2 not small) and would make P far worse conditioned than Q itself.
+constexpr double PC_MIN_DIAG_SHARE = 0.1;
+
+// build the preconditioner's features once per solver (null: the panel's kernel has none, the features do not fit this data,
+// or BQ_AS_CG_PC=0)
 static int as_pc_create(bq_solver *s, as_pc **out) {
     *out = nullptr;
     bq_problem *p = s->p;
     if (!as_env_on("BQ_AS_CG_PC")) return BQ_OK;
     if (p->X == nullptr || (p->structure != BQ_PLAIN && p->structure != BQ_SVC)) return BQ_OK;
-    int m;
-    const bool classes = p->kernel == BQ_KERNEL_RBF && p->structure == BQ_SVC && as_env_on("BQ_AS_CG_PC_CLASS");
-    if (p->kernel == BQ_KERNEL_RBF)
-        m = (int)p->d + 1 + (classes ? (int)p->d : 0);
-    else if (p->kernel == BQ_KERNEL_LINEAR && p->diag_add > 0.0)
-        m = (int)p->d;
-    else
-        return BQ_OK;
-    if (p->add_one) m += 1;
-    if (m > PC_MAX_M || p->d > PC_MAX_M) return BQ_OK;
+    if (p->kernel != BQ_KERNEL_RBF && !(p->kernel == BQ_KERNEL_LINEAR && p->diag_add > 0.0)) return BQ_OK;
     bq_ctx *ctx = p->ctx;
-    as_pc *pc = new as_pc();
-    pc->m = m;
-    pc->mp = bq_round_up(m, 128);
-    int rc = bq_chol_ws_create(ctx, pc->mp, &pc->ws);
-    hipError_t e = hipSuccess;
-    if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(double) * (size_t)m * s->ldN);
-    if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->dinv, sizeof(double) * s->ldN);
-    if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->z, sizeof(double) * s->ldN);
-    if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gpart, sizeof(double) * PC_SLICES * pc->mp * pc->mp);
-    if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->Gpart, 0, sizeof(double) * PC_SLICES * pc->mp * pc->mp, ctx->stream);
-    if (rc != BQ_OK || e != hipSuccess) {   // no room for the features: run unpreconditioned rather than fail
-        if (pc->ws) bq_chol_ws_destroy(pc->ws);
-        for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart})
-            if (ptr) hipFree(ptr);
-        delete pc;
-        (void)hipGetLastError();
-        return BQ_OK;
+    bool classes = p->kernel == BQ_KERNEL_RBF && p->structure == BQ_SVC && as_env_on("BQ_AS_CG_PC_CLASS");
+    std::vector<double> share((size_t)p->n);
+    for (int attempt = 0; attempt < 2; ++attempt) {   // with the class-interaction family, then without it
+        int m = p->kernel == BQ_KERNEL_RBF ? (int)p->d + 1 + (classes ? (int)p->d : 0) : (int)p->d;
+        if (p->add_one) m += 1;
+        if (m > PC_MAX_M || p->d > PC_MAX_M) return BQ_OK;
+        as_pc *pc = new as_pc();
+        pc->m = m;
+        pc->mp = bq_round_up(m, 128);
+        int rc = bq_chol_ws_create(ctx, pc->mp, &pc->ws);
+        hipError_t e = hipSuccess;
+        if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(double) * (size_t)m * s->ldN);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->dinv, sizeof(double) * s->ldN);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->z, sizeof(double) * s->ldN);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gpart, sizeof(double) * PC_SLICES * pc->mp * pc->mp);
+        if (rc == BQ_OK && e == hipSuccess)
+            e = hipMemsetAsync(pc->Gpart, 0, sizeof(double) * PC_SLICES * pc->mp * pc->mp, ctx->stream);
+        if (rc == BQ_OK && e == hipSuccess && classes) {
+            e = hipMalloc(&pc->cls, sizeof(double) * (2 * p->d + 2));
+            if (e == hipSuccess) e = hipMemsetAsync(pc->cls, 0, sizeof(double) * (2 * p->d + 2), ctx->stream);
+        }
+        if (rc != BQ_OK || e != hipSuccess) {   // no room for the features: run unpreconditioned rather than fail
+            as_pc_free(pc);
+            (void)hipGetLastError();
+            return BQ_OK;
+        }
+        if (classes) {
+            unsigned int *ticket = (unsigned int *)(pc->cls + 2 * p->d + 1);   // the spare slot, zeroed above
+            as_pc_class_kernel<<<(unsigned)p->d, 256, 0, ctx->stream>>>(p->n, p->d, p->X, p->sgn, pc->cls, ticket);
+        }
+        as_pc_features_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->kernel, p->n, p->d, s->ldN, p->X, p->sgn, pc->cls,
+                                                                                 p->gamma, p->add_one ? 1 : 0, p->diag_add, m,
+                                                                                 pc->Phi, pc->dinv, pc->z);
+        BQ_HIP(hipGetLastError());
+        BQ_HIP(hipMemcpyAsync(share.data(), pc->z, sizeof(double) * p->n, hipMemcpyDeviceToHost, ctx->stream));
+        BQ_HIP(hipStreamSynchronize(ctx->stream));
+        double lo = 1.0;
+        for (double v : share) lo = std::min(lo, v);
+        if (std::isfinite(lo) && (p->kernel == BQ_KERNEL_LINEAR || lo >= PC_MIN_DIAG_SHARE)) {   // linear: the model is exact
+            *out = pc;
+            return BQ_OK;
+        }
+        as_pc_free(pc);
+        if (!classes) break;
+        classes = false;
     }
-    if (classes) {
-        BQ_HIP(hipMalloc(&pc->cls, sizeof(double) * (2 * p->d + 2)));
-        BQ_HIP(hipMemsetAsync(pc->cls, 0, sizeof(double) * (2 * p->d + 2), ctx->stream));
-        unsigned int *ticket = (unsigned int *)(pc->cls + 2 * p->d + 1);   // the spare slot, zeroed above
-        as_pc_class_kernel<<<(unsigned)p->d, 256, 0, ctx->stream>>>(p->n, p->d, p->X, p->sgn, pc->cls, ticket);
-    }
-    as_pc_features_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->kernel, p->n, p->d, s->ldN, p->X, p->sgn, pc->cls,
-                                                                             p->gamma, p->add_one ? 1 : 0, p->diag_add, m, pc->Phi,
-                                                                             pc->dinv);
-    BQ_HIP(hipGetLastError());
-    *out = pc;
     return BQ_OK;
 }
 
