@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument('--sym-exchange', default='gather', choices=['gather', 'allreduce'],
                     help='closing collective of a symmetric product: all-gather of segment partials + ordered sum (default, '
                          'bit-identical for any N) or one all-reduce(sum)')
+    ap.add_argument('--rccl-init-timeout', type=float, default=240.0,
+                    help='seconds a rank waits inside the RCCL communicator bootstrap before the run is given up (exit 3)')
     ap.add_argument('--allow-host-exchange', action='store_true',
                     help='fall back to the host (gloo) exchange when the RCCL communicator cannot be created (default: exit 3)')
     ap.add_argument('--cpu-sizes', default='20000,30000', help='sample sizes of the CPU baseline leg (SURVEY 8d)')
@@ -676,10 +678,23 @@ def main():
         # gloo fallback (reported in config.exchange).
         exchange, ctx, err = args.exchange, None, ''
         if exchange == 'rccl':
+            # ncclCommInitRank has no timeout of its own: a bootstrap that never completes (a rank that died after the
+            # pre-flight, an unusable network interface) must end this run with a message, not sit until the caller's limit
+            import threading
+
+            def _give_up():
+                print(f'[bench] rank {rank}: the RCCL communicator was not created within {args.rccl_init_timeout:.0f} s '
+                      '(NCCL_DEBUG=INFO shows the bootstrap; NCCL_SOCKET_IFNAME selects its interface)', file=sys.stderr, flush=True)
+                os._exit(3)
+            watchdog = threading.Timer(args.rccl_init_timeout, _give_up)
+            watchdog.daemon = True
+            watchdog.start()
             try:
                 ctx = device.Context(comm=comm, exchange='rccl', sym_exchange=args.sym_exchange)
             except Exception as exc:  # noqa: BLE001
                 err = repr(exc)
+            finally:
+                watchdog.cancel()
             if comm.max_float(0.0 if ctx is not None else 1.0) > 0.0:
                 print(f'[bench] rank {rank}: RCCL context unavailable ({err or "failed on another rank"})', file=sys.stderr, flush=True)
                 if ctx is not None:
