@@ -1376,7 +1376,11 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
     for (int attempt = 0; attempt < 2; ++attempt) {   // with the class-interaction family, then without it
         int m = p->kernel == BQ_KERNEL_RBF ? (int)p->d + 1 + (classes ? (int)p->d : 0) : (int)p->d;
         if (p->add_one) m += 1;
-        if (m > PC_MAX_M || p->d > PC_MAX_M) return BQ_OK;
+        if (m > PC_MAX_M) {   // the apply kernel keeps the coefficients of all features in LDS
+            if (!classes) return BQ_OK;
+            classes = false;
+            continue;
+        }
         as_pc *pc = new as_pc();
         pc->m = m;
         pc->mp = bq_round_up(m, 128);
