@@ -765,6 +765,33 @@ def main():
     mv_ms, mv_cnt = ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     ex_ms, ex_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
     inner = (solver.inner_iters() - inner0) if ascg else 0
+    exchange_compare = None
+    if comm is not None and not al and not ascg and args.storage != 'stream':
+        # outside the timed region: the same few iterations with the OTHER closing collective of the symmetric product, so that
+        # one multi-GPU run shows both (all-gather of 8 segment vectors + ordered sum, bit-identical for any N, against one
+        # all-reduce of n doubles) — collective time per product, max over ranks
+        try:
+            other = 'allreduce' if cinfo['sym_exchange'] == 'gather' else 'gather'
+            ctx.set_sym_exchange(other)
+            s2 = _DeviceSolver(dev, _lib.PG if args.solver == 'pg' else _lib.FW, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
+            s2.run(3)
+            ctx.profile_read(_lib.PROF_EXCH, reset=True)
+            barrier()
+            t2 = time.perf_counter()
+            rows2, _ = s2.run(10)
+            dt2 = time.perf_counter() - t2
+            ex2_ms, ex2_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
+            s2.close()
+            exchange_compare = {
+                cinfo['sym_exchange']: {'exchange_ms_per_product': comm.max_float((ex_ms / ex_cnt) if ex_cnt else 0.0),
+                                        'ms_per_step': 1e3 * elapsed / max(done, 1)},
+                other: {'exchange_ms_per_product': comm.max_float((ex2_ms / ex2_cnt) if ex2_cnt else 0.0),
+                        'ms_per_step': comm.max_float(1e3 * dt2 / max(len(rows2), 1)), 'steps': len(rows2)}}
+        except Exception as exc:  # noqa: BLE001 — a side record must not cost the headline line
+            exchange_compare = {'error': repr(exc)}
+        finally:
+            ctx.set_sym_exchange(cinfo['sym_exchange'])
+            ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     per_rank = None
     if comm is not None:   # every rank's share and timings in the one line rank 0 prints
         cols = [comm.allgather_float(v) for v in (own_elapsed * 1e3 / max(done, 1), mv_ms / max(mv_cnt, 1),
@@ -830,6 +857,8 @@ def main():
         }
         if per_rank is not None:
             out['per_rank'] = per_rank
+        if exchange_compare is not None:
+            out['exchange_compare'] = exchange_compare
         if ascg:
             out['inner_products_per_step'] = inner / max(done, 1)
             out['inner_tol'] = args.inner_tol

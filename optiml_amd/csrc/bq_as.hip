@@ -40,6 +40,9 @@
 
 #include "bq_chol.h"
 #include "bq_qelem.h"
+#define BQ_EXP_ATTR __device__ __forceinline__
+#define BQ_EXP_LOINT(t) __double2loint(t)
+#include "bq_exp.h"
 
 #define ACT_TOL 1e-12
 constexpr int AS_SCHUR_MAX = 1536;   // capacity of the update slots
@@ -74,6 +77,10 @@ struct as_pc {
     double *dinv = nullptr;  // ldN: 1 / D_i
     double *z = nullptr;     // ldN: preconditioned residual
     double *Gpart = nullptr; // slices x mp x mp partial Gram sums
+    double *Gacc = nullptr;  // mp x mp: G = I + Phi_A' D_A^-1 Phi_A of the free set in `prev`, kept between outer iterations
+    unsigned char *prev = nullptr;   // ldN: the free set G was last brought up to
+    int *chg = nullptr;      // [0] changed indices since then, [1] need a full rebuild, [2 ..] index and sign (+1 freed / -1 bound)
+    int age = 0;             // outer iterations since the last full rebuild (rounding of the rank-one updates)
     double *cls = nullptr;   // class statistics (as_pc_class_kernel), BQ_SVC + RBF only
     bq_chol_ws *ws = nullptr;
 };
@@ -95,6 +102,13 @@ struct as_ws {
     as_cg_scal *cg = nullptr;
     int *cg_flag_host = nullptr;   // pinned: {done, info}
     long long cg_iters = 0;
+    double *Qdl = nullptr, *Qcand = nullptr;   // Q delta accumulated over the inner iterations; Q cand = Q z + Q delta
+    bool incq = true;              // BQ_AS_CG_INCQ=0: a fresh product Q x after every outer iteration (round 2)
+    bool colq = false;             // the start product of a warm-started solve is Q cand + a few columns of Q formed from X
+    double *sq = nullptr;          // ldN: squared row norms of X (the columns' RBF distances)
+    int *zchg = nullptr;           // [0] count, [1] 1 = columns suffice (the start product is skipped), [2 ..] indices
+    double *zdl = nullptr;         // bound - cand of those indices
+    int since_refresh = 0;         // outer iterations since Q x was last formed by a product
     as_pc *pc = nullptr;           // null: plain conjugate gradients
     bool have_cand = false;        // w->cand holds the candidate of the previous outer iteration (the warm start)
     bool warm = true;              // BQ_AS_CG_WARM=0: start every inner solve from the current point
@@ -549,15 +563,18 @@ __global__ void as_cg_pap_kernel(int64_t N, const double *__restrict__ pv, const
     }
 }
 
-// delta += alpha p;  r -= alpha m.(Qp);  beta = r'r(new) / r'r(old); stop tests
+// delta += alpha p;  r -= alpha m.(Qp);  beta = r'r(new) / r'r(old); stop tests.  Qdl += alpha Qp on ALL rows: Q delta, which
+// with the start point's product gives Q cand without another product (as_qcand_kernel)
 __global__ void as_cg_update_kernel(int64_t N, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
                                     double *__restrict__ dlt, double *__restrict__ r, const double *__restrict__ pv,
-                                    const double *__restrict__ Qp, double *part, int64_t nblk, as_cg_scal *cg) {
+                                    const double *__restrict__ Qp, double *__restrict__ Qdl, double *part, int64_t nblk,
+                                    as_cg_scal *cg) {
     if (cg->done) return;
     __shared__ double sh[4];
     const double alpha = cg->alpha;
     double s = 0.0;
     VEC_LOOP(i) {
+        if (i < N) Qdl[i] = Qdl[i] + __dmul_rn(alpha, Qp[i]);
         if (i < N && !(mL[i] | mU[i])) {
             dlt[i] = dlt[i] + __dmul_rn(alpha, pv[i]);
             const double ri = r[i] - __dmul_rn(alpha, Qp[i]);
@@ -586,6 +603,120 @@ __global__ void as_cg_dir_kernel(int64_t N, const double *__restrict__ r, double
     VEC_LOOP(i) {
         if (i < N) pv[i] = r[i] + __dmul_rn(beta, pv[i]);
     }
+}
+
+// Q cand = Q z + Q delta (z: the start point with the bound values, delta: what the iteration added on the free set)
+__global__ void as_qcand_kernel(int64_t N, const double *__restrict__ Qz, const double *__restrict__ Qdl, double *__restrict__ Qc) {
+    VEC_LOOP(i) {
+        Qc[i] = i < N ? Qz[i] + Qdl[i] : 0.0;
+    }
+}
+
+// after the ratio step x += t (cand - x):  Q x += t (Q cand - Q x)
+__global__ void as_qx_lerp_kernel(int64_t N, const bq_scal *sc, const double *__restrict__ Qc, double *__restrict__ Qx) {
+    const double t = sc->step;
+    VEC_LOOP(i) {
+        if (i < N) Qx[i] = Qx[i] + __dmul_rn(t, Qc[i] - Qx[i]);
+    }
+}
+
+constexpr int AS_MAX_COLS = 16;
+// Where the start vector z (the previous candidate with the CURRENT bound values) differs from that candidate: the variables
+// that reached a bound in the step since — a handful.  Index order, one workgroup (same bits on every rank).
+// zchg[1] = 1: at most AS_MAX_COLS of them, so Q z = Q cand + sum_j (bound_j - cand_j) Q[:, j] and the product is skipped.
+__global__ __launch_bounds__(1024) void as_zdiff_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                        const unsigned char *__restrict__ mU, const double *__restrict__ lb,
+                                                        const double *__restrict__ ub, const double *__restrict__ cand,
+                                                        int *__restrict__ zchg, double *__restrict__ zdl) {
+    __shared__ int wcnt[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t i0 = 0; i0 < N; i0 += 1024) {
+        const int64_t i = i0 + threadIdx.x;
+        double dl = 0.0;
+        if (i < N && (mL[i] | mU[i])) dl = (mU[i] ? ub[i] : lb[i]) - cand[i];
+        const int changed = dl != 0.0;
+        const unsigned long long bal = __ballot(changed);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; ++k) off += wcnt[k];
+        if (changed) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < AS_MAX_COLS) {
+                zchg[2 + pos] = (int)i;
+                zdl[pos] = dl;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < 16; ++k) tot += wcnt[k];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        zchg[0] = base;
+        zchg[1] = (base <= AS_MAX_COLS && isfinite((double)base)) ? 1 : 0;
+    }
+}
+
+// Qz = Q cand + sum_c dl_c Q[:, j_c] with the columns formed from X (replicated on every rank, so no exchange): the entry the
+// panel holds up to the rounding of its own dot products — K as the kernel maps of bq_gram.hip define it, rounded to the
+// panel's storage type, then the structure of the dual (bq_qelem.h).  Runs only when as_zdiff_kernel said the columns suffice.
+__global__ __launch_bounds__(256) void as_qz_cols_kernel(int64_t n, int64_t d, const double *__restrict__ X, const double *__restrict__ sq,
+                                                         const double *__restrict__ sgn, int kernel, double gamma, double coef0,
+                                                         int degree, int add_one, double diag_add, int f32,
+                                                         const int *__restrict__ zchg, const double *__restrict__ zdl,
+                                                         const double *__restrict__ Qc, double *__restrict__ Qz) {
+    if (!zchg[1]) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cnt = zchg[0];
+    double acc = Qc[i];
+    const double *xi = X + i * d;
+    for (int c = 0; c < cnt; ++c) {
+        const int64_t j = zchg[2 + c];
+        const double *xj = X + j * d;
+        double dot = 0.0;
+        for (int64_t k = 0; k < d; ++k) dot = fma(xi[k], xj[k], dot);
+        double kv;
+        if (kernel == BQ_KERNEL_RBF) {
+            double dist = -2.0 * dot;
+            dist += sq[i];
+            dist += sq[j];
+            dist = fmax(dist, 0.0);
+            if (i == j) dist = 0.0;
+            kv = bq_exp(-gamma * dist);
+        } else if (kernel == BQ_KERNEL_POLY) {
+            const double b = gamma * dot + coef0;
+            kv = degree == 2 ? b * b : (degree == 3 ? b * b * b : pow(b, (double)degree));
+        } else if (kernel == BQ_KERNEL_SIGMOID) {
+            kv = tanh(gamma * dot + coef0);
+        } else {
+            kv = dot;
+        }
+        if (f32) kv = (double)(float)kv;
+        double q = kv + (add_one ? 1.0 : 0.0);
+        if (sgn) q *= sgn[i] * sgn[j];
+        if (i == j) q += diag_add;
+        acc = fma(zdl[c], q, acc);
+    }
+    Qz[i] = acc;
+}
+
+__global__ void as_row_norms_kernel(const double *__restrict__ X, int64_t n, int64_t d, double *__restrict__ out, int64_t ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ld) return;
+    double v = 0.0;
+    if (i < n) {
+        const double *row = X + i * d;
+        for (int64_t k = 0; k < d; ++k) v = fma(row[k], row[k], v);
+    }
+    out[i] = v;
 }
 
 // sol[a] = x[idx[a]] + delta[idx[a]] (x: the point the iteration started from): the restricted solution in the compact order
@@ -707,7 +838,9 @@ __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t 
 // Gpart[slice][a][b] = sum over the slice's FREE samples of Phi[a][i] Phi[b][i] / D_i, lower tiles (b-tile <= a-tile)
 __global__ __launch_bounds__(256) void as_pc_gram_kernel(int m, int64_t mp, int64_t N, int64_t ld, const double *__restrict__ Phi,
                                                          const double *__restrict__ dinv, const unsigned char *__restrict__ mL,
-                                                         const unsigned char *__restrict__ mU, double *__restrict__ Gpart) {
+                                                         const unsigned char *__restrict__ mU, double *__restrict__ Gpart,
+                                                         const int *__restrict__ chg) {
+    if (!chg[1]) return;   // the rank-one updates brought G up to date
     __shared__ double As[PC_T][PC_C + 1], Bs[PC_T][PC_C + 1];
     // (ta, tb) from the linear lower-triangle tile index
     int ta = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -743,14 +876,82 @@ __global__ __launch_bounds__(256) void as_pc_gram_kernel(int m, int64_t mp, int6
         Gpart[((int64_t)blockIdx.y * mp + a0 + ty * 4 + j) * mp + b0 + tx] = acc[j];
 }
 
-// H = I + the slices of Gpart added in slice order (lower triangle; identity on the pad rows)
-__global__ void as_pc_gram_reduce_kernel(int m, int64_t mp, const double *__restrict__ Gpart, double *__restrict__ H, int64_t ldh) {
+// full rebuild: G = I + the slices of Gpart added in slice order (lower triangle; identity on the pad rows); every time: H = G
+__global__ void as_pc_gram_reduce_kernel(int m, int64_t mp, const double *__restrict__ Gpart, double *__restrict__ G,
+                                         double *__restrict__ H, int64_t ldh, const int *__restrict__ chg) {
     const int64_t a = blockIdx.y, b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b > a || b >= mp) return;
-    double v = (a == b) ? 1.0 : 0.0;
-    if (a < m)
-        for (int sidx = 0; sidx < PC_SLICES; ++sidx) v += Gpart[((int64_t)sidx * mp + a) * mp + b];
-    H[a * ldh + b] = v;
+    if (chg[1]) {
+        double v = (a == b) ? 1.0 : 0.0;
+        if (a < m)
+            for (int sidx = 0; sidx < PC_SLICES; ++sidx) v += Gpart[((int64_t)sidx * mp + a) * mp + b];
+        G[a * mp + b] = v;
+    }
+    H[a * ldh + b] = G[a * mp + b];
+}
+
+constexpr int PC_MAX_CHG = 64;
+// which samples entered / left the free set since G was last brought up to date, in index order (one workgroup: the order of
+// the rank-one updates must not depend on the launch geometry); more than PC_MAX_CHG of them, or `force`: full rebuild
+__global__ __launch_bounds__(1024) void as_pc_diff_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                          const unsigned char *__restrict__ mU, unsigned char *__restrict__ prev,
+                                                          int *__restrict__ chg, int force) {
+    __shared__ int wcnt[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t i0 = 0; i0 < N; i0 += 1024) {
+        const int64_t i = i0 + threadIdx.x;
+        int fr = 0, was = 0;
+        if (i < N) {
+            fr = !(mL[i] | mU[i]);
+            was = prev[i];
+            prev[i] = (unsigned char)fr;
+        }
+        const int changed = (i < N) && (fr != was);
+        const unsigned long long bal = __ballot(changed);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; ++k) off += wcnt[k];
+        if (changed) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < PC_MAX_CHG) {
+                chg[2 + 2 * pos] = (int)i;
+                chg[3 + 2 * pos] = fr ? 1 : -1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < 16; ++k) tot += wcnt[k];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        chg[0] = base;
+        chg[1] = (force || base > PC_MAX_CHG) ? 1 : 0;
+    }
+}
+
+// G += sign phi_i phi_i' / D_i for the changed samples, in list order (lower triangle)
+__global__ __launch_bounds__(256) void as_pc_rank1_kernel(int m, int64_t mp, int64_t ld, const double *__restrict__ Phi,
+                                                          const double *__restrict__ dinv, const int *__restrict__ chg,
+                                                          double *__restrict__ G) {
+    if (chg[1]) return;
+    const int cnt = chg[0];
+    if (cnt == 0) return;
+    const int64_t a = blockIdx.y, b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b > a || a >= m) return;
+    double v = G[a * mp + b];
+    for (int c = 0; c < cnt; ++c) {
+        const int64_t i = chg[2 + 2 * c];
+        const double wgt = (double)chg[3 + 2 * c] * dinv[i];
+        v = fma(Phi[a * ld + i] * wgt, Phi[b * ld + i], v);
+    }
+    G[a * mp + b] = v;
 }
 
 // t[j] = sum_i Phi[j][i] r_i / D_i   (r vanishes outside the free set); one workgroup per feature, fixed order
@@ -1392,6 +1593,11 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gpart, sizeof(double) * PC_SLICES * pc->mp * pc->mp);
         if (rc == BQ_OK && e == hipSuccess)
             e = hipMemsetAsync(pc->Gpart, 0, sizeof(double) * PC_SLICES * pc->mp * pc->mp, ctx->stream);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gacc, sizeof(double) * pc->mp * pc->mp);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->prev, (size_t)s->ldN);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->prev, 0, (size_t)s->ldN, ctx->stream);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->chg, sizeof(int) * (2 + 2 * PC_MAX_CHG));
+        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->chg, 0, sizeof(int) * (2 + 2 * PC_MAX_CHG), ctx->stream);
         if (rc == BQ_OK && e == hipSuccess && classes) {
             e = hipMalloc(&pc->cls, sizeof(double) * (2 * p->d + 2));
             if (e == hipSuccess) e = hipMemsetAsync(pc->cls, 0, sizeof(double) * (2 * p->d + 2), ctx->stream);
@@ -1427,7 +1633,8 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
 static void as_pc_free(as_pc *pc) {
     if (!pc) return;
     if (pc->ws) bq_chol_ws_destroy(pc->ws);
-    for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls})
+    for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls, (void *)pc->Gacc,
+                      (void *)pc->prev, (void *)pc->chg})
         if (ptr) hipFree(ptr);
     delete pc;
 }
@@ -1458,18 +1665,36 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
     as_pc *pc = w->pc;
     const double *start = (w->warm && w->have_cand) ? w->cand : s->x;
     as_make_xt_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, start, w->z);
-    BQ_TRY(bq_problem_apply(s->p, w->z, w->Qz, nullptr));
+    if (w->colq && start == w->cand) {
+        // z is the previous candidate except at the variables that reached a bound since: Q z = Q cand + those columns of Q,
+        // formed from X — the product below returns at once (its `done` flag) unless too many variables moved
+        bq_problem *p = s->p;
+        as_zdiff_kernel<<<1, 1024, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->zchg, w->zdl);
+        BQ_TRY(bq_problem_apply(p, w->z, w->Qz, w->zchg + 1));
+        as_qz_cols_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(p->n, p->d, p->X, w->sq, p->sgn, p->kernel, p->gamma, p->coef0,
+                                                                         p->degree, p->add_one ? 1 : 0, p->diag_add,
+                                                                         p->storage == BQ_F32 ? 1 : 0, w->zchg, w->zdl, w->Qcand, w->Qz);
+    } else {
+        BQ_TRY(bq_problem_apply(s->p, w->z, w->Qz, nullptr));
+    }
+    BQ_HIP(hipMemsetAsync(w->Qdl, 0, sizeof(double) * s->ldN, st));
     // s->Qd = Q x of the current point (eval_f at the end of the previous outer iteration, or of bq_as_start)
     as_cg_init_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->Qz, start == s->x ? w->Qz : s->Qd, s->p->q, w->dlt, w->r,
                                                      w->pv, s->partials, nblk, w->cg, s->inner_rtol, cap, pc ? 1 : 0);
     const double *zr = w->r;   // what the next direction is built from: the residual, or the preconditioned residual
     if (pc) {
-        // G = I + Phi_A' D_A^-1 Phi_A for the free set of this outer iteration, factorised once
+        // G = I + Phi_A' D_A^-1 Phi_A for the free set of this outer iteration, factorised once.  The set moves by an index or
+        // two per outer iteration: G follows by rank-one updates (in index order: the same bits on every rank), and is summed
+        // afresh over all samples every 128 outer iterations, at the start, and when more than 64 samples moved at once.
         const int tiles = (int)(pc->mp / PC_T);
+        const dim3 gtri((unsigned)((pc->mp + 255) / 256), (unsigned)pc->mp);
+        const int force = (pc->age == 0 || pc->age >= 128 || !as_env_on("BQ_AS_CG_PC_INCR")) ? 1 : 0;
+        pc->age = force ? 1 : pc->age + 1;
+        as_pc_diff_kernel<<<1, 1024, 0, st>>>(N, s->mL, s->mU, pc->prev, pc->chg, force);
+        as_pc_rank1_kernel<<<gtri, 256, 0, st>>>(pc->m, pc->mp, s->ldN, pc->Phi, pc->dinv, pc->chg, pc->Gacc);
         as_pc_gram_kernel<<<dim3((unsigned)(tiles * (tiles + 1) / 2), PC_SLICES), 256, 0, st>>>(pc->m, pc->mp, N, s->ldN, pc->Phi, pc->dinv,
-                                                                                               s->mL, s->mU, pc->Gpart);
-        as_pc_gram_reduce_kernel<<<dim3((unsigned)((pc->mp + 255) / 256), (unsigned)pc->mp), 256, 0, st>>>(pc->m, pc->mp, pc->Gpart,
-                                                                                                         pc->ws->H, pc->ws->ldh);
+                                                                                               s->mL, s->mU, pc->Gpart, pc->chg);
+        as_pc_gram_reduce_kernel<<<gtri, 256, 0, st>>>(pc->m, pc->mp, pc->Gpart, pc->Gacc, pc->ws->H, pc->ws->ldh, pc->chg);
         BQ_TRY(bq_chol_factor(pc->ws, pc->mp));
         BQ_TRY(as_pc_apply(s, w, 1));
         as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, pc->z, w->pv, w->cg);   // beta = 0: p = z
@@ -1486,7 +1711,7 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
         for (int b = 0; b < batch; ++b) {
             BQ_TRY(bq_problem_apply(s->p, w->pv, w->Qp, &w->cg->done));
             as_cg_pap_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, w->pv, w->Qp, s->partials, nblk, w->cg);
-            as_cg_update_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->dlt, w->r, w->pv, w->Qp, s->partials,
+            as_cg_update_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->dlt, w->r, w->pv, w->Qp, w->Qdl, s->partials,
                                                                nblk, w->cg);
             if (pc) BQ_TRY(as_pc_apply(s, w, 0));
             as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, zr, w->pv, w->cg);
@@ -1511,6 +1736,7 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
                      (long long)nA, (long long)h.iters);
         return BQ_ERR_NOT_PD;
     }
+    as_qcand_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, w->Qz, w->Qdl, w->Qcand);
     as_cg_gather_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(w->ints, w->idx, w->z, w->dlt, w->sol, N);
     as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
     as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, w->sol, s->lb, s->ub, w->cand);
@@ -1537,7 +1763,7 @@ int bq_as_start(bq_solver *s) {
         BQ_HIP(hipMemsetAsync(*v, 0, sizeof(double) * s->ldN, ctx->stream));
     }
     if (s->as_cg) {
-        for (double **v : {&w->dlt, &w->r, &w->pv, &w->Qp, &w->sol}) {
+        for (double **v : {&w->dlt, &w->r, &w->pv, &w->Qp, &w->sol, &w->Qdl, &w->Qcand}) {
             BQ_HIP(hipMalloc(v, sizeof(double) * s->ldN));
             BQ_HIP(hipMemsetAsync(*v, 0, sizeof(double) * s->ldN, ctx->stream));
         }
@@ -1545,6 +1771,20 @@ int bq_as_start(bq_solver *s) {
         BQ_HIP(hipMemsetAsync(w->cg, 0, sizeof(as_cg_scal), ctx->stream));
         BQ_HIP(hipHostMalloc(&w->cg_flag_host, 2 * sizeof(int)));
         w->warm = as_env_on("BQ_AS_CG_WARM");
+        w->incq = as_env_on("BQ_AS_CG_INCQ");
+        {
+            bq_problem *p = s->p;
+            w->colq = w->warm && as_env_on("BQ_AS_CG_COLQ") && p->X != nullptr && !p->streamed &&
+                      (p->structure == BQ_PLAIN || p->structure == BQ_SVC) && p->kernel >= BQ_KERNEL_LINEAR &&
+                      p->kernel <= BQ_KERNEL_SIGMOID;
+            if (w->colq) {
+                BQ_HIP(hipMalloc(&w->sq, sizeof(double) * s->ldN));
+                BQ_HIP(hipMalloc(&w->zchg, sizeof(int) * (2 + AS_MAX_COLS)));
+                BQ_HIP(hipMemsetAsync(w->zchg, 0, sizeof(int) * (2 + AS_MAX_COLS), ctx->stream));
+                BQ_HIP(hipMalloc(&w->zdl, sizeof(double) * AS_MAX_COLS));
+                as_row_norms_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->X, p->n, p->d, w->sq, s->ldN);
+            }
+        }
         BQ_TRY(as_pc_create(s, &w->pc));
     }
     BQ_HIP(hipMalloc(&s->mL, (size_t)s->ldN));
@@ -1559,7 +1799,7 @@ void bq_as_free(bq_solver *s) {
     if (!w) return;
     for (void *p : {(void *)w->idx, (void *)w->ints, (void *)w->cand, (void *)w->z, (void *)w->Qz, (void *)w->x_eval,
                     (void *)w->g_eval, (void *)w->dlt, (void *)w->r, (void *)w->pv, (void *)w->Qp, (void *)w->sol,
-                    (void *)w->cg})
+                    (void *)w->cg, (void *)w->Qdl, (void *)w->Qcand, (void *)w->sq, (void *)w->zchg, (void *)w->zdl})
         if (p) hipFree(p);
     if (w->cg_flag_host) hipHostFree(w->cg_flag_host);
     as_pc_free(w->pc);
@@ -1602,13 +1842,27 @@ int bq_as_iterate(bq_solver *s) {
 
     if (s->as_cg) {
         BQ_TRY(as_cg_solve(s, w));
+        // Q x of the new point without a product: Q cand is known from the inner iteration (Q z + Q delta), the ratio step is
+        // a convex combination.  Every 64th outer iteration forms it afresh so that rounding cannot accumulate.
+        const bool inc = w->incq && ++w->since_refresh < 64;
+        if (!inc) w->since_refresh = 0;
         if (w->host_ints[2]) {
             as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
-            BQ_TRY(eval_f(s, s->g));
+            if (inc) {
+                as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->Qcand, s->Qd);
+                BQ_TRY(bq_vec_eval_f(s->p, s->x, s->Qd, s->g, &s->sc->f));
+            } else {
+                BQ_TRY(eval_f(s, s->g));
+            }
             as_release_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
         } else {
             as_launch_step(s, w, st);
-            BQ_TRY(eval_f(s, nullptr));
+            if (inc) {
+                as_qx_lerp_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->sc, w->Qcand, s->Qd);
+                BQ_TRY(bq_vec_eval_f(s->p, s->x, s->Qd, nullptr, &s->sc->f));
+            } else {
+                BQ_TRY(eval_f(s, nullptr));
+            }
             as_launch_absorb(s, w, st);
         }
         BQ_HIP(hipGetLastError());

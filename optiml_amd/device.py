@@ -154,6 +154,12 @@ class Context:
         return {'kind': ('none', 'rccl', 'callback', 'share')[kind.value], 'rccl_ranks': ranks.value,
                 'sym_exchange': 'allreduce' if ar.value else 'gather'}
 
+    def set_sym_exchange(self, mode):
+        """'gather' or 'allreduce' for the products that follow (every rank must switch at the same point)."""
+        if mode not in ('gather', 'allreduce'):
+            raise ValueError(f"unknown sym_exchange '{mode}' (use 'gather' or 'allreduce')")
+        _lib.check(self._lib.bq_ctx_set_sym_allreduce(self.handle, 1 if mode == 'allreduce' else 0))
+
     def profile(self, enable=True):
         _lib.check(self._lib.bq_ctx_profile(self.handle, 1 if enable else 0))
 

@@ -1,7 +1,7 @@
 """Rank program for the multi-process tests (started by tests/test_distributed.py, one process per rank).
 
 usage: python tests/_dist_worker.py MODE OUTDIR      with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the env
-  cpu-torch / cpu-socket : communicator primitives + a row-sharded product with the CPU oracle's Hessian (no GPU)
+  cpu-torch / cpu-socket / cpu-fromenv-socket : communicator primitives + a row-sharded product with the CPU oracle's Hessian (no GPU)
   gpu-host               : every rank on GPU 0, row-block panels, host (gloo) exchange, PG + FW solves
   gpu-rccl               : RCCL exchange (world size 1 on a one-GPU box exercises init / all-gather / destroy)
   gpu-host-allreduce / gpu-rccl-allreduce : the same with sym_exchange='allreduce'
@@ -17,6 +17,12 @@ sys.path.insert(0, REPO)
 
 def make_comm(kind):
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if kind == 'fromenv-socket':   # what bench.py does on a host without torch (BQ_RENDEZVOUS=socket forces it)
+        from optiml_amd.dist import SocketComm, from_env
+        os.environ['BQ_RENDEZVOUS'] = 'socket'
+        comm = from_env(timeout=60.0)
+        assert isinstance(comm, SocketComm)
+        return comm
     if kind == 'socket':
         from optiml_amd.dist import SocketComm
         return SocketComm(rank, world, os.environ.get('MASTER_ADDR', '127.0.0.1'),
@@ -158,6 +164,8 @@ if __name__ == '__main__':
     mode, outdir = sys.argv[1], sys.argv[2]
     if mode == 'cpu-torch':
         cpu_mode('torch', outdir)
+    elif mode == 'cpu-fromenv-socket':
+        cpu_mode('fromenv-socket', outdir)
     elif mode == 'cpu-socket':
         cpu_mode('socket', outdir)
     elif mode == 'gpu-host':

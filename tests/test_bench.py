@@ -62,6 +62,25 @@ def test_self_launch_two_ranks_host_exchange_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_self_launch_without_torch_rendezvous():
+    """BQ_RENDEZVOUS=socket: the ranks meet over the package's own TCP communicator (what a host without torch gets); the N > 1
+    line carries every rank's share and timings."""
+    common = ['--samples', '6000', '--features', '16', '--steps', '6', '--warmup', '2', '--no-cpu', '--kkt', 'none']
+    r = _run(common + ['--gpus', '2', '--exchange', 'host'], env={'BQ_RENDEZVOUS': 'socket'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['n_gpus'] == 2 and rec['steps_done'] == 6 and rec['config']['exchange'] == 'host'
+    pr = rec['per_rank']
+    assert [p['rank'] for p in pr] == [0, 1] and sum(p['rows'] for p in pr) == 6000
+    nb = -(-6000 // 256)
+    assert sum(p['tiles'] for p in pr) == nb * (nb + 1) // 2
+    assert all(p['symv_tiles_ms'] > 0 and p['ms_per_step'] > 0 for p in pr)
+    ec = rec['exchange_compare']   # both closing collectives timed in the one run (the other one outside the timed region)
+    assert set(ec) == {'gather', 'allreduce'} and ec['allreduce']['steps'] == 10
+    assert all(v['exchange_ms_per_product'] > 0 and v['ms_per_step'] > 0 for v in ec.values())
+
+
+@pytest.mark.gpu
 def test_rccl_that_cannot_be_created_is_an_error_not_a_fallback():
     """Two ranks on ONE device cannot form an RCCL communicator: exit code 3, no JSON line; with --allow-host-exchange the
     run falls back and says so."""

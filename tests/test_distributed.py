@@ -59,7 +59,7 @@ def _launch(mode, world, outdir, timeout=300, extra_env=None):
     return [np.load(os.path.join(outdir, f'rank{r}.npz')) for r in range(world)]
 
 
-@pytest.mark.parametrize('kind', ['cpu-torch', 'cpu-socket'])
+@pytest.mark.parametrize('kind', ['cpu-torch', 'cpu-socket', 'cpu-fromenv-socket'])
 def test_two_rank_row_block_exchange_cpu(tmp_path, kind):
     res = _launch(kind, 2, tmp_path)
     for r in res:
