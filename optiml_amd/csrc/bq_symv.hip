@@ -309,10 +309,26 @@ static int launch_any(bq_ctx *ctx, const void *panel, int storage, bool add_one,
         case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
         case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
         case 88: return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
-        default:
-            // fp32 tiles are half as wide in bytes: 8 rows per step keep the same bytes in flight per lane
-            if (storage == BQ_F32) return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+        default: {
+            // fp32 tiles are half as wide in bytes: 8 rows per step keep the same bytes in flight per lane.  fp64: 4 rows per
+            // step, except on short grids whose LAST round of workgroups is sparsely filled (two workgroups per CU = 512 slots
+            // on this chip; a 1/8 share of n = 100 000 is ~1 200 strips = 2.3 rounds): there 8 rows per step — twice the loads in
+            // flight per wave — keep HBM busy while that round drains.  Measured (r03, `profiles/r03/symv_rows_per_step.txt`):
+            // 1 200 strips 0.85 -> 0.81 ms, 1 650 strips (n = 40 000) 1.07 -> 1.02 ms; grids whose last round is well filled
+            // are 2-6 % faster with 4 (n = 30 000: 1.86 rounds, 1/4 shares: 4.7 rounds), long grids do not care.  The rows of a
+            // step are independent sums and the lane butterfly pairs the same lanes in the same order: the bits do not depend
+            // on the choice (tests/test_distributed.py::test_rows_per_step_variants_are_bit_identical).
+            static const int force = [] {
+                const char *e = getenv("BQ_SYMV_ROWS_PER_STEP");   // 4 or 8: no heuristic
+                return e ? atoi(e) : 0;
+            }();
+            const int64_t strips = strips_before<JG_DEFAULT>(tab.cut[tab.hi]) - strips_before<JG_DEFAULT>(tab.cut[tab.lo]);
+            const int64_t slots = 2 * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256);
+            const bool sparse_tail = strips >= slots && strips < 8 * slots && 2 * (strips % slots) < slots;
+            const bool eight = force == 8 || (force != 4 && (storage == BQ_F32 || sparse_tail));
+            if (eight) return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
             return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+        }
     }
 }
 

@@ -258,3 +258,14 @@ def test_share_contexts_hold_one_ranks_part_of_the_product(world):
         quad.release()
         ctx.close()
     np.testing.assert_allclose(acc, full, rtol=1e-12, atol=1e-12 * np.abs(full).max())
+
+
+@pytest.mark.gpu
+def test_rows_per_step_variants_are_bit_identical(tmp_path, one_rank):
+    """The symmetric product streams 4 or 8 rows per step depending on how full the last round of workgroups of its grid is
+    (bq_symv.hip).  The choice must not change a bit — otherwise a rank count that changes the grid would change the iterates:
+    products, PG / FW / augmented-Lagrangian / ActiveSetCG runs forced to 4 and to 8 rows per step equal the default run."""
+    for rows in ('4', '8'):
+        res = _launch('gpu-host', 1, tmp_path / f'rows{rows}', extra_env={'BQ_SYMV_ROWS_PER_STEP': rows})[0]
+        for key in ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_f', 'ascg_kernel_x', 'ascg_kernel_f'):
+            assert np.array_equal(res[key], one_rank[key]), (rows, key)
