@@ -123,7 +123,9 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+        # few host threads per rank: the ranks do no heavy CPU work, and N x (cores / N) spinning OpenMP threads beside the HIP and
+        # gloo threads oversubscribe the host (r03: torch's intra-op pool turned a 0.5 MB host all-gather into 600 ms)
+        env.setdefault('OMP_NUM_THREADS', str(max(1, min(4, (os.cpu_count() or 8) // n))))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))   # rank 0 prints the JSON line
     rc = 0

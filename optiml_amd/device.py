@@ -110,13 +110,22 @@ class Context:
         elif exchange == 'host':
             self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'host'
 
+            debug = os.environ.get('BQ_DEBUG_EXCHANGE') == '1'
+
             def _exchange(user, buf, n, r0, r1, op):
                 try:
+                    if debug:
+                        import sys
+                        import time
+                        t0 = time.perf_counter()
                     view = np.ctypeslib.as_array(buf, shape=(n,))
                     if op == 0:
                         comm.allgather_rows(view, r0, r1)
                     else:
                         comm.allreduce_sum(view)
+                    if debug:
+                        print(f'[exchange] rank {comm.rank} op {op} n {n}: {1e3 * (time.perf_counter() - t0):.3f} ms in the communicator',
+                              file=sys.stderr, flush=True)
                     return 0
                 except Exception as exc:  # never let an exception cross the C boundary
                     import traceback

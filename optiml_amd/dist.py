@@ -62,17 +62,26 @@ class TorchComm(_Base):
 
     def allgather_rows(self, buf, r0, r1):
         import torch
+        dbg = os.environ.get('BQ_DEBUG_EXCHANGE') == '1'
+        t = [time.perf_counter()]
         n = buf.shape[0]
         blk = block_size(n, self.world_size)
         send = torch.zeros(blk, dtype=torch.float64)
         if r1 > r0:
             send[:r1 - r0] = torch.from_numpy(np.array(buf[r0:r1], copy=True))
+        t.append(time.perf_counter())
         parts = [torch.zeros(blk, dtype=torch.float64) for _ in range(self.world_size)]
         self._dist.all_gather(parts, send, group=self.group)
+        t.append(time.perf_counter())
         for r, part in enumerate(parts):
             b, e = self.rows_of(n, r)
             if e > b:
                 buf[b:e] = part[:e - b].numpy()
+        t.append(time.perf_counter())
+        if dbg and self.rank == 0:
+            import sys
+            print('[allgather_rows] read %.3f ms, all_gather %.3f ms, write %.3f ms' % tuple(1e3 * (b - a) for a, b in zip(t, t[1:])),
+                  file=sys.stderr, flush=True)
 
     def allreduce_sum(self, buf):
         import torch
