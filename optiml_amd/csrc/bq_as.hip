@@ -1602,10 +1602,17 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
             e = hipMalloc(&pc->cls, sizeof(double) * (2 * p->d + 2));
             if (e == hipSuccess) e = hipMemsetAsync(pc->cls, 0, sizeof(double) * (2 * p->d + 2), ctx->stream);
         }
-        if (rc != BQ_OK || e != hipSuccess) {   // no room for the features: run unpreconditioned rather than fail
+        if (rc != BQ_OK || e != hipSuccess) {   // no room for the features
             as_pc_free(pc);
             (void)hipGetLastError();
-            return BQ_OK;
+            if (ctx->world > 1) {
+                // every rank must run the SAME inner iteration (each product is a collective): a rank-local fallback to plain
+                // conjugate gradients would leave the ranks in different numbers of collectives
+                bq_set_error("cannot allocate the %.2f GB of preconditioner features on rank %d (BQ_AS_CG_PC=0 on every rank runs "
+                             "without them)", 8e-9 * (double)m * (double)s->ldN, ctx->rank);
+                return BQ_ERR_NOMEM;
+            }
+            return BQ_OK;   // single rank: run unpreconditioned rather than fail
         }
         if (classes) {
             unsigned int *ticket = (unsigned int *)(pc->cls + 2 * p->d + 1);   // the spare slot, zeroed above
