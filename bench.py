@@ -769,33 +769,6 @@ def main():
     mv_ms, mv_cnt = ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     ex_ms, ex_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
     inner = (solver.inner_iters() - inner0) if ascg else 0
-    exchange_compare = None
-    if comm is not None and not al and not ascg and args.storage != 'stream':
-        # outside the timed region: the same few iterations with the OTHER closing collective of the symmetric product, so that
-        # one multi-GPU run shows both (all-gather of 8 segment vectors + ordered sum, bit-identical for any N, against one
-        # all-reduce of n doubles) — collective time per product, max over ranks
-        try:
-            other = 'allreduce' if cinfo['sym_exchange'] == 'gather' else 'gather'
-            ctx.set_sym_exchange(other)
-            s2 = _DeviceSolver(dev, _lib.PG if args.solver == 'pg' else _lib.FW, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
-            s2.run(3)
-            ctx.profile_read(_lib.PROF_EXCH, reset=True)
-            barrier()
-            t2 = time.perf_counter()
-            rows2, _ = s2.run(10)
-            dt2 = time.perf_counter() - t2
-            ex2_ms, ex2_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
-            s2.close()
-            exchange_compare = {
-                cinfo['sym_exchange']: {'exchange_ms_per_product': comm.max_float((ex_ms / ex_cnt) if ex_cnt else 0.0),
-                                        'ms_per_step': 1e3 * elapsed / max(done, 1)},
-                other: {'exchange_ms_per_product': comm.max_float((ex2_ms / ex2_cnt) if ex2_cnt else 0.0),
-                        'ms_per_step': comm.max_float(1e3 * dt2 / max(len(rows2), 1)), 'steps': len(rows2)}}
-        except Exception as exc:  # noqa: BLE001 — a side record must not cost the headline line
-            exchange_compare = {'error': repr(exc)}
-        finally:
-            ctx.set_sym_exchange(cinfo['sym_exchange'])
-            ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     per_rank = None
     if comm is not None:   # every rank's share and timings in the one line rank 0 prints
         cols = [comm.allgather_float(v) for v in (own_elapsed * 1e3 / max(done, 1), mv_ms / max(mv_cnt, 1),
@@ -861,8 +834,6 @@ def main():
         }
         if per_rank is not None:
             out['per_rank'] = per_rank
-        if exchange_compare is not None:
-            out['exchange_compare'] = exchange_compare
         if ascg:
             out['inner_products_per_step'] = inner / max(done, 1)
             out['inner_tol'] = args.inner_tol
@@ -889,6 +860,48 @@ def main():
                                'row_block_equivalent_TFs': full / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                                'note': 'frac counts the MFMA flops actually issued (the tiles on/below the diagonal in this rank\'s tile rows); '
                                        'row_block_equivalent_TFs prices the launch at 2 rows n d, which is not what runs'}
+    if comm is not None and not al and not ascg and args.storage != 'stream':
+        # AFTER the headline record is complete and OUTSIDE the timed region: the same few iterations with the OTHER closing
+        # collective of the symmetric product, so that one multi-GPU run shows both (all-gather of 8 segment vectors + ordered sum,
+        # bit-identical for any N, against one all-reduce of n doubles) — collective time per product, max over ranks.  A side
+        # record must never cost the line: if it has not finished within 90 s, rank 0 prints the line without it and every rank
+        # leaves.
+        import threading
+
+        def _bail():
+            if rank == 0:
+                out['exchange_compare'] = {'error': 'the comparison run did not finish within 90 s'}
+                out['cpu_baseline'] = None
+                print(json.dumps(out), file=json_out, flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(90.0, _bail)
+        watchdog.daemon = True
+        watchdog.start()
+        exchange_compare = None
+        try:
+            other = 'allreduce' if cinfo['sym_exchange'] == 'gather' else 'gather'
+            ctx.set_sym_exchange(other)
+            s2 = _DeviceSolver(dev, _lib.PG if args.solver == 'pg' else _lib.FW, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
+            s2.run(3)
+            ctx.profile_read(_lib.PROF_EXCH, reset=True)
+            barrier()
+            t2 = time.perf_counter()
+            rows2, _ = s2.run(10)
+            dt2 = time.perf_counter() - t2
+            ex2_ms, ex2_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
+            s2.close()
+            exchange_compare = {
+                cinfo['sym_exchange']: {'exchange_ms_per_product': comm.max_float((ex_ms / ex_cnt) if ex_cnt else 0.0),
+                                        'ms_per_step': 1e3 * elapsed / max(done, 1)},
+                other: {'exchange_ms_per_product': comm.max_float((ex2_ms / ex2_cnt) if ex2_cnt else 0.0),
+                        'ms_per_step': comm.max_float(1e3 * dt2 / max(len(rows2), 1)), 'steps': len(rows2)}}
+        except Exception as exc:  # noqa: BLE001
+            exchange_compare = {'error': repr(exc)}
+        finally:
+            watchdog.cancel()
+            ctx.set_sym_exchange(cinfo['sym_exchange'])
+        if rank == 0:
+            out['exchange_compare'] = exchange_compare
     barrier()
     solver.close()
     quad.release()
