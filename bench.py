@@ -78,6 +78,11 @@ def parse(argv=None):
     ap.add_argument('--cpu-sizes', default='20000,30000', help='sample sizes of the CPU baseline leg (SURVEY 8d)')
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='timed seconds per CPU sample size')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-placement', action='store_true',
+                    help='take the panel where the first allocation puts it.  Default: the library\'s placement choice (BQ_PLACE_PANEL / '
+                         'KernelQuadratic(tune_placement=True), opt-in for SVC / SVR): the product is timed on the empty panel and up to '
+                         'two more allocations are tried if it streams below ~6.5 TB/s, the fastest is kept; the times of all candidates '
+                         'are in config.panel_placement_ms, the cost in problem_setup_s')
     ap.add_argument('--cpu-stream-iters', type=int, default=0,
                     help='also time a blocked Gram-streaming CPU product at the FULL n this many times (~35 s each at n=100000): a '
                          'measured CPU bound beside the extrapolated reference-formulation figure (SURVEY 8d)')
@@ -591,7 +596,7 @@ def share_timing(args):
         for k in range(G):
             ctx = device.Context(share=(k, G)) if G > 1 else device.Context()
             name = name or ctx.name
-            quad = KernelQuadratic(X, q, struct, kern, y=yy, storage=args.storage)
+            quad = KernelQuadratic(X, q, struct, kern, y=yy, storage=args.storage, tune_placement=not args.no_placement)
             ctx.profile(True)
             dev = quad.device_problem(ctx)
             gram_ms, _ = ctx.profile_read(_lib.PROF_GRAM, reset=True)
@@ -609,7 +614,7 @@ def share_timing(args):
             avg = mv_ms / max(mv_cnt, 1)
             step_ms = 1e3 * dt / max(len(rows), 1)
             shares.append({'rank': k, 'tile_rows': [i0, i1], 'rows': r1 - r0, 'tiles': tiles, 'strips': sum(I // 8 + 1 for I in range(i0, i1)),
-                           'panel_GB': tiles * T * T * esz / 1e9, 'gram_build_ms': gram_ms, 'steps_done': len(rows),
+                           'panel_GB': tiles * T * T * esz / 1e9, 'gram_build_ms': gram_ms, 'panel_placement_ms': dev.placement(), 'steps_done': len(rows),
                            'symv_tiles_ms': avg, 'symv_GBs': alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
                            'symv_frac_of_8TBs': alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0,
                            'ms_per_step': step_ms, 'fixed_cost_ms': step_ms - avg})
@@ -726,11 +731,12 @@ def main():
     if args.task == 'svc':
         X, y = make_blobs(n, d, seed=0, sigma=args.sigma)
         quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage, rank_one=not al,
-                               diag=0.5 if ascg else 0.0)
+                               diag=0.5 if ascg else 0.0, tune_placement=not args.no_placement)
         a_eq = y
     else:   # eps-insensitive SVR dual: 2n variables on one n x n panel (BASELINE config 4 shape)
         X, y = make_regression(n, d, seed=0)
-        quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', kern, storage=args.storage, rank_one=not al)
+        quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', kern, storage=args.storage, rank_one=not al,
+                               tune_placement=not args.no_placement)
         a_eq = np.hstack((np.ones(n), -np.ones(n)))
     N = quad.ndim
     ctx.profile(os.environ.get('BQ_BENCH_NOPROF', '0') != '1')   # HIP-event timing of the dominant kernel (roofline)
@@ -813,7 +819,8 @@ def main():
             'config': {'workload': workload, 'n': n, 'd': d, 'dual_dim': N, 'C': 1.0,
                        'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange, 'rccl_ranks': cinfo['rccl_ranks'],
                        'sym_exchange': cinfo['sym_exchange'] if world > 1 else 'none', 'blob_sigma': args.sigma,
-                       'rows_per_gpu': r1 - r0, 'device': ctx.name},
+                       'rows_per_gpu': r1 - r0, 'device': ctx.name,
+                       'panel_placement_ms': dev.placement()},
             'roofline': {'bound': 'hbm', 'kernel': 'symv_tiles_kernel (symmetric panel product Q*d)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'traffic_source': None, 'avg_launch_ms': avg_ms, 'launches': mv_cnt,

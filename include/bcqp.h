@@ -66,6 +66,14 @@ enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian 
  * the reference's own (not exactly symmetric) rounding of the RBF distances.  An option, not a default: measured on SMO
  * (single-row gathers) it changes nothing, n=100k fit 0.93 s either way — the sweeps are bound by one CU's gather rate. */
 #define BQ_FULL_PANEL 32
+/* OR-ed into the structure: choose WHERE the resident panel lives.  The rate at which the panel product streams a panel is a
+ * stable property of the allocation's physical placement (r03, tools/placement_probe.py: five panels of one n = 100 000 problem
+ * held at once ran 6.08 - 6.40 ms per product, each reproducible to 0.005 ms): with this flag the product kernel is timed on the
+ * freshly allocated (still empty) panel and, if it streams below ~6.5 TB/s, up to two more allocations are tried and the fastest
+ * kept (BQ_PANEL_CANDIDATES, BQ_PANEL_GOOD_GBS; the others are released; skipped when the device cannot hold a second panel).
+ * Costs ~4 products per candidate once per problem: for the product-bound solvers (PG, FW, ActiveSetCG, the augmented-Lagrangian
+ * rules), whose every iteration streams the panel; pointless for InteriorPoint / ActiveSet / SMO. */
+#define BQ_PLACE_PANEL 64
 enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3,                   /* solver kind */
        /* ActiveSet (active_set.py:82-237, same outer logic) whose restricted systems Q[A,A] xs = rhs are solved by
         * conjugate gradients on the masked panel product instead of a dense Cholesky factor: no n_A x n_A copy, so it
@@ -172,6 +180,9 @@ int bq_problem_gram_matvec(bq_problem *p, const double *w, double *out);
 int bq_problem_panel_rows(bq_problem *p, int64_t row0, int64_t nrows, double *out);
 /* time `reps` launches of the panel product with HIP events; returns the mean in ms */
 int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms);
+/* BQ_PLACE_PANEL: how many placements of the panel were timed (0: the flag was not given or did not apply) and the product's
+ * launch time on each, in the order tried (ms[0 .. min(*tried, cap))); the panel kept is the fastest of them */
+int bq_problem_placement(const bq_problem *p, int *tried, double *ms, int cap);
 
 /* ---- solvers (optiml/opti/constrained/, the four .py files) --------------------------------------------------- */
 /* lb/ub/x0: dual-dim fp64 host vectors (lb, x0 may be NULL: 0 and mid-box, constrained/_base.py:61-65).

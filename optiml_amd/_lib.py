@@ -22,6 +22,7 @@ STATUS = {0: 'unknown', 1: 'optimal', 2: 'stopped'}
 GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NOW, GET_DUAL = range(10)
 NO_RANK_ONE = 16
 FULL_PANEL = 32
+PLACE_PANEL = 64
 SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS, SMO_STATS = range(4)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
@@ -79,6 +80,7 @@ PROTOTYPES = {
     'bq_problem_gram_matvec': (C.c_int, [_vp, _dp, _dp]),
     'bq_problem_panel_rows': (C.c_int, [_vp, _i64, _i64, _dp]),
     'bq_problem_time_matvec': (C.c_int, [_vp, C.c_int, _dp]),
+    'bq_problem_placement': (C.c_int, [_vp, C.POINTER(C.c_int), _dp, C.c_int]),
     'bq_solver_create': (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.c_double, _i64, C.c_double, C.POINTER(_vp)]),
     'bq_solver_destroy': (C.c_int, [_vp]),
     'bq_solver_run': (C.c_int, [_vp, _i64, C.POINTER(IterStat), _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),

@@ -437,12 +437,90 @@ extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, co
     return BQ_OK;
 }
 
+// BQ_PLACE_PANEL (bcqp.h): time the product kernel on the freshly allocated, zeroed panel; while it streams below the "good" rate
+// and the device can hold one more panel, allocate another candidate and time it; keep the fastest, release the rest at the end
+// (released earlier, the allocator would hand the same memory back as the next candidate).
+static int place_panel(bq_problem *p) {
+    bq_ctx *c = p->ctx;
+    if (!p->symmetric || p->streamed || p->panel == nullptr || p->panel_bytes < ((size_t)1 << 30) || p->I1 <= p->I0) return BQ_OK;
+    const char *e = getenv("BQ_PANEL_CANDIDATES");
+    const int want = e ? std::max(1, std::min(atoi(e), 4)) : 3;
+    e = getenv("BQ_PANEL_GOOD_GBS");
+    const double good_gbs = e ? atof(e) : 6500.0;
+    bq_seg_table tab;
+    bq_sym_seg_table(p, &tab);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BQ_HIP(hipEventCreate(&e0));
+    BQ_HIP(hipEventCreate(&e1));
+    const bool prof = c->profiling;
+    c->profiling = false;
+    auto time_on = [&](void *panel, double *ms_out) -> int {
+        int rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr);   // warm
+        hipEventRecord(e0, c->stream);
+        for (int i = 0; rc == BQ_OK && i < 4; ++i)
+            rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr);
+        hipEventRecord(e1, c->stream);
+        hipError_t he = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+        if (rc == BQ_OK && he != hipSuccess) {
+            bq_set_error("timing a panel placement failed: %s", hipGetErrorString(he));
+            rc = BQ_ERR_HIP;
+        }
+        *ms_out = (double)ms / 4.0;
+        return rc;
+    };
+    std::vector<void *> losers;
+    double best = 0.0;
+    int rc = time_on(p->panel, &best);
+    p->place_tried = 1;
+    p->place_ms[0] = best;
+    while (rc == BQ_OK && p->place_tried < want && (double)p->panel_bytes / (best * 1e-3) / 1e9 < good_gbs) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < p->panel_bytes + p->panel_bytes / 16) break;
+        void *cand = nullptr;
+        if (hipMalloc(&cand, p->panel_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        hipError_t he = hipMemsetAsync(cand, 0, p->panel_bytes, c->stream);
+        double t = 0.0;
+        if (he == hipSuccess) rc = time_on(cand, &t);
+        if (he != hipSuccess || rc != BQ_OK) {
+            hipFree(cand);
+            if (he != hipSuccess) (void)hipGetLastError();
+            break;
+        }
+        p->place_ms[p->place_tried++] = t;
+        if (t < best) {
+            losers.push_back(p->panel);
+            p->panel = cand;
+            best = t;
+        } else {
+            losers.push_back(cand);
+        }
+    }
+    for (void *l : losers) hipFree(l);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    c->profiling = prof;
+    return rc;
+}
+
+extern "C" int bq_problem_placement(const bq_problem *p, int *tried, double *ms, int cap) {
+    BQ_ARG(p != nullptr && tried != nullptr, "NULL argument");
+    *tried = p->place_tried;
+    for (int i = 0; ms != nullptr && i < cap && i < p->place_tried; ++i) ms[i] = p->place_ms[i];
+    return BQ_OK;
+}
+
 extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int64_t d, const double *X,
                                         const double *y, int kernel, double gamma, double coef0, int degree,
                                         double diag_add, const double *q, int storage, bq_problem **out) {
     BQ_ARG(c && X && q && out, "NULL argument");
     const bool no_rank_one = (structure & BQ_NO_RANK_ONE) != 0, full_panel = (structure & BQ_FULL_PANEL) != 0;
-    structure &= ~(BQ_NO_RANK_ONE | BQ_FULL_PANEL);
+    const bool place = (structure & BQ_PLACE_PANEL) != 0;
+    structure &= ~(BQ_NO_RANK_ONE | BQ_FULL_PANEL | BQ_PLACE_PANEL);
     BQ_ARG(structure == BQ_PLAIN || structure == BQ_SVC || structure == BQ_SVR, "structure");
     BQ_ARG(structure != BQ_SVC || y != nullptr, "labels required for BQ_SVC");
     BQ_ARG(kernel >= BQ_KERNEL_LINEAR && kernel <= BQ_KERNEL_LAPLACIAN, "kernel");
@@ -469,6 +547,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     p->symmetric = p->streamed || !full_panel;
     int rc = problem_layout(p, n, structure == BQ_SVR ? 2 * n : n);
     if (rc == BQ_OK) rc = problem_alloc_common(p, q);
+    if (rc == BQ_OK && place) rc = place_panel(p);
     if (rc != BQ_OK) {
         bq_problem_destroy(p);
         return rc;

@@ -114,6 +114,8 @@ struct bq_problem {
     // symmetric mode (kernel-built panels): only tiles on/below the diagonal are stored and streamed; this rank owns
     // the 256-row tile rows [I0, I1) of nb, panel row 0 is global row I0*256
     size_t panel_bytes = 0;    // allocated size of `panel`
+    int place_tried = 0;       // BQ_PLACE_PANEL: placements timed, and the product's launch time on each
+    double place_ms[4] = {0.0, 0.0, 0.0, 0.0};
     bool symmetric = false;
     bool streamed = false;     // BQ_STREAM: no panel, Gram tiles recomputed inside every product (stream_img)
     void *stream_img = nullptr;

@@ -152,6 +152,18 @@ class SVM(BaseEstimator, ABC):
     def _is_stochastic(self):
         return self.dual and isinstance(self.optimizer, type) and issubclass(self.optimizer, StochasticOptimizer)
 
+    # Choose the panel's placement (`KernelQuadratic(tune_placement=True)`, BQ_PLACE_PANEL) for the optimizers whose every
+    # iteration is one panel product.  Off by default: it costs two more panel-sized allocations, which take from milliseconds to
+    # seconds on this platform (freshly released device memory is cleared before it is handed out), for ~5 % per iteration — it
+    # pays on long runs.  Set `SVC.tune_placement = True` (or on an instance) to opt in.
+    tune_placement = False
+
+    def _streams_panel(self):
+        from ...opti.constrained import ActiveSetCG, FrankWolfe, ProjectedGradient
+        return bool(self.tune_placement) and isinstance(self.optimizer, type) and (
+            issubclass(self.optimizer, (ProjectedGradient, FrankWolfe, ActiveSetCG)) or
+            issubclass(self.optimizer, StochasticOptimizer))
+
     def _check_bcqp(self):
         if not self.dual or isinstance(self.optimizer, str) or not (
                 isinstance(self.optimizer, type) and issubclass(self.optimizer, BoxConstrainedQuadraticOptimizer)):
@@ -232,7 +244,8 @@ class SVC(ClassifierMixin, SVM):
                 raise TypeError(f'{self.loss} is not an allowed loss')
             sq = self.loss == SquaredHinge   # Q += I/(2C), no upper bound (svm/_base.py:727-730, :778-794)
             obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage,
-                                  diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept)
+                                  diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept,
+                                  tune_placement=self._streams_panel())
             self._run_lagrangian(obj, None if self.reg_intercept else y, None if sq else np.ones(n) * self.C)
         else:
             self._check_bcqp()
@@ -241,7 +254,8 @@ class SVC(ClassifierMixin, SVM):
                 raise NotImplementedError('squared hinge is not available with box-constrained optimizers')
             if self.loss != Hinge:
                 raise TypeError(f'{self.loss} is not an allowed loss')
-            obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage)
+            obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage,
+                                  tune_placement=self._streams_panel())
             self._run(obj, np.ones(n) * self.C)
 
         sv = self.alphas_ > 1e-6
@@ -307,7 +321,8 @@ class SVR(RegressorMixin, SVM):
                 raise TypeError(f'{self.loss} is not an allowed loss')
             sq = self.loss == SquaredEpsilonInsensitive   # Q += I/(2C), no upper bound (svm/_base.py:1279-1283, :1332-1348)
             obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage,
-                                  diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept)
+                                  diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept,
+                                  tune_placement=self._streams_panel())
             e = np.hstack((np.ones(n), -np.ones(n)))   # equality row
             self._run_lagrangian(obj, None if self.reg_intercept else e, None if sq else np.ones(2 * n) * self.C)
         else:
@@ -318,7 +333,7 @@ class SVR(RegressorMixin, SVM):
                                           'optimizers')
             if self.loss != EpsilonInsensitive:
                 raise TypeError(f'{self.loss} is not an allowed loss')
-            obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage)
+            obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage, tune_placement=self._streams_panel())
             self._run(obj, np.ones(2 * n) * self.C)
 
         alphas_p, alphas_n = np.split(self.alphas_, 2)

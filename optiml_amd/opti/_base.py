@@ -101,6 +101,13 @@ class _DeviceProblem:
         _lib.check(self._lib.bq_problem_panel_rows(self._h, row0, nrows, _lib.ptr(out)))
         return out
 
+    def placement(self):
+        """Launch time (ms) of the panel product on every placement of the panel that was tried (`tune_placement`); [] if none."""
+        tried = C.c_int(0)
+        ms = np.zeros(4)
+        _lib.check(self._lib.bq_problem_placement(self._h, C.byref(tried), _lib.ptr(ms), 4))
+        return [float(v) for v in ms[:tried.value]]
+
     def time_matvec(self, reps=10):
         ms = C.c_double(0)
         _lib.check(self._lib.bq_problem_time_matvec(self._h, reps, C.byref(ms)))
@@ -194,13 +201,15 @@ class KernelQuadratic(Quadratic):
     `rank_one=False` leaves out the yy' / ee' term of the regularised intercept: the reg_intercept=False duals
     Q = K*yy' and [[K,-K],[-K,K]] (:552-555, :1096-1099) that the augmented-Lagrangian path solves with an equality row.
     `.Q` materialises the dense matrix from the device panel on demand (inspection / small problems only).
+    `tune_placement=True` lets the library pick the fastest of up to three allocations of the panel (`bq_problem_placement`).
     `storage='stream'` keeps NO panel: every product recomputes the Gram tiles on the MFMA (for n^2 beyond HBM; first-order
     solvers only, no `.Q`).
     """
 
     _STRUCT = {'plain': _lib.PLAIN, 'svc': _lib.SVC, 'svr': _lib.SVR}
 
-    def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64', rank_one=True, full_panel=False):
+    def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64', rank_one=True, full_panel=False,
+                 tune_placement=False):
         X = np.ascontiguousarray(X, dtype=float)
         if structure not in self._STRUCT:
             raise ValueError(f'unknown structure {structure}')
@@ -221,6 +230,9 @@ class KernelQuadratic(Quadratic):
         self.diag = float(diag)
         self.rank_one = bool(rank_one)
         self.full_panel = bool(full_panel)   # whole rows instead of the packed triangle (2x the memory)
+        # BQ_PLACE_PANEL: time the product on the fresh panel and try up to two more allocations if it streams slowly (panels of
+        # >= 1 GB; for solvers whose every iteration streams the panel)
+        self.tune_placement = bool(tune_placement)
         self.storage = storage
         self.kind, self.gamma, self.coef0, self.degree = kernel.device_spec(X)
         self._dev = None
@@ -231,7 +243,7 @@ class KernelQuadratic(Quadratic):
         n, d = self.X.shape
         _lib.check(lib.bq_problem_create_kernel(
             ctx.handle, self._STRUCT[self.structure] | (0 if self.rank_one else _lib.NO_RANK_ONE) |
-            (_lib.FULL_PANEL if self.full_panel else 0), n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
+            (_lib.FULL_PANEL if self.full_panel else 0) | (_lib.PLACE_PANEL if self.tune_placement else 0), n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,
             self.gamma, self.coef0, self.degree, self.diag, _lib.ptr(self.q),
             _lib.STORAGE[self.storage], C.byref(h)))
         return _DeviceProblem(ctx, h)

@@ -124,6 +124,36 @@ def test_kernel_quadratic_x_star_from_the_packed_panel(amd):
     quad.release()
 
 
+def test_panel_placement_selection(amd, monkeypatch):
+    """BQ_PLACE_PANEL / KernelQuadratic(tune_placement=True): the product kernel is timed on the fresh panel and further
+    allocations are tried while it streams below the 'good' rate; whichever allocation is kept, the panel's CONTENT and every
+    product are the same bits.  (Panels below 1 GB are left alone.)"""
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    n, d = 16640, 16                       # packed panel 1.1 GB
+    X, y = make_blobs(n, d, seed=3)
+    v = np.random.RandomState(0).standard_normal(n)
+    plain = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
+    ref = plain.device_problem().matvec(v)
+    assert plain.device_problem().placement() == []
+    plain.release()
+    monkeypatch.setenv('BQ_PANEL_GOOD_GBS', '1e9')         # nothing is good enough: all three candidates are tried
+    tuned = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)
+    ms = tuned.device_problem().placement()
+    assert len(ms) == 3 and all(t > 0 for t in ms)
+    assert np.array_equal(tuned.device_problem().matvec(v), ref)
+    tuned.release()
+    monkeypatch.setenv('BQ_PANEL_GOOD_GBS', '1')           # anything is good enough: the first allocation is kept
+    tuned = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)
+    assert len(tuned.device_problem().placement()) == 1
+    assert np.array_equal(tuned.device_problem().matvec(v), ref)
+    tuned.release()
+    small = KernelQuadratic(X[:2000], -np.ones(2000), 'svc', gaussian, y=y[:2000], tune_placement=True)
+    assert small.device_problem().placement() == []
+    small.release()
+
+
 def test_matvec_is_deterministic(amd):
     from optiml_amd.opti import Quadratic
     rs = np.random.RandomState(1)
