@@ -244,7 +244,7 @@ def cpu_baseline(args):
         expo = 2.0
     fitted = 1.0 / (last['s_per_iter'] * (args.n / last['n']) ** expo) if args.n > last['n'] else 1.0 / last['s_per_iter']
     desc = ', '.join(f"n={s['n']}: {s['iters']} it, {1e3 * s['s_per_iter']:.1f} ms/it ({s['GBs_of_Q']:.0f} GB/s of Q)" for s in samples)
-    out = {'value': n2, 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': args.n > last['n'],
+    out = {'value': n2, 'unit': 'iter/s', 'kind': 'port', 'kind_detail': 'extrapolated from the sizes sampled', 'extrapolated': args.n > last['n'],
            'law': 'n^2 (three dense n x n products per iteration)', 'fitted_exponent': expo, 'value_fitted_exponent': fitted,
            'sample': f'oracle {args.solver.upper()} (reference formulation: dense fp64 Q on host, 3 products/iter), d={args.d}: {desc}; '
                      f'value = rate at n={last["n"]} scaled to n={args.n} by (n_s/n)^2, the law of a bandwidth-bound dense product '
@@ -299,7 +299,7 @@ def cpu_baseline_as(args, info):
     t0 = time.perf_counter()
     res = bo.active_set(Q, -np.ones(ns), np.full(ns, np.inf), x0=np.ones(ns), max_iter=12)
     dt = (time.perf_counter() - t0) / max(res['iter'], 1)
-    out = {'value': 1.0 / (dt * (args.n / ns) ** 3), 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': True,
+    out = {'value': 1.0 / (dt * (args.n / ns) ** 3), 'unit': 'iter/s', 'kind': 'port', 'kind_detail': 'extrapolated from the sizes sampled', 'extrapolated': True,
            'sample': f'oracle ActiveSet (reference algorithm: cho_factor of Q[A,A] per iteration, dense fp64 Q on host) on the '
                      f'squared-hinge dual at n={ns} d={args.d}: {res["iter"]} iterations, {dt:.3f} s/it; value scaled by (n_s/n)^3 to n={args.n}',
            'measured_iter_per_s_at_sample': 1.0 / dt, 'sample_n': ns}
@@ -326,7 +326,7 @@ def cpu_baseline_al(args, info):
     res = ao.minimize(al, np.random.RandomState(0).uniform(size=N), 'adagrad', epochs=31, step_size=1.)
     dt = time.perf_counter() - t0
     rate = res['iter'] / dt
-    out = {'value': rate * (ns / args.n) ** 2, 'unit': 'iter/s', 'kind': 'port (extrapolated)', 'extrapolated': True,
+    out = {'value': rate * (ns / args.n) ** 2, 'unit': 'iter/s', 'kind': 'port', 'kind_detail': 'extrapolated from the sizes sampled', 'extrapolated': True,
            'sample': f'oracle AdaGrad on the augmented Lagrangian (dense fp64 Q and dense [a;-I;I] on host), n={ns} '
                      f'd={args.d}, {res["iter"]} iterations in {dt:.2f}s = {rate:.3f} iter/s measured; value scaled '
                      f'by (n_s/n)^2 to n={args.n}',
@@ -444,7 +444,7 @@ def kkt_smo(n, d, sigma, X=None, y=None, cpu=True, cpu_n=12000):
             samples.append({'n': ns, 's': time.perf_counter() - t0, 'outer_iterations': int(r['iter']), 'pair_steps': int(r['steps'])})
         last = samples[-1]
         expo = float(np.polyfit(np.log([v['n'] for v in samples]), np.log([v['s'] for v in samples]), 1)[0]) if len(samples) > 1 else 2.0
-        rec['cpu_baseline'] = {'value': last['s'] * (n / last['n']) ** 2, 'unit': 's', 'kind': 'port (extrapolated)', 'extrapolated': n > last['n'],
+        rec['cpu_baseline'] = {'value': last['s'] * (n / last['n']) ** 2, 'unit': 's', 'kind': 'port', 'kind_detail': 'extrapolated from the sizes sampled', 'extrapolated': n > last['n'],
                                'cores': 1, 'cores_note': 'SMO is a sequential chain of pair steps: one core is the algorithm\'s nature, not a choice',
                                'law': 'n^2 (pair steps grow ~linearly with n and each costs O(n))', 'fitted_exponent': expo,
                                # (the oracle's sweeps are not on a power law at these sizes — outer iterations and pair steps do not
@@ -529,7 +529,7 @@ def kkt_box(solver, n, d, sigma, cpu=True):
             if len(samples) > 1 else 3.0
         info = _cpu_info()
         rec['cpu_baseline'] = {'value': last['s_per_iteration'] * (n / last['n']) ** expo * o.iter, 'unit': 's',
-                               'kind': 'port (extrapolated)', 'extrapolated': n > last['n'], 'cores': info['cores'],
+                               'kind': 'port', 'kind_detail': 'extrapolated from the sizes sampled', 'extrapolated': n > last['n'], 'cores': info['cores'],
                                'cores_source': info['cores_source'], 'fitted_exponent': expo,
                                'law': 'fitted exponent between the two samples (a threaded dpotrf is not at its n^3 asymptote at these sizes)',
                                'value_n3_law': last['s_per_iteration'] * (n / last['n']) ** 3 * o.iter,
