@@ -713,6 +713,35 @@ def test_active_set_cg_preconditioner_and_warm_start(amd, monkeypatch):
     assert it <= 3 * len(h) and it < it0 / 3, (it, it0)
 
 
+@pytest.mark.parametrize('kind', ['rbf', 'linear', 'poly', 'laplacian'])
+@pytest.mark.parametrize('n,d', [(60, 3), (300, 20), (700, 40)])
+@pytest.mark.parametrize('storage', ['f64', 'f32'])
+def test_active_set_cg_on_kernel_panels_against_the_oracle(amd, kind, n, d, storage):
+    """ActiveSetCG on the squared-hinge dual of every kernel family, against the oracle's ActiveSet on the dense Q: same
+    iteration count, same point.  Exercises what round 3 put around the inner iteration for each of them: the preconditioner
+    (RBF features or refused, linear exact, none for poly / laplacian), the warm start, Q x carried without products, and the
+    start product from columns formed from X (rbf / linear / poly; laplacian keeps the product) — on fp64 and fp32 panels."""
+    from oracle import svm_oracle as so, bcqp_oracle as bo
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.kernels import GaussianKernel, LaplacianKernel, PolyKernel, linear
+    X, y = make_blobs(n, d, seed=n + d, sigma=6.0)
+    kern = {'rbf': GaussianKernel('scale'), 'linear': linear, 'poly': PolyKernel(3, 'scale', 1.0),
+            'laplacian': LaplacianKernel('scale')}[kind]
+    K = so.gram(kind, X, None, 'scale', 1.0 if kind == 'poly' else 0.0, 3)
+    if storage == 'f32':
+        K = K.astype(np.float32).astype(np.float64)
+    Q = K * np.outer(y, y) + np.outer(y, y) + 0.5 * np.eye(n)
+    ref = bo.active_set(Q, -np.ones(n), np.full(n, np.inf), x0=np.ones(n), max_iter=40)
+    quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, diag=0.5, storage=storage)
+    opt = _solvers()['ascg'](quad=quad, ub=np.full(n, np.inf), x=np.ones(n), max_iter=40).minimize()
+    assert opt.iter == ref['iter'] and opt.status == ref['status']
+    tol = 1e-6 if storage == 'f64' else 1e-4
+    np.testing.assert_allclose(opt.x, ref['x'], rtol=tol, atol=tol * np.abs(ref['x']).max())
+    np.testing.assert_allclose(opt.f_x, ref['f_x'], rtol=1e-9 if storage == 'f64' else 1e-6)
+    quad.release()
+
+
 def test_active_set_singular_system_uses_minres(amd, as_factor_mode):
     """Linear kernel, n > d + 1: Q[A,A] is singular, the reference's Cholesky raises and it falls back to scipy's
     minres on the normal equations (active_set.py:142-151).  The device path takes the same branch (persistent MINRES
