@@ -20,6 +20,12 @@ Rank 0 prints ONE JSON line with `roofline` (HIP-event timing of the panel-produ
 restates it in SURVEY 8(d)'s n^2*s bytes, which the kernel does not move), `cpu_baseline` (the NumPy oracle in the reference
 formulation timed at two sizes that fit the host and extrapolated with the fitted exponent) and `time_to_kkt`.
 
+The DEFAULT single-GPU line (no workload flag: what the driver runs) also carries, after the headline record is complete and each
+in a fresh child process of its own with a time budget (`--records`, `--budget-s`): `configs` = BASELINE's other GPU configs on
+this one GPU (c2, c4, c5, each with its own roofline), `shares` = every rank's share of the 2-, 4- and 8-way partitions of the
+headline panel (and of c4 over 4, c5 over 8) timed alone with the iteration rate they predict, and `collective_floor_us` = the
+closing collectives of the real message sizes on a ONE-rank RCCL communicator.  The parent process of that mode never touches HIP.
+
 Other workloads: --config c2|c3|c4|c5 (BASELINE.json configs), --solver fw|adagrad|ascg|smo|ip|as, --task svr, ...
 """
 import argparse
@@ -38,6 +44,8 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_MFMA_PEAK_TF = 78.6
+
+SIDE_RECORDS = ('c2', 'c4', 'c5', 'shares', 'collective', 'shares_c4', 'shares_c5')   # in the order they are measured
 
 CONFIGS = {   # BASELINE.json `configs` (C2 .. C5) and the headline
     'headline': dict(n=100000, d=128, solver='pg', task='svc', kernel='rbf', storage='f64'),
@@ -83,7 +91,16 @@ def parse(argv=None):
                          'KernelQuadratic(tune_placement=True), opt-in for SVC / SVR): the product is timed on the empty panel and up to '
                          'two more allocations are tried if it streams below ~6.5 TB/s, the fastest is kept; the times of all candidates '
                          'are in config.panel_placement_ms, the cost in problem_setup_s')
-    ap.add_argument('--cpu-stream-iters', type=int, default=0,
+    ap.add_argument('--records', default=None, metavar='all|none|NAME[,NAME...]',
+                    help='side records of the default single-GPU line, each measured in a fresh child process after the headline '
+                         'record is complete: ' + ','.join(SIDE_RECORDS) + '.  Default: all when no workload flag is given '
+                         '(the driver\'s command), none otherwise')
+    ap.add_argument('--budget-s', type=float, default=400.0,
+                    help='wall-clock budget of the whole default line: a side record that would not fit is skipped (and says so)')
+    ap.add_argument('--collective-floor', action='store_true',
+                    help='ONE-rank RCCL communicator: ncclAllGather / ncclAllReduce of the real message sizes of the headline, c4 '
+                         'and c5 products timed with HIP events (launch + local-copy floor of the one collective per product)')
+    ap.add_argument('--cpu-stream-iters', type=int, default=1,
                     help='also time a blocked Gram-streaming CPU product at the FULL n this many times (~35 s each at n=100000): a '
                          'measured CPU bound beside the extrapolated reference-formulation figure (SURVEY 8d)')
     ap.add_argument('--kkt', default='all', choices=['none', 'smo', 'ip', 'all', 'ip100k'],
@@ -107,6 +124,10 @@ def parse(argv=None):
                     help='CPU only (SURVEY 8d): the oracle timed at three sizes to check the n^2 (PG) / n^3 (Cholesky) laws '
                          'behind the extrapolated baseline, plus a blocked Gram-streaming product at the full n')
     args = ap.parse_args(argv)
+    # no workload flag at all = the driver's command: the line then carries the side records too
+    args.default_workload = args.config is None and all(getattr(args, k) is None for k in ('n', 'd', 'solver', 'task', 'kernel', 'storage'))
+    if args.records is None:
+        args.records = 'all' if args.default_workload else 'none'
     preset = CONFIGS[args.config or 'headline']
     for k, v in preset.items():
         if getattr(args, k) is None:
@@ -646,6 +667,172 @@ def share_timing(args):
     print(json.dumps(out), flush=True)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the default line: headline record + side records, each measured in a fresh child process (this parent never touches HIP)
+# ---------------------------------------------------------------------------------------------------------------------
+SIDE_COMMANDS = {   # name -> (arguments of the child, its time cap in seconds)
+    'c2': (['--config', 'c2', '--steps', '400', '--warmup', '20', '--no-cpu', '--kkt', 'none'], 90.0),
+    'c4': (['--config', 'c4', '--steps', '50', '--warmup', '5', '--no-cpu', '--kkt', 'none'], 90.0),
+    'c5': (['--config', 'c5', '--steps', '10', '--warmup', '2', '--no-cpu', '--kkt', 'none'], 150.0),
+    'shares': (['--emulate-shares', '2,4,8', '--steps', '30', '--warmup', '3'], 150.0),
+    'collective': (['--collective-floor'], 90.0),
+    'shares_c4': (['--config', 'c4', '--emulate-shares', '4', '--steps', '30', '--warmup', '3'], 90.0),
+    'shares_c5': (['--config', 'c5', '--solver', 'pg', '--emulate-shares', '8', '--steps', '20', '--warmup', '3'], 150.0),
+}
+
+
+def _run_child(argv, timeout):
+    """One fresh `python bench.py ... --records none` process; (last JSON object on its stdout | None, error text | None,
+    seconds).  Its stderr is this process's stderr (progress stays visible).  On expiry exactly that child is killed."""
+    t0 = time.perf_counter()
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ['--records', 'none'], stdout=subprocess.PIPE,
+                            text=True, cwd=REPO)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return None, f'not finished within its {timeout:.0f} s cap (killed)', time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    rec = None
+    for line in reversed(out.splitlines()):
+        line = line.strip()
+        if line.startswith('{'):
+            try:
+                rec = json.loads(line)
+                break
+            except ValueError:
+                continue
+    if proc.returncode != 0 or rec is None:
+        return rec, f'exit code {proc.returncode}' + ('' if rec is not None else ', no JSON line'), dt
+    return rec, None, dt
+
+
+def _compact_shares(rec):
+    """The share table of one --emulate-shares run without the per-share bulk."""
+    out = {'workload': rec['config']['workload'], 'steps': rec['config']['steps'], 'assumed_exchange_us': rec['assumed_exchange_us'],
+           'assumed_exchange_note': 'the one collective per product cannot be measured on one GPU: ASSUMED, see collective_floor_us '
+                                    'for its measured lower bound',
+           'partitions': []}
+    for part in rec['partitions']:
+        sh = part['shares']
+        out['partitions'].append({
+            'G': part['G'], 'slowest_share_ms_per_step': part['slowest_share_ms_per_step'],
+            'slowest_share_symv_tiles_ms': max(v['symv_tiles_ms'] for v in sh),
+            'min_symv_frac_of_8TBs': part['min_symv_frac_of_8TBs'],
+            'max_fixed_cost_ms': max(v['fixed_cost_ms'] for v in sh),
+            'predicted_iter_per_s_no_exchange': part['predicted_iter_per_s_no_exchange'],
+            'predicted_iter_per_s': part['predicted_iter_per_s'],
+            'per_share': [{'rank': v['rank'], 'tiles': v['tiles'], 'strips': v['strips'], 'symv_tiles_ms': v['symv_tiles_ms'],
+                           'symv_frac_of_8TBs': v['symv_frac_of_8TBs'], 'ms_per_step': v['ms_per_step']} for v in sh]})
+    return out
+
+
+def orchestrate(args):
+    """`python bench.py [--gpus 1 --steps K --warmup W]`: the headline record from a child running exactly this command, then
+    the side records (SIDE_RECORDS) from one child each, skipped with a reason when the budget would not hold them, then ONE
+    JSON line.  A failing side record never costs the line; a failing headline child is this process's failure."""
+    t_start = time.perf_counter()
+    want = list(SIDE_RECORDS) if args.records == 'all' else [r for r in args.records.split(',') if r]
+    bad = [r for r in want if r not in SIDE_COMMANDS]
+    if bad:
+        raise SystemExit(f'--records: unknown record(s) {bad}; known: {", ".join(SIDE_RECORDS)}')
+
+    def left():
+        return args.budget_s - (time.perf_counter() - t_start)
+
+    print('[bench] headline record (child process)', file=sys.stderr, flush=True)
+    head, err, dt = _run_child(sys.argv[1:], max(left(), 60.0))
+    if head is None or err is not None:
+        print(f'[bench] the headline run failed: {err}', file=sys.stderr, flush=True)
+        raise SystemExit(1)
+    timing = {'headline_s': dt}
+    side = {}
+    for name in want:
+        argv, cap = SIDE_COMMANDS[name]
+        if left() < 0.5 * cap:   # a record is started only when at least half of its cap is left; it is cut at what IS left
+            side[name] = {'skipped': f'{left():.0f} s of the {args.budget_s:.0f} s budget left, cap of this record {cap:.0f} s'}
+            continue
+        print(f'[bench] side record {name}: bench.py {" ".join(argv)}', file=sys.stderr, flush=True)
+        rec, err, dt = _run_child(argv, min(cap, max(left(), 10.0)))
+        timing[name + '_s'] = dt
+        if err is not None:
+            side[name] = {'error': err}
+            print(f'[bench] side record {name} failed: {err}', file=sys.stderr, flush=True)
+        else:
+            rec.pop('cpu_baseline', None)
+            rec['command'] = 'bench.py ' + ' '.join(argv)
+            side[name] = rec
+    configs = {k: side[k] for k in ('c2', 'c4', 'c5') if k in side}
+    if configs:
+        head['configs'] = configs
+    shares = {}
+    for key, name in (('headline', 'shares'), ('c4_over_4', 'shares_c4'), ('c5_over_8', 'shares_c5')):
+        if name in side:
+            shares[key] = _compact_shares(side[name]) if 'partitions' in side[name] else side[name]
+    if 'collective' in side:
+        head['collective_floor_us'] = side['collective']
+    # the G = 1 row of the headline table is the headline record itself; predictions also at the measured collective floor
+    floor = side.get('collective', {}).get('headline', {}) if 'collective' in side else {}
+    tab = shares.get('headline')
+    if tab and 'partitions' in tab:
+        base = head['ms_per_step']
+        tab['partitions'].insert(0, {'G': 1, 'slowest_share_ms_per_step': base, 'slowest_share_symv_tiles_ms': head['roofline']['avg_launch_ms'],
+                                     'min_symv_frac_of_8TBs': head['roofline']['frac'], 'predicted_iter_per_s': head['value'],
+                                     'predicted_iter_per_s_no_exchange': head['value'], 'source': 'the headline record of this line'})
+        for part in tab['partitions']:
+            part['predicted_speedup_vs_1'] = part['predicted_iter_per_s'] / head['value']
+            us = floor.get('gather_8_segments', {}).get('mean_us')
+            if us is not None and part['G'] > 1:
+                part['predicted_iter_per_s_at_collective_floor'] = 1e3 / (part['slowest_share_ms_per_step'] + us * 1e-3)
+    for key, cfg in (('c4_over_4', 'c4'), ('c5_over_8', 'c5')):   # the one-GPU record of the same config is the base of these
+        tab, one = shares.get(key), side.get(cfg)
+        if tab and 'partitions' in tab and one and 'ms_per_step' in one:
+            for part in tab['partitions']:
+                part['one_gpu_ms_per_step'] = one['ms_per_step']
+                if cfg == 'c5':   # the shares run PG's iteration (one product + O(n) kernels); an ActiveSetCG outer iteration is
+                    # `inner_products_per_step` such products + the work every rank repeats, measured on the one-GPU record
+                    prods = one.get('inner_products_per_step')
+                    full = one['roofline']['avg_launch_ms']
+                    if prods:
+                        repl = one['ms_per_step'] - prods * full
+                        share_ms = part['slowest_share_symv_tiles_ms'] + tab['assumed_exchange_us'] * 1e-3
+                        part['ascg_outer_iteration_ms_predicted'] = prods * share_ms + repl
+                        part['ascg_replicated_ms_per_outer_iteration'] = repl
+                        part['predicted_speedup_vs_1'] = one['ms_per_step'] / part['ascg_outer_iteration_ms_predicted']
+                else:
+                    part['predicted_speedup_vs_1'] = one['ms_per_step'] / (1e3 / part['predicted_iter_per_s'])
+    if shares:
+        head['shares'] = shares
+    timing['total_s'] = time.perf_counter() - t_start
+    head['records'] = {'requested': want, 'budget_s': args.budget_s, 'wall_s': timing,
+                       'note': 'headline record first (its own process, unchanged command); every side record in a fresh process '
+                               'of its own after it, inputs resident in HBM inside each timed region; this parent never touches HIP'}
+    print(json.dumps(head), flush=True)
+
+
+def collective_floor(args):
+    """--collective-floor: the closing collective of a product on a ONE-rank RCCL communicator, for the real message sizes: the
+    default all-gather of segment partial vectors (8 segments of nb*256 doubles in all, whatever the rank count) and the
+    alternative all-reduce(sum) of nb*256 doubles.  With one rank RCCL moves nothing between GPUs: this is the launch + local
+    copy floor of the call as the library issues it (same stream, same in-place buffers), a LOWER bound for N > 1."""
+    from optiml_amd import device
+    from optiml_amd.dist import SocketComm
+    ctx = device.Context(comm=SocketComm(0, 1), exchange='rccl')
+    info = ctx.comm_info()
+    out = {'what': 'collective_floor', 'unit': 'us', 'rccl_ranks': info['rccl_ranks'], 'device': ctx.name,
+           'note': 'ONE-rank RCCL communicator on one GPU: launch + local-copy floor of the one collective per product, HIP events '
+                   'around each of 50 calls on the compute stream; a lower bound of the N > 1 cost over xGMI, not an estimate of it'}
+    for key, n in (('headline', 100000), ('c4', 100000), ('c5', 250000)):
+        ln = -(-n // 256) * 256
+        g = ctx.probe_exchange('gather', 8 * ln, 50)        # one rank owns all 8 canonical segments: the whole gathered buffer
+        a = ctx.probe_exchange('allreduce', ln, 50)
+        out[key] = {'n': n, 'gather_8_segments': {'bytes': 8 * ln * 8, 'mean_us': g[0], 'min_us': g[1]},
+                    'allreduce': {'bytes': ln * 8, 'mean_us': a[0], 'min_us': a[1]}}
+    ctx.close()
+    print(json.dumps(out), flush=True)
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -653,6 +840,10 @@ def main():
         return cpu_study(args)
     if args.emulate_shares:
         return share_timing(args)
+    if args.collective_floor:
+        return collective_floor(args)
+    if args.records != 'none' and args.default_workload and args.gpus == 1 and 'WORLD_SIZE' not in os.environ:
+        return orchestrate(args)   # before anything in this process touches HIP
     if args.solver in ('ip', 'as', 'smo'):
         if args.gpus != 1:
             raise SystemExit('InteriorPoint / ActiveSet factorise on one GPU and SMO walks the samples sequentially '
@@ -874,28 +1065,41 @@ def main():
         # bit-identical for any N, against one all-reduce of n doubles) — collective time per product, max over ranks.  A side
         # record must never cost the line: if it has not finished within 90 s, rank 0 prints the line without it and every rank
         # leaves.
+        import copy
         import threading
+        snapshot = copy.deepcopy(out) if rank == 0 else None   # what the timer thread may print: never the dict the main thread edits
+        stage = {'at': 'start', 'steps': 0}
 
         def _bail():
+            # nothing but a collective or a kernel that never completes can expire this timer: that is a hang, and a hang is a
+            # failure — every rank says where it was and leaves with a non-zero code
+            print(f'[bench] rank {rank}: exchange_compare hung at "{stage["at"]}" (sym_exchange={stage.get("mode")}, '
+                  f'{stage["steps"]} comparison steps enqueued) — not finished within 90 s', file=sys.stderr, flush=True)
             if rank == 0:
-                out['exchange_compare'] = {'error': 'the comparison run did not finish within 90 s'}
-                out['cpu_baseline'] = None
-                print(json.dumps(out), file=json_out, flush=True)
-            os._exit(0)
+                snapshot['exchange_compare'] = {'error': 'the comparison run did not finish within 90 s', 'stuck_at': stage['at'],
+                                                'sym_exchange': stage.get('mode')}
+                snapshot['cpu_baseline'] = None
+                print(json.dumps(snapshot), file=json_out, flush=True)
+            os._exit(4)
         watchdog = threading.Timer(90.0, _bail)
         watchdog.daemon = True
         watchdog.start()
         exchange_compare = None
         try:
             other = 'allreduce' if cinfo['sym_exchange'] == 'gather' else 'gather'
+            stage.update(at='switching the closing collective', mode=other)
             ctx.set_sym_exchange(other)
             s2 = _DeviceSolver(dev, _lib.PG if args.solver == 'pg' else _lib.FW, np.zeros(N), ub, ub / 2, 1e-6, 10 ** 9)
+            stage.update(at='3 warm-up iterations', steps=3)
             s2.run(3)
             ctx.profile_read(_lib.PROF_EXCH, reset=True)
+            stage.update(at='barrier before the timed comparison')
             barrier()
             t2 = time.perf_counter()
+            stage.update(at='10 timed iterations', steps=13)
             rows2, _ = s2.run(10)
             dt2 = time.perf_counter() - t2
+            stage.update(at='max over ranks of the comparison times')
             ex2_ms, ex2_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
             s2.close()
             exchange_compare = {

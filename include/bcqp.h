@@ -139,6 +139,12 @@ int bq_ctx_probe_bandwidth(bq_ctx *ctx, int64_t bytes, int reps, double *read_gb
  * (first half warm-up: the clock settles under the load), in TFLOP/s — the yardstick beside the nominal 78.6 TFLOP/s for
  * the roofline fraction of the Cholesky (SURVEY 8d asks for nominal-peak and measured fractions) */
 int bq_ctx_probe_mfma_f64(bq_ctx *ctx, double seconds, double *tflops);
+/* measured cost of this context's closing collective of a product (ONE collective per Q*v), on the context's stream
+ * with HIP events around every call: kind 0 = the in-place all-gather of `count` doubles per rank (buffer world * count), kind 1
+ * = the in-place all-reduce(sum) of `count` doubles.  `reps` calls after 3 warm-up calls; mean and minimum in microseconds.
+ * On a ONE-rank RCCL communicator this is the launch + local-copy floor of the collective (a lower bound of what N > 1 ranks pay
+ * over xGMI, nothing more); on N > 1 ranks every rank must call it with the same arguments. */
+int bq_ctx_probe_exchange(bq_ctx *ctx, int kind, int64_t count, int reps, double *mean_us, double *min_us);
 /* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic): equal 128-aligned
  * blocks for dense panels; bq_sym_row_block: the balanced triangular partition (256-aligned) of the symmetric
  * kernel panels, whose ranks stream only the tiles on/below the diagonal */
@@ -205,6 +211,16 @@ int bq_solver_state(const bq_solver *s, int64_t *iter, int *status, double *f_x)
  * gradients; total inner iterations so far (0 for the other solvers). */
 int bq_solver_set_inner(bq_solver *s, double rtol, int64_t max_iter);
 int bq_solver_inner_iters(bq_solver *s, int64_t *total);
+/* ActiveSet bookkeeping, totals since the solver was created (0 for the other solvers):
+ *   BQ_COUNT_MINRES    iterations whose restricted system Q[A,A] was NOT factorised (non-positive pivot) and took the reference's
+ *                      minres branch (active_set.py:142-151) — what a test of the pivot threshold (BQ_AS_PIVOT_REL) looks at
+ *   BQ_COUNT_REFACTOR  base-set factorisations of the kept-factor path;  BQ_COUNT_REUSED  iterations solved through a kept factor
+ *   BQ_COUNT_INNER     = bq_solver_inner_iters */
+#define BQ_COUNT_INNER 0
+#define BQ_COUNT_MINRES 1
+#define BQ_COUNT_REFACTOR 2
+#define BQ_COUNT_REUSED 3
+int bq_solver_counter(bq_solver *s, int which, int64_t *value);
 int bq_solver_get(bq_solver *s, int what, double *out);
 
 /* ---- augmented-Lagrangian dual + first-order update rules ------------------------------------

@@ -27,6 +27,7 @@ SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS, SMO_STATS = range(4)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
+COUNT_INNER, COUNT_MINRES, COUNT_REFACTOR, COUNT_REUSED = range(4)
 ABI_VERSION = 1
 
 
@@ -67,6 +68,7 @@ PROTOTYPES = {
     'bq_ctx_profile_read': (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i64), C.c_int]),
     'bq_ctx_probe_bandwidth': (C.c_int, [_vp, _i64, C.c_int, _dp, _dp]),
     'bq_ctx_probe_mfma_f64': (C.c_int, [_vp, C.c_double, _dp]),
+    'bq_ctx_probe_exchange': (C.c_int, [_vp, C.c_int, _i64, C.c_int, _dp, _dp]),
     'bq_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_sym_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_problem_create_dense': (C.c_int, [_vp, _i64, _dp, _dp, C.c_int, C.POINTER(_vp)]),
@@ -88,6 +90,7 @@ PROTOTYPES = {
     'bq_solver_get': (C.c_int, [_vp, C.c_int, _dp]),
     'bq_solver_set_inner': (C.c_int, [_vp, C.c_double, _i64]),
     'bq_solver_inner_iters': (C.c_int, [_vp, C.POINTER(_i64)]),
+    'bq_solver_counter': (C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
     'bq_al_solver_create': (C.c_int, [_vp, C.POINTER(AlParams), _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     'bq_al_solver_dual_size': (C.c_int, [_vp, C.POINTER(_i64)]),
     'bq_al_solver_set_schedules': (C.c_int, [_vp, _dp, _dp, _i64]),

@@ -43,7 +43,9 @@ static int ctx_new(int device, bq_ctx **out) {
     hipDeviceProp_t prop;
     BQ_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
-    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    // hipDeviceProp_t::name comes back empty on some gfx950 boxes (BENCH_r03: " (gfx950:sramecc+:xnack-)"): say what is known
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name[0] ? prop.name : "AMD Instinct MI350-series [name not reported by the driver]",
+             prop.gcnArchName);
     BQ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const char *mode = getenv("BQ_SYM_EXCHANGE");
     c->sym_allreduce = mode != nullptr && strcmp(mode, "allreduce") == 0;
@@ -160,15 +162,25 @@ extern "C" int bq_ctx_profile(bq_ctx *c, int enable) {
 int bq_prof_begin(bq_ctx *c, int which, hipEvent_t *e0, hipEvent_t *e1) {
     *e0 = *e1 = nullptr;
     if (!c->profiling) return BQ_OK;
+    hipError_t err = hipSuccess;
     for (hipEvent_t *e : {e0, e1}) {
         if (!c->event_pool.empty()) {
             *e = c->event_pool.back();
             c->event_pool.pop_back();
-        } else {
-            BQ_HIP(hipEventCreate(e));
+        } else if ((err = hipEventCreate(e)) != hipSuccess) {
+            *e = nullptr;
+            break;
         }
     }
-    BQ_HIP(hipEventRecord(*e0, c->stream));
+    if (err == hipSuccess) err = hipEventRecord(*e0, c->stream);
+    if (err != hipSuccess) {   // nothing leaks on the error path: what was taken goes back to the pool
+        for (hipEvent_t *e : {e0, e1}) {
+            if (*e) c->event_pool.push_back(*e);
+            *e = nullptr;
+        }
+        bq_set_error("profiling events: %s", hipGetErrorString(err));
+        return BQ_ERR_HIP;
+    }
     (void)which;
     return BQ_OK;
 }
@@ -962,6 +974,13 @@ extern "C" int bq_solver_set_inner(bq_solver *s, double rtol, int64_t max_iter) 
 extern "C" int bq_solver_inner_iters(bq_solver *s, int64_t *total) {
     BQ_ARG(s && total, "NULL argument");
     *total = s->kind == BQ_AS ? bq_as_inner_iters(s) : 0;
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_counter(bq_solver *s, int which, int64_t *value) {
+    BQ_ARG(s && value, "NULL argument");
+    BQ_ARG(which >= BQ_COUNT_INNER && which <= BQ_COUNT_REUSED, "which: BQ_COUNT_*");
+    *value = s->kind == BQ_AS ? bq_as_counter(s, which) : 0;
     return BQ_OK;
 }
 

@@ -1821,6 +1821,18 @@ long long bq_as_inner_iters(bq_solver *s) {
     return w ? w->cg_iters : 0;
 }
 
+long long bq_as_counter(bq_solver *s, int which) {
+    as_ws *w = get_ws(s);
+    if (!w) return 0;
+    switch (which) {
+        case BQ_COUNT_INNER: return w->cg_iters;
+        case BQ_COUNT_MINRES: return w->minres_calls;
+        case BQ_COUNT_REFACTOR: return w->sch ? w->sch->refreshes : 0;
+        case BQ_COUNT_REUSED: return w->sch ? w->sch->reused : 0;
+        default: return 0;
+    }
+}
+
 const double *bq_as_view(bq_solver *s, int what) {
     as_ws *w = get_ws(s);
     if (!w || !s->started) return what == BQ_GET_X ? s->x : s->g;

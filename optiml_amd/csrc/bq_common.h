@@ -285,6 +285,7 @@ void bq_as_free(bq_solver *s);
 int bq_al_iterate(bq_solver *s);   // bq_al.hip
 const double *bq_as_view(bq_solver *s, int what);
 long long bq_as_inner_iters(bq_solver *s);
+long long bq_as_counter(bq_solver *s, int which);
 
 // bq_chol.hip
 int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out);

@@ -184,6 +184,14 @@ class Context:
         _lib.check(self._lib.bq_ctx_probe_bandwidth(self.handle, int(nbytes), int(reps), C.byref(r), C.byref(c)))
         return r.value, c.value
 
+    def probe_exchange(self, kind, count, reps=50):
+        """(mean_us, min_us) of this context's closing collective timed on its own: kind 'gather' = the in-place all-gather of
+        `count` doubles per rank, 'allreduce' = the all-reduce(sum) of `count` doubles (every rank calls it alike)."""
+        mean, mn = C.c_double(0), C.c_double(0)
+        _lib.check(self._lib.bq_ctx_probe_exchange(self.handle, {'gather': 0, 'allreduce': 1}[kind], int(count), int(reps),
+                                                   C.byref(mean), C.byref(mn)))
+        return mean.value, mn.value
+
     def probe_mfma_f64(self, seconds=1.0):
         """TFLOP/s that back-to-back fp64 MFMAs on register operands sustain on this GPU (clock under load included)."""
         t = C.c_double(0)

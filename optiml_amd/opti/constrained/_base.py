@@ -66,6 +66,12 @@ class _DeviceSolver:
         _lib.check(self._lib.bq_solver_inner_iters(self._h, C.byref(n)))
         return n.value
 
+    def counter(self, which):
+        """ActiveSet bookkeeping totals: _lib.COUNT_MINRES / COUNT_REFACTOR / COUNT_REUSED / COUNT_INNER."""
+        n = C.c_int64(0)
+        _lib.check(self._lib.bq_solver_counter(self._h, int(which), C.byref(n)))
+        return n.value
+
     def close(self):
         if self._h:
             self._lib.bq_solver_destroy(self._h)

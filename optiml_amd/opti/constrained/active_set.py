@@ -34,6 +34,8 @@ class ActiveSet(BoxConstrainedQuadraticOptimizer):
     def _finalize(self, solver):
         self.L = solver.get(_lib.GET_MASK_L) > 0
         self.U = solver.get(_lib.GET_MASK_U) > 0
+        # iterations that took the reference's minres branch (active_set.py:142-151: Q[A,A] not factorisable)
+        self.minres_iterations = solver.counter(_lib.COUNT_MINRES)
 
 
 class ActiveSetCG(ActiveSet):

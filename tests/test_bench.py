@@ -113,3 +113,77 @@ def test_launched_by_torch_distributed_run_like_the_driver():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps_done'] == 6 and rec['config']['exchange'] == 'host'
+
+
+def test_default_line_is_composed_from_child_records(monkeypatch, capsys):
+    """`python bench.py` with no workload flag: the parent composes ONE line from the headline child's record and the side
+    records (configs / shares / collective floor), never touching HIP itself; a failing or over-budget side record is reported
+    inside the line, not fatal."""
+    sys.path.insert(0, REPO)
+    import bench
+    args = bench.parse(['--gpus', '1', '--steps', '20', '--warmup', '5'])
+    assert args.default_workload and args.records == 'all' and args.cpu_stream_iters == 1
+    assert bench.parse(['--samples', '5000']).records == 'none'
+    calls = []
+
+    def share_rec(workload, gs, ms):
+        parts = []
+        for G in gs:
+            shares = [{'rank': k, 'tiles': 100, 'strips': 20, 'symv_tiles_ms': ms / G, 'symv_frac_of_8TBs': 0.8, 'ms_per_step': ms / G + 0.05,
+                       'fixed_cost_ms': 0.05} for k in range(G)]
+            parts.append({'G': G, 'shares': shares, 'slowest_share_ms_per_step': ms / G + 0.05, 'min_symv_frac_of_8TBs': 0.8,
+                          'predicted_iter_per_s_no_exchange': 1e3 / (ms / G + 0.05), 'predicted_iter_per_s': 1e3 / (ms / G + 0.1)})
+        return {'what': 'share_timing', 'config': {'workload': workload, 'steps': 30}, 'assumed_exchange_us': 50.0, 'partitions': parts}
+
+    def fake_child(argv, timeout):
+        calls.append((list(argv), timeout))
+        if '--collective-floor' in argv:
+            return {'what': 'collective_floor', 'headline': {'gather_8_segments': {'mean_us': 5.0}, 'allreduce': {'mean_us': 4.0}}}, None, 1.0
+        if '--emulate-shares' in argv:
+            if 'c5' in argv:
+                return None, 'exit code 1, no JSON line', 2.0
+            return share_rec('c4' if 'c4' in argv else 'headline', [int(g) for g in argv[argv.index('--emulate-shares') + 1].split(',')], 6.0), None, 3.0
+        if '--config' in argv:
+            cfg = argv[argv.index('--config') + 1]
+            rec = {'metric': 'dual_qp_iterations_per_sec', 'value': 10.0, 'ms_per_step': 100.0, 'config': {'workload': cfg},
+                   'roofline': {'frac': 0.8, 'avg_launch_ms': 9.0}, 'cpu_baseline': None}
+            if cfg == 'c5':
+                rec['inner_products_per_step'] = 10.0
+            return rec, None, 4.0
+        return {'metric': 'dual_qp_iterations_per_sec', 'value': 160.0, 'ms_per_step': 6.25, 'n_gpus': 1, 'steps': 20, 'warmup': 5,
+                'roofline': {'frac': 0.82, 'avg_launch_ms': 6.1}, 'cpu_baseline': {'value': 0.2}}, None, 100.0
+
+    monkeypatch.setattr(bench, '_run_child', fake_child)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
+    bench.orchestrate(args)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert calls[0][0] == ['--gpus', '1', '--steps', '20', '--warmup', '5']       # the headline child runs exactly the caller's command
+    assert [c[0][:2] for c in calls[1:4]] == [['--config', 'c2'], ['--config', 'c4'], ['--config', 'c5']]
+    assert rec['value'] == 160.0 and rec['steps'] == 20 and rec['cpu_baseline'] == {'value': 0.2}   # headline fields untouched
+    assert set(rec['configs']) == {'c2', 'c4', 'c5'} and 'cpu_baseline' not in rec['configs']['c2']
+    head = rec['shares']['headline']['partitions']
+    assert [p['G'] for p in head] == [1, 2, 4, 8] and head[0]['predicted_iter_per_s'] == 160.0
+    assert head[3]['predicted_speedup_vs_1'] == pytest.approx(head[3]['predicted_iter_per_s'] / 160.0)
+    assert head[3]['predicted_iter_per_s_at_collective_floor'] == pytest.approx(1e3 / (6.0 / 8 + 0.05 + 0.005))
+    assert rec['shares']['c4_over_4']['partitions'][0]['one_gpu_ms_per_step'] == 100.0
+    assert 'error' in rec['shares']['c5_over_8']                                  # a failing side record stays inside the line
+    assert rec['collective_floor_us']['headline']['allreduce']['mean_us'] == 4.0
+    assert rec['records']['requested'] == list(bench.SIDE_RECORDS)
+    # a budget that is already spent: the headline still runs, every side record is skipped with the reason
+    calls.clear()
+    args.budget_s = 1.0
+    bench.orchestrate(args)
+    rec = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert len(calls) == 1 and all('skipped' in v for v in rec['configs'].values())
+
+
+def test_default_line_without_a_gpu_fails_loudly():
+    """No GPU here: the headline child cannot create a context; the parent prints no JSON line and returns non-zero."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a GPU')
+    r = _run(['--steps', '2', '--warmup', '1', '--no-cpu', '--kkt', 'none'], timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ''
+    assert 'headline run failed' in r.stderr

@@ -812,6 +812,96 @@ def test_active_set_on_a_rank_deficient_problem_follows_the_oracle_to_the_end(am
     np.testing.assert_allclose(got.f_x, ref['f_x'], rtol=1e-10)
 
 
+def _pivot_threshold_cases():
+    """(name, Q, q, ub) of SPD but ill-conditioned hinge-dual Hessians whose FIRST restricted system is all of Q (x0 = C/2: every
+    variable free).  Three families: an RBF block with one near-duplicate pair of samples at distance e (the last pivot of the pair
+    is ~2 gamma e^2 of its diagonal: the family that walks the relative-pivot test directly), RBF blocks with shrinking gamma
+    (K -> 11'), and a synthetic log-spaced spectrum in a random orthogonal basis."""
+    from oracle import svm_oracle as so
+    rs = np.random.RandomState(3)
+    n, d = 64, 4
+    X0 = rs.standard_normal((n, d))
+    y = np.where(rs.rand(n) > .5, 1., -1.)
+    cases = []
+    for e in (1e-3, 1e-5, 1e-6, 3e-7, 1e-7, 1e-8, 0.0):
+        X = X0.copy()
+        X[1] = X[0] + e * rs.standard_normal(d)
+        yy = y.copy()
+        yy[1] = yy[0]
+        cases.append((f'near-duplicate pair e={e:g}',) + so.svc_dual(so.gram('rbf', X), yy, 1.0))
+    for g in (1e-1, 1e-2, 3e-3, 1e-3, 3e-4, 1e-5):
+        cases.append((f'rbf gamma={g:g}',) + so.svc_dual(so.gram('rbf', X0, None, g), y, 1.0))
+    V, _ = np.linalg.qr(rs.standard_normal((n, n)))
+    for ce in (8, 10, 12, 13, 14, 15, 16):
+        lam = np.logspace(0, -ce, n)
+        Q = (V * lam) @ V.T
+        Q = (Q + Q.T) / 2
+        cases.append((f'spectrum 1..1e-{ce}', Q, -Q @ rs.uniform(0.2, 0.8, n), np.ones(n)))
+    return cases
+
+
+def test_active_set_pivot_threshold_is_pinned_from_both_sides(amd, as_factor_mode, monkeypatch):
+    """The one deliberate deviation of ActiveSet (INTEGRATION.md "Deviations"): a pivot below 1e-13 x the original diagonal entry
+    counts as non-positive (bq_chol.h pivot_rel, BQ_AS_PIVOT_REL), LAPACK's test is `<= 0` (active_set.py:138-151 through
+    scipy.linalg.cho_factor).  20 SPD Hessians with cond(Q_AA) from 1e6 to beyond 1e16, on both sides of the threshold:
+
+      * cond <= 1e13 (in fact wherever the smallest relative pivot of the exact factorisation is >= 1e-12): the device takes the
+        Cholesky branch like the reference and follows its objective history — NO divergence below cond 1e13;
+      * smallest relative pivot <= 1e-14 (cond >= ~1e16 here: exact duplicates, gamma -> 0): the device takes the minres branch
+        deterministically, whatever LAPACK's rounding noise decides;
+      * BQ_AS_PIVOT_REL=0 restores LAPACK's test: Cholesky wherever the relative pivot is >= 1e-14.
+    The band between (relative pivot 1e-14 .. 1e-12, cond ~1e15 .. 1e16) is where the two tests can differ; what each side does
+    there is printed (and written to gpurun_out/pivot_threshold_table.txt when that directory exists), not asserted: scipy's own
+    branch in that band moves with the BLAS build."""
+    from oracle import bcqp_oracle as bo
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import ActiveSet
+    lines = ['%-30s %10s %12s %8s %14s %14s' % ('case', 'cond', 'min rel piv', 'scipy', 'device 1e-13', 'device rel=0')]
+    for name, Q, q, ub in _pivot_threshold_cases():
+        n = len(q)
+        w = np.linalg.eigvalsh(Q)
+        cond = w[-1] / max(abs(w[0]), 1e-300)
+        try:
+            L = np.linalg.cholesky(Q)
+            minrel = float((np.diag(L) ** 2 / np.diag(Q)).min())
+        except np.linalg.LinAlgError:
+            minrel = 0.0
+        ref = bo.active_set(Q, q, ub, max_iter=6, trace=True)
+        ref_minres = bool(ref['trace'][0]['used_minres'])
+        got = {}
+        for rel in ('default', '0'):
+            if rel == 'default':
+                monkeypatch.delenv('BQ_AS_PIVOT_REL', raising=False)
+            else:
+                monkeypatch.setenv('BQ_AS_PIVOT_REL', rel)
+            hist = []
+            cb = lambda o: hist.append(o.f_x)
+            cb._bq_needs_state = False
+            one = ActiveSet(quad=Quadratic(Q, q), ub=ub, max_iter=1).minimize()
+            run = ActiveSet(quad=Quadratic(Q, q), ub=ub, max_iter=6, callback=cb).minimize()
+            got[rel] = (one.minres_iterations, np.array(hist), run)
+        lines.append('%-30s %10.2e %12.2e %8s %14s %14s' % (name, cond, minrel, 'minres' if ref_minres else 'cholesky',
+                                                          'minres' if got['default'][0] else 'cholesky',
+                                                          'minres' if got['0'][0] else 'cholesky'))
+        if minrel >= 1e-12:
+            assert cond <= 1e16
+            assert not ref_minres and got['default'][0] == 0 and got['0'][0] == 0, lines[-1]
+            for rel in got:   # the reference's objective history (the candidate itself is only determined to cond * eps)
+                np.testing.assert_allclose(got[rel][1], ref['f_hist'][:len(got[rel][1])], rtol=1e-6, atol=1e-9, err_msg=name)
+                assert got[rel][2].iter == ref['iter'] and got[rel][2].status == ref['status']
+        if cond <= 1e13:
+            assert minrel >= 1e-12, lines[-1]   # every case below cond 1e13 is on the "same branch, same history" side
+        if minrel <= 1e-14:
+            assert got['default'][0] == 1, lines[-1]
+        elif minrel >= 3e-14:
+            assert got['0'][0] == 0, lines[-1]
+    table = '\n'.join(lines)
+    print(table)
+    if os.path.isdir('gpurun_out'):
+        with open(f'gpurun_out/pivot_threshold_table_{as_factor_mode}.txt', 'w') as fh:
+            fh.write(table + '\n')
+
+
 def test_active_set_singular_system_at_n10000(amd):
     """The reference falls through to minres on the normal equations whatever |A| is (active_set.py:142-151); round 1's device
     fallback stopped at |A| = 8192.  Linear kernel, n = 10 000, d = 20 (rank 21 Hessian): the first iterations against the
