@@ -886,8 +886,11 @@ def test_active_set_pivot_threshold_is_pinned_from_both_sides(amd, as_factor_mod
         if minrel >= 1e-12:
             assert cond <= 1e16
             assert not ref_minres and got['default'][0] == 0 and got['0'][0] == 0, lines[-1]
-            for rel in got:   # the reference's objective history (the candidate itself is only determined to cond * eps)
-                np.testing.assert_allclose(got[rel][1], ref['f_hist'][:len(got[rel][1])], rtol=1e-6, atol=1e-9, err_msg=name)
+            # the reference's objective history.  Both sides solve by Cholesky here, but a candidate is only determined to
+            # cond * eps (two correct factorisations of a cond 6e13 system differ by 1e-5 in f: measured), so the level moves with cond
+            for rel in got:
+                np.testing.assert_allclose(got[rel][1], ref['f_hist'][:len(got[rel][1])], rtol=max(1e-6, 1e-18 * cond), atol=1e-9,
+                                           err_msg=name)
                 assert got[rel][2].iter == ref['iter'] and got[rel][2].status == ref['status']
         if cond <= 1e13:
             assert minrel >= 1e-12, lines[-1]   # every case below cond 1e13 is on the "same branch, same history" side
