@@ -45,7 +45,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_MFMA_PEAK_TF = 78.6
 
-SIDE_RECORDS = ('c2', 'c4', 'c5', 'shares', 'collective', 'shares_c4', 'shares_c5')   # in the order they are measured
+SIDE_RECORDS = ('c2', 'c4', 'c5', 'shares', 'collective', 'shares_c4', 'shares_c5', 'fixed_cap', 'fixed_cap_c5')   # in the order they are measured
 
 CONFIGS = {   # BASELINE.json `configs` (C2 .. C5) and the headline
     'headline': dict(n=100000, d=128, solver='pg', task='svc', kernel='rbf', storage='f64'),
@@ -97,6 +97,12 @@ def parse(argv=None):
                          '(the driver\'s command), none otherwise')
     ap.add_argument('--budget-s', type=float, default=400.0,
                     help='wall-clock budget of the whole default line: a side record that would not fit is skipped (and says so)')
+    ap.add_argument('--fixed-cap', type=int, default=0, metavar='CAP',
+                    help='SURVEY 8(d): the solvers that do not reach their tolerance at these sizes, run to a fixed iteration cap: for '
+                         'each workload of --fixed-cap-configs (default: this one) iterations done, status, f and the projected-gradient '
+                         'norm computed the SAME way for every solver (d = -g with PG\'s masks, g from a fresh product at the final point), '
+                         'wall time; ActiveSetCG also |L| + |U| and the inner products')
+    ap.add_argument('--fixed-cap-configs', default=None, metavar='NAME[,NAME...]', help='--fixed-cap: workloads (headline, c2, c4, c5)')
     ap.add_argument('--collective-floor', action='store_true',
                     help='ONE-rank RCCL communicator: ncclAllGather / ncclAllReduce of the real message sizes of the headline, c4 '
                          'and c5 products timed with HIP events (launch + local-copy floor of the one collective per product)')
@@ -678,7 +684,10 @@ SIDE_COMMANDS = {   # name -> (arguments of the child, its time cap in seconds)
     'shares': (['--emulate-shares', '2,4,8', '--steps', '30', '--warmup', '3'], 150.0),
     'collective': (['--collective-floor'], 90.0),
     'shares_c4': (['--config', 'c4', '--emulate-shares', '4', '--steps', '30', '--warmup', '3'], 90.0),
-    'shares_c5': (['--config', 'c5', '--solver', 'pg', '--emulate-shares', '8', '--steps', '20', '--warmup', '3'], 150.0),
+    'shares_c5': (['--config', 'c5', '--solver', 'pg', '--emulate-shares', '1,8', '--steps', '20', '--warmup', '3'], 150.0),
+    'fixed_cap': (['--fixed-cap', '1000', '--fixed-cap-configs', 'headline,c2,c4'], 90.0),
+    # the reference's ActiveSet needs ~n outer iterations at config 5 (hours): the driver line holds 100 of them, profiles/r04/fixed_cap_c5.json 1 000
+    'fixed_cap_c5': (['--fixed-cap', '100', '--fixed-cap-configs', 'c5'], 90.0),
 }
 
 
@@ -773,6 +782,19 @@ def orchestrate(args):
             shares[key] = _compact_shares(side[name]) if 'partitions' in side[name] else side[name]
     if 'collective' in side:
         head['collective_floor_us'] = side['collective']
+    caps = {}
+    for name in ('fixed_cap', 'fixed_cap_c5'):
+        rec = side.get(name)
+        if rec is None:
+            continue
+        if 'runs' in rec:
+            for k, v in rec['runs'].items():
+                caps[k] = dict(v, cap=rec['cap'])
+            caps.setdefault('residual', rec['residual'])
+        else:
+            caps[name] = rec
+    if caps:
+        head['fixed_cap'] = caps
     # the G = 1 row of the headline table is the headline record itself; predictions also at the measured collective floor
     floor = side.get('collective', {}).get('headline', {}) if 'collective' in side else {}
     tab = shares.get('headline')
@@ -791,15 +813,23 @@ def orchestrate(args):
         if tab and 'partitions' in tab and one and 'ms_per_step' in one:
             for part in tab['partitions']:
                 part['one_gpu_ms_per_step'] = one['ms_per_step']
-                if cfg == 'c5':   # the shares run PG's iteration (one product + O(n) kernels); an ActiveSetCG outer iteration is
-                    # `inner_products_per_step` such products + the work every rank repeats, measured on the one-GPU record
+                if cfg == 'c5':
+                    # The shares run PG's iteration: one product (tiles + slab reduction) + a few O(n) kernels = P_G ms on a 1/G share.
+                    # An ActiveSetCG outer iteration is `inner_products_per_step` products + work every rank repeats (preconditioner
+                    # passes, O(n) kernels of the conjugate gradients, the m x m inverse): R = outer(1 GPU) - products x P_1, measured
+                    # on this GPU; predicted outer(G) = products x (P_G + the ASSUMED collective) + R.
                     prods = one.get('inner_products_per_step')
-                    full = one['roofline']['avg_launch_ms']
-                    if prods:
-                        repl = one['ms_per_step'] - prods * full
-                        share_ms = part['slowest_share_symv_tiles_ms'] + tab['assumed_exchange_us'] * 1e-3
+                    g1 = next((q for q in tab['partitions'] if q['G'] == 1), None)
+                    if prods and g1 and part['G'] > 1:
+                        # the product's own time is taken from the SAME process as the outer iteration it is subtracted from (the
+                        # panel's placement moves it by +-3 % from process to process: a difference of two processes' numbers is
+                        # noise); the share run contributes only what a product costs beside its tile kernel (slab reduction, O(n))
+                        p1 = one['roofline']['avg_launch_ms'] + (g1['slowest_share_ms_per_step'] - g1['slowest_share_symv_tiles_ms'])
+                        repl = one['ms_per_step'] - prods * p1
+                        share_ms = part['slowest_share_ms_per_step'] + tab['assumed_exchange_us'] * 1e-3
                         part['ascg_outer_iteration_ms_predicted'] = prods * share_ms + repl
                         part['ascg_replicated_ms_per_outer_iteration'] = repl
+                        part['ascg_one_gpu_product_step_ms'] = p1
                         part['predicted_speedup_vs_1'] = one['ms_per_step'] / part['ascg_outer_iteration_ms_predicted']
                 else:
                     part['predicted_speedup_vs_1'] = one['ms_per_step'] / (1e3 / part['predicted_iter_per_s'])
@@ -810,6 +840,78 @@ def orchestrate(args):
                        'note': 'headline record first (its own process, unchanged command); every side record in a fresh process '
                                'of its own after it, inputs resident in HBM inside each timed region; this parent never touches HIP'}
     print(json.dumps(head), flush=True)
+
+
+def fixed_cap(args):
+    """--fixed-cap CAP: SURVEY 8(d)'s report for the solvers that do not reach their own tolerance at these sizes (in the reference
+    either): each workload run for CAP iterations from the reference's start point, then, computed identically for all of them from
+    the final point: f = 1/2 x'Qx + q'x and g = Qx + q by ONE fresh product (bq_problem_eval), the projected-gradient norm |d|_2 with
+    d = -g, d_i = 0 where x_i sits on ub and d_i > 0 or on lb and d_i < 0 (projected_gradient.py:99-104, tolerance 1e-12)."""
+    from optiml_amd import _lib, device
+    from optiml_amd.datasets import make_blobs, make_regression
+    from optiml_amd.ml.svm.kernels import PolyKernel, gaussian, linear
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained._base import _DeviceSolver
+    ctx = device.get_context()
+    names = [c for c in (args.fixed_cap_configs or (args.config or 'headline')).split(',') if c]
+    out = {'what': 'fixed_cap', 'cap': args.fixed_cap, 'device': ctx.name,
+           'residual': '|d|_2, d = -g masked as ProjectedGradient masks it (active bounds, 1e-12); g = Qx + q from one fresh product at the final point',
+           'runs': {}}
+    for name in names:
+        cfg = CONFIGS[name]
+        n, d = cfg['n'], cfg['d']
+        kern = {'rbf': gaussian, 'poly': PolyKernel(3, 'scale', 1.0), 'linear': linear}[cfg['kernel']]
+        ascg = cfg['solver'] == 'ascg'
+        if cfg['solver'] not in ('pg', 'fw', 'ascg'):
+            out['runs'][name] = {'skipped': f"{cfg['solver']} reaches its own stop test: see time_to_kkt"}
+            continue
+        if cfg['task'] == 'svc':
+            X, y = make_blobs(n, d, seed=0, sigma=args.sigma)
+            quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=cfg['storage'], diag=0.5 if ascg else 0.0)
+        else:
+            X, y = make_regression(n, d, seed=0)
+            quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', kern, storage=cfg['storage'])
+        N = quad.ndim
+        t0 = time.perf_counter()
+        dev = quad.device_problem(ctx)
+        t_setup = time.perf_counter() - t0
+        lb = np.zeros(N)
+        if ascg:   # squared-hinge dual (SURVEY 8c.6): ub = +inf, x0 = 1
+            ub, x0 = np.full(N, np.inf), np.ones(N)
+            solver = _DeviceSolver(dev, _lib.AS_CG, lb, ub, x0, 1e-6, args.fixed_cap)
+            solver.set_inner(args.inner_tol, 0)
+        else:
+            ub = np.ones(N)
+            solver = _DeviceSolver(dev, _lib.PG if cfg['solver'] == 'pg' else _lib.FW, lb, ub, ub / 2, 1e-6, args.fixed_cap)
+        t0 = time.perf_counter()
+        done, status = 0, 'unknown'
+        while status == 'unknown' and done < args.fixed_cap + 1:
+            rows, status = solver.run(min(100, args.fixed_cap + 1 - done))   # chunks: a long run stays visible on stderr
+            done += len(rows)
+            print(f'[fixed-cap] {name}: {done} records, f = {rows["f"][-1] if len(rows) else float("nan"):.6f}, '
+                  f'{time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
+            if len(rows) == 0:
+                break
+        dt = time.perf_counter() - t0
+        it, status, f_solver = solver.state()
+        x = solver.get(_lib.GET_X_NOW)
+        f, g = dev.eval(x)
+        dvec = -g
+        dvec[(ub - x <= 1e-12) & (dvec > 0)] = 0.0
+        dvec[(x - lb <= 1e-12) & (dvec < 0)] = 0.0
+        rec = {'workload': name, 'n': n, 'd': d, 'dual_dim': N, 'solver': cfg['solver'], 'storage': cfg['storage'], 'iterations': int(it),
+               'status': status, 'f': float(f), 'f_solver_last_record': float(f_solver), 'proj_grad_norm_2': float(np.linalg.norm(dvec)),
+               'proj_grad_norm_inf': float(np.abs(dvec).max()), 'wall_s': dt, 'iter_per_s': it / dt if dt > 0 else None,
+               'problem_setup_s': t_setup, 'n_at_lower': int((x - lb <= 1e-12).sum()),
+               'n_at_upper': int((ub - x <= 1e-12).sum()), 'n_sv_alpha_gt_1e-6': int((x > 1e-6).sum())}
+        if ascg:
+            rec['inner_products'] = int(solver.inner_iters())
+            rec['inner_products_per_outer_iteration'] = rec['inner_products'] / max(int(it), 1)
+            rec['inner_tol'] = args.inner_tol
+        out['runs'][name] = rec
+        solver.close()
+        quad.release()
+    print(json.dumps(out), flush=True)
 
 
 def collective_floor(args):
@@ -842,6 +944,8 @@ def main():
         return share_timing(args)
     if args.collective_floor:
         return collective_floor(args)
+    if args.fixed_cap > 0:
+        return fixed_cap(args)
     if args.records != 'none' and args.default_workload and args.gpus == 1 and 'WORLD_SIZE' not in os.environ:
         return orchestrate(args)   # before anything in this process touches HIP
     if args.solver in ('ip', 'as', 'smo'):

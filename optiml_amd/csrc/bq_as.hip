@@ -65,7 +65,7 @@ struct as_cg_scal {
 };
 
 // Preconditioner of the inner conjugate gradients: P = D + Phi Phi' restricted to the free set, Phi (N x m, m << N) an
-// explicit low-rank factor of the smooth part of the Hessian and D the diagonal left over.  Applied through Woodbury:
+// explicit low-rank factor (stored in fp32) of the smooth part of the Hessian and D the diagonal left over.  Applied through Woodbury:
 //   P_AA^-1 r = D^-1 r - D^-1 Phi_A G^-1 Phi_A' D^-1 r,   G = I + Phi_A' D_A^-1 Phi_A  (m x m, factorised once per outer iteration).
 // RBF panels: the first-order Taylor features of exp(-g|x-x'|^2) = e^{-g|x|^2} e^{-g|x'|^2} (1 + 2g x.x' + ...), i.e.
 // Phi_i = y_i e^{-g|x_i|^2} [1, sqrt(2g) x_i] (+ the y_i column of the rank-one term): the d + 1 directions whose eigenvalues
@@ -73,14 +73,27 @@ struct as_cg_scal {
 struct as_pc {
     int m = 0;               // features
     int64_t mp = 0;          // m padded to the factorisation block
-    double *Phi = nullptr;   // m x ldN, feature-major (a column of the N x m matrix is contiguous)
+    float *Phi = nullptr;    // m8 x ldN fp32, feature-major (a column of the N x m matrix is contiguous; rows m .. m8 are zero).
+                             // fp32: P = D + Phi Phi' only has to be positive definite and the same on every rank, and a relative
+                             // error of 6e-8 on directions whose eigenvalues are ~1e5 stays far below the bulk (~1); the two passes
+                             // over Phi per inner iteration move half the bytes (round 4)
+    int64_t m8 = 0;          // m rounded up to the feature group of the t = Phi' D^-1 r kernel
+    double *tpart = nullptr; // nblk x mp: per-sample-block partial sums of t
+    unsigned int *tticket = nullptr;
     double *dinv = nullptr;  // ldN: 1 / D_i
     double *z = nullptr;     // ldN: preconditioned residual
     double *Gpart = nullptr; // slices x mp x mp partial Gram sums
-    double *Gacc = nullptr;  // mp x mp: G = I + Phi_A' D_A^-1 Phi_A of the free set in `prev`, kept between outer iterations
-    unsigned char *prev = nullptr;   // ldN: the free set G was last brought up to
+    double *Ginv = nullptr;  // mp x mp, full symmetric storage: G^-1, G = I + Phi_A' D_A^-1 Phi_A of the free set in `prev`.  Rebuilt
+                             // from a Cholesky factor of G summed afresh (first iteration, every 128th, > 64 changes at once, after a
+                             // failed update) and carried between rebuilds by Sherman-Morrison updates, one per sample that entered
+                             // or left the free set, in index order (as_pc_sm_kernel)
+    double *u = nullptr;     // mp: G^-1 t
+    int *sm_fail = nullptr;  // device flag: an update met a denominator <= 1e-8 (the caller rebuilds)
+    unsigned char *prev = nullptr;   // ldN: the free set G^-1 was last brought up to
     int *chg = nullptr;      // [0] changed indices since then, [1] need a full rebuild, [2 ..] index and sign (+1 freed / -1 bound)
-    int age = 0;             // outer iterations since the last full rebuild (rounding of the rank-one updates)
+    int host_chg[2] = {0, 1};        // chg[0 .. 1] as read at the top of the outer iteration
+    int age = 0;             // outer iterations since the last full rebuild (rounding of the rank-one updates); 0: rebuild now
+    long long rebuilds = 0;
     double *cls = nullptr;   // class statistics (as_pc_class_kernel), BQ_SVC + RBF only
     bq_chol_ws *ws = nullptr;
 };
@@ -101,6 +114,7 @@ struct as_ws {
     double *dlt = nullptr, *r = nullptr, *pv = nullptr, *Qp = nullptr, *sol = nullptr;
     as_cg_scal *cg = nullptr;
     int *cg_flag_host = nullptr;   // pinned: {done, info}
+    hipEvent_t cg_event = nullptr; // recorded behind the copy of the flag (lagged polling of the inner iteration)
     long long cg_iters = 0;
     double *Qdl = nullptr, *Qcand = nullptr;   // Q delta accumulated over the inner iterations; Q cand = Q z + Q delta
     bool incq = true;              // BQ_AS_CG_INCQ=0: a fresh product Q x after every outer iteration (round 2)
@@ -109,6 +123,8 @@ struct as_ws {
     int *zchg = nullptr;           // [0] count, [1] 1 = columns suffice (the start product is skipped), [2 ..] indices
     double *zdl = nullptr;         // bound - cand of those indices
     int since_refresh = 0;         // outer iterations since Q x was last formed by a product
+    bool anchor = false;           // the next solve forms its start product Q z by a real product (re-anchors Q z -> Q cand -> Q z ...)
+    long long pc_rebuilds = 0, pc_dropped = 0;   // Woodbury system not positive definite: G summed afresh / preconditioner given up
     as_pc *pc = nullptr;           // null: plain conjugate gradients
     bool have_cand = false;        // w->cand holds the candidate of the previous outer iteration (the warm start)
     bool warm = true;              // BQ_AS_CG_WARM=0: start every inner solve from the current point
@@ -620,48 +636,103 @@ __global__ void as_qx_lerp_kernel(int64_t N, const bq_scal *sc, const double *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short, index-ordered lists of the samples where a per-sample predicate holds (which variables moved since the previous outer
+// iteration), multi-block: pass 1 counts per block of 1024 samples and the last block to finish turns the counts into offsets
+// (the total and the "too many" verdict with them); pass 2 writes entry `offset + rank inside the block` when it is below the
+// list's capacity.  Index order = (block, item j, wave, lane) as everywhere in these kernels, so the list — and what is done in
+// its order — is the same on every rank and for every launch geometry.  (Round 3: one workgroup walked all N samples with three
+// barriers per 1024: 0.25 ms per list at n = 250 000.)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void as_list_count(int changed_bits, int *__restrict__ cnt, unsigned int *ticket, int *total_out) {
+    // changed_bits: bit j = item j of this thread is in the list
+    __shared__ int wt[4];
+    int c = __popc(changed_bits);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&cnt[blockIdx.x], wt[0] + wt[1] + wt[2] + wt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (as_last_block_mb(ticket) && threadIdx.x == 0) {
+        int run = 0;
+        for (unsigned int b = 0; b < gridDim.x; ++b) {
+            const int v = __hip_atomic_load(&cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cnt[b] = run;
+            run += v;
+        }
+        *total_out = run;
+    }
+}
+// position of item j of this thread in the list (valid where bit j of changed_bits is set)
+__device__ __forceinline__ void as_list_positions(int changed_bits, const int *__restrict__ cnt, int pos[BQ_VEC_ITEMS]) {
+    __shared__ int wt[BQ_VEC_ITEMS][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int within[BQ_VEC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        const unsigned long long bal = __ballot((changed_bits >> j) & 1);
+        within[j] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wt[j][wv] = __popcll(bal);
+    }
+    __syncthreads();
+    int off = cnt[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        int o = off;
+        for (int k = 0; k < wv; ++k) o += wt[j][k];
+        pos[j] = o + within[j];
+        off += wt[j][0] + wt[j][1] + wt[j][2] + wt[j][3];
+    }
+}
+
 constexpr int AS_MAX_COLS = 16;
 // Where the start vector z (the previous candidate with the CURRENT bound values) differs from that candidate: the variables
-// that reached a bound in the step since — a handful.  Index order, one workgroup (same bits on every rank).
+// that reached a bound in the step since — a handful.
 // zchg[1] = 1: at most AS_MAX_COLS of them, so Q z = Q cand + sum_j (bound_j - cand_j) Q[:, j] and the product is skipped.
-__global__ __launch_bounds__(1024) void as_zdiff_kernel(int64_t N, const unsigned char *__restrict__ mL,
-                                                        const unsigned char *__restrict__ mU, const double *__restrict__ lb,
-                                                        const double *__restrict__ ub, const double *__restrict__ cand,
-                                                        int *__restrict__ zchg, double *__restrict__ zdl) {
-    __shared__ int wcnt[16];
-    __shared__ int base;
-    if (threadIdx.x == 0) base = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int64_t i0 = 0; i0 < N; i0 += 1024) {
-        const int64_t i = i0 + threadIdx.x;
-        double dl = 0.0;
-        if (i < N && (mL[i] | mU[i])) dl = (mU[i] ? ub[i] : lb[i]) - cand[i];
-        const int changed = dl != 0.0;
-        const unsigned long long bal = __ballot(changed);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int k = 0; k < wv; ++k) off += wcnt[k];
-        if (changed) {
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < AS_MAX_COLS) {
-                zchg[2 + pos] = (int)i;
-                zdl[pos] = dl;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int k = 0; k < 16; ++k) tot += wcnt[k];
-            base += tot;
-        }
-        __syncthreads();
+__device__ __forceinline__ double as_zdiff_of(int64_t i, int64_t N, const unsigned char *mL, const unsigned char *mU,
+                                              const double *lb, const double *ub, const double *cand) {
+    if (i < N && (mL[i] | mU[i])) return (mU[i] ? ub[i] : lb[i]) - cand[i];
+    return 0.0;
+}
+__global__ __launch_bounds__(256) void as_zdiff_count_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                             const unsigned char *__restrict__ mU, const double *__restrict__ lb,
+                                                             const double *__restrict__ ub, const double *__restrict__ cand,
+                                                             int *__restrict__ cnt, unsigned int *ticket, int *__restrict__ zchg) {
+    int bits = 0;
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        const int64_t i = (int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x;
+        if (as_zdiff_of(i, N, mL, mU, lb, ub, cand) != 0.0) bits |= 1 << j;
     }
-    if (threadIdx.x == 0) {
-        zchg[0] = base;
-        zchg[1] = (base <= AS_MAX_COLS && isfinite((double)base)) ? 1 : 0;
+    __shared__ int total;
+    if (threadIdx.x == 0) total = -1;
+    as_list_count(bits, cnt, ticket, &total);
+    if (threadIdx.x == 0 && total >= 0) {
+        zchg[0] = total;
+        zchg[1] = total <= AS_MAX_COLS ? 1 : 0;
     }
+}
+__global__ __launch_bounds__(256) void as_zdiff_write_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                             const unsigned char *__restrict__ mU, const double *__restrict__ lb,
+                                                             const double *__restrict__ ub, const double *__restrict__ cand,
+                                                             const int *__restrict__ cnt, int *__restrict__ zchg,
+                                                             double *__restrict__ zdl) {
+    int bits = 0;
+    double dl[BQ_VEC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        const int64_t i = (int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x;
+        dl[j] = as_zdiff_of(i, N, mL, mU, lb, ub, cand);
+        if (dl[j] != 0.0) bits |= 1 << j;
+    }
+    int pos[BQ_VEC_ITEMS];
+    as_list_positions(bits, cnt, pos);
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j)
+        if (((bits >> j) & 1) && pos[j] < AS_MAX_COLS) {
+            zchg[2 + pos[j]] = (int)((int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x);
+            zdl[pos[j]] = dl[j];
+        }
 }
 
 // Qz = Q cand + sum_c dl_c Q[:, j_c] with the columns formed from X (replicated on every rank, so no exchange): the entry the
@@ -673,39 +744,46 @@ __global__ __launch_bounds__(256) void as_qz_cols_kernel(int64_t n, int64_t d, c
                                                          const int *__restrict__ zchg, const double *__restrict__ zdl,
                                                          const double *__restrict__ Qc, double *__restrict__ Qz) {
     if (!zchg[1]) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    // a WAVE per row, lanes along the features: a row of X is read in 512-byte runs (round 3 gave every lane a row of its own: 64
+    // cache lines per load instruction, 0.53 ms for the 0.5 GB of X at BASELINE config 5); the dot product is the lane-strided sum
+    // + a halving butterfly, the same on every rank
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int cnt = zchg[0];
-    double acc = Qc[i];
-    const double *xi = X + i * d;
-    for (int c = 0; c < cnt; ++c) {
-        const int64_t j = zchg[2 + c];
-        const double *xj = X + j * d;
-        double dot = 0.0;
-        for (int64_t k = 0; k < d; ++k) dot = fma(xi[k], xj[k], dot);
-        double kv;
-        if (kernel == BQ_KERNEL_RBF) {
-            double dist = -2.0 * dot;
-            dist += sq[i];
-            dist += sq[j];
-            dist = fmax(dist, 0.0);
-            if (i == j) dist = 0.0;
-            kv = bq_exp(-gamma * dist);
-        } else if (kernel == BQ_KERNEL_POLY) {
-            const double b = gamma * dot + coef0;
-            kv = degree == 2 ? b * b : (degree == 3 ? b * b * b : pow(b, (double)degree));
-        } else if (kernel == BQ_KERNEL_SIGMOID) {
-            kv = tanh(gamma * dot + coef0);
-        } else {
-            kv = dot;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const double *xi = X + i * d;
+        double acc = Qc[i];
+        for (int c = 0; c < cnt; ++c) {
+            const int64_t j = zchg[2 + c];
+            const double *xj = X + j * d;
+            double dot = 0.0;
+            for (int64_t k = lane; k < d; k += 64) dot = fma(xi[k], xj[k], dot);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            double kv;
+            if (kernel == BQ_KERNEL_RBF) {
+                double dist = -2.0 * dot;
+                dist += sq[i];
+                dist += sq[j];
+                dist = fmax(dist, 0.0);
+                if (i == j) dist = 0.0;
+                kv = bq_exp(-gamma * dist);
+            } else if (kernel == BQ_KERNEL_POLY) {
+                const double b = gamma * dot + coef0;
+                kv = degree == 2 ? b * b : (degree == 3 ? b * b * b : pow(b, (double)degree));
+            } else if (kernel == BQ_KERNEL_SIGMOID) {
+                kv = tanh(gamma * dot + coef0);
+            } else {
+                kv = dot;
+            }
+            if (f32) kv = (double)(float)kv;
+            double q = kv + (add_one ? 1.0 : 0.0);
+            if (sgn) q *= sgn[i] * sgn[j];
+            if (i == j) q += diag_add;
+            acc = fma(zdl[c], q, acc);
         }
-        if (f32) kv = (double)(float)kv;
-        double q = kv + (add_one ? 1.0 : 0.0);
-        if (sgn) q *= sgn[i] * sgn[j];
-        if (i == j) q += diag_add;
-        acc = fma(zdl[c], q, acc);
+        if (lane == 0) Qz[i] = acc;
     }
-    Qz[i] = acc;
 }
 
 __global__ void as_row_norms_kernel(const double *__restrict__ X, int64_t n, int64_t d, double *__restrict__ out, int64_t ld) {
@@ -779,12 +857,12 @@ __global__ __launch_bounds__(256) void as_pc_class_kernel(int64_t n, int64_t d, 
 //       grow like n (at BASELINE config 5 they sit at ~0.4 of family 1's)
 __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t ld, const double *__restrict__ X,
                                       const double *__restrict__ sgn, const double *__restrict__ cls, double gamma,
-                                      int add_one, double diag_add, int m, double *__restrict__ Phi, double *__restrict__ dinv,
+                                      int add_one, double diag_add, int m, float *__restrict__ Phi, double *__restrict__ dinv,
                                       double *__restrict__ share) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ld) return;
     if (i >= n) {
-        for (int j = 0; j < m; ++j) Phi[(int64_t)j * ld + i] = 0.0;
+        for (int j = 0; j < m; ++j) Phi[(int64_t)j * ld + i] = 0.f;
         dinv[i] = 0.0;
         share[i] = 1.0;
         return;
@@ -795,39 +873,31 @@ __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t 
     for (int64_t k = 0; k < d; ++k) sq = fma(x[k], x[k], sq);
     double s = 0.0, qii;
     int col = 0;
+    // every feature is rounded to fp32 where it is stored, and D is what THOSE values leave of the diagonal
+    auto put = [&](int64_t j, double v) {
+        const float vf = (float)v;
+        Phi[j * ld + i] = vf;
+        s = fma((double)vf, (double)vf, s);
+    };
     if (kernel == BQ_KERNEL_RBF) {
         const double e = exp(-gamma * sq);
         const double c0 = y * e, c1 = c0 * sqrt(2.0 * gamma);
-        Phi[i] = c0;
-        s = c0 * c0;
-        for (int64_t k = 0; k < d; ++k) {
-            const double v = c1 * x[k];
-            Phi[(1 + k) * ld + i] = v;
-            s = fma(v, v, s);
-        }
+        put(0, c0);
+        for (int64_t k = 0; k < d; ++k) put(1 + k, c1 * x[k]);
         col = (int)d + 1;
         if (cls != nullptr) {
             const double c2 = 2.0 * gamma * cls[2 * d] * e;
-            for (int64_t k = 0; k < d; ++k) {
-                const double v = c2 * (x[k] - cls[d + k] - y * cls[k]);
-                Phi[(col + k) * ld + i] = v;
-                s = fma(v, v, s);
-            }
+            for (int64_t k = 0; k < d; ++k) put(col + k, c2 * (x[k] - cls[d + k] - y * cls[k]));
             col += (int)d;
         }
         qii = 1.0;
-    } else {   // linear: exact features
-        for (int64_t k = 0; k < d; ++k) {
-            const double v = y * x[k];
-            Phi[k * ld + i] = v;
-            s = fma(v, v, s);
-        }
+    } else {   // linear: exact features (up to their fp32 rounding)
+        for (int64_t k = 0; k < d; ++k) put(k, y * x[k]);
         col = (int)d;
         qii = sq;
     }
     if (add_one) {
-        Phi[(int64_t)col * ld + i] = y;
-        s += 1.0;
+        put(col, y);
         qii += 1.0;
     }
     qii += diag_add;
@@ -836,11 +906,9 @@ __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t 
 }
 
 // Gpart[slice][a][b] = sum over the slice's FREE samples of Phi[a][i] Phi[b][i] / D_i, lower tiles (b-tile <= a-tile)
-__global__ __launch_bounds__(256) void as_pc_gram_kernel(int m, int64_t mp, int64_t N, int64_t ld, const double *__restrict__ Phi,
+__global__ __launch_bounds__(256) void as_pc_gram_kernel(int m, int64_t mp, int64_t N, int64_t ld, const float *__restrict__ Phi,
                                                          const double *__restrict__ dinv, const unsigned char *__restrict__ mL,
-                                                         const unsigned char *__restrict__ mU, double *__restrict__ Gpart,
-                                                         const int *__restrict__ chg) {
-    if (!chg[1]) return;   // the rank-one updates brought G up to date
+                                                         const unsigned char *__restrict__ mU, double *__restrict__ Gpart) {
     __shared__ double As[PC_T][PC_C + 1], Bs[PC_T][PC_C + 1];
     // (ta, tb) from the linear lower-triangle tile index
     int ta = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -859,8 +927,8 @@ __global__ __launch_bounds__(256) void as_pc_gram_kernel(int m, int64_t mp, int6
             const int64_t i = c + cc;
             double wgt = 0.0;
             if (i < i1 && !(mL[i] | mU[i])) wgt = dinv[i];
-            As[row][cc] = (a0 + row < m && wgt != 0.0) ? Phi[(int64_t)(a0 + row) * ld + i] * wgt : 0.0;
-            Bs[row][cc] = (b0 + row < m && i < i1) ? Phi[(int64_t)(b0 + row) * ld + i] : 0.0;
+            As[row][cc] = (a0 + row < m && wgt != 0.0) ? (double)Phi[(int64_t)(a0 + row) * ld + i] * wgt : 0.0;
+            Bs[row][cc] = (b0 + row < m && i < i1) ? (double)Phi[(int64_t)(b0 + row) * ld + i] : 0.0;
         }
         __syncthreads();
 #pragma unroll 8
@@ -876,133 +944,282 @@ __global__ __launch_bounds__(256) void as_pc_gram_kernel(int m, int64_t mp, int6
         Gpart[((int64_t)blockIdx.y * mp + a0 + ty * 4 + j) * mp + b0 + tx] = acc[j];
 }
 
-// full rebuild: G = I + the slices of Gpart added in slice order (lower triangle; identity on the pad rows); every time: H = G
-__global__ void as_pc_gram_reduce_kernel(int m, int64_t mp, const double *__restrict__ Gpart, double *__restrict__ G,
-                                         double *__restrict__ H, int64_t ldh, const int *__restrict__ chg) {
+// full rebuild: H = G = I + the slices of Gpart added in slice order (lower triangle; identity on the pad rows)
+__global__ void as_pc_gram_reduce_kernel(int m, int64_t mp, const double *__restrict__ Gpart, double *__restrict__ H, int64_t ldh) {
     const int64_t a = blockIdx.y, b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b > a || b >= mp) return;
-    if (chg[1]) {
-        double v = (a == b) ? 1.0 : 0.0;
-        if (a < m)
-            for (int sidx = 0; sidx < PC_SLICES; ++sidx) v += Gpart[((int64_t)sidx * mp + a) * mp + b];
-        G[a * mp + b] = v;
+    double v = (a == b) ? 1.0 : 0.0;
+    if (a < m)
+        for (int sidx = 0; sidx < PC_SLICES; ++sidx) v += Gpart[((int64_t)sidx * mp + a) * mp + b];
+    H[a * ldh + b] = v;
+}
+
+// G^-1 = L^-T L^-1 from the explicit inverse factor bq_chol_prepare_sweeps leaves (MT = L^-T, upper triangular, pitch 1024):
+// Ginv[a][b] = sum_k MT[a][k] MT[b][k] — 16 x 16 tiles through LDS, k ascending: one fixed order
+__global__ __launch_bounds__(256) void as_pc_ginv_kernel(int64_t mp, const double *__restrict__ MT, int64_t ldm, double *__restrict__ Ginv) {
+    __shared__ double As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t a0 = (int64_t)blockIdx.y * 16, b0 = (int64_t)blockIdx.x * 16;
+    double acc = 0.0;
+    const int64_t kstart = (a0 > b0 ? a0 : b0);   // MT[a][k] = 0 for k < a
+    for (int64_t k0 = kstart; k0 < mp; k0 += 16) {
+        As[ty][tx] = MT[(a0 + ty) * ldm + k0 + tx];
+        Bs[ty][tx] = MT[(b0 + ty) * ldm + k0 + tx];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(As[ty][k], Bs[tx][k], acc);
+        __syncthreads();
     }
-    H[a * ldh + b] = G[a * mp + b];
+    Ginv[(a0 + ty) * mp + b0 + tx] = acc;
+}
+
+// u = Ginv t: a wave per row, lanes along the columns, xor butterfly (every lane ends with the sum)
+__global__ __launch_bounds__(256) void as_pc_gemv_kernel(int64_t mp, const double *__restrict__ Ginv, const double *__restrict__ t,
+                                                         double *__restrict__ u, const as_cg_scal *cg) {
+    if (cg->done) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t a = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= mp) return;
+    const double *row = Ginv + a * mp;
+    double acc = 0.0;
+    for (int64_t b = lane; b < mp; b += 64) acc = fma(row[b], t[b], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) u[a] = acc;
 }
 
 constexpr int PC_MAX_CHG = 64;
-// which samples entered / left the free set since G was last brought up to date, in index order (one workgroup: the order of
-// the rank-one updates must not depend on the launch geometry); more than PC_MAX_CHG of them, or `force`: full rebuild
-__global__ __launch_bounds__(1024) void as_pc_diff_kernel(int64_t N, const unsigned char *__restrict__ mL,
-                                                          const unsigned char *__restrict__ mU, unsigned char *__restrict__ prev,
-                                                          int *__restrict__ chg, int force) {
-    __shared__ int wcnt[16];
-    __shared__ int base;
-    if (threadIdx.x == 0) base = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int64_t i0 = 0; i0 < N; i0 += 1024) {
-        const int64_t i = i0 + threadIdx.x;
-        int fr = 0, was = 0;
-        if (i < N) {
-            fr = !(mL[i] | mU[i]);
-            was = prev[i];
-            prev[i] = (unsigned char)fr;
-        }
-        const int changed = (i < N) && (fr != was);
-        const unsigned long long bal = __ballot(changed);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int k = 0; k < wv; ++k) off += wcnt[k];
-        if (changed) {
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < PC_MAX_CHG) {
-                chg[2 + 2 * pos] = (int)i;
-                chg[3 + 2 * pos] = fr ? 1 : -1;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int k = 0; k < 16; ++k) tot += wcnt[k];
-            base += tot;
-        }
-        __syncthreads();
+// which samples entered / left the free set since G was last brought up to date, in index order (the order of the rank-one
+// updates must not depend on the launch geometry: as_list_count / as_list_positions); more than PC_MAX_CHG of them, or `force`:
+// full rebuild
+__global__ __launch_bounds__(256) void as_pc_diff_count_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                               const unsigned char *__restrict__ mU,
+                                                               const unsigned char *__restrict__ prev, int *__restrict__ cnt,
+                                                               unsigned int *ticket, int *__restrict__ chg, int force) {
+    int bits = 0;
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        const int64_t i = (int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x;
+        if (i < N && (int)!(mL[i] | mU[i]) != (int)prev[i]) bits |= 1 << j;
     }
-    if (threadIdx.x == 0) {
-        chg[0] = base;
-        chg[1] = (force || base > PC_MAX_CHG) ? 1 : 0;
+    __shared__ int total;
+    if (threadIdx.x == 0) total = -1;
+    as_list_count(bits, cnt, ticket, &total);
+    if (threadIdx.x == 0 && total >= 0) {
+        chg[0] = total;
+        chg[1] = (force || total > PC_MAX_CHG) ? 1 : 0;
     }
 }
+__global__ __launch_bounds__(256) void as_pc_diff_write_kernel(int64_t N, const unsigned char *__restrict__ mL,
+                                                               const unsigned char *__restrict__ mU, unsigned char *__restrict__ prev,
+                                                               const int *__restrict__ cnt, int *__restrict__ chg) {
+    int bits = 0, fr[BQ_VEC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j) {
+        const int64_t i = (int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x;
+        fr[j] = 0;
+        if (i < N) {
+            fr[j] = !(mL[i] | mU[i]);
+            if (fr[j] != (int)prev[i]) bits |= 1 << j;
+            prev[i] = (unsigned char)fr[j];
+        }
+    }
+    int pos[BQ_VEC_ITEMS];
+    as_list_positions(bits, cnt, pos);
+#pragma unroll
+    for (int j = 0; j < BQ_VEC_ITEMS; ++j)
+        if (((bits >> j) & 1) && pos[j] < PC_MAX_CHG) {
+            chg[2 + 2 * pos[j]] = (int)((int64_t)blockIdx.x * BQ_VEC_TILE + (int64_t)j * BQ_VEC_BLOCK + threadIdx.x);
+            chg[3 + 2 * pos[j]] = fr[j] ? 1 : -1;
+        }
+}
 
-// G += sign phi_i phi_i' / D_i for the changed samples, in list order (lower triangle)
-__global__ __launch_bounds__(256) void as_pc_rank1_kernel(int m, int64_t mp, int64_t ld, const double *__restrict__ Phi,
-                                                          const double *__restrict__ dinv, const int *__restrict__ chg,
-                                                          double *__restrict__ G) {
-    if (chg[1]) return;
+// G -> G + s phi phi' / D for every sample that entered (s = +1) or left (s = -1) the free set, in list order, carried on the
+// INVERSE (Sherman-Morrison):  v = Ginv phi,  Ginv -= (s / D) / (1 + (s / D) phi'v) v v'.  One workgroup: the updates are a
+// chain, each is two passes over the m x m inverse (3 MB at m = 514: L2), and there are one or two of them per outer iteration
+// — against the m^3 / 3 factorisation + explicit inverse of round 3's every outer iteration (0.9 ms at BASELINE config 5).
+// G - phi phi'/D stays >= I, so every denominator is positive; one at or below 1e-8 (or not finite) raises *fail and the caller
+// sums G afresh.  Fixed order throughout: the same bits on every rank.
+__global__ __launch_bounds__(1024) void as_pc_sm_kernel(int m, int64_t mp, int64_t ld, const float *__restrict__ Phi,
+                                                        const double *__restrict__ dinv, const int *__restrict__ chg,
+                                                        double *__restrict__ Ginv, int *__restrict__ fail) {
+    __shared__ double phi[PC_MAX_M], v[PC_MAX_M];
+    __shared__ double red[16];
+    __shared__ double coef_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cnt = chg[0];
-    if (cnt == 0) return;
-    const int64_t a = blockIdx.y, b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b > a || a >= m) return;
-    double v = G[a * mp + b];
     for (int c = 0; c < cnt; ++c) {
         const int64_t i = chg[2 + 2 * c];
         const double wgt = (double)chg[3 + 2 * c] * dinv[i];
-        v = fma(Phi[a * ld + i] * wgt, Phi[b * ld + i], v);
+        for (int j = tid; j < m; j += 1024) phi[j] = (double)Phi[(int64_t)j * ld + i];
+        __syncthreads();
+        for (int a0 = wv * 2; a0 < m; a0 += 32) {   // two rows per wave and turn: two independent chains
+            const int a1 = a0 + 1 < m ? a0 + 1 : a0;
+            const double *r0 = Ginv + (int64_t)a0 * mp, *r1 = Ginv + (int64_t)a1 * mp;
+            double s0 = 0.0, s1 = 0.0;
+            for (int b = lane; b < m; b += 64) {
+                s0 = fma(r0[b], phi[b], s0);
+                s1 = fma(r1[b], phi[b], s1);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                s0 += __shfl_xor(s0, off, 64);
+                s1 += __shfl_xor(s1, off, 64);
+            }
+            if (lane == 0) {
+                v[a0] = s0;
+                v[a1] = s1;
+            }
+        }
+        __syncthreads();
+        double part = 0.0;
+        for (int j = tid; j < m; j += 1024) part = fma(phi[j], v[j], part);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) red[wv] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < 16; ++k) tot += red[k];
+            const double denom = 1.0 + wgt * tot;
+            if (!(denom > 1e-8) || !isfinite(denom)) {
+                *fail = 1;
+                coef_s = 0.0;
+            } else {
+                coef_s = wgt / denom;
+            }
+        }
+        __syncthreads();
+        const double coef = coef_s;
+        for (int a = wv; a < m; a += 16) {
+            double *row = Ginv + (int64_t)a * mp;
+            const double ca = coef * v[a];
+            for (int b = lane; b < m; b += 64) row[b] = fma(-ca, v[b], row[b]);
+        }
+        __syncthreads();
     }
-    G[a * mp + b] = v;
 }
 
-// t[j] = sum_i Phi[j][i] r_i / D_i   (r vanishes outside the free set); one workgroup per feature, fixed order
-__global__ __launch_bounds__(256) void as_pc_tphi_kernel(int m, int64_t N, int64_t ld, const double *__restrict__ Phi,
-                                                         const double *__restrict__ dinv, const double *__restrict__ r,
-                                                         double *__restrict__ tvec, const as_cg_scal *cg) {
+typedef float as_f4 __attribute__((ext_vector_type(4)));
+constexpr int PC_FG = 8;   // features per butterfly group of the t kernel
+
+// t[j] = sum_i Phi[j][i] r_i / D_i   (r vanishes outside the free set).  One workgroup per block of 1024 samples: a lane keeps
+// w = r / D of its four consecutive samples in registers and walks all features (one 16-byte load per feature: a 4 KiB run per
+// workgroup and feature row), eight features at a time through a halving butterfly over the 64 lanes (3 + 3 shuffle-adds for
+// eight sums), the four wave sums meet in LDS -> tpart[block][j]; the last workgroup to finish adds the blocks in block order.
+// Round 3 had one workgroup per FEATURE re-reading r and 1 / D for each of them: 2.5 GB of L2 traffic beside the 1 GB of
+// features, 0.40 ms per call at BASELINE config 5.  Fixed order throughout: the same bits on every rank.
+constexpr int PC_TSLICES_MAX = 4;   // feature slices of the t kernel (gridDim.y)
+__global__ __launch_bounds__(256) void as_pc_tphi_kernel(int m, int64_t m8, int64_t mp, int64_t N, int64_t ld,
+                                                         const float *__restrict__ Phi, const double *__restrict__ dinv,
+                                                         const double *__restrict__ r, double *__restrict__ tpart,
+                                                         double *__restrict__ tvec, unsigned int *ticket, const as_cg_scal *cg) {
     if (cg->done) return;
-    __shared__ double sh[4];
-    const int j = blockIdx.x;
-    if (j >= m) {
-        if (threadIdx.x == 0) tvec[j] = 0.0;
-        return;
+    __shared__ double wsum[4][PC_MAX_M];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + 4 * tid;   // ld is a multiple of the tile: always in range
+    // this workgroup's feature groups: a contiguous quarter of the m8 / 8 groups
+    const int64_t ngroups = m8 / PC_FG;
+    const int64_t g_lo = ngroups * blockIdx.y / gridDim.y, g_hi = ngroups * (blockIdx.y + 1) / gridDim.y;
+    const int64_t j_lo = g_lo * PC_FG, j_hi = g_hi * PC_FG;
+    double w4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = (base + k < N) ? r[base + k] * dinv[base + k] : 0.0;
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    const int rho = (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
+    for (int64_t j0 = j_lo; j0 < j_hi; j0 += PC_FG) {
+        double a[PC_FG];
+#pragma unroll
+        for (int f = 0; f < PC_FG; ++f) {
+            const as_f4 v = *reinterpret_cast<const as_f4 *>(Phi + (j0 + f) * ld + base);
+            a[f] = fma((double)v.w, w4[3], fma((double)v.z, w4[2], fma((double)v.y, w4[1], (double)v.x * w4[0])));
+        }
+        double u[4], t2[2], s1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double send = b5 ? a[i] : a[i + 4];
+            const double keep = b5 ? a[i + 4] : a[i];
+            u[i] = keep + __shfl_xor(send, 32, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double send = b4 ? u[i] : u[i + 2];
+            const double keep = b4 ? u[i + 2] : u[i];
+            t2[i] = keep + __shfl_xor(send, 16, 64);
+        }
+        {
+            const double send = b3 ? t2[0] : t2[1];
+            const double keep = b3 ? t2[1] : t2[0];
+            s1 = keep + __shfl_xor(send, 8, 64);
+        }
+        s1 += __shfl_xor(s1, 4, 64);
+        s1 += __shfl_xor(s1, 2, 64);
+        s1 += __shfl_xor(s1, 1, 64);
+        if ((lane & 7) == 0) wsum[wv][j0 - j_lo + rho] = s1;
     }
-    const double *col = Phi + (int64_t)j * ld;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int64_t i = threadIdx.x;
-    for (; i + 768 < N; i += 1024) {
-        s0 = fma(col[i], r[i] * dinv[i], s0);
-        s1 = fma(col[i + 256], r[i + 256] * dinv[i + 256], s1);
-        s2 = fma(col[i + 512], r[i + 512] * dinv[i + 512], s2);
-        s3 = fma(col[i + 768], r[i + 768] * dinv[i + 768], s3);
+    __syncthreads();
+    double *mine = tpart + (int64_t)blockIdx.x * mp;
+    for (int64_t j = j_lo + tid; j < j_hi; j += 256) {
+        const int64_t c = j - j_lo;
+        mine[j] = j < m ? ((wsum[0][c] + wsum[1][c]) + wsum[2][c]) + wsum[3][c] : 0.0;
     }
-    for (; i < N; i += 256) s0 = fma(col[i], r[i] * dinv[i], s0);
-    const double s = as_block_sum((s0 + s1) + (s2 + s3), sh);
-    if (threadIdx.x == 0) tvec[j] = s;
+    (void)tvec;
+    (void)ticket;
 }
 
-// z = P^-1 r on the free set: z_i = (r_i - Phi_i . u) / D_i, u = G^-1 t;  rz = r'z;  beta = rz / rz_old (first: 0)
-__global__ void as_pc_apply_kernel(int m, int64_t N, int64_t ld, const double *__restrict__ Phi, const double *__restrict__ dinv,
-                                   const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
-                                   const double *__restrict__ r, const double *__restrict__ u, double *__restrict__ z,
-                                   double *part, int64_t nblk, as_cg_scal *cg, int first) {
+// t[j] = the sample blocks' partial sums added in block order: 16 features x 16 interleaved runs of blocks per workgroup (a run's
+// loads are independent of each other: ~15 in flight per lane), the 16 runs then combined in run order.  (As the tail of the
+// kernel above, one workgroup walking 245 dependent, 5 KB-strided loads per feature, it cost more than the pass over Phi.)
+__global__ __launch_bounds__(256) void as_pc_treduce_kernel(int64_t m8, int64_t mp, int64_t nb, const double *__restrict__ tpart,
+                                                            double *__restrict__ tvec, const as_cg_scal *cg) {
+    if (cg->done) return;
+    __shared__ double red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    if (j < m8)
+        for (int64_t b = ty; b < nb; b += 16) acc += tpart[b * mp + j];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && j < mp) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][tx];
+        tvec[j] = v;
+    }
+}
+
+// z = P^-1 r on the free set: z_i = (r_i - Phi_i . u) / D_i, u = G^-1 t;  rz = r'z;  beta = rz / rz_old (first: 0).
+// A lane owns four consecutive samples (one 16-byte load per feature row), eight feature rows in flight.
+__global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int64_t N, int64_t ld, const float *__restrict__ Phi,
+                                                          const double *__restrict__ dinv, const unsigned char *__restrict__ mL,
+                                                          const unsigned char *__restrict__ mU, const double *__restrict__ r,
+                                                          const double *__restrict__ u, double *__restrict__ z, double *part,
+                                                          int64_t nblk, as_cg_scal *cg, int first) {
     if (cg->done) return;
     __shared__ double us[PC_MAX_M];
     __shared__ double sh[4];
-    for (int j = threadIdx.x; j < m; j += BQ_VEC_BLOCK) us[j] = u[j];
+    for (int j = threadIdx.x; j < m8; j += BQ_VEC_BLOCK) us[j] = j < m ? u[j] : 0.0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + threadIdx.x;
-    double acc[BQ_VEC_ITEMS];
+    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + 4 * threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t j0 = 0; j0 < m8; j0 += PC_FG) {
+        as_f4 v[PC_FG];
 #pragma unroll
-    for (int k = 0; k < BQ_VEC_ITEMS; ++k) acc[k] = 0.0;
-    for (int j = 0; j < m; ++j) {
-        const double *col = Phi + (int64_t)j * ld + base;   // ld is a multiple of the tile: always in range
-        const double uj = us[j];
+        for (int f = 0; f < PC_FG; ++f) v[f] = *reinterpret_cast<const as_f4 *>(Phi + (j0 + f) * ld + base);
 #pragma unroll
-        for (int k = 0; k < BQ_VEC_ITEMS; ++k) acc[k] = fma(col[k * BQ_VEC_BLOCK], uj, acc[k]);
+        for (int f = 0; f < PC_FG; ++f) {
+            const double uj = us[j0 + f];
+            acc[0] = fma((double)v[f].x, uj, acc[0]);
+            acc[1] = fma((double)v[f].y, uj, acc[1]);
+            acc[2] = fma((double)v[f].z, uj, acc[2]);
+            acc[3] = fma((double)v[f].w, uj, acc[3]);
+        }
     }
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < BQ_VEC_ITEMS; ++k) {
-        const int64_t i = base + (int64_t)k * BQ_VEC_BLOCK;
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k;
         double zi = 0.0;
         if (i < N && !(mL[i] | mU[i])) {
             zi = dinv[i] * (r[i] - acc[k]);
@@ -1587,13 +1804,21 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
         pc->mp = bq_round_up(m, 128);
         int rc = bq_chol_ws_create(ctx, pc->mp, &pc->ws);
         hipError_t e = hipSuccess;
-        if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(double) * (size_t)m * s->ldN);
+        pc->m8 = bq_round_up(m, PC_FG);
+        if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(float) * (size_t)pc->m8 * s->ldN);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->Phi, 0, sizeof(float) * (size_t)pc->m8 * s->ldN, ctx->stream);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->tpart, sizeof(double) * (size_t)s->nblk * pc->mp);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->tticket, sizeof(unsigned int));
+        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->tticket, 0, sizeof(unsigned int), ctx->stream);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->dinv, sizeof(double) * s->ldN);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->z, sizeof(double) * s->ldN);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gpart, sizeof(double) * PC_SLICES * pc->mp * pc->mp);
         if (rc == BQ_OK && e == hipSuccess)
             e = hipMemsetAsync(pc->Gpart, 0, sizeof(double) * PC_SLICES * pc->mp * pc->mp, ctx->stream);
-        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gacc, sizeof(double) * pc->mp * pc->mp);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Ginv, sizeof(double) * pc->mp * pc->mp);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->u, sizeof(double) * pc->mp);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->sm_fail, sizeof(int));
+        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->sm_fail, 0, sizeof(int), ctx->stream);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->prev, (size_t)s->ldN);
         if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->prev, 0, (size_t)s->ldN, ctx->stream);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->chg, sizeof(int) * (2 + 2 * PC_MAX_CHG));
@@ -1602,17 +1827,26 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
             e = hipMalloc(&pc->cls, sizeof(double) * (2 * p->d + 2));
             if (e == hipSuccess) e = hipMemsetAsync(pc->cls, 0, sizeof(double) * (2 * p->d + 2), ctx->stream);
         }
-        if (rc != BQ_OK || e != hipSuccess) {   // no room for the features
-            as_pc_free(pc);
-            (void)hipGetLastError();
-            if (ctx->world > 1) {
-                // every rank must run the SAME inner iteration (each product is a collective): a rank-local fallback to plain
-                // conjugate gradients would leave the ranks in different numbers of collectives
-                bq_set_error("cannot allocate the %.2f GB of preconditioner features on rank %d (BQ_AS_CG_PC=0 on every rank runs "
-                             "without them)", 8e-9 * (double)m * (double)s->ldN, ctx->rank);
-                return BQ_ERR_NOMEM;
+        // Do ALL ranks hold their features?  Every rank must run the SAME inner iteration (each product is a collective): a rank
+        // that fell back to plain conjugate gradients alone — or returned an error alone — would leave the others waiting in the
+        // next collective for ever.  So the outcome is agreed on (one all-reduce of a flag) and, if any rank has no room, every rank
+        // runs unpreconditioned.
+        double failed = (rc != BQ_OK || e != hipSuccess) ? 1.0 : 0.0;
+        if (failed != 0.0) (void)hipGetLastError();
+        if (ctx->world > 1 && ctx->comm_kind != BQ_COMM_SHARE) {
+            hipError_t ae = hipMemcpyAsync(s->partials, &failed, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+            int arc = ae == hipSuccess ? bq_exchange_sum(ctx, s->partials, 1) : BQ_ERR_HIP;
+            if (arc == BQ_OK) ae = hipMemcpyAsync(&failed, s->partials, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (arc == BQ_OK && ae == hipSuccess) ae = hipStreamSynchronize(ctx->stream);
+            if (arc != BQ_OK || ae != hipSuccess) {
+                as_pc_free(pc);
+                if (arc == BQ_OK) bq_set_error("agreeing on the preconditioner across ranks failed: %s", hipGetErrorString(ae));
+                return arc != BQ_OK ? arc : BQ_ERR_HIP;
             }
-            return BQ_OK;   // single rank: run unpreconditioned rather than fail
+        }
+        if (failed != 0.0) {   // no room for the features on some rank: all ranks run plain conjugate gradients
+            as_pc_free(pc);
+            return BQ_OK;
         }
         if (classes) {
             unsigned int *ticket = (unsigned int *)(pc->cls + 2 * p->d + 1);   // the spare slot, zeroed above
@@ -1621,9 +1855,14 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
         as_pc_features_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->kernel, p->n, p->d, s->ldN, p->X, p->sgn, pc->cls,
                                                                                  p->gamma, p->add_one ? 1 : 0, p->diag_add, m,
                                                                                  pc->Phi, pc->dinv, pc->z);
-        BQ_HIP(hipGetLastError());
-        BQ_HIP(hipMemcpyAsync(share.data(), pc->z, sizeof(double) * p->n, hipMemcpyDeviceToHost, ctx->stream));
-        BQ_HIP(hipStreamSynchronize(ctx->stream));
+        hipError_t fe = hipGetLastError();
+        if (fe == hipSuccess) fe = hipMemcpyAsync(share.data(), pc->z, sizeof(double) * p->n, hipMemcpyDeviceToHost, ctx->stream);
+        if (fe == hipSuccess) fe = hipStreamSynchronize(ctx->stream);
+        if (fe != hipSuccess) {
+            as_pc_free(pc);
+            bq_set_error("building the preconditioner features failed: %s", hipGetErrorString(fe));
+            return BQ_ERR_HIP;
+        }
         double lo = 1.0;
         for (double v : share) lo = std::min(lo, v);
         if (std::isfinite(lo) && (p->kernel == BQ_KERNEL_LINEAR || lo >= PC_MIN_DIAG_SHARE)) {   // linear: the model is exact
@@ -1640,8 +1879,8 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
 static void as_pc_free(as_pc *pc) {
     if (!pc) return;
     if (pc->ws) bq_chol_ws_destroy(pc->ws);
-    for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls, (void *)pc->Gacc,
-                      (void *)pc->prev, (void *)pc->chg})
+    for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls, (void *)pc->Ginv,
+                      (void *)pc->u, (void *)pc->sm_fail, (void *)pc->prev, (void *)pc->chg, (void *)pc->tpart, (void *)pc->tticket})
         if (ptr) hipFree(ptr);
     delete pc;
 }
@@ -1650,10 +1889,16 @@ static void as_pc_free(as_pc *pc) {
 static int as_pc_apply(bq_solver *s, as_ws *w, int first) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
-    as_pc_tphi_kernel<<<(unsigned)pc->mp, 256, 0, st>>>(pc->m, s->N, s->ldN, pc->Phi, pc->dinv, w->r, pc->ws->rhs, w->cg);
-    BQ_TRY(bq_chol_solve(pc->ws, pc->mp));
-    as_pc_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(pc->m, s->N, s->ldN, pc->Phi, pc->dinv, s->mL, s->mU, w->r,
-                                                               pc->ws->rhs, pc->z, s->partials, s->nblk, w->cg, first);
+    static const int tslices = [] {
+        const char *e = getenv("BQ_AS_PC_TSLICES");
+        return e ? std::max(1, std::min(atoi(e), PC_TSLICES_MAX)) : 1;
+    }();
+    as_pc_tphi_kernel<<<dim3(vgrid(s->ldN).x, (unsigned)tslices), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, pc->mp, s->N, s->ldN, pc->Phi, pc->dinv, w->r,
+                                                                                        pc->tpart, pc->ws->rhs, pc->tticket, w->cg);
+    as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(pc->m8, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ws->rhs, w->cg);
+    as_pc_gemv_kernel<<<(unsigned)((pc->mp + 3) / 4), 256, 0, st>>>(pc->mp, pc->Ginv, pc->ws->rhs, pc->u, w->cg);   // u = G^-1 t
+    as_pc_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, s->N, s->ldN, pc->Phi, pc->dinv, s->mL, s->mU, w->r,
+                                                               pc->u, pc->z, s->partials, s->nblk, w->cg, first);
     return BQ_OK;
 }
 
@@ -1662,7 +1907,8 @@ static int as_pc_apply(bq_solver *s, as_ws *w, int first) {
 //   start: the candidate of the previous outer iteration (the free set has moved by one index since, so it solves the new
 //   system up to one column of Q), else the current point;  BQ_AS_CG_WARM=0: always the current point
 //   preconditioner: struct as_pc (RBF and linear panels);   BQ_AS_CG_PC=0: none
-static int as_cg_solve(bq_solver *s, as_ws *w) {
+static int as_cg_solve_once(bq_solver *s, as_ws *w, int *pc_failed) {
+    *pc_failed = 0;
     bq_ctx *ctx = s->p->ctx;
     hipStream_t st = ctx->stream;
     const int64_t N = s->N, nblk = s->nblk;
@@ -1672,13 +1918,17 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
     as_pc *pc = w->pc;
     const double *start = (w->warm && w->have_cand) ? w->cand : s->x;
     as_make_xt_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, start, w->z);
-    if (w->colq && start == w->cand) {
+    const bool anchor = w->anchor;
+    w->anchor = false;
+    if (w->colq && start == w->cand && !anchor) {
         // z is the previous candidate except at the variables that reached a bound since: Q z = Q cand + those columns of Q,
         // formed from X — the product below returns at once (its `done` flag) unless too many variables moved
         bq_problem *p = s->p;
-        as_zdiff_kernel<<<1, 1024, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->zchg, w->zdl);
+        int *lcnt = reinterpret_cast<int *>(s->partials + s->nblk);   // the slice as_launch_compact uses between its two passes
+        as_zdiff_count_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, lcnt, &s->sc->pad1[0], w->zchg);
+        as_zdiff_write_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, lcnt, w->zchg, w->zdl);
         BQ_TRY(bq_problem_apply(p, w->z, w->Qz, w->zchg + 1));
-        as_qz_cols_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(p->n, p->d, p->X, w->sq, p->sgn, p->kernel, p->gamma, p->coef0,
+        as_qz_cols_kernel<<<(unsigned)std::min<int64_t>((p->n + 3) / 4, 8192), 256, 0, st>>>(p->n, p->d, p->X, w->sq, p->sgn, p->kernel, p->gamma, p->coef0,
                                                                          p->degree, p->add_one ? 1 : 0, p->diag_add,
                                                                          p->storage == BQ_F32 ? 1 : 0, w->zchg, w->zdl, w->Qcand, w->Qz);
     } else {
@@ -1690,52 +1940,64 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
                                                      w->pv, s->partials, nblk, w->cg, s->inner_rtol, cap, pc ? 1 : 0);
     const double *zr = w->r;   // what the next direction is built from: the residual, or the preconditioned residual
     if (pc) {
-        // G = I + Phi_A' D_A^-1 Phi_A for the free set of this outer iteration, factorised once.  The set moves by an index or
-        // two per outer iteration: G follows by rank-one updates (in index order: the same bits on every rank), and is summed
-        // afresh over all samples every 128 outer iterations, at the start, and when more than 64 samples moved at once.
-        const int tiles = (int)(pc->mp / PC_T);
-        const dim3 gtri((unsigned)((pc->mp + 255) / 256), (unsigned)pc->mp);
-        const int force = (pc->age == 0 || pc->age >= 128 || !as_env_on("BQ_AS_CG_PC_INCR")) ? 1 : 0;
-        pc->age = force ? 1 : pc->age + 1;
-        as_pc_diff_kernel<<<1, 1024, 0, st>>>(N, s->mL, s->mU, pc->prev, pc->chg, force);
-        as_pc_rank1_kernel<<<gtri, 256, 0, st>>>(pc->m, pc->mp, s->ldN, pc->Phi, pc->dinv, pc->chg, pc->Gacc);
-        as_pc_gram_kernel<<<dim3((unsigned)(tiles * (tiles + 1) / 2), PC_SLICES), 256, 0, st>>>(pc->m, pc->mp, N, s->ldN, pc->Phi, pc->dinv,
-                                                                                               s->mL, s->mU, pc->Gpart, pc->chg);
-        as_pc_gram_reduce_kernel<<<gtri, 256, 0, st>>>(pc->m, pc->mp, pc->Gpart, pc->Gacc, pc->ws->H, pc->ws->ldh, pc->chg);
-        BQ_TRY(bq_chol_factor(pc->ws, pc->mp));
+        // G^-1, G = I + Phi_A' D_A^-1 Phi_A, for the free set of this outer iteration.  The set moves by an index or two per outer
+        // iteration (the list was made at the top of the iteration, as_pc_diff_*): G^-1 follows by Sherman-Morrison updates in index
+        // order (the same bits on every rank), and is rebuilt from G summed afresh over all samples at the start, every 128 outer
+        // iterations, when more than 64 samples moved at once, and after an update that failed.
+        const bool rebuild = pc->host_chg[1] != 0 || pc->age == 0;
+        pc->age = rebuild ? 1 : pc->age + 1;
+        if (rebuild) {
+            const int tiles = (int)(pc->mp / PC_T);
+            const dim3 gtri((unsigned)((pc->mp + 255) / 256), (unsigned)pc->mp);
+            as_pc_gram_kernel<<<dim3((unsigned)(tiles * (tiles + 1) / 2), PC_SLICES), 256, 0, st>>>(pc->m, pc->mp, N, s->ldN, pc->Phi,
+                                                                                                   pc->dinv, s->mL, s->mU, pc->Gpart);
+            as_pc_gram_reduce_kernel<<<gtri, 256, 0, st>>>(pc->m, pc->mp, pc->Gpart, pc->ws->H, pc->ws->ldh);
+            BQ_TRY(bq_chol_factor(pc->ws, pc->mp));
+            BQ_TRY(bq_chol_prepare_sweeps(pc->ws, pc->mp));   // the explicit inverse factor (mp <= 1024: one block)
+            as_pc_ginv_kernel<<<dim3((unsigned)(pc->mp / 16), (unsigned)(pc->mp / 16)), 256, 0, st>>>(pc->mp, pc->ws->bigMT, 1024, pc->Ginv);
+            BQ_HIP(hipMemsetAsync(pc->sm_fail, 0, sizeof(int), st));
+            pc->rebuilds += 1;
+        } else {
+            as_pc_sm_kernel<<<1, 1024, 0, st>>>(pc->m, pc->mp, s->ldN, pc->Phi, pc->dinv, pc->chg, pc->Ginv, pc->sm_fail);
+        }
         BQ_TRY(as_pc_apply(s, w, 1));
         as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, pc->z, w->pv, w->cg);   // beta = 0: p = z
         zr = pc->z;
     }
-    // batches of inner iterations between looks at the done flag; after it is set every kernel of the rest of the batch —
-    // the panel product included — returns at once, so an over-long batch costs launches, not products
-    int batch = 8;
+    // The host looks at the `done` flag after EVERY inner iteration, one iteration late: iteration k + 1 is enqueued, then the
+    // host waits for the copy of the flag recorded behind iteration k.  The device never runs dry (an iteration is a panel
+    // product: 2.5 - 20 ms at BASELINE config 5, far longer than the host's turn) and exactly ONE enqueued iteration is wasted per
+    // solve — it returns at once on the flag — where round 3's batches of 8 -> 32 wasted 12 launches per solve, 0.17 ms each for the
+    // empty 60 000-workgroup product grid alone (profiles/r04/c5_per_outer_iteration_kernel_ms_before.csv).  Every rank sees the
+    // same flag values at the same iteration (replicated, bit-identical scalars), so all ranks enqueue the same collectives.
     long long queued = 0;
-    while (true) {
+    BQ_HIP(hipMemcpyAsync(w->cg_flag_host, &w->cg->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));   // the flag the start leaves
+    BQ_HIP(hipEventRecord(w->cg_event, st));
+    while (queued < cap) {
+        BQ_TRY(bq_problem_apply(s->p, w->pv, w->Qp, &w->cg->done));
+        as_cg_pap_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, w->pv, w->Qp, s->partials, nblk, w->cg);
+        as_cg_update_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->dlt, w->r, w->pv, w->Qp, w->Qdl, s->partials,
+                                                           nblk, w->cg);
+        if (pc) BQ_TRY(as_pc_apply(s, w, 0));
+        as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, zr, w->pv, w->cg);
+        ++queued;
+        BQ_HIP(hipEventSynchronize(w->cg_event));   // the flag as it stood BEFORE the iteration just enqueued
+        if (w->cg_flag_host[0]) break;
         BQ_HIP(hipMemcpyAsync(w->cg_flag_host, &w->cg->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-        BQ_HIP(hipStreamSynchronize(st));
-        if (w->cg_flag_host[0] || queued >= cap) break;
-        for (int b = 0; b < batch; ++b) {
-            BQ_TRY(bq_problem_apply(s->p, w->pv, w->Qp, &w->cg->done));
-            as_cg_pap_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, w->pv, w->Qp, s->partials, nblk, w->cg);
-            as_cg_update_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, w->dlt, w->r, w->pv, w->Qp, w->Qdl, s->partials,
-                                                               nblk, w->cg);
-            if (pc) BQ_TRY(as_pc_apply(s, w, 0));
-            as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, zr, w->pv, w->cg);
-        }
-        queued += batch;
-        if (batch < 32) batch *= 2;
+        BQ_HIP(hipEventRecord(w->cg_event, st));
     }
     as_cg_scal h;
     BQ_HIP(hipMemcpyAsync(&h, w->cg, sizeof(as_cg_scal), hipMemcpyDeviceToHost, st));
-    int pc_info = 0;
+    int pc_info = 0, sm_fail = 0;
     if (pc) BQ_HIP(hipMemcpyAsync(&pc_info, pc->ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (pc) BQ_HIP(hipMemcpyAsync(&sm_fail, pc->sm_fail, sizeof(int), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     w->cg_iters += h.iters;
-    if (pc_info != 0 || h.info == 2) {
+    if (pc_info != 0 || sm_fail != 0 || h.info == 2) {   // the caller sums G afresh and tries again, then gives the preconditioner up
         bq_set_error("the preconditioner of the inner conjugate gradients is not positive definite (pivot %d, |A| = %lld): "
                      "BQ_AS_CG_PC=0 runs without it", pc_info, (long long)nA);
-        return BQ_ERR_NOT_PD;
+        *pc_failed = 1;
+        return BQ_OK;
     }
     if (h.info != 0 || !std::isfinite(h.rr)) {
         bq_set_error("conjugate gradients on the restricted Hessian Q[A,A] (|A| = %lld) met a direction of non-positive "
@@ -1751,6 +2013,28 @@ static int as_cg_solve(bq_solver *s, as_ws *w) {
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
     return BQ_OK;
+}
+
+// A Woodbury system G that is not positive definite (or r'z <= 0) says something about the MODEL P, not about Q: its Gram matrix
+// has drifted under the rank-one updates, or the features do not fit this free set.  First G is summed afresh and the solve
+// repeated; if that fails too the preconditioner is dropped for the rest of the run (plain conjugate gradients).  Every rank
+// reads the same replicated scalars, so all ranks take the same turn here and stay in the same collectives.
+static int as_cg_solve(bq_solver *s, as_ws *w) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        int pc_failed = 0;
+        BQ_TRY(as_cg_solve_once(s, w, &pc_failed));
+        if (!pc_failed) return BQ_OK;
+        if (w->pc == nullptr) break;
+        if (attempt == 0) {
+            w->pc->age = 0;
+            w->pc_rebuilds += 1;
+        } else {
+            as_pc_free(w->pc);
+            w->pc = nullptr;
+            w->pc_dropped += 1;
+        }
+    }
+    return BQ_ERR_NOT_PD;
 }
 
 int bq_as_start(bq_solver *s) {
@@ -1777,6 +2061,7 @@ int bq_as_start(bq_solver *s) {
         BQ_HIP(hipMalloc(&w->cg, sizeof(as_cg_scal)));
         BQ_HIP(hipMemsetAsync(w->cg, 0, sizeof(as_cg_scal), ctx->stream));
         BQ_HIP(hipHostMalloc(&w->cg_flag_host, 2 * sizeof(int)));
+        BQ_HIP(hipEventCreateWithFlags(&w->cg_event, hipEventDisableTiming));
         w->warm = as_env_on("BQ_AS_CG_WARM");
         w->incq = as_env_on("BQ_AS_CG_INCQ");
         {
@@ -1809,6 +2094,7 @@ void bq_as_free(bq_solver *s) {
                     (void *)w->cg, (void *)w->Qdl, (void *)w->Qcand, (void *)w->sq, (void *)w->zchg, (void *)w->zdl})
         if (p) hipFree(p);
     if (w->cg_flag_host) hipHostFree(w->cg_flag_host);
+    if (w->cg_event) hipEventDestroy(w->cg_event);
     as_pc_free(w->pc);
     as_schur_free(w);
     delete w;
@@ -1853,6 +2139,17 @@ int bq_as_iterate(bq_solver *s) {
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, w->g_eval);
         s->started = true;
     }
+    if (s->as_cg && w->pc) {
+        // which samples entered / left the free set since the preconditioner's G^-1 was brought up to date: the list (and whether
+        // it is short enough for rank-one updates) rides on this iteration's one look at the device, so that the host knows
+        // whether to enqueue the update kernel or a rebuild without a synchronisation of its own
+        as_pc *pc = w->pc;
+        const int force = (pc->age == 0 || pc->age >= 128 || !as_env_on("BQ_AS_CG_PC_INCR")) ? 1 : 0;
+        int *lcnt = reinterpret_cast<int *>(s->partials + s->nblk);
+        as_pc_diff_count_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, pc->prev, lcnt, &s->sc->pad1[0], pc->chg, force);
+        as_pc_diff_write_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, pc->prev, lcnt, pc->chg);
+        BQ_HIP(hipMemcpyAsync(pc->host_chg, pc->chg, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipStreamSynchronize(st));
@@ -1864,7 +2161,13 @@ int bq_as_iterate(bq_solver *s) {
         // Q x of the new point without a product: Q cand is known from the inner iteration (Q z + Q delta), the ratio step is
         // a convex combination.  Every 64th outer iteration forms it afresh so that rounding cannot accumulate.
         const bool inc = w->incq && ++w->since_refresh < 64;
-        if (!inc) w->since_refresh = 0;
+        if (!inc) {
+            w->since_refresh = 0;
+            // ... and the start product of the NEXT solve is a real product too: Q z = Q cand + columns, Q cand = Q z + Q delta is a
+            // chain that the refresh of Q x alone does not re-anchor (the columns are rounded like the panel's entries,
+            // not bit-equal to them, and BASELINE config 5 runs ~n outer iterations)
+            w->anchor = true;
+        }
         if (w->host_ints[2]) {
             as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
             if (inc) {

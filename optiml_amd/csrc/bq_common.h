@@ -236,15 +236,19 @@ struct bq_seg_table {
     long long cut[BQ_SYM_SEG_MAX + 1];      // tile-row boundaries
 };
 // tiles of the segments [tab.lo, tab.hi) + their sum in segment order -> out (nb*256)
+struct bq_epilogue;   // bq_epilogue.h: the PG / FW step fused into the kernel that finishes the product (null: none)
 int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                   const double *w, double *slab, double *out, const int *done);
+                   const double *w, double *slab, double *out, const int *done, const bq_epilogue *epi = nullptr);
 // the same with the segment partials written to `gath` (slots of this rank) instead of one summed vector; and the closing
 // sum of all S gathered segment vectors -> out
 int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
                             const double *w, double *slab, double *gath, const int *done);
-int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done);
+int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done,
+                          const bq_epilogue *epi = nullptr);
 void bq_sym_seg_table(const bq_problem *p, bq_seg_table *tab);
-int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done);  // -> p->s (complete on all ranks)
+// -> p->s (complete on all ranks).  epi: fuse the PG / FW epilogue into the closing kernel where the path has one (*fused says so)
+int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done, const bq_epilogue *epi = nullptr,
+                     bool *fused = nullptr);
 
 // bq_gemv.hip: s[r0 + i] = sum_j elem(panel[i][j]) * w[j], i in [0, nrows)
 int bq_launch_gemv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nrows, int64_t ld,

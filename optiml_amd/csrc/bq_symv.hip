@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "bq_common.h"
+#include "bq_epilogue.h"
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
@@ -221,9 +222,10 @@ __device__ __forceinline__ double seg_partial(const double *__restrict__ p, int6
 
 // out[a*T + r] = sum over the segments [tab.lo, tab.hi) of their partial sums, in segment order — the canonical order of
 // the product: the same association whether the segments were summed here (one rank) or gathered from their owners
-template <int JG>
+// EPI: the PG / FW epilogue of bq_epilogue.h goes on from the summed product (out is still written: other consumers read p->s)
+template <int JG, bool EPI>
 __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, bq_seg_table tab,
-                                                           double *__restrict__ out, const int *__restrict__ done) {
+                                                           double *__restrict__ out, const int *__restrict__ done, bq_epilogue epi) {
     if (done != nullptr && *done) return;
     __shared__ double part[4][ST];
     const int64_t a = blockIdx.x;
@@ -232,6 +234,10 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
     double acc = 0.0;
     for (int s = tab.lo; s < tab.hi; ++s) acc += seg_partial<JG>(p, a, tab.cut[s], tab.cut[s + 1], q, r, part);
     if (q == 0) out[a * ST + r] = acc;
+    if constexpr (EPI) {
+        const double c = q == 0 ? bq_epi_element(epi, a * ST + r, acc) : 0.0;
+        bq_epi_finish(epi, a, nb, c, gridDim.x);
+    }
 }
 
 // the per-segment partial vectors of this rank's segments, each to its slot of the gathered buffer
@@ -247,15 +253,16 @@ __global__ __launch_bounds__(1024) void symv_reduce_seg_kernel(const double *__r
     if (q == 0) gath[((int64_t)tab.slot[s] * nb + a) * ST + r] = v;
 }
 
-// out = sum of all S gathered segment vectors in segment order (every rank: identical bits)
+// out = sum of all S gathered segment vectors in segment order (every rank: identical bits); EPI: as symv_reduce_kernel
+template <bool EPI>
 __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restrict__ gath, int64_t len, bq_seg_table tab,
-                                                          double *__restrict__ out, const int *__restrict__ done) {
+                                                          double *__restrict__ out, const int *__restrict__ done, bq_epilogue epi) {
     if (done != nullptr && *done) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= len) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // len = nb * 256: always in range
     double acc = 0.0;
     for (int s = 0; s < tab.count; ++s) acc += gath[(int64_t)tab.slot[s] * len + i];
     out[i] = acc;
+    if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, acc), gridDim.x);
 }
 
 template <int JG, int SR>
@@ -286,10 +293,12 @@ static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_on
 // mode 0: tiles + the sum over this launch's segments -> out (nb*256);  mode 1: tiles + one vector per segment -> gath slots
 template <int JG, int SR>
 static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                          const double *w, double *slab, double *out, int mode, const int *done) {
+                          const double *w, double *slab, double *out, int mode, const int *done, const bq_epilogue *epi) {
     BQ_TRY((launch_tiles<JG, SR>(ctx, panel, storage, add_one, tab.cut[tab.lo], tab.cut[tab.hi], nb, w, slab, done)));
-    if (mode == 0)
-        symv_reduce_kernel<JG><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done);
+    if (mode == 0 && epi != nullptr)
+        symv_reduce_kernel<JG, true><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, *epi);
+    else if (mode == 0)
+        symv_reduce_kernel<JG, false><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, bq_epilogue{});
     else if (tab.hi > tab.lo)
         symv_reduce_seg_kernel<JG><<<dim3((unsigned)nb, (unsigned)(tab.hi - tab.lo)), 1024, 0, ctx->stream>>>(slab, nb, tab, out, done);
     BQ_HIP(hipGetLastError());
@@ -297,18 +306,18 @@ static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_
 }
 
 static int launch_any(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                      const double *w, double *slab, double *out, int mode, const int *done) {
+                      const double *w, double *slab, double *out, int mode, const int *done, const bq_epilogue *epi = nullptr) {
     // BQ_SYMV_VARIANT=<tiles per strip><rows per step> selects a tuning variant (benchmarking only)
     static const int variant = [] {
         const char *e = getenv("BQ_SYMV_VARIANT");
         return e ? atoi(e) : 84;
     }();
     switch (variant) {
-        case 44: return launch_variant<4, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
-        case 48: return launch_variant<4, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
-        case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
-        case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
-        case 88: return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+        case 44: return launch_variant<4, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
+        case 48: return launch_variant<4, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
+        case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
+        case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
+        case 88: return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
         default: {
             // fp32 tiles are half as wide in bytes: 8 rows per step keep the same bytes in flight per lane.  fp64: 4 rows per
             // step, except on short grids whose LAST round of workgroups is sparsely filled (two workgroups per CU = 512 slots
@@ -326,15 +335,15 @@ static int launch_any(bq_ctx *ctx, const void *panel, int storage, bool add_one,
             const int64_t slots = 2 * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256);
             const bool sparse_tail = strips >= slots && strips < 8 * slots && 2 * (strips % slots) < slots;
             const bool eight = force == 8 || (force != 4 && (storage == BQ_F32 || sparse_tail));
-            if (eight) return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
-            return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done);
+            if (eight) return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
+            return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
         }
     }
 }
 
 int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                   const double *w, double *slab, double *out, const int *done) {
-    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, out, 0, done);
+                   const double *w, double *slab, double *out, const int *done, const bq_epilogue *epi) {
+    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, out, 0, done, epi);
 }
 
 int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
@@ -342,9 +351,13 @@ int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool ad
     return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, gath, 1, done);
 }
 
-int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done) {
+int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done,
+                          const bq_epilogue *epi) {
     const int64_t len = nb * ST;
-    symv_segsum_kernel<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(gath, len, tab, out, done);
+    if (epi != nullptr)
+        symv_segsum_kernel<true><<<(unsigned)nb, 256, 0, ctx->stream>>>(gath, len, tab, out, done, *epi);
+    else
+        symv_segsum_kernel<false><<<(unsigned)nb, 256, 0, ctx->stream>>>(gath, len, tab, out, done, bq_epilogue{});
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

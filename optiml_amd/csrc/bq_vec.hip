@@ -10,8 +10,10 @@
 // Reference sites: projected_gradient.py:82-129, frank_wolfe.py:96-151, interior_point.py:180-267
 // (all under optiml/opti/constrained/), objective/gradient optiml/opti/_base.py:282,291.
 #include "bq_common.h"
+#include "bq_epilogue.h"
 
 #include <cmath>
+#include <cstdlib>
 
 #define ACT_TOL 1e-12
 #define CURV_TOL 1e-16
@@ -96,8 +98,9 @@ __global__ void finish_kernel(int structure, int64_t n, int64_t N, double diag_a
 // p->s = P w on every rank, P the resident panel (elements optionally +1).  Row-block panels: local rows + all-gather;
 // symmetric tile panels: local lower-triangle tiles (both contributions), one partial vector per canonical segment,
 // all-gather of the segment vectors + their sum in segment order (or, BQ_SYM_EXCHANGE=allreduce, one all-reduce(sum)).
-int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done) {
+int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done, const bq_epilogue *epi, bool *fused) {
     bq_ctx *ctx = p->ctx;
+    if (fused) *fused = false;
     if (p->streamed) {   // no panel: the lower-triangle Gram tiles of this rank's segments recomputed inside the product, each
                          // used for its rows and its columns; exchange exactly as for the resident symmetric panels
         bq_seg_table tab;
@@ -114,7 +117,8 @@ int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *do
         } else {
             BQ_TRY(prod(p->gath, 1));
             BQ_TRY(bq_exchange_gather(ctx, p->gath, (int64_t)p->seg_cmax * p->nb * BQ_SYM_TILE));
-            BQ_TRY(bq_launch_symv_segsum(ctx, p->nb, tab, p->gath, p->s, done));
+            BQ_TRY(bq_launch_symv_segsum(ctx, p->nb, tab, p->gath, p->s, done, epi));
+            if (fused) *fused = epi != nullptr;
         }
         return BQ_OK;
     }
@@ -122,14 +126,16 @@ int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *do
         bq_seg_table tab;
         bq_sym_seg_table(p, &tab);
         if (ctx->comm_kind == BQ_COMM_NONE) {
-            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->s, done));
+            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->s, done, epi));
+            if (fused) *fused = epi != nullptr;
         } else if (ctx->sym_allreduce) {   // rank partials meet in one all-reduce(sum): association depends on the transport
             BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->s, done));
             BQ_TRY(bq_exchange_sum(ctx, p->s, p->nb * BQ_SYM_TILE));
         } else {   // default: all-gather of the segment vectors, summed in segment order on every rank (bit-identical for any world)
             BQ_TRY(bq_launch_symv_segments(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->gath, done));
             BQ_TRY(bq_exchange_gather(ctx, p->gath, (int64_t)p->seg_cmax * p->nb * BQ_SYM_TILE));
-            BQ_TRY(bq_launch_symv_segsum(ctx, p->nb, tab, p->gath, p->s, done));
+            BQ_TRY(bq_launch_symv_segsum(ctx, p->nb, tab, p->gath, p->s, done, epi));
+            if (fused) *fused = epi != nullptr;
         }
     } else {
         BQ_TRY(bq_launch_gemv(ctx, p->panel, p->storage, add_one, p->r1 - p->r0, p->ld, w, p->s + p->r0, done));
@@ -473,10 +479,30 @@ int bq_pgfw_iterate(bq_solver *s) {
         prep_kernel<<<vec_grid(p->ld), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, s->d, p->sgn, p->w, done);
         w = p->w;
     }
-    BQ_TRY(bq_panel_product(p, p->add_one, w, done));
-    finish_den_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, p->N, p->diag_add, p->s, s->d, p->sgn,
-                                                                s->Qd, s->sc, s->partials, s->nblk, s->kind == BQ_PG ? 0 : 1,
-                                                                s->stats);
+    // the kernel that finishes the product also finishes the iteration (Qd, d'Qd, the step length) where the path has one such
+    // kernel (symmetric panels: the slab reduction / the ordered segment sum); dense row-block panels keep the separate launch
+    static const bool fuse = [] {
+        const char *e = getenv("BQ_PGFW_FUSE");
+        return e == nullptr || atoi(e) != 0;
+    }();
+    bq_epilogue epi;
+    epi.structure = p->structure;
+    epi.kind = s->kind == BQ_PG ? 0 : 1;
+    epi.n = p->n;
+    epi.N = p->N;
+    epi.diag_add = p->diag_add;
+    epi.d = s->d;
+    epi.sgn = p->sgn;
+    epi.Qd = s->Qd;
+    epi.sc = s->sc;
+    epi.part = s->partials;
+    epi.stats = s->stats;
+    bool fused = false;
+    BQ_TRY(bq_panel_product(p, p->add_one, w, done, fuse ? &epi : nullptr, &fused));
+    if (!fused)
+        finish_den_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, p->N, p->diag_add, p->s, s->d, p->sgn,
+                                                                    s->Qd, s->sc, s->partials, s->nblk, s->kind == BQ_PG ? 0 : 1,
+                                                                    s->stats);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

@@ -713,6 +713,55 @@ def test_active_set_cg_preconditioner_and_warm_start(amd, monkeypatch):
     assert it <= 3 * len(h) and it < it0 / 3, (it, it0)
 
 
+@pytest.mark.parametrize('storage', ['f64', 'f32'])
+def test_active_set_cg_product_free_bookkeeping_does_not_drift_over_hundreds_of_iterations(amd, monkeypatch, storage):
+    """ActiveSetCG carries Q x, Q cand and the start product Q z of the next solve WITHOUT products (Q cand = Q z + Q delta from the
+    inner iteration, Q z = Q cand + the columns of the variables that reached a bound, formed from X and rounded like the panel's
+    entries).  Every 64th outer iteration re-anchors the whole chain by real products (the refresh of Q x alone did not
+    cover Q z -> Q cand -> Q z).  260 outer iterations — four refresh periods — against the same run with every shortcut off
+    (a product wherever the reference has one): same bound counts in every iteration, objective history to 1e-9, iterate to the
+    inner tolerance; and the chain, left un-anchored, is what this test would catch on the fp32 panel, where a column formed from
+    X can round to a different float than the panel's entry."""
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.opti.constrained import ActiveSetCG
+    from optiml_amd.ml.svm.kernels import gaussian
+
+    class Solver(ActiveSetCG):
+        inner_tol = 1e-11
+
+    n, d, iters = 2500, 24, 260
+    X, y = make_blobs(n, d, seed=11, sigma=8.0)
+
+    def run(shortcuts):
+        for var in ('BQ_AS_CG_INCQ', 'BQ_AS_CG_COLQ'):
+            monkeypatch.setenv(var, '1' if shortcuts else '0')
+        hist = []
+        cb = lambda o: hist.append((o.f_x, o.n_bound))
+        cb._bq_needs_state = False
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, diag=0.5, storage=storage)
+        opt = Solver(quad=quad, ub=np.full(n, np.inf), x=np.ones(n), max_iter=iters, callback=cb).minimize()
+        quad.release()
+        return np.array(hist), opt.x, opt.iter, opt.inner_iters
+
+    h0, x0, it0, in0 = run(False)
+    h1, x1, it1, in1 = run(True)
+    assert it0 == it1 == iters
+    assert np.array_equal(h1[:, 1], h0[:, 1])
+    np.testing.assert_allclose(h1[:, 0], h0[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(x1, x0, rtol=0, atol=1e-7 * np.abs(x0).max())
+    # the preconditioner's G^-1 is carried through these 260 free-set changes by Sherman-Morrison updates (rebuilt every 128):
+    # against the same run with G summed afresh and factorised in EVERY outer iteration the inner iteration counts agree —
+    # the carried inverse is as good a preconditioner as the fresh one — and the outer path is the same
+    monkeypatch.setenv('BQ_AS_CG_PC_INCR', '0')
+    h2, x2, it2, in2 = run(True)
+    monkeypatch.delenv('BQ_AS_CG_PC_INCR')
+    assert np.array_equal(h2[:, 1], h1[:, 1])
+    np.testing.assert_allclose(h2[:, 0], h1[:, 0], rtol=1e-9)
+    assert abs(in2 - in1) <= 0.03 * in2 + 5, (in1, in2)
+    print(f'inner iterations over {iters} outer: shortcuts off {in0}, on {in1}, on + fresh G every iteration {in2}')
+
+
 @pytest.mark.parametrize('kind', ['rbf', 'linear', 'poly', 'laplacian'])
 @pytest.mark.parametrize('n,d', [(60, 3), (300, 20), (700, 40)])
 @pytest.mark.parametrize('storage', ['f64', 'f32'])
