@@ -67,12 +67,14 @@ enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian 
  * (single-row gathers) it changes nothing, n=100k fit 0.93 s either way — the sweeps are bound by one CU's gather rate. */
 #define BQ_FULL_PANEL 32
 /* OR-ed into the structure: choose WHERE the resident panel lives.  The rate at which the panel product streams a panel is a
- * stable property of the allocation's physical placement (r03, tools/placement_probe.py: five panels of one n = 100 000 problem
- * held at once ran 6.08 - 6.40 ms per product, each reproducible to 0.005 ms): with this flag the product kernel is timed on the
- * freshly allocated (still empty) panel and, if it streams below ~6.5 TB/s, up to two more allocations are tried and the fastest
- * kept (BQ_PANEL_CANDIDATES, BQ_PANEL_GOOD_GBS; the others are released; skipped when the device cannot hold a second panel).
- * Costs ~4 products per candidate once per problem: for the product-bound solvers (PG, FW, ActiveSetCG, the augmented-Lagrangian
- * rules), whose every iteration streams the panel; pointless for InteriorPoint / ActiveSet / SMO. */
+ * stable property of the physical region the allocation landed in (five panels of one n = 100 000 problem held at once ran 6.04 -
+ * 6.50 ms per product, each reproducible to 0.005 ms; NOT of its base address, nor of the contiguity the API can ask for:
+ * profiles/r04/placement_*.txt): with this flag the product kernel is timed on the freshly allocated (still empty) panel and, if
+ * it streams below ~6.5 TB/s, further allocations are tried while they fit a time budget (BQ_PLACE_BUDGET_MS, default 200 ms; at
+ * most BQ_PANEL_CANDIDATES = 3; a candidate is priced at what the first allocation cost) and the fastest is kept (the others are
+ * released; skipped when the device cannot hold a second panel).  For the product-bound solvers (PG, FW, ActiveSetCG, the
+ * augmented-Lagrangian rules), whose every iteration streams the panel — SVC / SVR.fit set it for those; pointless for
+ * InteriorPoint / ActiveSet / SMO.  Per rank, before the first collective. */
 #define BQ_PLACE_PANEL 64
 enum { BQ_PG = 0, BQ_FW = 1, BQ_AS = 2, BQ_IP = 3,                   /* solver kind */
        /* ActiveSet (active_set.py:82-237, same outer logic) whose restricted systems Q[A,A] xs = rhs are solved by
@@ -145,6 +147,15 @@ int bq_ctx_probe_mfma_f64(bq_ctx *ctx, double seconds, double *tflops);
  * On a ONE-rank RCCL communicator this is the launch + local-copy floor of the collective (a lower bound of what N > 1 ranks pay
  * over xGMI, nothing more); on N > 1 ranks every rank must call it with the same arguments. */
 int bq_ctx_probe_exchange(bq_ctx *ctx, int kind, int64_t count, int reps, double *mean_us, double *min_us);
+/* Bound the collectives of an RCCL context in time (0: no bound, the default; also BQ_COLLECTIVE_TIMEOUT_S through the Python
+ * Context).  RCCL itself never gives up on a collective whose peer does not arrive (a rank-local error, a dead process): with a
+ * timeout a watchdog thread aborts the communicator (ncclCommAbort) once the host has waited on the compute stream for longer,
+ * the call in progress returns BQ_ERR_RCCL and the context is unusable afterwards.  The callback transport is bounded by the
+ * caller's own communicator.  Set it from the thread that owns the context, while no call is in progress. */
+int bq_ctx_set_collective_timeout(bq_ctx *ctx, double seconds);
+/* occupy the compute stream for `milliseconds` (one lane spinning on the wall clock; it ends by itself) and wait for it through
+ * the library's bounded wait: the end-to-end test of the watchdog on one GPU (BQ_ERR_RCCL when it fired) */
+int bq_ctx_probe_stall(bq_ctx *ctx, double milliseconds);
 /* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic): equal 128-aligned
  * blocks for dense panels; bq_sym_row_block: the balanced triangular partition (256-aligned) of the symmetric
  * kernel panels, whose ranks stream only the tiles on/below the diagonal */

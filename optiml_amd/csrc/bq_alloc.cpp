@@ -69,6 +69,8 @@ hipError_t bq_device_malloc(void **ptr, size_t bytes) {
         std::lock_guard<std::mutex> lk(g_mu);
         for (bq_ctx *c : g_live) simulated = simulated || c->panel_cache != nullptr;
     }
+    // (hipExtMallocWithFlags(hipDeviceMallocContiguous) for the panels was tried in round 4: the launch-time spread of the panel
+    // product is the same with it — profiles/r04/placement_contiguous_flag.txt)
     if (simulated)
         e = hipErrorOutOfMemory;
     else

@@ -1,5 +1,6 @@
 // C-ABI entry points (include/bcqp.h): contexts, the device-resident quadratic, solver drivers.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -115,13 +116,15 @@ extern "C" int bq_ctx_destroy(bq_ctx *c) {
     }
     hipSetDevice(c->device);
     bq_ctx_register(c, false);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    bq_watchdog_stop(c);
+    if (c->stream && !c->comm_aborted) hipStreamSynchronize(c->stream);
     bq_comm_destroy(c);
     for (auto &slot : c->prof)
         for (auto &pr : slot.pending) {
             hipEventDestroy(pr.first);
             hipEventDestroy(pr.second);
         }
+    if (c->prof_skip) hipFree(c->prof_skip);
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->pinned) hipHostFree(c->pinned);
     bq_ctx_drop_cache(c);
@@ -185,30 +188,65 @@ int bq_prof_begin(bq_ctx *c, int which, hipEvent_t *e0, hipEvent_t *e1) {
     return BQ_OK;
 }
 
+void bq_prof_skip_arg(bq_ctx *c, hipEvent_t e0, int **slot, int *seq) {
+    *slot = nullptr;
+    *seq = 0;
+    c->prof_cur_idx = -1;
+    if (e0 == nullptr) return;   // not profiling
+    if (c->prof_skip == nullptr) {
+        if (hipMalloc(&c->prof_skip, sizeof(int) * BQ_PROF_SKIP_CAP) != hipSuccess ||
+            hipMemsetAsync(c->prof_skip, 0, sizeof(int) * BQ_PROF_SKIP_CAP, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            c->prof_skip = nullptr;
+            return;
+        }
+    }
+    if ((int64_t)c->prof[BQ_PROF_MATVEC].pending.size() >= BQ_PROF_SKIP_CAP - 1) return;   // ring full until the next read
+    c->prof_seq += 1;
+    c->prof_cur_idx = (int)(c->prof_seq % BQ_PROF_SKIP_CAP);
+    c->prof_cur_seq = (int)(c->prof_seq & 0x7fffffff) | 1;   // never 0 (the ring starts zeroed)
+    *slot = c->prof_skip + c->prof_cur_idx;
+    *seq = c->prof_cur_seq;
+}
+
 int bq_prof_end(bq_ctx *c, int which, hipEvent_t e0, hipEvent_t e1) {
     if (e0 == nullptr) return BQ_OK;
     BQ_HIP(hipEventRecord(e1, c->stream));
-    c->prof[which].pending.emplace_back(e0, e1);
+    bq_prof_pending pe;
+    pe.first = e0;
+    pe.second = e1;
+    if (which == BQ_PROF_MATVEC && c->prof_cur_idx >= 0) {
+        pe.skip_idx = c->prof_cur_idx;
+        pe.skip_seq = c->prof_cur_seq;
+    }
+    c->prof_cur_idx = -1;
+    c->prof[which].pending.push_back(pe);
     return BQ_OK;
 }
 
 extern "C" int bq_ctx_profile_read(bq_ctx *c, int which, double *total_ms, int64_t *launches, int reset) {
     BQ_ARG(c != nullptr && which >= 0 && which < BQ_PROF_COUNT, "ctx/which");
-    BQ_HIP(hipStreamSynchronize(c->stream));
+    BQ_SYNC(c);
     bq_prof_slot &s = c->prof[which];
-    std::vector<float> ms(s.pending.size(), 0.f);
-    float longest = 0.f;
-    for (size_t i = 0; i < s.pending.size(); ++i) {
-        BQ_HIP(hipEventElapsedTime(&ms[i], s.pending[i].first, s.pending[i].second));
-        longest = std::max(longest, ms[i]);
-        c->event_pool.push_back(s.pending[i].first);
-        c->event_pool.push_back(s.pending[i].second);
+    std::vector<int> ring;
+    bool any_tag = false;
+    for (const bq_prof_pending &pe : s.pending) any_tag = any_tag || pe.skip_idx >= 0;
+    if (any_tag && c->prof_skip != nullptr) {
+        ring.resize(BQ_PROF_SKIP_CAP);
+        BQ_HIP(hipMemcpy(ring.data(), c->prof_skip, sizeof(int) * BQ_PROF_SKIP_CAP, hipMemcpyDeviceToHost));
     }
-    for (float v : ms) {
-        // a panel product enqueued behind a solver's `done` flag returns at once (bq_as.hip: the rest of a batch of inner
-        // iterations): such a launch is no product and is left out of the mean
-        if (which == BQ_PROF_MATVEC && v < 0.02f * longest) continue;
-        s.total_ms += v;
+    for (const bq_prof_pending &pe : s.pending) {
+        float ms = 0.f;
+        BQ_HIP(hipEventElapsedTime(&ms, pe.first, pe.second));
+        c->event_pool.push_back(pe.first);
+        c->event_pool.push_back(pe.second);
+        // a launch that returned at once on its `done` flag said so itself (bq_prof_skip_arg): it is no product and stays out of
+        // the mean — exactly those launches, whatever their duration
+        if (pe.skip_idx >= 0 && !ring.empty() && ring[(size_t)pe.skip_idx] == pe.skip_seq) {
+            s.skipped += 1;
+            continue;
+        }
+        s.total_ms += ms;
         s.launches += 1;
     }
     s.pending.clear();
@@ -217,6 +255,7 @@ extern "C" int bq_ctx_profile_read(bq_ctx *c, int which, double *total_ms, int64
     if (reset) {
         s.total_ms = 0.0;
         s.launches = 0;
+        s.skipped = 0;
     }
     return BQ_OK;
 }
@@ -342,18 +381,38 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
     // symmetric panels are stored packed: tile row I keeps (I+1)*256 columns
     const size_t elems = p->symmetric ? (size_t)(bq_sym_off(p->I1) - bq_sym_off(p->I0))
                                       : (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld;
-    const size_t bytes = (elems > 0 ? elems : 1) * esz;
+    size_t bytes = (elems > 0 ? elems : 1) * esz;
+    // BQ_PLACE_OFFSETS (experiment): room behind the panel so that place_panel can try the SAME allocation at several offsets
+    static const size_t slack = [] {
+        const char *e = getenv("BQ_PLACE_OFFSETS");
+        size_t mx = 0;
+        for (const char *q = e; q && *q;) {
+            char *end = nullptr;
+            const unsigned long long v = strtoull(q, &end, 10);
+            if (end == q) break;
+            mx = std::max(mx, (size_t)v);
+            q = *end == ',' ? end + 1 : end;
+        }
+        return mx;
+    }();
+    const size_t data_bytes = bytes;
+    if (p->symmetric && bytes >= ((size_t)1 << 30)) bytes += slack;
     hipError_t e = hipSuccess;
     size_t cached = 0;
     if (void *kept = bq_ctx_cache_take(c, bytes, &cached)) {
         p->panel = kept;   // the panel a destroyed problem left behind
         p->panel_bytes = cached;
     } else {
+        const auto t0 = std::chrono::steady_clock::now();
         e = hipMalloc(&p->panel, bytes);   // bq_device_malloc: drops the cached panel and retries on failure
+        p->alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         p->panel_bytes = bytes;
     }
+    p->panel_alloc = p->panel;
+    (void)data_bytes;
     if (e != hipSuccess) {
         p->panel = nullptr;
+        p->panel_alloc = nullptr;
         bq_set_error("cannot allocate the %lld x %lld panel (%.1f GB): %s", (long long)rows, (long long)p->ld,
                      bytes / 1e9, hipGetErrorString(e));
         return BQ_ERR_NOMEM;
@@ -379,11 +438,12 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
     }
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
-    if (p->panel && p->panel_bytes >= ((size_t)1 << 30)) {   // keep one large panel for the next problem (see bq_ctx)
-        bq_ctx_cache_put(p->ctx, p->panel, p->panel_bytes);
-        p->panel = nullptr;
+    if (p->panel_alloc && p->panel_bytes >= ((size_t)1 << 30)) {   // keep one large panel for the next problem (see bq_ctx)
+        bq_ctx_cache_put(p->ctx, p->panel_alloc, p->panel_bytes);
+        p->panel_alloc = nullptr;
     }
-    for (void *ptr : {(void *)p->panel, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
+    p->panel = nullptr;
+    for (void *ptr : {(void *)p->panel_alloc, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
                       (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab, (void *)p->gath})
         if (ptr) hipFree(ptr);
     bq_stream_free(p->stream_img);
@@ -444,37 +504,60 @@ extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, co
             }
         }
     }
-    BQ_HIP(hipStreamSynchronize(c->stream));
+    BQ_SYNC(c);
     *out = p;
     return BQ_OK;
 }
 
-// BQ_PLACE_PANEL (bcqp.h): time the product kernel on the freshly allocated, zeroed panel; while it streams below the "good" rate
-// and the device can hold one more panel, allocate another candidate and time it; keep the fastest, release the rest at the end
-// (released earlier, the allocator would hand the same memory back as the next candidate).
-static int place_panel(bq_problem *p) {
+// BQ_PLACE_PANEL (bcqp.h): time the product kernel on the freshly allocated, zeroed panel; while it streams below the "good" rate,
+// the device can hold one more panel and the TIME BUDGET allows it, allocate another candidate and time it; keep the fastest,
+// release the rest at the end (released earlier, the allocator would hand the same memory back as the next candidate).
+//
+// What a slow placement is (round 4, profiles/r04/placement_*.txt): a property of the physical region the driver handed out, stable
+// for the life of the allocation (6.04 ... 6.50 ms in clusters) — NOT of the base address (the same allocation at 8 - 20 byte
+// offsets up to 1 GiB: flat to 0.5 %), not of the page-table contiguity the API can ask for (hipDeviceMallocContiguous: same
+// spread), not of the translation caches (UTCL1 misses equal); on a slow panel the fabric sees FEWER requests in flight and LOWER
+// latency (TCC_EA0_RDREQ_LEVEL -10 %, DRAM credit stalls -30 %) while the vector L1 waits longer (TCP_PENDING_STALL +8 %).  Nothing
+// on the allocation side changes it, so the remedy stays a choice among allocations — bounded in time so that it can be ON by
+// default (SVC / SVR.fit and bench.py alike): BQ_PLACE_BUDGET_MS (200) covers the timing of the first panel (5 products) and
+// as many further candidates as fit, each priced at what the FIRST allocation of this size cost (freshly released device memory
+// is cleared by the driver before it is handed out: seconds, not milliseconds — then no candidate fits the budget).
+// Per rank and before the first collective of a multi-rank job: the other ranks wait at most the budget.
+static int place_panel(bq_problem *p, double first_alloc_ms) {
     bq_ctx *c = p->ctx;
     if (!p->symmetric || p->streamed || p->panel == nullptr || p->panel_bytes < ((size_t)1 << 30) || p->I1 <= p->I0) return BQ_OK;
     const char *e = getenv("BQ_PANEL_CANDIDATES");
     const int want = e ? std::max(1, std::min(atoi(e), 4)) : 3;
     e = getenv("BQ_PANEL_GOOD_GBS");
     const double good_gbs = e ? atof(e) : 6500.0;
+    e = getenv("BQ_PLACE_BUDGET_MS");
+    const double budget_ms = e ? atof(e) : 200.0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     bq_seg_table tab;
     bq_sym_seg_table(p, &tab);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    BQ_HIP(hipEventCreate(&e0));
-    BQ_HIP(hipEventCreate(&e1));
-    const bool prof = c->profiling;
+    struct scope {   // events and the profiling switch go back on every exit path
+        bq_ctx *c;
+        bool prof;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~scope() {
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+            c->profiling = prof;
+        }
+    } sc{c, c->profiling};
     c->profiling = false;
+    BQ_HIP(hipEventCreate(&sc.e0));
+    BQ_HIP(hipEventCreate(&sc.e1));
     auto time_on = [&](void *panel, double *ms_out) -> int {
         int rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr);   // warm
-        hipEventRecord(e0, c->stream);
+        hipEventRecord(sc.e0, c->stream);
         for (int i = 0; rc == BQ_OK && i < 4; ++i)
             rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr);
-        hipEventRecord(e1, c->stream);
-        hipError_t he = hipEventSynchronize(e1);
+        hipEventRecord(sc.e1, c->stream);
+        hipError_t he = hipEventSynchronize(sc.e1);
         float ms = 0.f;
-        if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+        if (he == hipSuccess) he = hipEventElapsedTime(&ms, sc.e0, sc.e1);
         if (rc == BQ_OK && he != hipSuccess) {
             bq_set_error("timing a panel placement failed: %s", hipGetErrorString(he));
             rc = BQ_ERR_HIP;
@@ -484,10 +567,35 @@ static int place_panel(bq_problem *p) {
     };
     std::vector<void *> losers;
     double best = 0.0;
+    if (const char *offs = getenv("BQ_PLACE_OFFSETS")) {
+        // diagnostic (tools/placement_offsets.py): the launch time of the product on this ONE allocation at a list of byte offsets
+        // (problem_layout left zero-filled room behind the panel); the fastest offset is kept
+        int rc = BQ_OK;
+        size_t best_off = 0;
+        p->place_tried = 0;
+        for (const char *q = offs; q && *q && rc == BQ_OK && p->place_tried < 32;) {
+            char *end = nullptr;
+            const size_t off = (size_t)strtoull(q, &end, 10) & ~(size_t)4095;
+            if (end == q) break;
+            q = *end == ',' ? end + 1 : end;
+            double t = 0.0;
+            rc = time_on((char *)p->panel_alloc + off, &t);
+            p->place_ms[p->place_tried++] = t;
+            if (p->place_tried == 1 || t < best) {
+                best = t;
+                best_off = off;
+            }
+        }
+        p->panel = (char *)p->panel_alloc + best_off;
+        return rc;
+    }
     int rc = time_on(p->panel, &best);
     p->place_tried = 1;
     p->place_ms[0] = best;
-    while (rc == BQ_OK && p->place_tried < want && (double)p->panel_bytes / (best * 1e-3) / 1e9 < good_gbs) {
+    // what one more candidate costs: an allocation like the first one + clearing it + five products on it
+    const double cand_ms = first_alloc_ms + (double)p->panel_bytes / 4.0e9 + 6.0 * best;
+    while (rc == BQ_OK && p->place_tried < want && (double)p->panel_bytes / (best * 1e-3) / 1e9 < good_gbs &&
+           elapsed_ms() + cand_ms <= budget_ms) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < p->panel_bytes + p->panel_bytes / 16) break;
         void *cand = nullptr;
@@ -507,15 +615,13 @@ static int place_panel(bq_problem *p) {
         if (t < best) {
             losers.push_back(p->panel);
             p->panel = cand;
+            p->panel_alloc = cand;
             best = t;
         } else {
             losers.push_back(cand);
         }
     }
     for (void *l : losers) hipFree(l);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    c->profiling = prof;
     return rc;
 }
 
@@ -559,7 +665,7 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
     p->symmetric = p->streamed || !full_panel;
     int rc = problem_layout(p, n, structure == BQ_SVR ? 2 * n : n);
     if (rc == BQ_OK) rc = problem_alloc_common(p, q);
-    if (rc == BQ_OK && place) rc = place_panel(p);
+    if (rc == BQ_OK && place) rc = place_panel(p, p->alloc_ms);
     if (rc != BQ_OK) {
         bq_problem_destroy(p);
         return rc;
@@ -611,7 +717,7 @@ extern "C" int bq_problem_matvec(bq_problem *p, const double *v, double *out) {
     BQ_TRY(upload_padded(p, v, p->va, p->N, p->ldN));
     BQ_TRY(bq_problem_apply(p, p->va, p->vb, nullptr));
     BQ_HIP(hipMemcpyAsync(out, p->vb, sizeof(double) * p->N, hipMemcpyDeviceToHost, p->ctx->stream));
-    BQ_HIP(hipStreamSynchronize(p->ctx->stream));
+    BQ_SYNC(p->ctx);
     return BQ_OK;
 }
 
@@ -623,7 +729,7 @@ extern "C" int bq_problem_eval(bq_problem *p, const double *x, double *f, double
     BQ_TRY(bq_vec_eval_f(p, p->va, p->vb, g ? p->vb : nullptr, p->scal));
     BQ_HIP(hipMemcpyAsync(f, p->scal, sizeof(double), hipMemcpyDeviceToHost, p->ctx->stream));
     if (g) BQ_HIP(hipMemcpyAsync(g, p->vb, sizeof(double) * p->N, hipMemcpyDeviceToHost, p->ctx->stream));
-    BQ_HIP(hipStreamSynchronize(p->ctx->stream));
+    BQ_SYNC(p->ctx);
     return BQ_OK;
 }
 
@@ -636,7 +742,7 @@ extern "C" int bq_problem_gram_matvec(bq_problem *p, const double *w, double *ou
     BQ_HIP(hipMemcpyAsync(p->w, w, sizeof(double) * p->n, hipMemcpyHostToDevice, c->stream));
     BQ_TRY(bq_panel_product(p, false, p->w, nullptr));
     BQ_HIP(hipMemcpyAsync(out, p->s, sizeof(double) * p->n, hipMemcpyDeviceToHost, c->stream));
-    BQ_HIP(hipStreamSynchronize(c->stream));
+    BQ_SYNC(c);
     return BQ_OK;
 }
 
@@ -656,7 +762,7 @@ extern "C" int bq_problem_panel_rows(bq_problem *p, int64_t row0, int64_t nrows,
             const int64_t len = std::min(p->n, bq_sym_pitch(i / BQ_SYM_TILE));
             BQ_HIP(hipMemcpyAsync(tmp.data(), (const unsigned char *)p->panel + (size_t)bq_sym_addr(i, 0, p->I0) * esz,
                                   (size_t)len * esz, hipMemcpyDeviceToHost, c->stream));
-            BQ_HIP(hipStreamSynchronize(c->stream));
+            BQ_SYNC(c);
             double *o = out + r * p->n;
             for (int64_t j = 0; j < len; ++j)
                 o[j] = p->storage == BQ_F64 ? ((const double *)tmp.data())[j] : (double)((const float *)tmp.data())[j];
@@ -668,12 +774,12 @@ extern "C" int bq_problem_panel_rows(bq_problem *p, int64_t row0, int64_t nrows,
     if (p->storage == BQ_F64) {
         BQ_HIP(hipMemcpy2DAsync(out, p->n * 8, (const double *)p->panel + lr * p->ld, p->ld * 8, p->n * 8, nrows,
                                 hipMemcpyDeviceToHost, c->stream));
-        BQ_HIP(hipStreamSynchronize(c->stream));
+        BQ_SYNC(c);
     } else {
         std::vector<float> tmp((size_t)nrows * p->n);
         BQ_HIP(hipMemcpy2DAsync(tmp.data(), p->n * 4, (const float *)p->panel + lr * p->ld, p->ld * 4, p->n * 4, nrows,
                                 hipMemcpyDeviceToHost, c->stream));
-        BQ_HIP(hipStreamSynchronize(c->stream));
+        BQ_SYNC(c);
         for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
     }
     return BQ_OK;
@@ -837,6 +943,30 @@ extern "C" int bq_ctx_probe_mfma_f64(bq_ctx *c, double seconds, double *tflops) 
         return BQ_ERR_HIP;
     }
     *tflops = flop_per_launch * launches / (ms * 1e-3) / 1e12;
+    return BQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stream occupancy probe (tests of the collective watchdog): ONE lane spins on the constant-rate wall clock for the given
+// time and then returns — it always terminates by itself, whatever the host does
+// ---------------------------------------------------------------------------------------------
+__global__ void probe_stall_kernel(long long ticks, long long *sink) {
+    const long long t0 = wall_clock64();
+    long long t = t0;
+    while (t - t0 < ticks) t = wall_clock64();
+    if (ticks < 0) *sink = t;   // never: keeps the loop
+}
+
+extern "C" int bq_ctx_probe_stall(bq_ctx *c, double milliseconds) {
+    BQ_ARG(c != nullptr, "ctx is NULL");
+    BQ_ARG(milliseconds > 0.0 && milliseconds <= 5000.0, "milliseconds in (0, 5000]");
+    BQ_HIP(hipSetDevice(c->device));
+    int rate_khz = 0;
+    BQ_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device));
+    if (rate_khz <= 0) rate_khz = 100000;   // 100 MHz on every part this library is built for
+    probe_stall_kernel<<<1, 1, 0, c->stream>>>((long long)(milliseconds * (double)rate_khz), nullptr);
+    BQ_HIP(hipGetLastError());
+    BQ_SYNC(c);
     return BQ_OK;
 }
 
@@ -1199,7 +1329,7 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
         if ((k + 1) % poll == 0 && k + 1 < max_steps) {
             if (lagged) {
                 if (pending) {
-                    BQ_HIP(hipEventSynchronize(s->flag_event));
+                    BQ_TRY(bq_ctx_event_sync(c, s->flag_event));
                     if (*s->flag_host) break;
                 }
                 BQ_HIP(hipMemcpyAsync(s->flag_host, &s->sc->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1207,13 +1337,13 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
                 pending = true;
             } else {
                 BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));
-                BQ_HIP(hipStreamSynchronize(c->stream));
+                BQ_SYNC(c);
                 if (s->host.done) break;
             }
         }
     }
     BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));
-    BQ_HIP(hipStreamSynchronize(c->stream));
+    BQ_SYNC(c);
     if (s->host.status < 0) {  // a kernel flagged a numerical failure (codes mirror BQ_ERR_*)
         bq_set_error(s->host.status == BQ_ERR_NOT_PD ? "Cholesky met a non-positive pivot"
                                                      : "non-finite values in the solver state");
@@ -1224,7 +1354,7 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
     if (rows < 0) rows = 0;
     if (stats && rows > 0) {
         BQ_HIP(hipMemcpyAsync(stats, s->stats, sizeof(bq_iter_stat) * rows, hipMemcpyDeviceToHost, c->stream));
-        BQ_HIP(hipStreamSynchronize(c->stream));
+        BQ_SYNC(c);
     }
     *n_stats = rows;
     *status = s->host.status;
@@ -1254,7 +1384,7 @@ extern "C" int bq_solver_get(bq_solver *s, int what, double *out) {
                 BQ_HIP(hipMemcpyAsync(o, v, sizeof(double) * s->N, hipMemcpyDeviceToHost, c->stream));
                 o += s->N;
             }
-        BQ_HIP(hipStreamSynchronize(c->stream));
+        BQ_SYNC(c);
         return BQ_OK;
     }
     switch (what) {
@@ -1272,13 +1402,13 @@ extern "C" int bq_solver_get(bq_solver *s, int what, double *out) {
         BQ_ARG(m != nullptr, "masks exist for ActiveSet only");
         std::vector<unsigned char> tmp((size_t)s->N);
         BQ_HIP(hipMemcpyAsync(tmp.data(), m, (size_t)s->N, hipMemcpyDeviceToHost, c->stream));
-        BQ_HIP(hipStreamSynchronize(c->stream));
+        BQ_SYNC(c);
         for (int64_t i = 0; i < s->N; ++i) out[i] = tmp[i] ? 1.0 : 0.0;
         return BQ_OK;
     }
     BQ_ARG(src != nullptr, "vector not available for this solver");
     BQ_HIP(hipMemcpyAsync(out, src, sizeof(double) * s->N, hipMemcpyDeviceToHost, c->stream));
-    BQ_HIP(hipStreamSynchronize(c->stream));
+    BQ_SYNC(c);
     return BQ_OK;
 }
 

@@ -1555,7 +1555,7 @@ static int as_schur_refresh(bq_solver *s, as_ws *w, int64_t nA, bool *ok) {
     BQ_TRY(bq_chol_factor(ws, np0));
     int info = 0;
     BQ_HIP(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipStreamSynchronize(st));
+    BQ_SYNC(s->p->ctx);
     if (info != 0) {
         *ok = false;
         return BQ_OK;
@@ -1702,7 +1702,7 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
             BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
             have_t = true;
         }
-        BQ_HIP(hipStreamSynchronize(st));
+        BQ_SYNC(s->p->ctx);
         for (int i = 0; i <= k; ++i) {
             if (!std::isfinite(host_small[i])) return BQ_OK;
             c->C[(size_t)i * AS_SCHUR_MAX + k] = host_small[i];
@@ -1715,7 +1715,7 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
             as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
                                                       s->ub, p->q, w->Qz, c->small + 2 * AS_SCHUR_MAX);
             BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
-            BQ_HIP(hipStreamSynchronize(st));
+            BQ_SYNC(s->p->ctx);
         }
         if (!as_ldl_solve(c, m, host_t, coef)) {   // incremental factorisation first, pivoted elimination as the fallback
             c->ldl_n = 0;
@@ -1731,7 +1731,7 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
                                                                                   c->y, c->small + AS_SCHUR_MAX, w->cand, w->ints);
     }
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipStreamSynchronize(st));
+    BQ_SYNC(s->p->ctx);
     BQ_HIP(hipGetLastError());
     *good = true;
     return BQ_OK;
@@ -1981,7 +1981,7 @@ static int as_cg_solve_once(bq_solver *s, as_ws *w, int *pc_failed) {
         if (pc) BQ_TRY(as_pc_apply(s, w, 0));
         as_cg_dir_kernel<<<grid, BQ_VEC_BLOCK, 0, st>>>(N, zr, w->pv, w->cg);
         ++queued;
-        BQ_HIP(hipEventSynchronize(w->cg_event));   // the flag as it stood BEFORE the iteration just enqueued
+        BQ_TRY(bq_ctx_event_sync(ctx, w->cg_event));   // the flag as it stood BEFORE the iteration just enqueued
         if (w->cg_flag_host[0]) break;
         BQ_HIP(hipMemcpyAsync(w->cg_flag_host, &w->cg->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         BQ_HIP(hipEventRecord(w->cg_event, st));
@@ -1991,7 +1991,7 @@ static int as_cg_solve_once(bq_solver *s, as_ws *w, int *pc_failed) {
     int pc_info = 0, sm_fail = 0;
     if (pc) BQ_HIP(hipMemcpyAsync(&pc_info, pc->ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
     if (pc) BQ_HIP(hipMemcpyAsync(&sm_fail, pc->sm_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipStreamSynchronize(st));
+    BQ_SYNC(s->p->ctx);
     w->cg_iters += h.iters;
     if (pc_info != 0 || sm_fail != 0 || h.info == 2) {   // the caller sums G afresh and tries again, then gives the preconditioner up
         bq_set_error("the preconditioner of the inner conjugate gradients is not positive definite (pivot %d, |A| = %lld): "
@@ -2011,7 +2011,7 @@ static int as_cg_solve_once(bq_solver *s, as_ws *w, int *pc_failed) {
     as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, w->sol, s->lb, s->ub, w->cand);
     w->have_cand = true;
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipStreamSynchronize(st));
+    BQ_SYNC(s->p->ctx);
     return BQ_OK;
 }
 
@@ -2152,7 +2152,7 @@ int bq_as_iterate(bq_solver *s) {
     }
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipStreamSynchronize(st));
+    BQ_SYNC(s->p->ctx);
     if (s->host.done) return BQ_OK;
     const int64_t nA = w->host_ints[0];
 
@@ -2220,7 +2220,7 @@ int bq_as_iterate(bq_solver *s) {
     int info = 0;
     BQ_HIP(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipStreamSynchronize(st));
+    BQ_SYNC(s->p->ctx);
     if (info != 0) {
         // Q[A,A] is not positive definite: the reference's bare `except` switches to scipy's minres on the normal
         // equations (active_set.py:142-151).  Rebuild the (destroyed) restricted Hessian with both triangles, solve,
@@ -2232,7 +2232,7 @@ int bq_as_iterate(bq_solver *s) {
         as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
         as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, ws->rhs, s->lb, s->ub, w->cand);
         BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
-        BQ_HIP(hipStreamSynchronize(st));
+        BQ_SYNC(s->p->ctx);
         w->minres_calls += 1;
     }
     w->last_branch = w->host_ints[2] ? 1 : 0;

@@ -13,7 +13,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
+#include <thread>
 
 #include "bq_common.h"
 
@@ -25,6 +30,7 @@ struct rccl_api {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -47,6 +53,7 @@ int load_rccl() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
     g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
@@ -156,9 +163,127 @@ void bq_comm_destroy(bq_ctx *ctx) {
     ctx->nccl_comm = nullptr;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Bounded collectives.  After ncclCommInitRank nothing in RCCL bounds a collective in time: if a peer
+// stops taking part — an error on that rank only, a crashed process — this rank's collective kernel spins for ever and the
+// host sits in the next wait on the stream.  A launcher that kills the job on the first non-zero exit hides that
+// (bench.py spawn_ranks, torch.distributed.run); a library user has no such parent.  With a timeout set
+// (bq_ctx_set_collective_timeout, BQ_COLLECTIVE_TIMEOUT_S) a watchdog thread watches the host's waits on the compute
+// stream (bq_ctx_sync / bq_ctx_event_sync stamp them); a wait older than the limit gets the communicator aborted
+// (ncclCommAbort ends its kernels), the wait returns and the call fails with BQ_ERR_RCCL, as does every later collective of
+// the context.  The callback transport needs no watchdog: its exchange runs on the host inside the caller's communicator,
+// whose own timeout (SocketComm / gloo / ThreadComm) ends the call.
+// ---------------------------------------------------------------------------------------------------------------------
+struct bq_watchdog {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    double timeout_s = 0.0;
+    std::atomic<long long> wait_since_ns{0};   // 0: the host is not inside a stream wait
+    std::atomic<bool> fired{false};
+};
+
+namespace {
+long long now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void watchdog_loop(bq_ctx *ctx, bq_watchdog *wd) {
+    std::unique_lock<std::mutex> lk(wd->m);
+    while (!wd->stop) {
+        wd->cv.wait_for(lk, std::chrono::milliseconds(20));
+        if (wd->stop) break;
+        const long long since = wd->wait_since_ns.load();
+        if (since == 0 || wd->fired.load()) continue;
+        if ((double)(now_ns() - since) * 1e-9 < wd->timeout_s) continue;
+        // still under the mutex: the waiting thread cannot leave its wait scope (it takes the mutex to clear the stamp) while
+        // the communicator is being torn down under it
+        wd->fired.store(true);
+        ctx->comm_aborted = true;
+        if (ctx->comm_kind == BQ_COMM_RCCL && ctx->nccl_comm && g_rccl.CommAbort) {
+            g_rccl.CommAbort((ncclComm_t)ctx->nccl_comm);
+            ctx->nccl_comm = nullptr;   // aborted: never destroyed again
+        }
+    }
+}
+
+struct wait_scope {   // stamps a host wait on the stream; the stamp is cleared under the watchdog's mutex
+    bq_watchdog *wd;
+    explicit wait_scope(bq_ctx *ctx) : wd(ctx->watchdog) {
+        if (wd) wd->wait_since_ns.store(now_ns());
+    }
+    ~wait_scope() {
+        if (!wd) return;
+        std::lock_guard<std::mutex> lk(wd->m);
+        wd->wait_since_ns.store(0);
+    }
+};
+
+int aborted_error(bq_ctx *ctx) {
+    bq_set_error("a collective did not complete within %.1f s (a peer rank stopped taking part?): the communicator of rank %d was "
+                 "aborted; this context is unusable", ctx->watchdog ? ctx->watchdog->timeout_s : 0.0, ctx->rank);
+    return BQ_ERR_RCCL;
+}
+}  // namespace
+
+int bq_ctx_sync(bq_ctx *ctx) {
+    hipError_t e;
+    {
+        wait_scope scope(ctx);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (ctx->comm_aborted) return aborted_error(ctx);
+    if (e != hipSuccess) {
+        bq_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e));
+        return BQ_ERR_HIP;
+    }
+    return BQ_OK;
+}
+
+int bq_ctx_event_sync(bq_ctx *ctx, hipEvent_t ev) {
+    hipError_t e;
+    {
+        wait_scope scope(ctx);
+        e = hipEventSynchronize(ev);
+    }
+    if (ctx->comm_aborted) return aborted_error(ctx);
+    if (e != hipSuccess) {
+        bq_set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
+        return BQ_ERR_HIP;
+    }
+    return BQ_OK;
+}
+
+void bq_watchdog_stop(bq_ctx *ctx) {
+    bq_watchdog *wd = ctx->watchdog;
+    if (!wd) return;
+    {
+        std::lock_guard<std::mutex> lk(wd->m);
+        wd->stop = true;
+    }
+    wd->cv.notify_all();
+    if (wd->th.joinable()) wd->th.join();
+    delete wd;
+    ctx->watchdog = nullptr;
+}
+
+extern "C" int bq_ctx_set_collective_timeout(bq_ctx *ctx, double seconds) {
+    BQ_ARG(ctx != nullptr, "ctx is NULL");
+    BQ_ARG(seconds >= 0.0 && seconds <= 86400.0, "timeout in [0, 86400] seconds (0: none)");
+    bq_watchdog_stop(ctx);
+    if (seconds == 0.0) return BQ_OK;
+    bq_watchdog *wd = new bq_watchdog();
+    wd->timeout_s = seconds;
+    ctx->watchdog = wd;
+    wd->th = std::thread(watchdog_loop, ctx, wd);
+    return BQ_OK;
+}
+
 // buf holds world*chunk doubles; this rank's chunk (at rank*chunk) is fresh on entry, all chunks on return
 int bq_exchange_gather(bq_ctx *ctx, double *buf, int64_t chunk) {
     if (ctx->comm_kind == BQ_COMM_NONE || ctx->comm_kind == BQ_COMM_SHARE) return BQ_OK;
+    if (ctx->comm_aborted) return aborted_error(ctx);
     prof_scope prof(ctx);
     BQ_TRY(prof.begin());
     if (ctx->comm_kind == BQ_COMM_RCCL) {
@@ -187,6 +312,7 @@ int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0,
 // in-place all-reduce(sum) of v[0:count) — BQ_SYM_EXCHANGE=allreduce: every rank holds partial sums for every output block
 int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count) {
     if (ctx->comm_kind == BQ_COMM_NONE || ctx->comm_kind == BQ_COMM_SHARE) return BQ_OK;
+    if (ctx->comm_aborted) return aborted_error(ctx);
     prof_scope prof(ctx);
     BQ_TRY(prof.begin());
     if (ctx->comm_kind == BQ_COMM_RCCL) {

@@ -67,11 +67,16 @@ enum { BQ_PROF_MATVEC = 0, BQ_PROF_GRAM = 1, BQ_PROF_CHOL = 2, BQ_PROF_EXCH = 3,
 // products hold this rank's contributions only.  It exists to time and inspect a share on a single GPU (bq_ctx_create_share).
 enum { BQ_COMM_NONE = 0, BQ_COMM_RCCL = 1, BQ_COMM_CALLBACK = 2, BQ_COMM_SHARE = 3 };
 
+struct bq_prof_pending {
+    hipEvent_t first = nullptr, second = nullptr;
+    int skip_idx = -1, skip_seq = 0;   // slot of bq_ctx::prof_skip the kernel writes skip_seq into when it returned on a `done` flag
+};
 struct bq_prof_slot {
     double total_ms = 0.0;
-    int64_t launches = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int64_t launches = 0, skipped = 0;
+    std::vector<bq_prof_pending> pending;
 };
+constexpr int BQ_PROF_SKIP_CAP = 16384;
 
 struct bq_ctx {
     int device = 0, rank = 0, world = 1;
@@ -88,6 +93,12 @@ struct bq_ctx {
     size_t pinned_cap = 0;
     bool profiling = false;
     bq_prof_slot prof[BQ_PROF_COUNT];
+    // a product enqueued behind a solver's `done` flag returns at once when the flag is up: such a launch writes its sequence
+    // number into its slot of this ring, and bq_ctx_profile_read leaves exactly those launches out of the mean (it
+    // used to guess them from their duration)
+    int *prof_skip = nullptr;
+    long long prof_seq = 0;
+    int prof_cur_idx = -1, prof_cur_seq = 0;   // the slot handed to the launch between bq_prof_begin and bq_prof_end
     std::vector<hipEvent_t> event_pool;
     // One released panel is kept for the next problem of about the same size: on this platform a 40 GB hipMalloc issued
     // right after a 40 GB hipFree takes 1-2 s instead of 0.04 s (measured), and fits in a loop — multi-class, parameter
@@ -98,7 +109,18 @@ struct bq_ctx {
     // problems alive on this context; a context destroyed while some are is only marked and goes with the last of them
     int refs = 0;
     bool zombie = false;
+    // bounded collectives (bq_ctx_set_collective_timeout): a watchdog thread looks at how long the host has been inside a wait on
+    // the compute stream; past the limit it aborts the RCCL communicator — the kernel of a collective whose peer never arrives
+    // ends, the wait returns, and every later call on this context fails with BQ_ERR_RCCL
+    struct bq_watchdog *watchdog = nullptr;
+    bool comm_aborted = false;
 };
+// every host wait on the compute stream of a (possibly multi-rank) context: stamps the wait for the watchdog and turns an abort
+// into BQ_ERR_RCCL
+int bq_ctx_sync(bq_ctx *ctx);
+int bq_ctx_event_sync(bq_ctx *ctx, hipEvent_t ev);
+void bq_watchdog_stop(bq_ctx *ctx);   // joins the thread (context destruction)
+#define BQ_SYNC(ctx) BQ_TRY(bq_ctx_sync(ctx))
 
 struct bq_problem {
     bq_ctx *ctx = nullptr;
@@ -113,9 +135,11 @@ struct bq_problem {
     int64_t r0 = 0, r1 = 0, blk = 0;  // my rows [r0,r1) and the per-rank block size (row-block mode)
     // symmetric mode (kernel-built panels): only tiles on/below the diagonal are stored and streamed; this rank owns
     // the 256-row tile rows [I0, I1) of nb, panel row 0 is global row I0*256
-    size_t panel_bytes = 0;    // allocated size of `panel`
+    size_t panel_bytes = 0;    // allocated size of `panel_alloc`
+    void *panel_alloc = nullptr;   // what the allocator handed out; `panel` = panel_alloc + the chosen offset (BQ_PLACE_OFFSETS)
     int place_tried = 0;       // BQ_PLACE_PANEL: placements timed, and the product's launch time on each
-    double place_ms[4] = {0.0, 0.0, 0.0, 0.0};
+    double place_ms[32] = {0.0};
+    double alloc_ms = 0.0;     // what the driver took to hand out the panel (0: it came from the context's cache)
     bool symmetric = false;
     bool streamed = false;     // BQ_STREAM: no panel, Gram tiles recomputed inside every product (stream_img)
     void *stream_img = nullptr;
@@ -198,6 +222,9 @@ struct bq_solver {
 // bq_ctx.cpp / bq_api.hip
 int bq_prof_begin(bq_ctx *ctx, int which, hipEvent_t *e0, hipEvent_t *e1);
 int bq_prof_end(bq_ctx *ctx, int which, hipEvent_t e0, hipEvent_t e1);
+// between bq_prof_begin and the launch of a kernel that may return on a `done` flag: where that kernel reports "skipped"
+// (*slot null when not profiling); the kernel does `if (*done) { if (slot && first thread) *slot = seq; return; }`
+void bq_prof_skip_arg(bq_ctx *ctx, hipEvent_t e0, int **slot, int *seq);
 int bq_exchange_rows(bq_ctx *ctx, double *s, int64_t n, int64_t blk, int64_t r0, int64_t r1);
 int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count);  // all-reduce(sum) of a replicated-length vector
 // in-place all-gather of equal chunks: buf holds world*chunk doubles, this rank's chunk (at rank*chunk) is fresh on entry

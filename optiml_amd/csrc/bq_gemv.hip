@@ -48,8 +48,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <typename VT, int R, bool ADD_ONE, int UNROLL>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const VT *__restrict__ panel, int64_t ldv, int64_t nrows,
                                                         const d2_t *__restrict__ w, double *__restrict__ out,
-                                                        const int *__restrict__ done) {
-    if (done != nullptr && *done) return;
+                                                        const int *__restrict__ done, int *__restrict__ skip, int skip_seq) {
+    if (done != nullptr && *done) {
+        if (skip != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *skip = skip_seq;   // bq_prof_skip_arg
+        return;
+    }
     constexpr int WPL = vt_traits<VT>::elems / 2;  // d2 loads of w per lane per step
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * R;
@@ -93,17 +96,17 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const VT *__restrict__ p
 
 template <typename VT, bool ADD_ONE>
 static void launch_r(hipStream_t st, const void *panel, int64_t ldv, int64_t nrows, const double *w, double *out,
-                     const int *done) {
+                     const int *done, int *skip, int skip_seq) {
     const VT *P = reinterpret_cast<const VT *>(panel);
     const d2_t *W = reinterpret_cast<const d2_t *>(w);
     if (nrows >= 8192) {
-        gemv_rows_kernel<VT, 8, ADD_ONE, 2><<<dim3((unsigned)((nrows + 7) / 8)), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done);
+        gemv_rows_kernel<VT, 8, ADD_ONE, 2><<<dim3((unsigned)((nrows + 7) / 8)), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done, skip, skip_seq);
     } else if (nrows >= 2048) {
-        gemv_rows_kernel<VT, 4, ADD_ONE, 2><<<dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done);
+        gemv_rows_kernel<VT, 4, ADD_ONE, 2><<<dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done, skip, skip_seq);
     } else if (nrows >= 512) {
-        gemv_rows_kernel<VT, 2, ADD_ONE, 4><<<dim3((unsigned)((nrows + 1) / 2)), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done);
+        gemv_rows_kernel<VT, 2, ADD_ONE, 4><<<dim3((unsigned)((nrows + 1) / 2)), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done, skip, skip_seq);
     } else {
-        gemv_rows_kernel<VT, 1, ADD_ONE, 4><<<dim3((unsigned)nrows), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done);
+        gemv_rows_kernel<VT, 1, ADD_ONE, 4><<<dim3((unsigned)nrows), dim3(256), 0, st>>>(P, ldv, nrows, W, out, done, skip, skip_seq);
     }
 }
 
@@ -113,18 +116,20 @@ int bq_launch_gemv(bq_ctx *ctx, const void *panel, int storage, bool add_one, in
     BQ_ARG(ld % BQ_PAD == 0, "panel pitch must be a multiple of 1024 elements");
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
+    int *skip = nullptr, skip_seq = 0;
+    if (done_flag != nullptr) bq_prof_skip_arg(ctx, e0, &skip, &skip_seq);
     if (storage == BQ_F64) {
         const int64_t ldv = ld / 2;
         if (add_one)
-            launch_r<d2_t, true>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag);
+            launch_r<d2_t, true>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag, skip, skip_seq);
         else
-            launch_r<d2_t, false>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag);
+            launch_r<d2_t, false>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag, skip, skip_seq);
     } else {
         const int64_t ldv = ld / 4;
         if (add_one)
-            launch_r<f4_t, true>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag);
+            launch_r<f4_t, true>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag, skip, skip_seq);
         else
-            launch_r<f4_t, false>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag);
+            launch_r<f4_t, false>(ctx->stream, panel, ldv, nrows, w, s_rows, done_flag, skip, skip_seq);
     }
     BQ_HIP(hipGetLastError());
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));

@@ -542,8 +542,12 @@ struct bq_stream_images {
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void gram_stream_sym_kernel(gram_params P, const double *__restrict__ w, int add_one,
                                                                  const int *__restrict__ unit, double *__restrict__ SU,
-                                                                 double *__restrict__ slab, int64_t t0, const int *done) {
-    if (done != nullptr && *done) return;
+                                                                 double *__restrict__ slab, int64_t t0, const int *done,
+                                                                 int *__restrict__ skip, int skip_seq) {
+    if (done != nullptr && *done) {
+        if (skip != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *skip = skip_seq;   // bq_prof_skip_arg
+        return;
+    }
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     __shared__ double rowsum[4][64];
     __shared__ double rowsq[4][64];
@@ -775,20 +779,22 @@ int bq_stream_sym_product(bq_ctx *ctx, void *h, int64_t n, int64_t nb, const bq_
     P.stagger_mode = P.stagger_unit = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
+    int *skip = nullptr, skip_seq = 0;
+    if (done != nullptr) bq_prof_skip_arg(ctx, e0, &skip, &skip_seq);
     const unsigned nu = (unsigned)st->nunits;
     if (nu > 0) {
         switch (kernel) {
             case BQ_KERNEL_RBF:
-                gram_stream_sym_kernel<BQ_KERNEL_RBF><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                gram_stream_sym_kernel<BQ_KERNEL_RBF><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done, skip, skip_seq);
                 break;
             case BQ_KERNEL_POLY:
-                gram_stream_sym_kernel<BQ_KERNEL_POLY><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                gram_stream_sym_kernel<BQ_KERNEL_POLY><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done, skip, skip_seq);
                 break;
             case BQ_KERNEL_SIGMOID:
-                gram_stream_sym_kernel<BQ_KERNEL_SIGMOID><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                gram_stream_sym_kernel<BQ_KERNEL_SIGMOID><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done, skip, skip_seq);
                 break;
             default:
-                gram_stream_sym_kernel<BQ_KERNEL_LINEAR><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done);
+                gram_stream_sym_kernel<BQ_KERNEL_LINEAR><<<nu, 256, 0, ctx->stream>>>(P, w, add_one ? 1 : 0, st->unit, st->SU, st->slab, st->t0, done, skip, skip_seq);
                 break;
         }
     }

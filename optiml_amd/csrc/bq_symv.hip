@@ -60,8 +60,12 @@ __device__ __host__ __forceinline__ int64_t strips_before(int64_t I) {  // sum_{
 template <typename T, bool ADD_ONE, int JG, int SR>
 __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict__ panel, int64_t ld, int64_t I0,
                                                             int64_t nb, const double *__restrict__ w,
-                                                            double *__restrict__ slab, const int *__restrict__ done) {
-    if (done != nullptr && *done) return;
+                                                            double *__restrict__ slab, const int *__restrict__ done,
+                                                            int *__restrict__ skip, int skip_seq) {
+    if (done != nullptr && *done) {
+        if (skip != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *skip = skip_seq;   // bq_prof_skip_arg: "this launch was no product"
+        return;
+    }
     __shared__ double colred[4][ST];
     // decode (I, g) from the linear strip index
     const int64_t t = (int64_t)blockIdx.x + strips_before<JG>(I0);
@@ -272,18 +276,20 @@ static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_on
     const int64_t ld = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
+    int *skip = nullptr, skip_seq = 0;
+    if (done != nullptr) bq_prof_skip_arg(ctx, e0, &skip, &skip_seq);
     if (nstrips > 0) {
         dim3 grid((unsigned)nstrips);
         if (storage == BQ_F64) {
             if (add_one)
-                symv_tiles_kernel<double, true, JG, SR><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<double, true, JG, SR><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done, skip, skip_seq);
             else
-                symv_tiles_kernel<double, false, JG, SR><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<double, false, JG, SR><<<grid, 256, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, done, skip, skip_seq);
         } else {
             if (add_one)
-                symv_tiles_kernel<float, true, JG, SR><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<float, true, JG, SR><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done, skip, skip_seq);
             else
-                symv_tiles_kernel<float, false, JG, SR><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done);
+                symv_tiles_kernel<float, false, JG, SR><<<grid, 256, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, done, skip, skip_seq);
         }
     }
     BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));

@@ -223,7 +223,6 @@ __device__ __forceinline__ bool last_block(unsigned int *ticket) {
 
 __device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
 __device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
-__device__ __forceinline__ void step_body(int kind, bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
 
 // apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and its reductions; the last
 // block finalises them: objective, |d|, record, stop tests (projected_gradient.py:81-110)
@@ -303,55 +302,14 @@ __device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, 
     }
 }
 
-// finish (gathered panel output -> Q d) fused with the partial sums of d'Qd
-__global__ void finish_den_kernel(int structure, int64_t n, int64_t N, double diag_add, const double *__restrict__ sv,
-                                  const double *__restrict__ d, const double *__restrict__ sgn,
-                                  double *__restrict__ Qd, bq_scal *sc, double *part, int64_t nblk, int kind,
-                                  bq_iter_stat *stats) {
-    if (sc->done) return;
-    __shared__ double sh[4];
-    double a = 0.0;
-    VEC_LOOP(i) {
-        double r = 0.0;
-        if (i < N) {
-            if (structure == BQ_PLAIN)
-                r = sv[i];
-            else if (structure == BQ_SVC)
-                r = sgn[i] * sv[i];
-            else
-                r = (i < n) ? sv[i] : -sv[i - n];
-            const double di = d[i];
-            if (diag_add != 0.0) r += diag_add * di;
-            a += di * r;
-        }
-        Qd[i] = r;
-    }
-    a = block_sum(a, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = a;
-    if (last_block(&sc->ticket[1])) {   // the last block turns d'Qd into the step length (and closes the iteration)
-        step_body(kind, sc, part, nblk, stats);
-        if (threadIdx.x == 0) sc->ticket[1] = 0;
-    }
-}
-
-// kind 0: PG  t = max_t if den <= 1e-16 else min(-g'd/den, max_t);  kind 1: FW  a = 1 if ... else min(-g'd/den, 1)
-__device__ __forceinline__ void step_body(int kind, bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh[4];
-    const double den = final_sum(part, nblk, sh);
-    if (threadIdx.x == 0) {
-        const double cap = (kind == 0) ? sc->max_t : 1.0;
-        const double t = (den <= CURV_TOL) ? cap : fmin(-sc->gd / den, cap);
-        sc->den = den;
-        sc->t = t;
-        const long long row = sc->iter - sc->stat_base;
-        if (row >= 0 && row < sc->stat_cap) {
-            if (kind == 0)
-                stats[row].r2 = t;
-            else
-                stats[row].r3 = t;
-        }
-        sc->iter += 1;
-    }
+// finish (gathered panel output -> Q d) fused with the partial sums of d'Qd and the step length: the stand-alone form of the
+// epilogue (bq_epilogue.h) for the paths whose product has no closing kernel of its own to carry it (dense row-block panels, the
+// one-rank streamed product, BQ_SYM_EXCHANGE=allreduce).  One workgroup per 256 rows, exactly as inside symv_reduce_kernel /
+// symv_segsum_kernel: d'Qd — and with it the step length — has the same bits whichever kernel closed the product.
+__global__ __launch_bounds__(256) void finish_den_kernel(const double *__restrict__ sv, bq_epilogue epi) {
+    if (epi.sc->done) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, i < epi.n ? sv[i] : 0.0), gridDim.x);
 }
 
 // FW: apply pending step, pick the vertex, form the (optionally trust-clipped) direction
@@ -499,10 +457,7 @@ int bq_pgfw_iterate(bq_solver *s) {
     epi.stats = s->stats;
     bool fused = false;
     BQ_TRY(bq_panel_product(p, p->add_one, w, done, fuse ? &epi : nullptr, &fused));
-    if (!fused)
-        finish_den_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, p->N, p->diag_add, p->s, s->d, p->sgn,
-                                                                    s->Qd, s->sc, s->partials, s->nblk, s->kind == BQ_PG ? 0 : 1,
-                                                                    s->stats);
+    if (!fused) finish_den_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(p->s, epi);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

@@ -43,13 +43,18 @@ def _agree(comm, failure, what):
 
 
 class Context:
-    def __init__(self, device=None, comm=None, exchange='rccl', sym_exchange=None, share=None):
+    def __init__(self, device=None, comm=None, exchange='rccl', sym_exchange=None, share=None, collective_timeout=None):
         """exchange: 'rccl' (RCCL over xGMI) or 'host' (the communicator's host collectives; tests).  sym_exchange: how the
         products of symmetric kernel panels are closed — 'gather' (default: all-gather of the per-segment partial vectors,
         added in segment order on every rank, bit-identical iterates for any rank count) or 'allreduce' (one all-reduce(sum);
         the association of the rank sum then belongs to the transport).  None: the BQ_SYM_EXCHANGE environment variable.
         share=(k, G): rank k's share of a G-way partition with no transport (collectives are no-ops, products are partial) —
         for timing one share on one GPU, never for solving.
+
+        collective_timeout (seconds; None: the BQ_COLLECTIVE_TIMEOUT_S environment variable, else no bound): RCCL never gives up
+        on a collective whose peer does not arrive; with a timeout a watchdog aborts the communicator when the host has waited
+        on the stream for longer, the call in progress raises BcqpError(ERR_RCCL) and the context is unusable afterwards.  (The
+        host exchange is bounded by the communicator's own timeout.)
 
         device=None: LOCAL_RANK.  An RCCL rank needs a device of its own: LOCAL_RANK >= the visible device count is an
         error there (agreed on by all ranks before the communicator is created); ranks of the host exchange may share a
@@ -142,6 +147,10 @@ class Context:
             if sym_exchange not in ('gather', 'allreduce'):
                 raise ValueError(f"unknown sym_exchange '{sym_exchange}' (use 'gather' or 'allreduce')")
             _lib.check(lib.bq_ctx_set_sym_allreduce(self._h, 1 if sym_exchange == 'allreduce' else 0))
+        if collective_timeout is None and os.environ.get('BQ_COLLECTIVE_TIMEOUT_S'):
+            collective_timeout = float(os.environ['BQ_COLLECTIVE_TIMEOUT_S'])
+        if collective_timeout:
+            self.set_collective_timeout(collective_timeout)
 
     @property
     def handle(self):
@@ -183,6 +192,14 @@ class Context:
         r, c = C.c_double(0), C.c_double(0)
         _lib.check(self._lib.bq_ctx_probe_bandwidth(self.handle, int(nbytes), int(reps), C.byref(r), C.byref(c)))
         return r.value, c.value
+
+    def set_collective_timeout(self, seconds):
+        """Abort the RCCL communicator when a wait on the stream lasts longer than `seconds` (0: never)."""
+        _lib.check(self._lib.bq_ctx_set_collective_timeout(self.handle, float(seconds)))
+
+    def probe_stall(self, milliseconds):
+        """Occupy the stream for `milliseconds` and wait for it through the bounded wait (the watchdog's one-GPU test)."""
+        _lib.check(self._lib.bq_ctx_probe_stall(self.handle, float(milliseconds)))
 
     def probe_exchange(self, kind, count, reps=50):
         """(mean_us, min_us) of this context's closing collective timed on its own: kind 'gather' = the in-place all-gather of

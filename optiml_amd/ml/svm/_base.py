@@ -153,10 +153,12 @@ class SVM(BaseEstimator, ABC):
         return self.dual and isinstance(self.optimizer, type) and issubclass(self.optimizer, StochasticOptimizer)
 
     # Choose the panel's placement (`KernelQuadratic(tune_placement=True)`, BQ_PLACE_PANEL) for the optimizers whose every
-    # iteration is one panel product.  Off by default: it costs two more panel-sized allocations, which take from milliseconds to
-    # seconds on this platform (freshly released device memory is cleared before it is handed out), for ~5 % per iteration — it
-    # pays on long runs.  Set `SVC.tune_placement = True` (or on an instance) to opt in.
-    tune_placement = False
+    # iteration is one panel product: the launch time of the product is a stable property of where the allocation landed (6.04 ...
+    # 6.50 ms at n = 100 000) and nothing on the allocation side changes it, so the library times the product on the
+    # fresh panel and, if it streams slowly, on as many further allocations as fit a 0.2 s budget (BQ_PLACE_BUDGET_MS), and keeps
+    # the fastest.  On by default since round 4 — the path bench.py measures is the path `fit` runs; `SVC.tune_placement = False`
+    # (class or instance) takes the first allocation.
+    tune_placement = True
 
     def _streams_panel(self):
         from ...opti.constrained import ActiveSetCG, FrankWolfe, ProjectedGradient

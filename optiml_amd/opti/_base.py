@@ -104,8 +104,8 @@ class _DeviceProblem:
     def placement(self):
         """Launch time (ms) of the panel product on every placement of the panel that was tried (`tune_placement`); [] if none."""
         tried = C.c_int(0)
-        ms = np.zeros(4)
-        _lib.check(self._lib.bq_problem_placement(self._h, C.byref(tried), _lib.ptr(ms), 4))
+        ms = np.zeros(32)
+        _lib.check(self._lib.bq_problem_placement(self._h, C.byref(tried), _lib.ptr(ms), 32))
         return [float(v) for v in ms[:tried.value]]
 
     def time_matvec(self, reps=10):

@@ -158,6 +158,81 @@ def gpu_c4(outdir):
     np.savez(os.path.join(outdir, f'rank{comm.rank}.npz'), **res)
 
 
+def gpu_watchdog(outdir):
+    """One rank, an RCCL communicator of its own, collectives bounded to 0.4 s: short waits pass, a 1.5 s occupation of the stream
+    (bq_ctx_probe_stall: a lane spinning on the wall clock, it ends by itself) trips the watchdog — the communicator is aborted,
+    the call raises ERR_RCCL, later collectives fail at once, closing the context does not hang."""
+    import time
+    from optiml_amd import _lib, device
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.dist import SocketComm
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    ctx = device.set_context(device.Context(comm=SocketComm(0, 1), exchange='rccl', device=0, collective_timeout=0.4))
+    res = {'rccl_ranks': np.array(ctx.comm_info()['rccl_ranks'])}
+    X, y = make_blobs(700, 12, seed=5)
+    quad = KernelQuadratic(X, -np.ones(700), 'svc', gaussian, y=y)
+    v = np.random.RandomState(2).standard_normal(700)
+    res['matvec'] = quad.device_problem().matvec(v)            # a product with its (one-rank) all-gather: no false alarm
+    ctx.probe_stall(100.0)                                      # a wait shorter than the limit: nothing happens
+    res['matvec_again'] = quad.device_problem().matvec(v)
+    t0 = time.perf_counter()
+    try:
+        ctx.probe_stall(1500.0)
+        res['stall_error'] = np.array(0)
+    except _lib.BcqpError as err:
+        res['stall_error'], res['stall_msg'] = np.array(err.code), np.array(str(err))
+    res['stall_s'] = np.array(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    try:
+        quad.device_problem().matvec(v)
+        res['after_error'] = np.array(0)
+    except _lib.BcqpError as err:
+        res['after_error'] = np.array(err.code)
+    res['after_s'] = np.array(time.perf_counter() - t0)
+    res['rccl_ranks_after'] = np.array(ctx.comm_info()['rccl_ranks'])
+    t0 = time.perf_counter()
+    quad.release()
+    ctx.close()
+    res['close_s'] = np.array(time.perf_counter() - t0)
+    np.savez(os.path.join(outdir, 'rank0.npz'), **res)
+
+
+def gpu_peer_leaves(outdir):
+    """Two ranks on GPU 0, host exchange over the package's TCP communicator (5 s timeout).  Rank 1 meets a rank-local error
+    after the first product and stops taking part (it leaves WITHOUT a non-zero exit: nothing outside kills the job); rank 0
+    enters its second product and must come back with an error, not hang."""
+    import time
+    from optiml_amd import _lib, device
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.dist import SocketComm
+    from optiml_amd.ml.svm.kernels import gaussian
+    from optiml_amd.opti import KernelQuadratic
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    comm = SocketComm(rank, world, '127.0.0.1', int(os.environ['MASTER_PORT']) + 1, timeout=5.0)
+    device.init_distributed(comm, exchange='host', device=0)
+    X, y = make_blobs(700, 12, seed=5)
+    quad = KernelQuadratic(X, -np.ones(700), 'svc', gaussian, y=y)
+    v = np.random.RandomState(2).standard_normal(700)
+    res = {'first': quad.device_problem().matvec(v)}
+    if rank == 1:
+        try:
+            raise RuntimeError('rank-local failure before the second product')
+        except RuntimeError as err:
+            res['left_because'] = np.array(str(err))
+        np.savez(os.path.join(outdir, f'rank{rank}.npz'), **res)
+        comm.close()
+        return
+    t0 = time.perf_counter()
+    try:
+        quad.device_problem().matvec(v)
+        res['second_error'] = np.array(0)
+    except _lib.BcqpError as err:
+        res['second_error'], res['second_msg'] = np.array(err.code), np.array(str(err))
+    res['second_s'] = np.array(time.perf_counter() - t0)
+    np.savez(os.path.join(outdir, f'rank{rank}.npz'), **res)
+
+
 if __name__ == '__main__':
     import faulthandler
     faulthandler.dump_traceback_later(90, exit=False)   # a stuck rank shows where (its log is printed by the launcher)
@@ -178,5 +253,9 @@ if __name__ == '__main__':
         gpu_mode('host', outdir, 'allreduce')
     elif mode == 'gpu-rccl-allreduce':
         gpu_mode('rccl', outdir, 'allreduce')
+    elif mode == 'gpu-watchdog':
+        gpu_watchdog(outdir)
+    elif mode == 'gpu-peer-leaves':
+        gpu_peer_leaves(outdir)
     else:
         raise SystemExit('unknown mode ' + mode)

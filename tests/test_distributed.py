@@ -269,3 +269,31 @@ def test_rows_per_step_variants_are_bit_identical(tmp_path, one_rank):
         res = _launch('gpu-host', 1, tmp_path / f'rows{rows}', extra_env={'BQ_SYMV_ROWS_PER_STEP': rows})[0]
         for key in ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_f', 'ascg_kernel_x', 'ascg_kernel_f'):
             assert np.array_equal(res[key], one_rank[key]), (rows, key)
+
+
+@pytest.mark.gpu
+def test_collective_watchdog_aborts_a_wait_that_outlasts_the_timeout(tmp_path):
+    """bq_ctx_set_collective_timeout on a one-rank RCCL context (a child process: an aborted communicator is the end of its
+    context): normal products and a short occupation of the stream pass; a 1.5 s occupation against a 0.4 s limit makes the
+    watchdog abort the communicator — ERR_RCCL from the call in progress within about its own length, ERR_RCCL at once from
+    the next collective, and closing the context returns."""
+    from optiml_amd import _lib
+    got = _launch('gpu-watchdog', 1, tmp_path, timeout=120)[0]
+    assert int(got['rccl_ranks']) == 1
+    assert np.array_equal(got['matvec'], got['matvec_again'])
+    assert int(got['stall_error']) == _lib.ERR_RCCL and 'did not complete within' in str(got['stall_msg'])
+    assert 1.0 < float(got['stall_s']) < 4.0
+    assert int(got['after_error']) == _lib.ERR_RCCL and float(got['after_s']) < 1.0
+    assert int(got['rccl_ranks_after']) == 0 and float(got['close_s']) < 5.0
+
+
+@pytest.mark.gpu
+def test_a_rank_that_leaves_does_not_hang_its_peer(tmp_path):
+    """a rank-local failure mid-run on one of two ranks (host exchange, 5 s communicator timeout); the rank
+    that goes on must get an error from its next product in bounded time, with nothing outside to kill it."""
+    from optiml_amd import _lib
+    r0, r1 = _launch('gpu-peer-leaves', 2, tmp_path, timeout=120)
+    assert 'rank-local failure' in str(r1['left_because'])
+    assert np.array_equal(r0['first'], r1['first'])
+    assert int(r0['second_error']) == _lib.ERR_RCCL, r0['second_error']
+    assert float(r0['second_s']) < 15.0
