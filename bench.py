@@ -682,7 +682,7 @@ SIDE_COMMANDS = {   # name -> (arguments of the child, its time cap in seconds)
     'c4': (['--config', 'c4', '--steps', '50', '--warmup', '5', '--no-cpu', '--kkt', 'none'], 90.0),
     'c5': (['--config', 'c5', '--steps', '10', '--warmup', '2', '--no-cpu', '--kkt', 'none'], 150.0),
     'shares': (['--emulate-shares', '2,4,8', '--steps', '30', '--warmup', '3'], 150.0),
-    'collective': (['--collective-floor'], 90.0),
+    'collective': (['--collective-floor'], 150.0),   # (a cold box pages librccl.so in: seen to take > 90 s once)
     'shares_c4': (['--config', 'c4', '--emulate-shares', '4', '--steps', '30', '--warmup', '3'], 90.0),
     'shares_c5': (['--config', 'c5', '--solver', 'pg', '--emulate-shares', '1,8', '--steps', '20', '--warmup', '3'], 150.0),
     'fixed_cap': (['--fixed-cap', '1000', '--fixed-cap-configs', 'headline,c2,c4'], 90.0),

@@ -1326,6 +1326,12 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
     bool pending = false;
     for (int64_t k = 0; k < max_steps; ++k) {
         BQ_TRY(solver_iterate(s));
+        if (s->kind == BQ_AS) {
+            // ActiveSet looks at the device at the top of every iteration anyway (bq_as_iterate: the order of the restricted
+            // system comes from there) and leaves s->host current: a second look here was one more stream drain per iteration
+            if (s->host.done) break;
+            continue;
+        }
         if ((k + 1) % poll == 0 && k + 1 < max_steps) {
             if (lagged) {
                 if (pending) {

@@ -106,7 +106,13 @@ struct as_ws {
     double *Qz = nullptr;      // (ldN)
     double *x_eval = nullptr;  // x / g at the top of the current iteration (what a callback must see)
     double *g_eval = nullptr;
-    int host_ints[32];
+    // PINNED host copies of the per-iteration records: a device-to-host copy into pageable memory goes through the runtime's
+    // staging path and cost ~30 us of stream idle per look at the device (three looks per ActiveSet iteration: 0.18 ms of a 1.4 ms
+    // iteration at n = 20 000, profiles/r04/as_n20k_stream_idle_before.txt); into pinned memory it is a plain DMA
+    int *host_ints = nullptr;        // 32 ints: the copy of `ints`
+    bq_scal *host_scal = nullptr;    // the copy of the solver's device scalars (moved into s->host after the wait)
+    int *host_info = nullptr;        // 4 ints: factorisation info words
+    as_cg_scal *host_cg = nullptr;   // the inner solver's scalars at the end of a solve
     long long minres_calls = 0;
     struct as_schur *sch = nullptr;   // factor re-use (Schur-complement updates of a base factorisation)
     int last_branch = -1;             // what the previous iteration did: 1 release, 0 ratio step + absorb, -1 nothing yet
@@ -1553,9 +1559,9 @@ static int as_schur_refresh(bq_solver *s, as_ws *w, int64_t nA, bool *ok) {
     int64_t np0 = 0;
     BQ_TRY(bq_chol_build_h(ws, s->p, c->idx0, nA, nullptr, &np0));
     BQ_TRY(bq_chol_factor(ws, np0));
-    int info = 0;
-    BQ_HIP(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipMemcpyAsync(w->host_info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
     BQ_SYNC(s->p->ctx);
+    const int info = w->host_info[0];
     if (info != 0) {
         *ok = false;
         return BQ_OK;
@@ -1986,12 +1992,13 @@ static int as_cg_solve_once(bq_solver *s, as_ws *w, int *pc_failed) {
         BQ_HIP(hipMemcpyAsync(w->cg_flag_host, &w->cg->done, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         BQ_HIP(hipEventRecord(w->cg_event, st));
     }
-    as_cg_scal h;
-    BQ_HIP(hipMemcpyAsync(&h, w->cg, sizeof(as_cg_scal), hipMemcpyDeviceToHost, st));
-    int pc_info = 0, sm_fail = 0;
-    if (pc) BQ_HIP(hipMemcpyAsync(&pc_info, pc->ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (pc) BQ_HIP(hipMemcpyAsync(&sm_fail, pc->sm_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipMemcpyAsync(w->host_cg, w->cg, sizeof(as_cg_scal), hipMemcpyDeviceToHost, st));
+    w->host_info[1] = w->host_info[2] = 0;
+    if (pc) BQ_HIP(hipMemcpyAsync(w->host_info + 1, pc->ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (pc) BQ_HIP(hipMemcpyAsync(w->host_info + 2, pc->sm_fail, sizeof(int), hipMemcpyDeviceToHost, st));
     BQ_SYNC(s->p->ctx);
+    const int pc_info = w->host_info[1], sm_fail = w->host_info[2];
+    const as_cg_scal h = *w->host_cg;
     w->cg_iters += h.iters;
     if (pc_info != 0 || sm_fail != 0 || h.info == 2) {   // the caller sums G afresh and tries again, then gives the preconditioner up
         bq_set_error("the preconditioner of the inner conjugate gradients is not positive definite (pivot %d, |A| = %lld): "
@@ -2049,6 +2056,12 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipMemsetAsync(w->idx, 0, sizeof(int) * (s->N + 1), ctx->stream));
     BQ_HIP(hipMalloc(&w->ints, sizeof(int) * 32));
     BQ_HIP(hipMemsetAsync(w->ints, 0, sizeof(int) * 32, ctx->stream));
+    BQ_HIP(hipHostMalloc(&w->host_ints, sizeof(int) * 32));
+    BQ_HIP(hipHostMalloc(&w->host_scal, sizeof(bq_scal)));
+    BQ_HIP(hipHostMalloc(&w->host_info, sizeof(int) * 4));
+    BQ_HIP(hipHostMalloc(&w->host_cg, sizeof(as_cg_scal)));
+    memset(w->host_ints, 0, sizeof(int) * 32);
+    memset(w->host_info, 0, sizeof(int) * 4);
     for (double **v : {&w->cand, &w->z, &w->Qz, &w->x_eval, &w->g_eval}) {
         BQ_HIP(hipMalloc(v, sizeof(double) * s->ldN));
         BQ_HIP(hipMemsetAsync(*v, 0, sizeof(double) * s->ldN, ctx->stream));
@@ -2093,6 +2106,8 @@ void bq_as_free(bq_solver *s) {
                     (void *)w->g_eval, (void *)w->dlt, (void *)w->r, (void *)w->pv, (void *)w->Qp, (void *)w->sol,
                     (void *)w->cg, (void *)w->Qdl, (void *)w->Qcand, (void *)w->sq, (void *)w->zchg, (void *)w->zdl})
         if (p) hipFree(p);
+    for (void *hp : {(void *)w->host_ints, (void *)w->host_scal, (void *)w->host_info, (void *)w->host_cg})
+        if (hp) hipHostFree(hp);
     if (w->cg_flag_host) hipHostFree(w->cg_flag_host);
     if (w->cg_event) hipEventDestroy(w->cg_event);
     as_pc_free(w->pc);
@@ -2151,8 +2166,9 @@ int bq_as_iterate(bq_solver *s) {
         BQ_HIP(hipMemcpyAsync(pc->host_chg, pc->chg, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     }
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipMemcpyAsync(w->host_scal, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
     BQ_SYNC(s->p->ctx);
+    s->host = *w->host_scal;
     if (s->host.done) return BQ_OK;
     const int64_t nA = w->host_ints[0];
 
@@ -2217,10 +2233,10 @@ int bq_as_iterate(bq_solver *s) {
     BQ_TRY(bq_chol_solve(ws, np));
     as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
     as_cand_scatter_idx_kernel<<<vgrid(s->ldN).x * (BQ_VEC_TILE / 256), 256, 0, st>>>(w->idx, w->ints, ws->rhs, s->lb, s->ub, w->cand);
-    int info = 0;
-    BQ_HIP(hipMemcpyAsync(&info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
+    BQ_HIP(hipMemcpyAsync(w->host_info, ws->info, sizeof(int), hipMemcpyDeviceToHost, st));
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_SYNC(s->p->ctx);
+    const int info = w->host_info[0];
     if (info != 0) {
         // Q[A,A] is not positive definite: the reference's bare `except` switches to scipy's minres on the normal
         // equations (active_set.py:142-151).  Rebuild the (destroyed) restricted Hessian with both triangles, solve,
