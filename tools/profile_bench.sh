@@ -10,7 +10,7 @@ name=$1; shift
 out=gpurun_out/$name
 mkdir -p "$out"
 export TMPDIR=/tmp
-args=("$@" --no-cpu --kkt none)
+args=("$@" --no-cpu --kkt none --records none)
 rocprofv3 --kernel-trace --stats -d "$out/trace" -- python3 bench.py "${args[@]}" > "$out/bench_under_rocprof.json" 2> "$out/trace.err" || { tail -5 "$out/trace.err"; exit 1; }
 db=$(find "$out/trace" -name '*_results.db' | head -1)
 if [ -n "$db" ]; then python3 tools/rocpd_stats.py "$db" > "$out/kernel_stats.csv"; else cp $(find "$out/trace" -name '*kernel_stats.csv' | head -1) "$out/kernel_stats.csv"; fi
