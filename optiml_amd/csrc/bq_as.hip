@@ -1308,7 +1308,8 @@ __global__ void as_schur_rhs0_kernel(int64_t n0, int64_t np0, const int *__restr
 template <typename T>
 __global__ void as_schur_col_kernel(int kind, int var, int pos, int64_t n0, int64_t np0, const int *__restrict__ idx0,
                                     int structure, const T *__restrict__ panel, int64_t ldp, int packed, int64_t n,
-                                    const double *__restrict__ sgn, double diag_add, double *__restrict__ out) {
+                                    const double *__restrict__ sgn, double diag_add, double *__restrict__ out,
+                                    double *__restrict__ out2) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= np0) return;
     double v = 0.0;
@@ -1317,71 +1318,117 @@ __global__ void as_schur_col_kernel(int kind, int var, int pos, int64_t n0, int6
     else if (a < n0)
         v = bq_q_elem(structure, panel, ldp, packed, n, sgn, diag_add, (int64_t)idx0[a], (int64_t)var);
     out[a] = v;
+    out2[a] = v;   // the right-hand side of the solve that follows (was a device-to-device copy)
 }
 
 // block i: out[i] = extra_i - U[i]'v.  mode 0 (v = W[k]): extra = V_ik = Q[var_i, var_k] when both were freed, else 0.
 // mode 1 (v = y0): extra = the right-hand side of row i: the bound of a pinned variable, -(q + Qz) of a freed one.
+// mode 2: BOTH in one pass over U[i] (the usual iteration: one new slot k = m - 1, then the right-hand side): out[i] as mode 0
+// with v = v0, out1[i] as mode 1 with v = v1 — each dot product summed exactly as in its own launch (same bits).
 template <typename T>
 __global__ __launch_bounds__(256) void as_schur_dots_kernel(int mode, int k, const double *__restrict__ U,
-                                                            const double *__restrict__ v, int64_t cap, int64_t np0,
+                                                            const double *__restrict__ v, const double *__restrict__ v1,
+                                                            int64_t cap, int64_t np0,
                                                             const int *__restrict__ meta, int structure,
                                                             const T *__restrict__ panel, int64_t ldp, int packed, int64_t n,
                                                             const double *__restrict__ sgn, double diag_add,
                                                             const unsigned char *__restrict__ mU,
                                                             const double *__restrict__ lb, const double *__restrict__ ub,
                                                             const double *__restrict__ q, const double *__restrict__ Qz,
-                                                            double *__restrict__ out) {
-    __shared__ double sh[4];
+                                                            double *__restrict__ out, double *__restrict__ out1) {
+    __shared__ double sh[4], sh1[4];
     const int i = blockIdx.x;
     const double *u = U + (int64_t)i * cap;
-    double s = 0.0;
-    for (int64_t a = threadIdx.x; a < np0; a += 256) s += __dmul_rn(u[a], v[a]);
+    double s = 0.0, t = 0.0;
+    if (mode == 2) {
+        for (int64_t a = threadIdx.x; a < np0; a += 256) {
+            const double ua = u[a];
+            s += __dmul_rn(ua, v[a]);
+            t += __dmul_rn(ua, v1[a]);
+        }
+    } else {
+        for (int64_t a = threadIdx.x; a < np0; a += 256) s += __dmul_rn(u[a], v[a]);
+    }
     s = as_wsum_any(s);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    if (mode == 2) t = as_wsum_any(t);
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = s;
+        sh1[threadIdx.x >> 6] = t;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         const double dot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
         const int ki = meta[i], vi = meta[AS_SCHUR_MAX + i];
-        double extra = 0.0;
-        if (mode == 0) {
+        if (mode != 1) {
             const int kk = meta[k], vk = meta[AS_SCHUR_MAX + k];
+            double extra = 0.0;
             if (ki == 1 && kk == 1) extra = bq_q_elem(structure, panel, ldp, packed, n, sgn, diag_add, (int64_t)vi, (int64_t)vk);
-        } else {
-            extra = ki == 0 ? (mU[vi] ? ub[vi] : lb[vi]) : -(q[vi] + Qz[vi]);
+            out[i] = extra - dot;
         }
-        out[i] = extra - dot;
+        if (mode != 0) {
+            const double d1 = mode == 1 ? dot : ((sh1[0] + sh1[1]) + sh1[2]) + sh1[3];
+            const double extra = ki == 0 ? (mU[vi] ? ub[vi] : lb[vi]) : -(q[vi] + Qz[vi]);
+            (mode == 1 ? out : out1)[i] = extra - d1;
+        }
     }
 }
 
-// y = y0 - sum_k coef[k] W[k]
-__global__ void as_schur_combine_kernel(int64_t np0, int m, const double *__restrict__ y0, const double *__restrict__ W,
-                                        int64_t cap, const double *__restrict__ coef, double *__restrict__ y) {
-    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= np0) return;
-    double v = y0[a];
-    for (int k = 0; k < m; ++k) v -= __dmul_rn(coef[k], W[(int64_t)k * cap + a]);
-    y[a] = v;
+// y = y0 - sum_k coef[k] W[k]: 256 rows x 4 interleaved runs of slots per workgroup (1024 threads: four times the loads in
+// flight of the one-thread-per-row form, which ran this m x np0 product at 0.65 TB/s), the four runs added in run order
+__global__ __launch_bounds__(1024) void as_schur_combine_kernel(int64_t np0, int m, const double *__restrict__ y0,
+                                                                const double *__restrict__ W, int64_t cap,
+                                                                const double *__restrict__ coef, double *__restrict__ y) {
+    __shared__ double part[4][256];
+    const int r = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const int64_t a = (int64_t)blockIdx.x * 256 + r;
+    double v = 0.0;
+    if (a < np0)
+        for (int k = g; k < m; k += 4) v += __dmul_rn(coef[k], W[(int64_t)k * cap + a]);
+    part[g][r] = v;
+    __syncthreads();
+    if (g == 0 && a < np0) y[a] = y0[a] - (((part[0][r] + part[1][r]) + part[2][r]) + part[3][r]);
 }
 
 // C = L D L' of the m x m Schur complement, kept on the host and grown by one row per new slot (O(m^2)); C is symmetric
 // quasi-definite — minus a positive definite block for the pinned variables, a positive definite one for the freed —
 // so it factorises without pivoting in any order.  as_ldl_solve checks the residual; on failure the caller falls back
 // to the pivoted elimination below (and from there to a fresh base factor).
-// sum_j a[j] * b[j] with four independent partial sums (the host compiler does not re-associate a scalar reduction: this is
-// the difference between ~1 and ~4 flop per cycle on the m^2 loops below, which sit on every iteration's critical path)
-static inline double as_dot4(const double *a, const double *b, int n) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int j = 0;
-    for (; j + 4 <= n; j += 4) {
-        s0 += a[j] * b[j];
-        s1 += a[j + 1] * b[j + 1];
-        s2 += a[j + 2] * b[j + 2];
-        s3 += a[j + 3] * b[j + 3];
-    }
-    for (; j < n; ++j) s0 += a[j] * b[j];
-    return (s0 + s1) + (s2 + s3);
+// The host's share of a kept-factor iteration is this O(m^2) work between two waits on the stream (the device idles meanwhile:
+// profiles/r04/as_n20k_stream_idle_*.txt), so it is compiled a second time for AVX2 + FMA hosts and picked at load time
+// (function multi-versioning; the device pass of hipcc does not know the attribute).  The sums may be re-associated by the
+// vectoriser: the small system's solution moves in its last bits with the host's vector width, as it would with another BLAS.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BQ_HOST_SIMD
+#else
+#define BQ_HOST_SIMD __attribute__((target_clones("arch=x86-64-v3", "default")))
+#endif
+
+// sum_j a[j] * b[j]
+BQ_HOST_SIMD static double as_dot4(const double *__restrict__ a, const double *__restrict__ b, int n) {
+#pragma clang fp reassociate(on)
+    double s = 0.0;
+#pragma clang loop vectorize(enable) interleave_count(4)
+    for (int j = 0; j < n; ++j) s += a[j] * b[j];
+    return s;
+}
+// sum_j |a[j] * b[j]|
+BQ_HOST_SIMD static double as_absdot(const double *__restrict__ a, const double *__restrict__ b, int n) {
+#pragma clang fp reassociate(on)
+    double s = 0.0;
+#pragma clang loop vectorize(enable) interleave_count(4)
+    for (int j = 0; j < n; ++j) s += std::fabs(a[j] * b[j]);
+    return s;
+}
+// y[0:n) -= l[0:n) * w
+BQ_HOST_SIMD static void as_axpy_neg(double *__restrict__ y, const double *__restrict__ l, double w, int n) {
+#pragma clang loop vectorize(enable) interleave_count(4)
+    for (int j = 0; j < n; ++j) y[j] -= l[j] * w;
 }
 
+// C = L D L' of the m x m Schur complement, kept on the host and grown by one row per new slot (O(m^2)); C is symmetric
+// quasi-definite — minus a positive definite block for the pinned variables, a positive definite one for the freed —
+// so it factorises without pivoting in any order.  as_ldl_solve checks the residual; on failure the caller falls back
+// to the pivoted elimination below (and from there to a fresh base factor).
 static bool as_ldl_extend(as_schur *c, int m) {
     const size_t ld = AS_SCHUR_MAX;
     std::vector<double> z;
@@ -1389,8 +1436,9 @@ static bool as_ldl_extend(as_schur *c, int m) {
         double *lk = &c->Lc[(size_t)k * ld];
         // L z = C[0:k, k]  (forward), l = z / D, d = C[k][k] - sum l z
         z.assign((size_t)k + 1, 0.0);
+        const double *ck = &c->C[(size_t)k * ld];   // row k = column k (symmetric): contiguous
         for (int i = 0; i < k; ++i) {
-            const double v = c->C[(size_t)i * ld + k] - as_dot4(&c->Lc[(size_t)i * ld], z.data(), i);
+            const double v = ck[i] - as_dot4(&c->Lc[(size_t)i * ld], z.data(), i);
             z[i] = v;
             lk[i] = v / c->Dc[i];
         }
@@ -1414,24 +1462,16 @@ static bool as_ldl_solve(as_schur *c, int m, const double *t, double *w) {
     for (int i = m - 1; i >= 0; --i) {
         const double wi = y[i];
         w[i] = wi;
-        const double *li = &c->Lc[(size_t)i * ld];
-        for (int j = 0; j < i; ++j) y[j] -= li[j] * wi;
+        as_axpy_neg(y.data(), &c->Lc[(size_t)i * ld], wi, i);
     }
     // residual against the stored C
     double worst = 0.0, scale = 0.0;
     for (int i = 0; i < m; ++i) {
         const double *ci = &c->C[(size_t)i * ld];
         const double r = t[i] - as_dot4(ci, w, m);
-        double s0 = 0.0, s1 = 0.0;
-        int j = 0;
-        for (; j + 2 <= m; j += 2) {
-            s0 += std::fabs(ci[j] * w[j]);
-            s1 += std::fabs(ci[j + 1] * w[j + 1]);
-        }
-        for (; j < m; ++j) s0 += std::fabs(ci[j] * w[j]);
         if (!std::isfinite(r)) return false;
         worst = std::max(worst, std::fabs(r));
-        scale = std::max(scale, std::fabs(t[i]) + s0 + s1);
+        scale = std::max(scale, std::fabs(t[i]) + as_absdot(ci, w, m));
     }
     return worst <= 1e-11 * scale;
 }
@@ -1693,20 +1733,21 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
     bool have_t = false;
     for (int k = computed; k < m; ++k) {   // the columns of the new slots and their rows of C
         double *uk = c->U + (int64_t)k * c->cap, *wk = c->W + (int64_t)k * c->cap;
+        // the column goes to its slot AND to the right-hand side of the solve; the solve leaves its result in the slot of W too
         as_schur_col_kernel<T><<<gb, 256, 0, st>>>(c->kind[k], c->var[k], c->kind[k] == 0 ? c->hpos0[(size_t)c->var[k]] : -1, n0,
-                                                  np0, c->idx0, AS_PANEL_ARGS(T), uk);
-        BQ_HIP(hipMemcpyAsync(ws->rhs, uk, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
+                                                  np0, c->idx0, AS_PANEL_ARGS(T), uk, ws->rhs);
         // a pinned base variable's column is a unit vector: the forward sweep starts at its row
-        BQ_TRY(bq_chol_solve(ws, np0, c->kind[k] == 0 ? (int64_t)c->hpos0[(size_t)c->var[k]] : 0));
-        BQ_HIP(hipMemcpyAsync(wk, ws->rhs, sizeof(double) * np0, hipMemcpyDeviceToDevice, st));
-        as_schur_dots_kernel<T><<<k + 1, 256, 0, st>>>(0, k, c->U, wk, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
-                                                      s->ub, p->q, w->Qz, c->small);
-        BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
-        if (k == m - 1) {   // the right-hand side of the small system needs nothing from the host: same round trip
-            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
-                                                      s->ub, p->q, w->Qz, c->small + 2 * AS_SCHUR_MAX);
+        BQ_TRY(bq_chol_solve(ws, np0, c->kind[k] == 0 ? (int64_t)c->hpos0[(size_t)c->var[k]] : 0, wk));
+        if (k == m - 1) {   // the right-hand side of the small system needs nothing from the host: same pass over U, same round trip
+            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(2, k, c->U, wk, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                      s->ub, p->q, w->Qz, c->small, c->small + 2 * AS_SCHUR_MAX);
+            BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
             BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
             have_t = true;
+        } else {
+            as_schur_dots_kernel<T><<<k + 1, 256, 0, st>>>(0, k, c->U, wk, nullptr, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU,
+                                                          s->lb, s->ub, p->q, w->Qz, c->small, nullptr);
+            BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
         }
         BQ_SYNC(s->p->ctx);
         for (int i = 0; i <= k; ++i) {
@@ -1718,8 +1759,8 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
     double *coef = c->coef_pin;
     if (m > 0) {
         if (!have_t) {
-            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
-                                                      s->ub, p->q, w->Qz, c->small + 2 * AS_SCHUR_MAX);
+            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, nullptr, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                      s->ub, p->q, w->Qz, c->small + 2 * AS_SCHUR_MAX, nullptr);
             BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
             BQ_SYNC(s->p->ctx);
         }
@@ -1729,7 +1770,7 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         }
         BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
     }
-    as_schur_combine_kernel<<<gb, 256, 0, st>>>(np0, m, c->y0, c->W, c->cap, c->small + AS_SCHUR_MAX, c->y);
+    as_schur_combine_kernel<<<gb, 1024, 0, st>>>(np0, m, c->y0, c->W, c->cap, c->small + AS_SCHUR_MAX, c->y);
     as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
     {
         const int64_t span = n0 > m ? (n0 > 0 ? n0 : 1) : (int64_t)m;

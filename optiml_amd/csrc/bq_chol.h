@@ -37,7 +37,8 @@ struct bq_chol_ws {
 };
 
 int bq_chol_factor(bq_chol_ws *ws, int64_t np);
-int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero = 0);   // rhs[0:first_nonzero) is known to be zero
+// rhs[0:first_nonzero) is known to be zero; also (may be null): the solution is written there as well as into ws->rhs
+int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero = 0, double *also = nullptr);
 // after a successful bq_chol_factor of a factor that will be solved with many times: two launches per 1024 rows and
 // direction instead of one per 128 (writes L^T into the upper triangle of H)
 int bq_chol_prepare_sweeps(bq_chol_ws *ws, int64_t np);

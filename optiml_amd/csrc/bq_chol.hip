@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ 
 // 1024-block (rows r, columns up to / from r's own 128-block).  c_lo even, rows 16-byte aligned.
 __global__ __launch_bounds__(256) void sweep_gemv_kernel(const double *__restrict__ A, int64_t lda, int64_t row0, int64_t nrows,
                                                          int64_t c_lo, int64_t c_hi, int mode, const double *__restrict__ v,
-                                                         const double *base, double sign, double *out) {
+                                                         const double *base, double sign, double *out, double *out2) {
     constexpr int R = 4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * R;
@@ -581,7 +581,9 @@ __global__ __launch_bounds__(256) void sweep_gemv_kernel(const double *__restric
     __syncthreads();
     if (tid < R && r0 + tid < nrows) {
         const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-        out[r0 + tid] = (base ? base[r0 + tid] : 0.0) + sign * s;
+        const double val = (base ? base[r0 + tid] : 0.0) + sign * s;
+        out[r0 + tid] = val;
+        if (out2 != nullptr) out2[r0 + tid] = val;   // the caller's copy of the solution (saves a device-to-device copy per solve)
     }
 }
 
@@ -611,7 +613,7 @@ int bq_chol_prepare_sweeps(bq_chol_ws *ws, int64_t np) {
     return BQ_OK;
 }
 
-static int chol_solve_fast(bq_chol_ws *ws, int64_t np, int64_t first_nonzero) {
+static int chol_solve_fast(bq_chol_ws *ws, int64_t np, int64_t first_nonzero, double *also) {
     hipStream_t st = ws->ctx->stream;
     const int64_t ldh = ws->ldh, nbb = (np + BB - 1) / BB;
     auto rows_of = [&](int64_t K) { return np - K * BB < BB ? np - K * BB : BB; };
@@ -623,30 +625,31 @@ static int chol_solve_fast(bq_chol_ws *ws, int64_t np, int64_t first_nonzero) {
         const unsigned g = (unsigned)((nr + 3) / 4);
         const double *in = rhs + r0;
         if (K > Kb) {
-            sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->H, ldh, r0, nr, Kb * BB, r0, 0, rhs, rhs + r0, -1.0, t);
+            sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->H, ldh, r0, nr, Kb * BB, r0, 0, rhs, rhs + r0, -1.0, t, nullptr);
             in = t;
         } else {
             BQ_HIP(hipMemcpyAsync(t, rhs + r0, sizeof(double) * nr, hipMemcpyDeviceToDevice, st));
             in = t;
         }
-        sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->bigM + K * BB * BB, BB, 0, nr, 0, nr, 1, in, nullptr, 1.0, rhs + r0);
+        sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->bigM + K * BB * BB, BB, 0, nr, 0, nr, 1, in, nullptr, 1.0, rhs + r0, nullptr);
     }
     // backward: t = y_K - L^T[K, K+1:] x (L^T lives in the upper triangle of H);  x_K = M_K^T t
     for (int64_t K = nbb - 1; K >= 0; --K) {
         const int64_t r0 = K * BB, nr = rows_of(K);
         const unsigned g = (unsigned)((nr + 3) / 4);
         if (K < nbb - 1)
-            sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->H, ldh, r0, nr, r0 + BB, np, 0, rhs, rhs + r0, -1.0, t);
+            sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->H, ldh, r0, nr, r0 + BB, np, 0, rhs, rhs + r0, -1.0, t, nullptr);
         else
             BQ_HIP(hipMemcpyAsync(t, rhs + r0, sizeof(double) * nr, hipMemcpyDeviceToDevice, st));
-        sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->bigMT + K * BB * BB, BB, 0, nr, 0, nr, 2, t, nullptr, 1.0, rhs + r0);
+        sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->bigMT + K * BB * BB, BB, 0, nr, 0, nr, 2, t, nullptr, 1.0, rhs + r0,
+                                             also ? also + r0 : nullptr);
     }
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
 
-int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero) {
-    if (ws->sweep_np == np) return chol_solve_fast(ws, np, first_nonzero);
+int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero, double *also) {
+    if (ws->sweep_np == np) return chol_solve_fast(ws, np, first_nonzero, also);
     hipStream_t st = ws->ctx->stream;
     const int64_t ldh = ws->ldh;
     auto Linv = [&](int64_t k0) { return ws->LinvT + (k0 / NB) * NB * NB; };
@@ -667,6 +670,7 @@ int bq_chol_solve(bq_chol_ws *ws, int64_t np, int64_t first_nonzero) {
     for (int64_t k0 = np - NB; k0 > 0; k0 -= NB)
         bwd_update_kernel<<<(unsigned)(k0 / NB), 256, 0, st>>>(ws->H, ldh, k0, ws->rhs + k0, ws->rhs, Linv(k0 - NB),
                                                                ws->ticket);
+    if (also != nullptr) BQ_HIP(hipMemcpyAsync(also, ws->rhs, sizeof(double) * np, hipMemcpyDeviceToDevice, st));
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
