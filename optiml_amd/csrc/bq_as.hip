@@ -111,7 +111,7 @@ struct as_ws {
     // iteration at n = 20 000, profiles/r04/as_n20k_stream_idle_before.txt); into pinned memory it is a plain DMA
     int *host_ints = nullptr;        // 32 ints: the copy of `ints`
     bq_scal *host_scal = nullptr;    // the copy of the solver's device scalars (moved into s->host after the wait)
-    int *host_info = nullptr;        // 4 ints: factorisation info words
+    int *host_info = nullptr;        // 8 ints: [0] factorisation info, [1] preconditioner info, [2] update failure, [4 .. 5] chg[0 .. 1]
     as_cg_scal *host_cg = nullptr;   // the inner solver's scalars at the end of a solve
     long long minres_calls = 0;
     struct as_schur *sch = nullptr;   // factor re-use (Schur-complement updates of a base factorisation)
@@ -2099,10 +2099,10 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipMemsetAsync(w->ints, 0, sizeof(int) * 32, ctx->stream));
     BQ_HIP(hipHostMalloc(&w->host_ints, sizeof(int) * 32));
     BQ_HIP(hipHostMalloc(&w->host_scal, sizeof(bq_scal)));
-    BQ_HIP(hipHostMalloc(&w->host_info, sizeof(int) * 4));
+    BQ_HIP(hipHostMalloc(&w->host_info, sizeof(int) * 8));
     BQ_HIP(hipHostMalloc(&w->host_cg, sizeof(as_cg_scal)));
     memset(w->host_ints, 0, sizeof(int) * 32);
-    memset(w->host_info, 0, sizeof(int) * 4);
+    memset(w->host_info, 0, sizeof(int) * 8);
     for (double **v : {&w->cand, &w->z, &w->Qz, &w->x_eval, &w->g_eval}) {
         BQ_HIP(hipMalloc(v, sizeof(double) * s->ldN));
         BQ_HIP(hipMemsetAsync(*v, 0, sizeof(double) * s->ldN, ctx->stream));
@@ -2204,12 +2204,16 @@ int bq_as_iterate(bq_solver *s) {
         int *lcnt = reinterpret_cast<int *>(s->partials + s->nblk);
         as_pc_diff_count_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, pc->prev, lcnt, &s->sc->pad1[0], pc->chg, force);
         as_pc_diff_write_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, pc->prev, lcnt, pc->chg);
-        BQ_HIP(hipMemcpyAsync(pc->host_chg, pc->chg, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        BQ_HIP(hipMemcpyAsync(w->host_info + 4, pc->chg, 2 * sizeof(int), hipMemcpyDeviceToHost, st));   // pinned, like the rest
     }
     BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
     BQ_HIP(hipMemcpyAsync(w->host_scal, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
     BQ_SYNC(s->p->ctx);
     s->host = *w->host_scal;
+    if (s->as_cg && w->pc) {
+        w->pc->host_chg[0] = w->host_info[4];
+        w->pc->host_chg[1] = w->host_info[5];
+    }
     if (s->host.done) return BQ_OK;
     const int64_t nA = w->host_ints[0];
 
