@@ -594,6 +594,9 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
     int rc = time_on(p->panel, &best);
     p->place_tried = 1;
     p->place_ms[0] = best;
+    // a panel that came from the context's cache (a destroyed problem of the same size left it: fit loops) was chosen when IT was
+    // allocated, and a fresh allocation right after that release is the slow kind: it is kept as it is
+    if (first_alloc_ms <= 0.0) return rc;
     // what one more candidate costs: an allocation like the first one + clearing it + five products on it
     const double cand_ms = first_alloc_ms + (double)p->panel_bytes / 4.0e9 + 6.0 * best;
     while (rc == BQ_OK && p->place_tried < want && (double)p->panel_bytes / (best * 1e-3) / 1e9 < good_gbs &&

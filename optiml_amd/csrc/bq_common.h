@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -113,7 +114,7 @@ struct bq_ctx {
     // the compute stream; past the limit it aborts the RCCL communicator — the kernel of a collective whose peer never arrives
     // ends, the wait returns, and every later call on this context fails with BQ_ERR_RCCL
     struct bq_watchdog *watchdog = nullptr;
-    bool comm_aborted = false;
+    std::atomic<bool> comm_aborted{false};   // written by the watchdog thread
 };
 // every host wait on the compute stream of a (possibly multi-rank) context: stamps the wait for the watchdog and turns an abort
 // into BQ_ERR_RCCL

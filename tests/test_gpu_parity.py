@@ -137,18 +137,25 @@ def test_panel_placement_selection(amd, monkeypatch):
     plain = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
     ref = plain.device_problem().matvec(v)
     assert plain.device_problem().placement() == []
-    plain.release()
-    monkeypatch.setenv('BQ_PANEL_GOOD_GBS', '1e9')         # nothing is good enough: all three candidates are tried
-    tuned = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)
+    monkeypatch.setenv('BQ_PANEL_GOOD_GBS', '1e9')         # nothing is good enough ...
+    monkeypatch.setenv('BQ_PLACE_BUDGET_MS', '60000')      # ... and there is time: all three candidates are tried
+    tuned = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)   # (`plain` still holds its panel: a fresh allocation)
     ms = tuned.device_problem().placement()
     assert len(ms) == 3 and all(t > 0 for t in ms)
     assert np.array_equal(tuned.device_problem().matvec(v), ref)
-    tuned.release()
-    monkeypatch.setenv('BQ_PANEL_GOOD_GBS', '1')           # anything is good enough: the first allocation is kept
-    tuned = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)
-    assert len(tuned.device_problem().placement()) == 1
-    assert np.array_equal(tuned.device_problem().matvec(v), ref)
-    tuned.release()
+    monkeypatch.setenv('BQ_PLACE_BUDGET_MS', '0')          # no time for anything but the first timing (another fresh allocation)
+    hurried = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)
+    assert len(hurried.device_problem().placement()) == 1
+    assert np.array_equal(hurried.device_problem().matvec(v), ref)
+    hurried.release()                                       # its panel is now the context's cached one
+    monkeypatch.setenv('BQ_PLACE_BUDGET_MS', '60000')
+    # a panel taken from the cache was chosen when it was allocated (and a fresh allocation right after a release is the slow
+    # kind): it is timed and kept, whatever the budget
+    cached = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)
+    assert len(cached.device_problem().placement()) == 1
+    assert np.array_equal(cached.device_problem().matvec(v), ref)
+    for quad in (cached, tuned, plain):
+        quad.release()
     small = KernelQuadratic(X[:2000], -np.ones(2000), 'svc', gaussian, y=y[:2000], tune_placement=True)
     assert small.device_problem().placement() == []
     small.release()
