@@ -542,23 +542,25 @@ def kkt_box(solver, n, d, sigma, cpu=True):
     if cpu:
         from oracle import bcqp_oracle as bo, svm_oracle as so
         fn = bo.interior_point if solver == 'ip' else bo.active_set
-        sizes = (6000, 12000) if solver == 'ip' else (2000, 4000)
-        k = 3 if solver == 'ip' else 12
+        # InteriorPoint: a third, larger sample (one iteration: ~10 s) so that the exponent the extrapolation uses is fitted between
+        # n = 12 000 and 24 000, where a threaded dpotrf is much nearer its n^3 asymptote than between 6 000 and 12 000 (r03: 1.99)
+        sizes = ((6000, 3), (12000, 3), (24000, 1)) if solver == 'ip' else ((2000, 12), (4000, 12))
         samples = []
-        for ns in sorted({min(v, n) for v in sizes}):
+        for ns, k in sorted({(min(v, n), it) for v, it in sizes}):
             Q, q, ub = so.svc_dual(so.gram('rbf', X[:ns]), y[:ns], 1.0)
             t0 = time.perf_counter()
             r = fn(Q, q, ub, max_iter=k)
             samples.append({'n': ns, 's_per_iteration': (time.perf_counter() - t0) / max(r['iter'], 1), 'iterations': int(r['iter'])})
             del Q
         last = samples[-1]
-        expo = float(np.polyfit(np.log([v['n'] for v in samples]), np.log([v['s_per_iteration'] for v in samples]), 1)[0]) \
-            if len(samples) > 1 else 3.0
+        fit = samples[-2:]   # the two largest sizes
+        expo = float(np.polyfit(np.log([v['n'] for v in fit]), np.log([v['s_per_iteration'] for v in fit]), 1)[0]) \
+            if len(fit) > 1 and fit[0]['n'] != fit[1]['n'] else 3.0
         info = _cpu_info()
         rec['cpu_baseline'] = {'value': last['s_per_iteration'] * (n / last['n']) ** expo * o.iter, 'unit': 's',
                                'kind': 'port', 'kind_detail': 'extrapolated from the sizes sampled', 'extrapolated': n > last['n'], 'cores': info['cores'],
                                'cores_source': info['cores_source'], 'fitted_exponent': expo,
-                               'law': 'fitted exponent between the two samples (a threaded dpotrf is not at its n^3 asymptote at these sizes)',
+                               'law': 'exponent fitted between the two LARGEST samples (a threaded dpotrf approaches its n^3 asymptote slowly)',
                                'value_n3_law': last['s_per_iteration'] * (n / last['n']) ** 3 * o.iter,
                                'measured_s_per_iteration_at_sample': last['s_per_iteration'], 'sample_n': last['n'], 'samples': samples,
                                'sample': f'oracle {solver.upper()} (reference algorithm in NumPy/SciPy: cho_factor per iteration, dense Q on host): '
