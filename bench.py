@@ -81,6 +81,10 @@ def parse(argv=None):
                          'bit-identical for any N) or one all-reduce(sum)')
     ap.add_argument('--rccl-init-timeout', type=float, default=240.0,
                     help='seconds a rank waits inside the RCCL communicator bootstrap before the run is given up (exit 3)')
+    ap.add_argument('--collective-timeout', type=float, default=None,
+                    help='N > 1 over RCCL: seconds a host wait on the stream may last before the library aborts the communicator '
+                         '(bq_ctx_set_collective_timeout: a rank whose peer stopped taking part then FAILS instead of sitting in the '
+                         'collective until the caller\'s limit).  Default: 120 + 0.1 per step; 0: no bound')
     ap.add_argument('--allow-host-exchange', action='store_true',
                     help='fall back to the host (gloo) exchange when the RCCL communicator cannot be created (default: exit 3)')
     ap.add_argument('--cpu-sizes', default='20000,30000', help='sample sizes of the CPU baseline leg (SURVEY 8d)')
@@ -997,7 +1001,8 @@ def main():
             watchdog.daemon = True
             watchdog.start()
             try:
-                ctx = device.Context(comm=comm, exchange='rccl', sym_exchange=args.sym_exchange)
+                tmo = args.collective_timeout if args.collective_timeout is not None else 120.0 + 0.1 * (args.steps + args.warmup)
+                ctx = device.Context(comm=comm, exchange='rccl', sym_exchange=args.sym_exchange, collective_timeout=tmo or None)
             except Exception as exc:  # noqa: BLE001
                 err = repr(exc)
             finally:
