@@ -227,6 +227,8 @@ int aborted_error(bq_ctx *ctx) {
 }
 }  // namespace
 
+// (A spin-on-query before blocking was measured in round 4: dense ActiveSet at n = 20 000 to 'optimal' 18.03 s with, 18.01 s without —
+// hipStreamSynchronize does not add a wake-up latency worth removing on this stack.)
 int bq_ctx_sync(bq_ctx *ctx) {
     hipError_t e;
     {
