@@ -151,7 +151,8 @@ int bq_ctx_probe_exchange(bq_ctx *ctx, int kind, int64_t count, int reps, double
  * Context).  RCCL itself never gives up on a collective whose peer does not arrive (a rank-local error, a dead process): with a
  * timeout a watchdog thread aborts the communicator (ncclCommAbort) once the host has waited on the compute stream for longer,
  * the call in progress returns BQ_ERR_RCCL and the context is unusable afterwards.  The callback transport is bounded by the
- * caller's own communicator.  Set it from the thread that owns the context, while no call is in progress. */
+ * caller's own communicator (and on every context without an RCCL communicator the setting is accepted and does nothing).  Set it
+ * from the thread that owns the context, while no call is in progress. */
 int bq_ctx_set_collective_timeout(bq_ctx *ctx, double seconds);
 /* occupy the compute stream for `milliseconds` (one lane spinning on the wall clock; it ends by itself) and wait for it through
  * the library's bounded wait: the end-to-end test of the watchdog on one GPU (BQ_ERR_RCCL when it fired) */

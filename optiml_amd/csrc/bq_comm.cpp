@@ -274,7 +274,9 @@ extern "C" int bq_ctx_set_collective_timeout(bq_ctx *ctx, double seconds) {
     BQ_ARG(ctx != nullptr, "ctx is NULL");
     BQ_ARG(seconds >= 0.0 && seconds <= 86400.0, "timeout in [0, 86400] seconds (0: none)");
     bq_watchdog_stop(ctx);
-    if (seconds == 0.0) return BQ_OK;
+    // only an RCCL communicator can leave the host waiting for a peer for ever; on any other context the setting is accepted and
+    // does nothing (a global BQ_COLLECTIVE_TIMEOUT_S must not cut short the long, legitimate waits of a single-GPU factorisation)
+    if (seconds == 0.0 || ctx->comm_kind != BQ_COMM_RCCL) return BQ_OK;
     bq_watchdog *wd = new bq_watchdog();
     wd->timeout_s = seconds;
     ctx->watchdog = wd;

@@ -275,3 +275,17 @@ def test_lagrangian_surface_and_validation_mirror_reference():
     np.testing.assert_array_equal(sched._step_schedule, [1., .5, .25])          # one value per iteration, drawn up front
     np.testing.assert_allclose(sched._momentum_schedule, [0.75, 1 - 2 ** (-1 - np.log2(3)), 0.875])
     assert st.AdaGrad(f=al, step_size=lambda: st.schedules.decaying(2., .5)).step_size == 2.   # callable: first value
+
+
+@pytest.mark.gpu
+def test_collective_timeout_is_inert_without_an_rccl_communicator():
+    """bq_ctx_set_collective_timeout on a plain (single-GPU) context is accepted and does nothing: a global
+    BQ_COLLECTIVE_TIMEOUT_S must not cut short the long, legitimate waits of a single-GPU run.  (The watchdog itself: one-rank
+    RCCL context, tests/test_distributed.py.)"""
+    from optiml_amd import device
+    ctx = device.Context(collective_timeout=0.1)
+    ctx.probe_stall(500.0)          # five times the "limit": returns normally
+    assert ctx.comm_info()['kind'] == 'none'
+    r, c = ctx.probe_bandwidth(1 << 26, 2)
+    assert r > 0 and c > 0
+    ctx.close()
