@@ -220,8 +220,8 @@ __global__ __launch_bounds__(NW * 64, 2) void symv_tiles_kernel(const T *__restr
 // parallelism); the four partial sums are combined in the fixed order q = 0..3.  Every thread returns the combined value.
 // p2 (null: uncut strips): the second slab of row-cut strips; a column part is then (E0 + E1) + E2 (symv_tiles_kernel, NW = 2)
 template <int JG>
-__device__ __forceinline__ double seg_partial(const double *__restrict__ p, const double *__restrict__ p2, int64_t a, int64_t c0,
-                                              int64_t c1, int q, int r, double (*part)[ST]) {
+__device__ __forceinline__ double seg_thread_sum(const double *__restrict__ p, const double *__restrict__ p2, int64_t a, int64_t c0,
+                                                 int64_t c1, int q) {
     auto col = [&](int64_t b) -> double {
         const double e0 = p[b * ST];
         if (p2 == nullptr) return e0;
@@ -245,7 +245,14 @@ __device__ __forceinline__ double seg_partial(const double *__restrict__ p, cons
         s0 += col(bs + k);
         if (k + 4 < ncol) s1 += col(bs + k + 4);
     }
-    part[q][r] = s0 + s1;
+    return s0 + s1;   // this thread's share (every 4th entry, q = its phase) of the segment's entry list
+}
+
+// the four phases of a segment's sum combined in the fixed order q = 0..3; every thread returns the combined value
+template <int JG>
+__device__ __forceinline__ double seg_partial(const double *__restrict__ p, const double *__restrict__ p2, int64_t a, int64_t c0,
+                                              int64_t c1, int q, int r, double (*part)[ST]) {
+    part[q][r] = seg_thread_sum<JG>(p, p2, a, c0, c1, q);
     __syncthreads();
     const double v = ((part[0][r] + part[1][r]) + part[2][r]) + part[3][r];
     __syncthreads();
@@ -260,13 +267,23 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
                                                            int64_t nb, bq_seg_table tab, double *__restrict__ out,
                                                            const int *__restrict__ done, bq_epilogue epi) {
     if (done != nullptr && *done) return;
-    __shared__ double part[4][ST];
+    // the phase sums of up to eight segments (all of them on one rank) meet in LDS in ONE round of barriers — one round per segment
+    // made sixteen barriers of 1 024 threads, a third of this kernel's length; the association per segment and the segment order
+    // of the final sum are what they were
+    __shared__ double part[BQ_SYM_SEG][4][ST];
     const int64_t a = blockIdx.x;
     const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
     const double *p = slab + a * nb * ST + r;
     const double *p2 = slab2 ? slab2 + a * nb * 2 * ST + r : nullptr;
     double acc = 0.0;
-    for (int s = tab.lo; s < tab.hi; ++s) acc += seg_partial<JG>(p, p2, a, tab.cut[s], tab.cut[s + 1], q, r, part);
+    for (int s0 = tab.lo; s0 < tab.hi; s0 += BQ_SYM_SEG) {
+        const int ns = tab.hi - s0 < BQ_SYM_SEG ? tab.hi - s0 : BQ_SYM_SEG;
+        for (int k = 0; k < ns; ++k) part[k][q][r] = seg_thread_sum<JG>(p, p2, a, tab.cut[s0 + k], tab.cut[s0 + k + 1], q);
+        __syncthreads();
+        if (q == 0)
+            for (int k = 0; k < ns; ++k) acc += ((part[k][0][r] + part[k][1][r]) + part[k][2][r]) + part[k][3][r];
+        __syncthreads();
+    }
     if (q == 0) out[a * ST + r] = acc;
     if constexpr (EPI) {
         const double c = q == 0 ? bq_epi_element(epi, a * ST + r, acc) : 0.0;

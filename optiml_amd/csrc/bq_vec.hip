@@ -45,6 +45,44 @@ __device__ __forceinline__ double block_min(double v, double *sh) {
     __syncthreads();
     return r;
 }
+// three sums and a minimum of a 256-thread block in ONE round of barriers (each quantity through exactly the tree of block_sum /
+// block_min: the same bits; four separate calls cost eight barriers in a kernel whose length is its chain of dependent steps)
+struct red4 {
+    double a, b, c, m;
+};
+__device__ __forceinline__ red4 block_reduce4(double a, double b, double c, double m, double (*sh4)[4]) {
+    a = wsum(a);
+    b = wsum(b);
+    c = wsum(c);
+    m = wmin(m);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sh4[0][w] = a;
+        sh4[1][w] = b;
+        sh4[2][w] = c;
+        sh4[3][w] = m;
+    }
+    __syncthreads();
+    red4 r;
+    r.a = ((sh4[0][0] + sh4[0][1]) + sh4[0][2]) + sh4[0][3];
+    r.b = ((sh4[1][0] + sh4[1][1]) + sh4[1][2]) + sh4[1][3];
+    r.c = ((sh4[2][0] + sh4[2][1]) + sh4[2][2]) + sh4[2][3];
+    r.m = fmin(fmin(sh4[3][0], sh4[3][1]), fmin(sh4[3][2], sh4[3][3]));
+    __syncthreads();
+    return r;
+}
+// ... and the same over the per-block partial sums of a launch (the strided accumulation of final_sum / final_min, then the tree)
+__device__ __forceinline__ red4 final_reduce4(const double *pa, const double *pb, const double *pc, const double *pm, int64_t nblk,
+                                              double (*sh4)[4]) {
+    double a = 0.0, b = 0.0, c = 0.0, m = INFINITY;
+    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) {
+        a += pa[i];
+        b += pb[i];
+        c += pc[i];
+        if (pm != nullptr) m = fmin(m, pm[i]);
+    }
+    return block_reduce4(a, b, c, m, sh4);
+}
 __device__ __forceinline__ double final_sum(const double *part, int64_t nblk, double *sh) {
     double a = 0.0;
     for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) a += part[i];
@@ -229,7 +267,7 @@ __device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, 
 __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
                                       const double *__restrict__ sgn, double *__restrict__ w_out, bq_iter_stat *stats) {
     if (sc->done) return;
-    __shared__ double sh[4];
+    __shared__ double sh4[4][4];
     const double t = do_update ? sc->t : 0.0;
     double sd2 = 0.0, sgd = 0.0, sxg = 0.0, rmin = INFINITY;
     VEC_LOOP(i) {
@@ -254,15 +292,12 @@ __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
             if (di < 0.0) rmin = fmin(rmin, (lbi - xi) / di);
         }
     }
-    sd2 = block_sum(sd2, sh);
-    sgd = block_sum(sgd, sh);
-    sxg = block_sum(sxg, sh);
-    rmin = block_min(rmin, sh);
+    const red4 br = block_reduce4(sd2, sgd, sxg, rmin, sh4);
     if (threadIdx.x == 0) {
-        part[0 * nblk + blockIdx.x] = sd2;
-        part[1 * nblk + blockIdx.x] = sgd;
-        part[2 * nblk + blockIdx.x] = sxg;
-        part[3 * nblk + blockIdx.x] = rmin;
+        part[0 * nblk + blockIdx.x] = br.a;
+        part[1 * nblk + blockIdx.x] = br.b;
+        part[2 * nblk + blockIdx.x] = br.c;
+        part[3 * nblk + blockIdx.x] = br.m;
     }
     if (last_block(&sc->ticket[0])) {
         pg_decide_body(sc, part, nblk, stats);
@@ -271,11 +306,9 @@ __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
 }
 
 __device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh[4];
-    const double sd2 = final_sum(part + 0 * nblk, nblk, sh);
-    const double sgd = final_sum(part + 1 * nblk, nblk, sh);
-    const double sxg = final_sum(part + 2 * nblk, nblk, sh);
-    const double rmin = final_min(part + 3 * nblk, nblk, sh);
+    __shared__ double sh4[4][4];
+    const red4 fr = final_reduce4(part + 0 * nblk, part + 1 * nblk, part + 2 * nblk, part + 3 * nblk, nblk, sh4);
+    const double sd2 = fr.a, sgd = fr.b, sxg = fr.c, rmin = fr.m;
     if (threadIdx.x == 0) {
         const double f = 0.5 * sxg, ng = sqrt(sd2);
         sc->f = f;
@@ -316,7 +349,7 @@ __global__ __launch_bounds__(256) void finish_den_kernel(const double *__restric
 __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
                                       const double *__restrict__ sgn, double *__restrict__ w_out, bq_iter_stat *stats) {
     if (sc->done) return;
-    __shared__ double sh[4];
+    __shared__ double sh4[4][4];
     const double a = do_update ? sc->t : 0.0;
     const double tr = sc->fw_t;
     double sgy = 0.0, sgd = 0.0, sxg = 0.0;
@@ -343,13 +376,11 @@ __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
             sxg += xi * (gi + V.q[i]);
         }
     }
-    sgy = block_sum(sgy, sh);
-    sgd = block_sum(sgd, sh);
-    sxg = block_sum(sxg, sh);
+    const red4 br = block_reduce4(sgy, sgd, sxg, INFINITY, sh4);
     if (threadIdx.x == 0) {
-        part[0 * nblk + blockIdx.x] = sgy;
-        part[1 * nblk + blockIdx.x] = sgd;
-        part[2 * nblk + blockIdx.x] = sxg;
+        part[0 * nblk + blockIdx.x] = br.a;
+        part[1 * nblk + blockIdx.x] = br.b;
+        part[2 * nblk + blockIdx.x] = br.c;
     }
     if (last_block(&sc->ticket[0])) {
         fw_decide_body(sc, part, nblk, stats);
@@ -358,10 +389,9 @@ __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
 }
 
 __device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh[4];
-    const double sgy = final_sum(part + 0 * nblk, nblk, sh);
-    const double sgd = final_sum(part + 1 * nblk, nblk, sh);
-    const double sxg = final_sum(part + 2 * nblk, nblk, sh);
+    __shared__ double sh4[4][4];
+    const red4 fr = final_reduce4(part + 0 * nblk, part + 1 * nblk, part + 2 * nblk, nullptr, nblk, sh4);
+    const double sgy = fr.a, sgd = fr.b, sxg = fr.c;
     if (threadIdx.x == 0) {
         const double f = 0.5 * sxg;
         const double low = f + sgy;
