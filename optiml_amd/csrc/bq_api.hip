@@ -162,7 +162,10 @@ extern "C" int bq_ctx_profile(bq_ctx *c, int enable) {
     return BQ_OK;
 }
 
-int bq_prof_begin(bq_ctx *c, int which, hipEvent_t *e0, hipEvent_t *e1) {
+// bracket == true: the pair brackets a region of the stream (e0 is recorded here, e1 by bq_prof_end).  bracket == false: the pair is
+// handed to ONE kernel launch (hipExtLaunchKernelGGL(..., e0, e1, ...)), whose own dispatch carries the two timestamps — the
+// kernel's duration as the tracer sees it, and no event packets on the stream; bq_prof_end is then called with recorded == true.
+int bq_prof_begin(bq_ctx *c, int which, hipEvent_t *e0, hipEvent_t *e1, bool bracket) {
     *e0 = *e1 = nullptr;
     if (!c->profiling) return BQ_OK;
     hipError_t err = hipSuccess;
@@ -175,7 +178,7 @@ int bq_prof_begin(bq_ctx *c, int which, hipEvent_t *e0, hipEvent_t *e1) {
             break;
         }
     }
-    if (err == hipSuccess) err = hipEventRecord(*e0, c->stream);
+    if (err == hipSuccess && bracket) err = hipEventRecord(*e0, c->stream);
     if (err != hipSuccess) {   // nothing leaks on the error path: what was taken goes back to the pool
         for (hipEvent_t *e : {e0, e1}) {
             if (*e) c->event_pool.push_back(*e);
@@ -186,6 +189,12 @@ int bq_prof_begin(bq_ctx *c, int which, hipEvent_t *e0, hipEvent_t *e1) {
     }
     (void)which;
     return BQ_OK;
+}
+
+void bq_prof_drop(bq_ctx *c, hipEvent_t e0, hipEvent_t e1) {
+    if (e0) c->event_pool.push_back(e0);
+    if (e1) c->event_pool.push_back(e1);
+    c->prof_cur_idx = -1;
 }
 
 void bq_prof_skip_arg(bq_ctx *c, hipEvent_t e0, int **slot, int *seq) {
@@ -209,9 +218,9 @@ void bq_prof_skip_arg(bq_ctx *c, hipEvent_t e0, int **slot, int *seq) {
     *seq = c->prof_cur_seq;
 }
 
-int bq_prof_end(bq_ctx *c, int which, hipEvent_t e0, hipEvent_t e1) {
+int bq_prof_end(bq_ctx *c, int which, hipEvent_t e0, hipEvent_t e1, bool recorded) {
     if (e0 == nullptr) return BQ_OK;
-    BQ_HIP(hipEventRecord(e1, c->stream));
+    if (!recorded) BQ_HIP(hipEventRecord(e1, c->stream));
     bq_prof_pending pe;
     pe.first = e0;
     pe.second = e1;
@@ -1309,9 +1318,11 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
         BQ_TRY(solver_first(s));
         s->initialised = true;
     }
-    // How often the host looks at the device `done` flag (a D2H copy + stream sync, ~30 us): kernels early-exit on the
-    // flag, so a late look only costs a few no-op launches.  The factorising solvers are host-enqueued O(n^3) work per
-    // iteration and look every time; PG/FW look about every 2 ms of estimated panel streaming time.
+    // How often the host looks at the device `done` flag: kernels early-exit on the flag, so a late look only costs a few
+    // no-op launches (~20 us per skipped iteration).  The factorising solvers are host-enqueued O(n^3) work per iteration
+    // and look every time; PG/FW look about every 20 ms of estimated panel streaming time.  A look is a 4-byte copy to the
+    // host plus an event on the stream — not free between two short kernels: at 2 ms (round 3) BASELINE config 2 ran 0.3035 ms
+    // per iteration, at 20 ms 0.286 ms (profiles/r04/share_gaps_events.txt).
     int64_t poll = 1;
     if (s->kind == BQ_PG || s->kind == BQ_FW || s->kind == BQ_AL) {
         // The interval must be the SAME on every rank (each iteration contains a collective: ranks that stopped enqueueing at
@@ -1320,7 +1331,7 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
         const double esz = s->p->storage == BQ_F64 ? 8.0 : 4.0;
         const double rows = (double)s->p->n / (double)c->world;
         const double iter_s = rows * (double)s->p->n * esz * (s->p->symmetric ? 0.5 : 1.0) / 5.0e12 + 30e-6;
-        poll = (int64_t)(2.0e-3 / iter_s);
+        poll = (int64_t)(20.0e-3 / iter_s);
         poll = poll < 1 ? 1 : (poll > 64 ? 64 : poll);
     }
     // The product-bound solvers look at the flag with a LAG of one chunk: the copy of the flag is followed by an event,

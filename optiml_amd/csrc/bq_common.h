@@ -222,8 +222,9 @@ struct bq_solver {
 // cross-file launchers (each defined next to its kernels)
 // ---------------------------------------------------------------------------------------------
 // bq_ctx.cpp / bq_api.hip
-int bq_prof_begin(bq_ctx *ctx, int which, hipEvent_t *e0, hipEvent_t *e1);
-int bq_prof_end(bq_ctx *ctx, int which, hipEvent_t e0, hipEvent_t e1);
+int bq_prof_begin(bq_ctx *ctx, int which, hipEvent_t *e0, hipEvent_t *e1, bool bracket = true);
+int bq_prof_end(bq_ctx *ctx, int which, hipEvent_t e0, hipEvent_t e1, bool recorded = false);
+void bq_prof_drop(bq_ctx *ctx, hipEvent_t e0, hipEvent_t e1);   // a pair that was taken and never used goes back to the pool
 // between bq_prof_begin and the launch of a kernel that may return on a `done` flag: where that kernel reports "skipped"
 // (*slot null when not profiling); the kernel does `if (*done) { if (slot && first thread) *slot = seq; return; }`
 void bq_prof_skip_arg(bq_ctx *ctx, hipEvent_t e0, int **slot, int *seq);

@@ -19,6 +19,8 @@
 // its own segments and the rank partials meet in one ncclAllReduce — the sum's association then depends on the ring.)
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "bq_common.h"
 #include "bq_epilogue.h"
 
@@ -318,31 +320,59 @@ __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restri
     if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, acc), gridDim.x);
 }
 
+// The timed launch: when the context is profiling, the kernel's own dispatch carries the two timestamps (hipExtLaunchKernelGGL with a
+// start and a stop event) instead of two events recorded around it on the stream: the duration is the kernel's own, as rocprofv3's
+// kernel trace reports it, and the stream carries nothing a solve without profiling would not (measured: 1-2 us per product less than
+// the bracketing, profiles/r04/share_gaps_events.txt; BQ_PROF_BRACKET=1 brings the bracketing back, to compare).
+template <typename K, typename... A>
+static hipError_t launch_timed(bq_ctx *ctx, bool ext, hipEvent_t e0, hipEvent_t e1, K kernel, dim3 grid, dim3 block, A... args) {
+    if (ext)
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, e0, e1, 0, args...);
+    else
+        kernel<<<grid, block, 0, ctx->stream>>>(args...);
+    return hipGetLastError();
+}
+
 template <int JG, int SR, int NW>
 static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
                         const double *w, double *slab, double *slab2, const int *done) {
+    static const bool bracket = [] {
+        const char *e = getenv("BQ_PROF_BRACKET");
+        return e && atoi(e) != 0;
+    }();
     const int64_t nstrips = strips_before<JG>(I1) - strips_before<JG>(I0);
     const int64_t ld = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
+    BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1, bracket));
+    if (nstrips <= 0) {
+        if (!bracket) {
+            bq_prof_drop(ctx, e0, e1);
+            return BQ_OK;
+        }
+        return bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1);
+    }
     int *skip = nullptr, skip_seq = 0;
     if (done != nullptr) bq_prof_skip_arg(ctx, e0, &skip, &skip_seq);
-    if (nstrips > 0) {
-        const dim3 grid((unsigned)(NW == 4 ? nstrips : 2 * nstrips)), block(NW * 64);
-        if (storage == BQ_F64) {
-            if (add_one)
-                symv_tiles_kernel<double, true, JG, SR, NW><<<grid, block, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
-            else
-                symv_tiles_kernel<double, false, JG, SR, NW><<<grid, block, 0, ctx->stream>>>((const double *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
-        } else {
-            if (add_one)
-                symv_tiles_kernel<float, true, JG, SR, NW><<<grid, block, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
-            else
-                symv_tiles_kernel<float, false, JG, SR, NW><<<grid, block, 0, ctx->stream>>>((const float *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
-        }
+    const bool ext = !bracket && e0 != nullptr;
+    const dim3 grid((unsigned)(NW == 4 ? nstrips : 2 * nstrips)), block(NW * 64);
+    hipError_t err;
+    if (storage == BQ_F64) {
+        if (add_one)
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<double, true, JG, SR, NW>, grid, block, (const double *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
+        else
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<double, false, JG, SR, NW>, grid, block, (const double *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
+    } else {
+        if (add_one)
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<float, true, JG, SR, NW>, grid, block, (const float *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
+        else
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<float, false, JG, SR, NW>, grid, block, (const float *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
     }
-    BQ_TRY(bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1));
-    return BQ_OK;
+    if (err != hipSuccess) {
+        bq_prof_drop(ctx, e0, e1);
+        bq_set_error("symv_tiles launch: %s", hipGetErrorString(err));
+        return BQ_ERR_HIP;
+    }
+    return bq_prof_end(ctx, BQ_PROF_MATVEC, e0, e1, ext);
 }
 
 // mode 0: tiles + the sum over this launch's segments -> out (nb*256);  mode 1: tiles + one vector per segment -> gath slots
