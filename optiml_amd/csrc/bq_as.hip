@@ -35,6 +35,7 @@
 #include <cmath>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 
@@ -113,6 +114,22 @@ struct as_ws {
     bq_scal *host_scal = nullptr;    // the copy of the solver's device scalars (moved into s->host after the wait)
     int *host_info = nullptr;        // 8 ints: [0] factorisation info, [1] preconditioner info, [2] update failure, [4 .. 5] chg[0 .. 1]
     as_cg_scal *host_cg = nullptr;   // the inner solver's scalars at the end of a solve
+    // The dense iteration's three looks at the device without a copy command or a stream drain (second half of round 4): host_ints /
+    // host_scal (and the kept-factor path's small_pin) are MAPPED, coherent pinned memory; the kernel that completes a record stores
+    // it there itself and then posts a sequence number into `mail` — [0] top of the iteration (as_top_kernel), [1] the dot
+    // products of a new slot (as_schur_dots_kernel), [2] the candidate's feasibility (as_cand_scatter_kernel) — on which the host
+    // spins (bq_ctx_wait_flag).  BQ_AS_MAILBOX=0: copies + hipStreamSynchronize as before.
+    int *mail = nullptr;
+    int mail_seq[3] = {0, 0, 0};
+    unsigned int *mail_ticket = nullptr;   // device: last-workgroup tickets of the two multi-block posters
+    bool mailbox = true;
+    // BQ_AS_TIMING=1: where the host's time goes per kept-factor iteration (printed by bq_as_free): [0] wait for the top record,
+    // [1] host work up to the launch of the dot products, [2] wait for them, [3] the small system on the host, [4] launches up
+    // to the candidate, [5] wait for its record, [6] launches of the branch, [7] iterations counted
+    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool timing = false;
+    double tm_last = 0.0, tm_classic = 0.0, classic_order = 0.0;   // iterations that factorise Q[A,A] afresh: host time from their
+    long long n_classic = 0;                                       // launch to the end of bq_as_iterate, and the mean order
     long long minres_calls = 0;
     struct as_schur *sch = nullptr;   // factor re-use (Schur-complement updates of a base factorisation)
     int last_branch = -1;             // what the previous iteration did: 1 release, 0 ratio step + absorb, -1 nothing yet
@@ -148,24 +165,43 @@ __device__ __forceinline__ double as_wmin(double v) {
     return v;
 }
 
-__global__ void as_top_kernel(bq_scal *sc, int *__restrict__ ints, bq_iter_stat *stats, int n_all) {
-    ints[27] = n_all;   // as_release_mb_kernel: running minima of the candidate indices
-    ints[28] = n_all;
-    if (sc->done) return;
-    const long long row = sc->iter - sc->stat_base;
-    if (row >= 0 && row < sc->stat_cap) {
-        bq_iter_stat st;
-        st.iter = sc->iter;
-        st.f = sc->f;
-        st.r1 = (double)ints[1];
-        st.r2 = -1.0;
-        st.r3 = 0.0;
-        stats[row] = st;
+// a record for the host: system-scope release store of its sequence number, after the data (as_ws::mail)
+__device__ __forceinline__ void as_post(int *flag, int seq) {
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// one wave; lane 0 opens the iteration's record, then (mailbox) the wave hands `ints` and the solver's scalars to the host
+__global__ __launch_bounds__(64) void as_top_kernel(bq_scal *sc, int *__restrict__ ints, bq_iter_stat *stats, int n_all,
+                                                    int *__restrict__ mail_ints, int *__restrict__ mail_scal, int *mail, int seq) {
+    if (threadIdx.x == 0) {
+        ints[27] = n_all;   // as_release_mb_kernel: running minima of the candidate indices
+        ints[28] = n_all;
+        if (!sc->done) {
+            const long long row = sc->iter - sc->stat_base;
+            if (row >= 0 && row < sc->stat_cap) {
+                bq_iter_stat st;
+                st.iter = sc->iter;
+                st.f = sc->f;
+                st.r1 = (double)ints[1];
+                st.r2 = -1.0;
+                st.r3 = 0.0;
+                stats[row] = st;
+            }
+            if (sc->iter >= sc->max_iter) {
+                sc->status = BQ_STATUS_STOPPED;
+                sc->done = 1;
+            }
+        }
+        __threadfence();
     }
-    if (sc->iter >= sc->max_iter) {
-        sc->status = BQ_STATUS_STOPPED;
-        sc->done = 1;
-    }
+    if (mail == nullptr) return;
+    __syncthreads();
+    const int l = threadIdx.x;
+    if (l < 32) mail_ints[l] = __hip_atomic_load(ints + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = l; j < (int)(sizeof(bq_scal) / sizeof(int)); j += 64)
+        mail_scal[j] = __hip_atomic_load(reinterpret_cast<int *>(sc) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    if (l == 0) as_post(mail, seq);
 }
 
 __global__ void as_make_z_kernel(int64_t N, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
@@ -445,7 +481,8 @@ __global__ void as_cand_scatter_kernel(int64_t n0, int m, const int *__restrict_
                                        const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
                                        const double *__restrict__ lb, const double *__restrict__ ub,
                                        const double *__restrict__ y, const double *__restrict__ coef,
-                                       double *__restrict__ cand, int *__restrict__ ints) {
+                                       double *__restrict__ cand, int *__restrict__ ints, unsigned int *ticket,
+                                       int *__restrict__ mail_ints, int *mail, int seq) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;
     if (a < n0) {
@@ -463,6 +500,21 @@ __global__ void as_cand_scatter_kernel(int64_t n0, int m, const int *__restrict_
         bad = bad || !(v <= ub[i] + ACT_TOL && v >= lb[i] - ACT_TOL);
     }
     if (bad) ints[2] = 0;   // benign race: every writer stores 0
+    if (mail == nullptr) return;
+    // the last workgroup to get here hands the record (feasibility flag and all) to the host
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < 32) mail_ints[threadIdx.x] = __hip_atomic_load(ints + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        *ticket = 0;
+        as_post(mail, seq);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1274,9 +1326,12 @@ struct as_schur {
     int *meta = nullptr;              // device: kind[], var[] of the slots (2 x AS_SCHUR_MAX)
     // pinned staging of the per-iteration transfers (slot table up, dot products down, coefficients up): asynchronous copies
     // from / to pageable stack arrays needed a stream synchronisation each just to keep the array alive
+    // (mailbox, as_ws::mail: the three are mapped, coherent pinned memory and the kernels use them in place — the slot table and
+    // the coefficients are READ by the kernels straight from the host's buffer, the dot products are WRITTEN there: no copy commands)
     int *meta_pin = nullptr;
     double *small_pin = nullptr, *coef_pin = nullptr;
     long long refreshes = 0, reused = 0;
+    long long rows_extended = 0, rows_solved = 0, drops = 0;   // BQ_AS_TIMING: rows the small factorisation (re)built / orders solved / slots dropped
     bool y0_valid = false;   // y0 = Q00^-1 b0 is current: b0 only moves when a variable OUTSIDE the base changes sides
 };
 
@@ -1335,7 +1390,8 @@ __global__ __launch_bounds__(256) void as_schur_dots_kernel(int mode, int k, con
                                                             const unsigned char *__restrict__ mU,
                                                             const double *__restrict__ lb, const double *__restrict__ ub,
                                                             const double *__restrict__ q, const double *__restrict__ Qz,
-                                                            double *__restrict__ out, double *__restrict__ out1) {
+                                                            double *__restrict__ out, double *__restrict__ out1,
+                                                            unsigned int *ticket, int *mail, int seq) {
     __shared__ double sh[4], sh1[4];
     const int i = blockIdx.x;
     const double *u = U + (int64_t)i * cap;
@@ -1369,6 +1425,14 @@ __global__ __launch_bounds__(256) void as_schur_dots_kernel(int mode, int k, con
             const double d1 = mode == 1 ? dot : ((sh1[0] + sh1[1]) + sh1[2]) + sh1[3];
             const double extra = ki == 0 ? (mU[vi] ? ub[vi] : lb[vi]) : -(q[vi] + Qz[vi]);
             (mode == 1 ? out : out1)[i] = extra - d1;
+        }
+        if (mail != nullptr) {   // out / out1 are the host's (mapped) buffers: the last workgroup posts the record
+            __threadfence_system();
+            if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+                *ticket = 0;
+                __threadfence_system();
+                as_post(mail, seq);
+            }
         }
     }
 }
@@ -1432,6 +1496,8 @@ BQ_HOST_SIMD static void as_axpy_neg(double *__restrict__ y, const double *__res
 static bool as_ldl_extend(as_schur *c, int m) {
     const size_t ld = AS_SCHUR_MAX;
     std::vector<double> z;
+    c->rows_extended += m - c->ldl_n;
+    c->rows_solved += m;
     for (int k = c->ldl_n; k < m; ++k) {
         double *lk = &c->Lc[(size_t)k * ld];
         // L z = C[0:k, k]  (forward), l = z / D, d = C[k][k] - sum l z
@@ -1451,12 +1517,18 @@ static bool as_ldl_extend(as_schur *c, int m) {
     return true;
 }
 
+static double g_c_us = 0.0;
+static double g_ldl_us[4] = {0, 0, 0, 0};   // BQ_AS_TIMING: extend | forward | back | residual
+static inline double ldl_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool as_ldl_solve(as_schur *c, int m, const double *t, double *w) {
+    const double t0 = ldl_now();
     if (!as_ldl_extend(c, m)) return false;
+    const double t1 = ldl_now();
     const size_t ld = AS_SCHUR_MAX;
     std::vector<double> y(t, t + m);
     for (int i = 0; i < m; ++i) y[i] -= as_dot4(&c->Lc[(size_t)i * ld], y.data(), i);   // L y = t, rows of L contiguous
     for (int i = 0; i < m; ++i) y[i] /= c->Dc[i];
+    const double t2 = ldl_now();
     // L' w = y by columns of L' = rows of L: once w[i] is final it is eliminated from the unknowns above it (contiguous row i;
     // the dot-product form walked a COLUMN of the 1536-pitch factor per unknown: one cache line per element)
     for (int i = m - 1; i >= 0; --i) {
@@ -1464,6 +1536,11 @@ static bool as_ldl_solve(as_schur *c, int m, const double *t, double *w) {
         w[i] = wi;
         as_axpy_neg(y.data(), &c->Lc[(size_t)i * ld], wi, i);
     }
+    const double t3 = ldl_now();
+    g_ldl_us[0] += t1 - t0;
+    g_ldl_us[1] += t2 - t1;
+    g_ldl_us[2] += t3 - t2;
+    struct tail { double t; ~tail() { g_ldl_us[3] += ldl_now() - t; } } tl{t3};
     // residual against the stored C
     double worst = 0.0, scale = 0.0;
     for (int i = 0; i < m; ++i) {
@@ -1536,9 +1613,13 @@ static int eval_f(bq_solver *s, double *g_out) {
 }
 
 // ---- factor re-use: host side --------------------------------------------------------------------------------
+// Smallest free set that goes through the kept factor.  Through round 4's first half this was 1024: below it every iteration
+// factorised Q[A,A] afresh — a small factorisation, but with it the bound product Q z (a whole panel product) and a blocking look
+// per iteration: 3 921 of the 22 897 iterations of BASELINE config 2's shape, 0.67 ms each.  Measured to 'optimal' at n = 20 000
+// (profiles/r04/as_schur_min_sweep.txt): 1024 17.5 s, 256 16.5 s, 64 16.3 s, 16 16.1 s, 0 16.1 s — any non-empty free set now.
 static int as_schur_min() {   // read per iteration: tests switch it between solves
     const char *e = getenv("BQ_AS_SCHUR_MIN");
-    return e ? atoi(e) : 1024;
+    return e ? atoi(e) : 1;
 }
 static bool as_schur_enabled() {
     const char *e = getenv("BQ_AS_SCHUR");
@@ -1559,6 +1640,26 @@ static void as_schur_free(as_ws *w) {
     w->sch = nullptr;
 }
 
+// mapped, coherent pinned memory: the device stores into / loads from it in place (as_ws::mail)
+constexpr unsigned int AS_MAPPED = hipHostMallocMapped | hipHostMallocCoherent;
+template <typename P>
+static P *as_dev(P *host) {
+    void *d = nullptr;
+    return (host != nullptr && hipHostGetDevicePointer(&d, host, 0) == hipSuccess) ? static_cast<P *>(d) : host;
+}
+// one look of the host at the device: the record `which` (as_ws::mail) has been posted / the stream has drained behind the copies
+static int as_look(bq_ctx *ctx, as_ws *w, int which) {
+    if (!w->mailbox) return bq_ctx_sync(ctx);
+    return bq_ctx_wait_flag(ctx, w->mail + which, w->mail_seq[which]);
+}
+
+static inline void as_tick(as_ws *w, int slot) {   // BQ_AS_TIMING: the time since the previous tick goes to `slot`
+    if (!w->timing) return;
+    const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (slot >= 0) w->tm[slot] += now - w->tm_last;
+    w->tm_last = now;
+}
+
 static int as_schur_setup(bq_solver *s, as_ws *w) {
     if (w->sch) return BQ_OK;
     as_schur *c = new as_schur();
@@ -1572,9 +1673,9 @@ static int as_schur_setup(bq_solver *s, as_ws *w) {
     BQ_HIP(hipMalloc(&c->y, sizeof(double) * c->cap));
     BQ_HIP(hipMalloc(&c->small, sizeof(double) * 3 * AS_SCHUR_MAX));   // dots of a new column | coefficients | dots with y0
     BQ_HIP(hipMalloc(&c->meta, sizeof(int) * 2 * AS_SCHUR_MAX));
-    BQ_HIP(hipHostMalloc(&c->meta_pin, sizeof(int) * 2 * AS_SCHUR_MAX));
-    BQ_HIP(hipHostMalloc(&c->small_pin, sizeof(double) * 2 * AS_SCHUR_MAX));
-    BQ_HIP(hipHostMalloc(&c->coef_pin, sizeof(double) * AS_SCHUR_MAX));
+    BQ_HIP(hipHostMalloc(&c->meta_pin, sizeof(int) * 2 * AS_SCHUR_MAX, AS_MAPPED));
+    BQ_HIP(hipHostMalloc(&c->small_pin, sizeof(double) * 2 * AS_SCHUR_MAX, AS_MAPPED));
+    BQ_HIP(hipHostMalloc(&c->coef_pin, sizeof(double) * AS_SCHUR_MAX, AS_MAPPED));
     memset(c->meta_pin, 0, sizeof(int) * 2 * AS_SCHUR_MAX);
     c->hpos0.assign((size_t)s->N, -1);
     c->C.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
@@ -1643,7 +1744,8 @@ static int as_schur_drop(bq_solver *s, as_schur *c, int j) {
     }
     c->kind.pop_back();
     c->var.pop_back();
-    c->ldl_n = 0;   // a removed row / column: the small factorisation starts again
+    c->drops += 1;
+    c->ldl_n = std::min(c->ldl_n, j);   // rows < j of the small factorisation only know C[0:j, 0:j], which the swap left alone
     return BQ_OK;
 }
 
@@ -1720,7 +1822,13 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         hmeta[k] = c->kind[k];
         hmeta[AS_SCHUR_MAX + k] = c->var[k];
     }
-    BQ_HIP(hipMemcpyAsync(c->meta, hmeta, sizeof(int) * 2 * AS_SCHUR_MAX, hipMemcpyHostToDevice, st));
+    const bool mbx = w->mailbox;
+    const int *meta = mbx ? as_dev(c->meta_pin) : c->meta;
+    if (!mbx) BQ_HIP(hipMemcpyAsync(c->meta, hmeta, sizeof(int) * 2 * AS_SCHUR_MAX, hipMemcpyHostToDevice, st));
+    // where the dot products go and how the host learns that they are there
+    double *dots_out = mbx ? as_dev(c->small_pin) : c->small, *t_out = mbx ? as_dev(c->small_pin) + AS_SCHUR_MAX : c->small + 2 * AS_SCHUR_MAX;
+    unsigned int *tk = mbx ? w->mail_ticket : nullptr;
+    int *post = mbx ? as_dev(w->mail) + 1 : nullptr;
     if (!c->y0_valid) {   // while only base variables reach bounds, b0 and Q00^-1 b0 stay what they were
         as_schur_z_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, c->pos0, w->z);
         BQ_TRY(bq_problem_apply(p, w->z, w->Qz, nullptr));
@@ -1739,47 +1847,59 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         // a pinned base variable's column is a unit vector: the forward sweep starts at its row
         BQ_TRY(bq_chol_solve(ws, np0, c->kind[k] == 0 ? (int64_t)c->hpos0[(size_t)c->var[k]] : 0, wk));
         if (k == m - 1) {   // the right-hand side of the small system needs nothing from the host: same pass over U, same round trip
-            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(2, k, c->U, wk, c->y0, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
-                                                      s->ub, p->q, w->Qz, c->small, c->small + 2 * AS_SCHUR_MAX);
-            BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
-            BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(2, k, c->U, wk, c->y0, c->cap, np0, meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                      s->ub, p->q, w->Qz, dots_out, t_out, tk, post, ++w->mail_seq[1]);
+            if (!mbx) {
+                BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
+                BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+            }
             have_t = true;
         } else {
-            as_schur_dots_kernel<T><<<k + 1, 256, 0, st>>>(0, k, c->U, wk, nullptr, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU,
-                                                          s->lb, s->ub, p->q, w->Qz, c->small, nullptr);
-            BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
+            as_schur_dots_kernel<T><<<k + 1, 256, 0, st>>>(0, k, c->U, wk, nullptr, c->cap, np0, meta, AS_PANEL_ARGS(T), s->mU,
+                                                          s->lb, s->ub, p->q, w->Qz, dots_out, nullptr, tk, post, ++w->mail_seq[1]);
+            if (!mbx) BQ_HIP(hipMemcpyAsync(host_small, c->small, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, st));
         }
-        BQ_SYNC(s->p->ctx);
+        as_tick(w, 1);
+        BQ_TRY(as_look(s->p->ctx, w, 1));
+        as_tick(w, 2);
+        const double tc0 = w->timing ? ldl_now() : 0.0;
         for (int i = 0; i <= k; ++i) {
             if (!std::isfinite(host_small[i])) return BQ_OK;
             c->C[(size_t)i * AS_SCHUR_MAX + k] = host_small[i];
             c->C[(size_t)k * AS_SCHUR_MAX + i] = host_small[i];
         }
+        if (w->timing) g_c_us += ldl_now() - tc0;
     }
     double *coef = c->coef_pin;
     if (m > 0) {
         if (!have_t) {
-            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, nullptr, c->cap, np0, c->meta, AS_PANEL_ARGS(T), s->mU, s->lb,
-                                                      s->ub, p->q, w->Qz, c->small + 2 * AS_SCHUR_MAX, nullptr);
-            BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
-            BQ_SYNC(s->p->ctx);
+            as_schur_dots_kernel<T><<<m, 256, 0, st>>>(1, 0, c->U, c->y0, nullptr, c->cap, np0, meta, AS_PANEL_ARGS(T), s->mU, s->lb,
+                                                      s->ub, p->q, w->Qz, t_out, nullptr, tk, post, ++w->mail_seq[1]);
+            if (!mbx) BQ_HIP(hipMemcpyAsync(host_t, c->small + 2 * AS_SCHUR_MAX, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+            BQ_TRY(as_look(s->p->ctx, w, 1));
         }
         if (!as_ldl_solve(c, m, host_t, coef)) {   // incremental factorisation first, pivoted elimination as the fallback
             c->ldl_n = 0;
             if (!as_small_solve(m, c->C, host_t, coef)) return BQ_OK;
         }
-        BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
+        if (!mbx) BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
     }
-    as_schur_combine_kernel<<<gb, 1024, 0, st>>>(np0, m, c->y0, c->W, c->cap, c->small + AS_SCHUR_MAX, c->y);
+    as_tick(w, 3);
+    const double *coef_dev = mbx ? as_dev(c->coef_pin) : c->small + AS_SCHUR_MAX;
+    as_schur_combine_kernel<<<gb, 1024, 0, st>>>(np0, m, c->y0, c->W, c->cap, coef_dev, c->y);
     as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
     {
         const int64_t span = n0 > m ? (n0 > 0 ? n0 : 1) : (int64_t)m;
-        as_cand_scatter_kernel<<<dim3((unsigned)((span + 255) / 256)), 256, 0, st>>>(n0, m, c->idx0, c->meta, s->mL, s->mU, s->lb, s->ub,
-                                                                                  c->y, c->small + AS_SCHUR_MAX, w->cand, w->ints);
+        as_cand_scatter_kernel<<<dim3((unsigned)((span + 255) / 256)), 256, 0, st>>>(n0, m, c->idx0, meta, s->mL, s->mU, s->lb, s->ub,
+                                                                                  c->y, coef_dev, w->cand, w->ints,
+                                                                                  mbx ? w->mail_ticket + 1 : nullptr, as_dev(w->host_ints),
+                                                                                  mbx ? as_dev(w->mail) + 2 : nullptr, ++w->mail_seq[2]);
     }
-    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
-    BQ_SYNC(s->p->ctx);
     BQ_HIP(hipGetLastError());
+    if (!mbx) BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
+    as_tick(w, 4);
+    BQ_TRY(as_look(s->p->ctx, w, 2));
+    as_tick(w, 5);
     *good = true;
     return BQ_OK;
 }
@@ -2097,8 +2217,14 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipMemsetAsync(w->idx, 0, sizeof(int) * (s->N + 1), ctx->stream));
     BQ_HIP(hipMalloc(&w->ints, sizeof(int) * 32));
     BQ_HIP(hipMemsetAsync(w->ints, 0, sizeof(int) * 32, ctx->stream));
-    BQ_HIP(hipHostMalloc(&w->host_ints, sizeof(int) * 32));
-    BQ_HIP(hipHostMalloc(&w->host_scal, sizeof(bq_scal)));
+    BQ_HIP(hipHostMalloc(&w->host_ints, sizeof(int) * 32, AS_MAPPED));
+    BQ_HIP(hipHostMalloc(&w->host_scal, sizeof(bq_scal), AS_MAPPED));
+    BQ_HIP(hipHostMalloc(&w->mail, sizeof(int) * 16, AS_MAPPED));
+    memset(w->mail, 0, sizeof(int) * 16);
+    BQ_HIP(hipMalloc(&w->mail_ticket, sizeof(unsigned int) * 2));
+    BQ_HIP(hipMemsetAsync(w->mail_ticket, 0, sizeof(unsigned int) * 2, s->p->ctx->stream));
+    w->mailbox = !s->as_cg && as_env_on("BQ_AS_MAILBOX");
+    if (const char *e = getenv("BQ_AS_TIMING")) w->timing = atoi(e) != 0;
     BQ_HIP(hipHostMalloc(&w->host_info, sizeof(int) * 8));
     BQ_HIP(hipHostMalloc(&w->host_cg, sizeof(as_cg_scal)));
     memset(w->host_ints, 0, sizeof(int) * 32);
@@ -2143,11 +2269,26 @@ int bq_as_start(bq_solver *s) {
 void bq_as_free(bq_solver *s) {
     as_ws *w = get_ws(s);
     if (!w) return;
+    if (w->timing && w->tm[7] > 0) {
+        const double it = w->tm[7];
+        fprintf(stderr, "BQ_AS_TIMING  %.0f iterations, us per iteration: wait top %.1f | host to dots %.1f | wait dots %.1f | small system %.1f | "
+                        "launch to candidate %.1f | wait candidate %.1f | launch branch + top %.1f\n", it, w->tm[0] / it, w->tm[1] / it, w->tm[2] / it,
+                w->tm[3] / it, w->tm[4] / it, w->tm[5] / it, w->tm[6] / it);
+        fprintf(stderr, "BQ_AS_TIMING  host LDL, us per iteration: new row %.1f | forward %.1f | back %.1f | residual check %.1f | C row/column %.1f\n", g_ldl_us[0] / it,
+                g_ldl_us[1] / it, g_ldl_us[2] / it, g_ldl_us[3] / it, g_c_us / it);
+        fprintf(stderr, "BQ_AS_TIMING  iterations that factorised Q[A,A] afresh: %lld, mean order %.0f, %.1f us each (launch to the candidate's record)\n", w->n_classic,
+                w->classic_order / std::max(1.0, (double)w->n_classic), w->tm_classic / std::max(1.0, (double)w->n_classic));
+        if (w->sch)
+            fprintf(stderr, "BQ_AS_TIMING  small system: %lld solves, mean order %.1f, rows (re)factorised per solve %.2f, slots dropped %lld, base factorisations %lld\n",
+                    w->sch->reused + w->sch->refreshes, (double)w->sch->rows_solved / std::max(1.0, (double)(w->sch->reused + w->sch->refreshes)),
+                    (double)w->sch->rows_extended / std::max(1.0, (double)(w->sch->reused + w->sch->refreshes)), w->sch->drops, w->sch->refreshes);
+    }
     for (void *p : {(void *)w->idx, (void *)w->ints, (void *)w->cand, (void *)w->z, (void *)w->Qz, (void *)w->x_eval,
                     (void *)w->g_eval, (void *)w->dlt, (void *)w->r, (void *)w->pv, (void *)w->Qp, (void *)w->sol,
-                    (void *)w->cg, (void *)w->Qdl, (void *)w->Qcand, (void *)w->sq, (void *)w->zchg, (void *)w->zdl})
+                    (void *)w->cg, (void *)w->Qdl, (void *)w->Qcand, (void *)w->sq, (void *)w->zchg, (void *)w->zdl,
+                    (void *)w->mail_ticket})
         if (p) hipFree(p);
-    for (void *hp : {(void *)w->host_ints, (void *)w->host_scal, (void *)w->host_info, (void *)w->host_cg})
+    for (void *hp : {(void *)w->host_ints, (void *)w->host_scal, (void *)w->host_info, (void *)w->host_cg, (void *)w->mail})
         if (hp) hipHostFree(hp);
     if (w->cg_flag_host) hipHostFree(w->cg_flag_host);
     if (w->cg_event) hipEventDestroy(w->cg_event);
@@ -2189,7 +2330,9 @@ int bq_as_iterate(bq_solver *s) {
     const int64_t N = s->N;
 
     as_launch_compact(s, w, st);
-    as_top_kernel<<<1, 1, 0, st>>>(s->sc, w->ints, s->stats, (int)N);
+    const bool mbx = w->mailbox;
+    as_top_kernel<<<1, 64, 0, st>>>(s->sc, w->ints, s->stats, (int)N, as_dev(w->host_ints), reinterpret_cast<int *>(as_dev(w->host_scal)),
+                                   mbx ? as_dev(w->mail) : nullptr, mbx ? ++w->mail_seq[0] : 0);
     if (!s->host.done) {  // snapshot of the point this record describes
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->x, w->x_eval);
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, w->g_eval);
@@ -2206,9 +2349,15 @@ int bq_as_iterate(bq_solver *s) {
         as_pc_diff_write_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, pc->prev, lcnt, pc->chg);
         BQ_HIP(hipMemcpyAsync(w->host_info + 4, pc->chg, 2 * sizeof(int), hipMemcpyDeviceToHost, st));   // pinned, like the rest
     }
-    BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
-    BQ_HIP(hipMemcpyAsync(w->host_scal, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
-    BQ_SYNC(s->p->ctx);
+    if (!mbx) {
+        BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
+        BQ_HIP(hipMemcpyAsync(w->host_scal, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, st));
+    }
+    BQ_HIP(hipGetLastError());
+    as_tick(w, w->tm[7] > 0 ? 6 : -1);
+    BQ_TRY(as_look(ctx, w, 0));
+    as_tick(w, 0);
+    w->tm[7] += 1;
     s->host = *w->host_scal;
     if (s->as_cg && w->pc) {
         w->pc->host_chg[0] = w->host_info[4];
@@ -2269,6 +2418,16 @@ int bq_as_iterate(bq_solver *s) {
         BQ_HIP(hipGetLastError());
         return BQ_OK;
     }
+    w->n_classic += 1;
+    w->classic_order += (double)nA;
+    const double tcl0 = w->timing ? ldl_now() : 0.0;
+    struct classic_tail {
+        as_ws *w;
+        double t0;
+        ~classic_tail() {
+            if (w->timing) w->tm_classic += ldl_now() - t0;
+        }
+    } ctail{w, tcl0};
     as_make_z_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->z);
     BQ_TRY(bq_problem_apply(s->p, w->z, w->Qz, nullptr));
     int64_t np = 0;

@@ -243,6 +243,34 @@ int bq_ctx_sync(bq_ctx *ctx) {
     return BQ_OK;
 }
 
+// The host waits for a word the DEVICE stores into mapped, coherent pinned memory (a kernel's last workgroup: system-scope fence, then
+// the sequence number) instead of draining the stream: no copy command, no wait for the stream's completion signal — the data the
+// host wants rides in the same pinned buffer and is complete when the word arrives (tools/look_probe.hip: 5.7 us per look against
+// 13.5 us for hipMemcpyAsync + hipStreamSynchronize).  The spin looks at the stream now and then: a stream that has drained (or
+// failed) without the word having arrived is an error, never an endless wait; the watchdog sees the wait like any other.
+int bq_ctx_wait_flag(bq_ctx *ctx, const volatile int *flag, int want) {
+    wait_scope scope(ctx);
+    for (unsigned long long spins = 1;; ++spins) {
+        if (__atomic_load_n(const_cast<const int *>(flag), __ATOMIC_ACQUIRE) == want) return BQ_OK;
+        if ((spins & 0xffff) == 0) {
+            if (ctx->comm_aborted) return aborted_error(ctx);
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {   // everything enqueued has run: the word is there now, or it never will be
+                if (__atomic_load_n(const_cast<const int *>(flag), __ATOMIC_ACQUIRE) == want) return BQ_OK;
+                bq_set_error("the stream drained without the device posting its record (expected %d, found %d)", want, (int)*flag);
+                return BQ_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) {
+                bq_set_error("hipStreamQuery failed while waiting for a device record: %s", hipGetErrorString(q));
+                return BQ_ERR_HIP;
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
 int bq_ctx_event_sync(bq_ctx *ctx, hipEvent_t ev) {
     hipError_t e;
     {

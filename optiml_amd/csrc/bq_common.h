@@ -120,6 +120,7 @@ struct bq_ctx {
 // into BQ_ERR_RCCL
 int bq_ctx_sync(bq_ctx *ctx);
 int bq_ctx_event_sync(bq_ctx *ctx, hipEvent_t ev);
+int bq_ctx_wait_flag(bq_ctx *ctx, const volatile int *flag, int want);   // a word the device posts into mapped pinned memory
 void bq_watchdog_stop(bq_ctx *ctx);   // joins the thread (context destruction)
 #define BQ_SYNC(ctx) BQ_TRY(bq_ctx_sync(ctx))
 
