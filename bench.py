@@ -45,7 +45,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_MFMA_PEAK_TF = 78.6
 
-SIDE_RECORDS = ('c2', 'c4', 'c5', 'shares', 'collective', 'shares_c4', 'shares_c5', 'fixed_cap', 'fixed_cap_c5')   # in the order they are measured
+SIDE_RECORDS = ('c2', 'c4', 'c5', 'shares', 'collective', 'shares_c4', 'shares_c5', 'fixed_cap', 'fixed_cap_c5', 'as_c2')   # in the order they are measured
 
 CONFIGS = {   # BASELINE.json `configs` (C2 .. C5) and the headline
     'headline': dict(n=100000, d=128, solver='pg', task='svc', kernel='rbf', storage='f64'),
@@ -694,6 +694,8 @@ SIDE_COMMANDS = {   # name -> (arguments of the child, its time cap in seconds)
     'fixed_cap': (['--fixed-cap', '1000', '--fixed-cap-configs', 'headline,c2,c4'], 90.0),
     # the reference's ActiveSet needs ~n outer iterations at config 5 (hours): the driver line holds 100 of them, profiles/r04/fixed_cap_c5.json 1 000
     'fixed_cap_c5': (['--fixed-cap', '100', '--fixed-cap-configs', 'c5'], 90.0),
+    # dense ActiveSet (the reference's own class, active_set.py:82-237) to 'optimal' on config 2's shape: lands in time_to_kkt
+    'as_c2': (['--solver', 'as', '--samples', '20000', '--features', '64', '--no-cpu'], 90.0),
 }
 
 
@@ -801,6 +803,11 @@ def orchestrate(args):
             caps[name] = rec
     if caps:
         head['fixed_cap'] = caps
+    if 'as_c2' in side:
+        rec = side['as_c2']
+        keep = ('value', 'unit', 'iterations', 'status', 'f', 'n_sv', 's_per_iteration', 'stop_test', 'includes', 'route', 'config', 'roofline',
+                'command', 'error', 'skipped')
+        head.setdefault('time_to_kkt', {})['as_config2_shape'] = {k: rec[k] for k in keep if k in rec}
     # the G = 1 row of the headline table is the headline record itself; predictions also at the measured collective floor
     floor = side.get('collective', {}).get('headline', {}) if 'collective' in side else {}
     tab = shares.get('headline')

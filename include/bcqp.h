@@ -227,11 +227,14 @@ int bq_solver_inner_iters(bq_solver *s, int64_t *total);
  *   BQ_COUNT_MINRES    iterations whose restricted system Q[A,A] was NOT factorised (non-positive pivot) and took the reference's
  *                      minres branch (active_set.py:142-151) — what a test of the pivot threshold (BQ_AS_PIVOT_REL) looks at
  *   BQ_COUNT_REFACTOR  base-set factorisations of the kept-factor path;  BQ_COUNT_REUSED  iterations solved through a kept factor
- *   BQ_COUNT_INNER     = bq_solver_inner_iters */
+ *   BQ_COUNT_INNER     = bq_solver_inner_iters
+ *   BQ_COUNT_NO_PRODUCT  ratio-step iterations (active_set.py:152-176) whose f(x) came from the line-search identity
+ *                      f(x + t d) = f(x) + (t - t^2/2) g_A'd_A instead of a product with Q (BQ_AS_F_CHAIN=0: none) */
 #define BQ_COUNT_INNER 0
 #define BQ_COUNT_MINRES 1
 #define BQ_COUNT_REFACTOR 2
 #define BQ_COUNT_REUSED 3
+#define BQ_COUNT_NO_PRODUCT 4
 int bq_solver_counter(bq_solver *s, int which, int64_t *value);
 int bq_solver_get(bq_solver *s, int what, double *out);
 

@@ -27,7 +27,7 @@ SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS, SMO_STATS = range(4)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
-COUNT_INNER, COUNT_MINRES, COUNT_REFACTOR, COUNT_REUSED = range(4)
+COUNT_INNER, COUNT_MINRES, COUNT_REFACTOR, COUNT_REUSED, COUNT_NO_PRODUCT = range(5)
 ABI_VERSION = 1
 
 

@@ -1123,7 +1123,7 @@ extern "C" int bq_solver_inner_iters(bq_solver *s, int64_t *total) {
 
 extern "C" int bq_solver_counter(bq_solver *s, int which, int64_t *value) {
     BQ_ARG(s && value, "NULL argument");
-    BQ_ARG(which >= BQ_COUNT_INNER && which <= BQ_COUNT_REUSED, "which: BQ_COUNT_*");
+    BQ_ARG(which >= BQ_COUNT_INNER && which <= BQ_COUNT_NO_PRODUCT, "which: BQ_COUNT_*");
     *value = s->kind == BQ_AS ? bq_as_counter(s, which) : 0;
     return BQ_OK;
 }

@@ -123,6 +123,13 @@ struct as_ws {
     int mail_seq[3] = {0, 0, 0};
     unsigned int *mail_ticket = nullptr;   // device: last-workgroup tickets of the two multi-block posters
     bool mailbox = true;
+    // product-free f of a ratio step (as_step_min_kernel): allowed at all / a run is open / its length since f was last formed by a
+    // product / how many steps went without a product (bq_solver_counter)
+    bool f_chain = true, chain_ok = false;
+    double *g0 = nullptr;             // the gradient at the starting point (device, ldN)
+    const double *gref = nullptr;     // the gradient the run scales: g0 until the first release, s->g after it
+    int chain_len = 0;
+    long long chain_steps = 0;
     // BQ_AS_TIMING=1: where the host's time goes per kept-factor iteration (printed by bq_as_free): [0] wait for the top record,
     // [1] host work up to the launch of the dot products, [2] wait for them, [3] the small system on the host, [4] launches up
     // to the candidate, [5] wait for its record, [6] launches of the branch, [7] iterations counted
@@ -300,34 +307,67 @@ __global__ __launch_bounds__(256) void as_write_free_kernel(int64_t N, const uns
 }
 
 // ratio test of the step towards the candidate: sc->step = min over the free set (active_set.py:166-173), partial minima per
-// block, the last block takes the minimum over them
+// block, the last block takes the minimum over them.
+//
+// chain != 0 — f(x + t d) WITHOUT a panel product (the second half of round 4).  The reference evaluates f afresh after the ratio
+// step (active_set.py:172-176: three products with Q).  But d = cand - x lives on the free set A and cand solves the restricted
+// system, so Q_AA d_A = -g_A(x) (a Newton step on A), hence  d'Qd = -g_A'd_A  and
+//       f(x + t d) = f(x) + t g_A'd_A + t^2/2 d'Qd = f(x) + (t - t^2/2) g_A'd_A,      g_A(x + t d) = (1 - t) g_A(x):
+// along a run of ratio steps the gradient on the (shrinking) free set is the gradient g0 of the last RELEASE iteration — the one
+// s->g still holds, fresh from that iteration's product — times gamma = prod (1 - t_j).  So the kernel also sums g0_A'd_A over the
+// free set (fixed order: per block, then over the blocks) and its last block moves f and gamma (sc->aux[0]; as_release_mb_kernel
+// sets it back to 1).  The host asks for this only while every candidate since that release came from a factorisation (not from
+// the minimum-residual branch) and forms f by a product again every 64th step of a run (chain == 2: only gamma moves; as_finish_iteration);
+// BQ_AS_F_CHAIN=0: never.
 __global__ __launch_bounds__(256) void as_step_min_kernel(int64_t N, const unsigned char *__restrict__ mL,
                                                           const unsigned char *__restrict__ mU, const double *__restrict__ cand,
                                                           const double *__restrict__ lb, const double *__restrict__ ub,
-                                                          const double *__restrict__ x, double *part, bq_scal *sc) {
-    __shared__ double sh[4];
-    double rmin = INFINITY;
+                                                          const double *__restrict__ x, const double *__restrict__ g0, double *part,
+                                                          double *part_s, bq_scal *sc, int chain) {
+    __shared__ double sh[4], shs[4];
+    double rmin = INFINITY, sgd = 0.0;
     VEC_LOOP(i) {
         if (i < N && !(mL[i] | mU[i])) {
             const double d = cand[i] - x[i];
             if (d > 0.0) rmin = fmin(rmin, (ub[i] - x[i]) / d);
             if (d < 0.0) rmin = fmin(rmin, (lb[i] - x[i]) / d);
+            if (chain == 1) sgd = fma(g0[i], d, sgd);
         }
     }
     rmin = as_wmin(rmin);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = rmin;
+    if (chain) sgd = as_wsum_any(sgd);
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = rmin;
+        shs[threadIdx.x >> 6] = sgd;
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         __hip_atomic_store(&part[blockIdx.x], fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (chain) __hip_atomic_store(&part_s[blockIdx.x], ((shs[0] + shs[1]) + shs[2]) + shs[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (as_last_block_mb(&sc->ticket[0])) {
-        double m = INFINITY;
-        for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256)
+        double m = INFINITY, a = 0.0;
+        for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256) {
             m = fmin(m, __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (chain) a += __hip_atomic_load(&part_s[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         m = as_wmin(m);
+        if (chain) a = as_wsum_any(a);
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+        if ((threadIdx.x & 63) == 0) {
+            sh[threadIdx.x >> 6] = m;
+            shs[threadIdx.x >> 6] = a;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) sc->step = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+        if (threadIdx.x == 0) {
+            const double t = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+            sc->step = t;
+            if (chain == 1) {
+                const double gd = sc->aux[0] * (((shs[0] + shs[1]) + shs[2]) + shs[3]);
+                sc->f = sc->f + (t - 0.5 * t * t) * gd;
+            }
+            if (chain) sc->aux[0] = sc->aux[0] * (1.0 - t);   // chain == 2: f comes from a product this time, the run goes on
+        }
     }
 }
 __global__ void as_step_apply_kernel(int64_t N, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
@@ -433,6 +473,7 @@ __global__ __launch_bounds__(256) void as_release_mb_kernel(int64_t N, const dou
         const long long ghu = __hip_atomic_load(&ints[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ints[3] = (int)ghl;
         ints[4] = (int)ghu;
+        sc->aux[0] = 1.0;   // g is fresh: a run of product-free ratio steps starts here (as_step_min_kernel)
         const long long row = sc->iter - sc->stat_base;
         const bool rec = row >= 0 && row < sc->stat_cap;
         if (ghl < N) {
@@ -1597,8 +1638,10 @@ static void as_launch_compact(bq_solver *s, as_ws *w, hipStream_t st) {
     as_count_free_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, cnt, w->ints, &s->sc->pad1[0]);
     as_write_free_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, cnt, w->idx);
 }
-static void as_launch_step(bq_solver *s, as_ws *w, hipStream_t st) {
-    as_step_min_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, w->cand, s->lb, s->ub, s->x, s->partials, s->sc);
+static_assert(BQ_MAX_PARTIAL_Q >= 4, "as_launch_step: a fourth slice of the partials buffer");
+static void as_launch_step(bq_solver *s, as_ws *w, hipStream_t st, int chain = 0) {
+    as_step_min_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, w->cand, s->lb, s->ub, s->x, w->gref ? w->gref : s->g,
+                                                              s->partials, s->partials + 3 * s->nblk, s->sc, chain);
     as_step_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->mL, s->mU, w->cand, s->x, s->sc);
 }
 static void as_launch_absorb(bq_solver *s, as_ws *w, hipStream_t st) {
@@ -1610,6 +1653,35 @@ static int eval_f(bq_solver *s, double *g_out) {
     // Qd = Q x ; f = 1/2 x'Qx + q'x -> sc->f ; optionally g = Qx + q
     BQ_TRY(bq_problem_apply(s->p, s->x, s->Qd, nullptr));
     return bq_vec_eval_f(s->p, s->x, s->Qd, g_out, &s->sc->f);
+}
+
+// the dense iteration's two branches once the candidate is known (w->host_ints[2]: it is feasible).  `exact`: the candidate came
+// from a factorisation (kept or fresh), not from the minimum-residual branch — the condition of the product-free f of a ratio step
+static int as_finish_iteration(bq_solver *s, as_ws *w, hipStream_t st, bool exact) {
+    const int64_t N = s->N;
+    if (w->host_ints[2]) {
+        as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
+        BQ_TRY(eval_f(s, s->g));
+        as_release_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
+        w->chain_ok = exact && w->f_chain;   // x solves its restricted system and g is fresh: a run may start
+        w->gref = s->g;
+        w->chain_len = 0;
+    } else {
+        const bool run = w->chain_ok && exact;          // the run's identity holds for this step
+        const bool chain = run && w->chain_len < 64;    // ... and f is taken from it (every 64th step of a run: from a product)
+        as_launch_step(s, w, st, chain ? 1 : (run ? 2 : 0));
+        if (chain) {
+            w->chain_len += 1;
+            w->chain_steps += 1;
+        } else {
+            BQ_TRY(eval_f(s, nullptr));
+            w->chain_len = 0;          // f is anchored again; the run itself goes on as long as the candidates stay exact
+            if (!exact) w->chain_ok = false;
+        }
+        as_launch_absorb(s, w, st);
+    }
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
 }
 
 // ---- factor re-use: host side --------------------------------------------------------------------------------
@@ -2224,6 +2296,7 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipMalloc(&w->mail_ticket, sizeof(unsigned int) * 2));
     BQ_HIP(hipMemsetAsync(w->mail_ticket, 0, sizeof(unsigned int) * 2, s->p->ctx->stream));
     w->mailbox = !s->as_cg && as_env_on("BQ_AS_MAILBOX");
+    w->f_chain = !s->as_cg && as_env_on("BQ_AS_F_CHAIN");
     if (const char *e = getenv("BQ_AS_TIMING")) w->timing = atoi(e) != 0;
     BQ_HIP(hipHostMalloc(&w->host_info, sizeof(int) * 8));
     BQ_HIP(hipHostMalloc(&w->host_cg, sizeof(as_cg_scal)));
@@ -2263,6 +2336,17 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipMalloc(&s->mU, (size_t)s->ldN));
     BQ_HIP(hipMemsetAsync(s->mL, 0, (size_t)s->ldN, ctx->stream));
     BQ_HIP(hipMemsetAsync(s->mU, 0, (size_t)s->ldN, ctx->stream));
+    if (w->f_chain) {
+        // the gradient at x0 rides on the product of f(x0): with every index free, x0 + t d obeys the ratio step's identity from the
+        // first iteration on (as_step_min_kernel).  Kept apart from s->g, which the reference does not touch before a release.
+        BQ_HIP(hipMalloc(&w->g0, sizeof(double) * s->ldN));
+        BQ_HIP(hipMemsetAsync(w->g0, 0, sizeof(double) * s->ldN, ctx->stream));
+        static const double one = 1.0;   // gamma of the first run (as_release_mb_kernel sets it for the later ones)
+        BQ_HIP(hipMemcpyAsync(&s->sc->aux[0], &one, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        w->gref = w->g0;
+        w->chain_ok = true;
+        return eval_f(s, w->g0);
+    }
     return eval_f(s, nullptr);  // f(x0), active_set.py:84
 }
 
@@ -2286,7 +2370,7 @@ void bq_as_free(bq_solver *s) {
     for (void *p : {(void *)w->idx, (void *)w->ints, (void *)w->cand, (void *)w->z, (void *)w->Qz, (void *)w->x_eval,
                     (void *)w->g_eval, (void *)w->dlt, (void *)w->r, (void *)w->pv, (void *)w->Qp, (void *)w->sol,
                     (void *)w->cg, (void *)w->Qdl, (void *)w->Qcand, (void *)w->sq, (void *)w->zchg, (void *)w->zdl,
-                    (void *)w->mail_ticket})
+                    (void *)w->mail_ticket, (void *)w->g0})
         if (p) hipFree(p);
     for (void *hp : {(void *)w->host_ints, (void *)w->host_scal, (void *)w->host_info, (void *)w->host_cg, (void *)w->mail})
         if (hp) hipHostFree(hp);
@@ -2312,6 +2396,7 @@ long long bq_as_counter(bq_solver *s, int which) {
         case BQ_COUNT_MINRES: return w->minres_calls;
         case BQ_COUNT_REFACTOR: return w->sch ? w->sch->refreshes : 0;
         case BQ_COUNT_REUSED: return w->sch ? w->sch->reused : 0;
+        case BQ_COUNT_NO_PRODUCT: return w->chain_steps;
         default: return 0;
     }
 }
@@ -2406,17 +2491,7 @@ int bq_as_iterate(bq_solver *s) {
     if (!solved && w->sch) w->sch->valid = false;   // the classic path below overwrites the kept factor
     if (solved) {
         w->last_branch = w->host_ints[2] ? 1 : 0;
-        if (w->host_ints[2]) {
-            as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
-            BQ_TRY(eval_f(s, s->g));
-            as_release_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
-        } else {
-            as_launch_step(s, w, st);
-            BQ_TRY(eval_f(s, nullptr));
-            as_launch_absorb(s, w, st);
-        }
-        BQ_HIP(hipGetLastError());
-        return BQ_OK;
+        return as_finish_iteration(s, w, st, true);
     }
     w->n_classic += 1;
     w->classic_order += (double)nA;
@@ -2456,15 +2531,5 @@ int bq_as_iterate(bq_solver *s) {
         w->minres_calls += 1;
     }
     w->last_branch = w->host_ints[2] ? 1 : 0;
-    if (w->host_ints[2]) {
-        as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, w->cand, s->x);
-        BQ_TRY(eval_f(s, s->g));
-        as_release_mb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, s->mL, s->mU, s->sc, w->ints, s->stats);
-    } else {
-        as_launch_step(s, w, st);
-        BQ_TRY(eval_f(s, nullptr));
-        as_launch_absorb(s, w, st);
-    }
-    BQ_HIP(hipGetLastError());
-    return BQ_OK;
+    return as_finish_iteration(s, w, st, info == 0);
 }

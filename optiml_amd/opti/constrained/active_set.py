@@ -36,6 +36,8 @@ class ActiveSet(BoxConstrainedQuadraticOptimizer):
         self.U = solver.get(_lib.GET_MASK_U) > 0
         # iterations that took the reference's minres branch (active_set.py:142-151: Q[A,A] not factorisable)
         self.minres_iterations = solver.counter(_lib.COUNT_MINRES)
+        # ratio-step iterations whose f(x) came from the line-search identity instead of a product with Q
+        self.product_free_iterations = solver.counter(_lib.COUNT_NO_PRODUCT)
 
 
 class ActiveSetCG(ActiveSet):

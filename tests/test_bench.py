@@ -143,6 +143,9 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys):
             if 'c5' in argv:
                 return None, 'exit code 1, no JSON line', 2.0
             return share_rec('c4' if 'c4' in argv else 'headline', [int(g) for g in argv[argv.index('--emulate-shares') + 1].split(',')], 6.0), None, 3.0
+        if '--solver' in argv and argv[argv.index('--solver') + 1] == 'as':
+            return {'metric': 'time_to_kkt_tol', 'value': 10.0, 'unit': 's', 'iterations': 22897, 'status': 'optimal', 'f': -57.5,
+                    'config': {'workload': 'svc_hinge_rbf_as_dual_n20000_d64'}, 'cpu_baseline': None}, None, 12.0
         if '--config' in argv:
             cfg = argv[argv.index('--config') + 1]
             rec = {'metric': 'dual_qp_iterations_per_sec', 'value': 10.0, 'ms_per_step': 100.0, 'config': {'workload': cfg},
@@ -171,6 +174,7 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys):
     assert 'error' in rec['shares']['c5_over_8']                                  # a failing side record stays inside the line
     assert rec['collective_floor_us']['headline']['allreduce']['mean_us'] == 4.0
     assert rec['records']['requested'] == list(bench.SIDE_RECORDS)
+    assert rec['time_to_kkt']['as_config2_shape']['iterations'] == 22897 and rec['time_to_kkt']['as_config2_shape']['status'] == 'optimal'
     # a budget that is already spent: the headline still runs, every side record is skipped with the reason
     calls.clear()
     args.budget_s = 1.0

@@ -36,8 +36,8 @@ AS_KINDS = ['as', 'ascg']
 @pytest.fixture(params=['refactor', 'reuse'])
 def as_factor_mode(request, monkeypatch):
     """The dense-factor ActiveSet either re-factorises Q[A,A] in every iteration (what the reference does) or keeps the
-    factor of a base set and carries the changes through a Schur complement (csrc/bq_as.hip; the default from |A| = 1024
-    on — BQ_AS_SCHUR_MIN=0 switches it on for the small fixtures).  Both must follow the reference's trajectory."""
+    factor of a base set and carries the changes through a Schur complement (csrc/bq_as.hip; the default for every non-empty
+    free set since round 4 — BQ_AS_SCHUR_MIN=0 states it).  Both must follow the reference's trajectory."""
     if request.param == 'reuse':
         monkeypatch.setenv('BQ_AS_SCHUR_MIN', '0')
     else:
@@ -866,6 +866,51 @@ def test_active_set_on_a_rank_deficient_problem_follows_the_oracle_to_the_end(am
     assert got.status == 'optimal' and got.iter == ref['iter']
     np.testing.assert_allclose(got.x, ref['x'], rtol=0, atol=1e-9)
     np.testing.assert_allclose(got.f_x, ref['f_x'], rtol=1e-10)
+
+
+def test_active_set_objective_without_a_product_on_ratio_steps(amd, as_factor_mode, monkeypatch):
+    """INTEGRATION.md "Deviations": after a ratio step the reference evaluates f(x) with products by Q (active_set.py:172-176); the
+    device uses the step's own identity f(x + t d) = f(x) + (t - t^2/2) g_A'd_A (d is a Newton step on the free set) and forms f by a
+    product only at release iterations and every 64th step of a run (bq_as.hip, as_step_min_kernel).  Same iterates by construction;
+    here: the recorded objective follows the ORACLE's (a product per iteration) and the run with BQ_AS_F_CHAIN=0, on a dual whose
+    trajectory has long runs of ratio steps (hundreds of iterations before the first release) and on one with lower bounds != 0."""
+    from oracle import bcqp_oracle as bo
+    from optiml_amd import _lib
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import ActiveSet
+    rng = np.random.default_rng(11)
+    cases = []
+    n = 400
+    X = rng.standard_normal((n, 6))
+    y = np.where(X[:, 0] + 0.4 * rng.standard_normal(n) > 0, 1.0, -1.0)
+    K = np.exp(-0.5 * ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1))
+    cases.append(('hinge dual, rbf, n=400', (K + 1.0) * np.outer(y, y), -np.ones(n), np.zeros(n), np.ones(n)))
+    m = 120
+    M = rng.standard_normal((m, m))
+    cases.append(('random spd, lb != 0, n=120', M @ M.T + 0.05 * np.eye(m), 4.0 * rng.standard_normal(m), np.full(m, -0.3), np.full(m, 0.7)))
+    for name, Q, q, lb, ub in cases:
+        runs = {}
+        for chain in ('1', '0'):
+            monkeypatch.setenv('BQ_AS_F_CHAIN', chain)
+            hist = []
+            cb = lambda o: hist.append(o.f_x)
+            cb._bq_needs_state = False
+            kw = dict(quad=Quadratic(Q, q), ub=ub, max_iter=5000, callback=cb)
+            if np.any(lb != 0):
+                kw['lb'] = lb
+            opt = ActiveSet(**kw).minimize()
+            runs[chain] = (opt, np.array(hist))
+        on, off = runs['1'], runs['0']
+        assert on[0].status == off[0].status == 'optimal', name
+        assert on[0].iter == off[0].iter and len(on[1]) == len(off[1]), name
+        np.testing.assert_array_equal(on[0].x, off[0].x, err_msg=name)   # the iterates do not know how f was formed
+        assert off[0].product_free_iterations == 0, name
+        assert on[0].product_free_iterations >= on[0].iter // 4, (name, on[0].product_free_iterations, on[0].iter)
+        scale = np.abs(off[1]).max()
+        np.testing.assert_allclose(on[1], off[1], rtol=1e-11, atol=1e-13 * scale, err_msg=name)
+        ref = bo.active_set(Q, q, ub, lb=lb, max_iter=5000)
+        assert ref['iter'] == on[0].iter and ref['status'] == on[0].status, name
+        np.testing.assert_allclose(on[1], ref['f_hist'][:len(on[1])], rtol=1e-9, atol=1e-11 * scale, err_msg=name)
 
 
 def _pivot_threshold_cases():
