@@ -1373,6 +1373,9 @@ struct as_schur {
     double *small_pin = nullptr, *coef_pin = nullptr;
     long long refreshes = 0, reused = 0;
     long long rows_extended = 0, rows_solved = 0, drops = 0;   // BQ_AS_TIMING: rows the small factorisation (re)built / orders solved / slots dropped
+    bool timing = false;                  // BQ_AS_TIMING: host microseconds spent in ...
+    double t_ldl[4] = {0, 0, 0, 0};       // ... the new row | the forward solve | the backward solve | the residual check
+    double t_c = 0.0;                     // ... storing the new row / column of C
     bool y0_valid = false;   // y0 = Q00^-1 b0 is current: b0 only moves when a variable OUTSIDE the base changes sides
 };
 
@@ -1558,18 +1561,16 @@ static bool as_ldl_extend(as_schur *c, int m) {
     return true;
 }
 
-static double g_c_us = 0.0;
-static double g_ldl_us[4] = {0, 0, 0, 0};   // BQ_AS_TIMING: extend | forward | back | residual
 static inline double ldl_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool as_ldl_solve(as_schur *c, int m, const double *t, double *w) {
-    const double t0 = ldl_now();
+    const double t0 = c->timing ? ldl_now() : 0.0;
     if (!as_ldl_extend(c, m)) return false;
-    const double t1 = ldl_now();
+    const double t1 = c->timing ? ldl_now() : 0.0;
     const size_t ld = AS_SCHUR_MAX;
     std::vector<double> y(t, t + m);
     for (int i = 0; i < m; ++i) y[i] -= as_dot4(&c->Lc[(size_t)i * ld], y.data(), i);   // L y = t, rows of L contiguous
     for (int i = 0; i < m; ++i) y[i] /= c->Dc[i];
-    const double t2 = ldl_now();
+    const double t2 = c->timing ? ldl_now() : 0.0;
     // L' w = y by columns of L' = rows of L: once w[i] is final it is eliminated from the unknowns above it (contiguous row i;
     // the dot-product form walked a COLUMN of the 1536-pitch factor per unknown: one cache line per element)
     for (int i = m - 1; i >= 0; --i) {
@@ -1577,11 +1578,17 @@ static bool as_ldl_solve(as_schur *c, int m, const double *t, double *w) {
         w[i] = wi;
         as_axpy_neg(y.data(), &c->Lc[(size_t)i * ld], wi, i);
     }
-    const double t3 = ldl_now();
-    g_ldl_us[0] += t1 - t0;
-    g_ldl_us[1] += t2 - t1;
-    g_ldl_us[2] += t3 - t2;
-    struct tail { double t; ~tail() { g_ldl_us[3] += ldl_now() - t; } } tl{t3};
+    const double t3 = c->timing ? ldl_now() : 0.0;
+    c->t_ldl[0] += t1 - t0;
+    c->t_ldl[1] += t2 - t1;
+    c->t_ldl[2] += t3 - t2;
+    struct tail {
+        as_schur *c;
+        double t;
+        ~tail() {
+            if (c->timing) c->t_ldl[3] += ldl_now() - t;
+        }
+    } tl{c, t3};
     // residual against the stored C
     double worst = 0.0, scale = 0.0;
     for (int i = 0; i < m; ++i) {
@@ -1736,6 +1743,7 @@ static int as_schur_setup(bq_solver *s, as_ws *w) {
     if (w->sch) return BQ_OK;
     as_schur *c = new as_schur();
     w->sch = c;
+    c->timing = w->timing;
     c->cap = s->chol->cap;
     BQ_HIP(hipMalloc(&c->idx0, sizeof(int) * (s->N + 1)));
     BQ_HIP(hipMalloc(&c->pos0, sizeof(int) * (s->N + 1)));
@@ -1940,7 +1948,7 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
             c->C[(size_t)i * AS_SCHUR_MAX + k] = host_small[i];
             c->C[(size_t)k * AS_SCHUR_MAX + i] = host_small[i];
         }
-        if (w->timing) g_c_us += ldl_now() - tc0;
+        if (w->timing) c->t_c += ldl_now() - tc0;
     }
     double *coef = c->coef_pin;
     if (m > 0) {
@@ -2358,8 +2366,9 @@ void bq_as_free(bq_solver *s) {
         fprintf(stderr, "BQ_AS_TIMING  %.0f iterations, us per iteration: wait top %.1f | host to dots %.1f | wait dots %.1f | small system %.1f | "
                         "launch to candidate %.1f | wait candidate %.1f | launch branch + top %.1f\n", it, w->tm[0] / it, w->tm[1] / it, w->tm[2] / it,
                 w->tm[3] / it, w->tm[4] / it, w->tm[5] / it, w->tm[6] / it);
-        fprintf(stderr, "BQ_AS_TIMING  host LDL, us per iteration: new row %.1f | forward %.1f | back %.1f | residual check %.1f | C row/column %.1f\n", g_ldl_us[0] / it,
-                g_ldl_us[1] / it, g_ldl_us[2] / it, g_ldl_us[3] / it, g_c_us / it);
+        if (w->sch)
+            fprintf(stderr, "BQ_AS_TIMING  host LDL, us per iteration: new row %.1f | forward %.1f | back %.1f | residual check %.1f | C row/column %.1f\n",
+                    w->sch->t_ldl[0] / it, w->sch->t_ldl[1] / it, w->sch->t_ldl[2] / it, w->sch->t_ldl[3] / it, w->sch->t_c / it);
         fprintf(stderr, "BQ_AS_TIMING  iterations that factorised Q[A,A] afresh: %lld, mean order %.0f, %.1f us each (launch to the candidate's record)\n", w->n_classic,
                 w->classic_order / std::max(1.0, (double)w->n_classic), w->tm_classic / std::max(1.0, (double)w->n_classic));
         if (w->sch)

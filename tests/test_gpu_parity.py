@@ -913,6 +913,32 @@ def test_active_set_objective_without_a_product_on_ratio_steps(amd, as_factor_mo
         np.testing.assert_allclose(on[1], ref['f_hist'][:len(on[1])], rtol=1e-9, atol=1e-11 * scale, err_msg=name)
 
 
+def test_active_set_mailbox_looks_change_nothing(amd, monkeypatch):
+    """The dense ActiveSet's three looks per iteration are records the kernels post into mapped pinned memory (as_ws::mail,
+    bq_ctx_wait_flag; slot table and coefficients read by the kernels from the host's buffers).  BQ_AS_MAILBOX=0 is the round-3 way
+    (hipMemcpyAsync + hipStreamSynchronize, device copies of the tables): how the host learns a record must not move a bit."""
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained import ActiveSet
+    rng = np.random.default_rng(5)
+    n = 300
+    M = rng.standard_normal((n, 40))
+    Q = M @ M.T + 0.3 * np.eye(n)
+    q = 5.0 * rng.standard_normal(n)
+    ub = np.full(n, 1.0)
+    runs = {}
+    for mail in ('1', '0'):
+        monkeypatch.setenv('BQ_AS_MAILBOX', mail)
+        hist = []
+        cb = lambda o: hist.append(o.f_x)
+        cb._bq_needs_state = False
+        opt = ActiveSet(quad=Quadratic(Q, q), ub=ub, max_iter=3000, callback=cb).minimize()
+        runs[mail] = (opt, np.array(hist))
+    a, b = runs['1'], runs['0']
+    assert a[0].status == b[0].status == 'optimal' and a[0].iter == b[0].iter > 50
+    np.testing.assert_array_equal(a[0].x, b[0].x)
+    np.testing.assert_array_equal(a[1], b[1])
+
+
 def _pivot_threshold_cases():
     """(name, Q, q, ub) of SPD but ill-conditioned hinge-dual Hessians whose FIRST restricted system is all of Q (x0 = C/2: every
     variable free).  Three families: an RBF block with one near-duplicate pair of samples at distance e (the last pivot of the pair
