@@ -120,6 +120,7 @@ struct as_ws {
     // products of a new slot (as_schur_dots_kernel), [2] the candidate's feasibility (as_cand_scatter_kernel) — on which the host
     // spins (bq_ctx_wait_flag).  BQ_AS_MAILBOX=0: copies + hipStreamSynchronize as before.
     int *mail = nullptr;
+    int *mail_d = nullptr, *host_ints_d = nullptr, *host_scal_d = nullptr;   // the device's addresses of mail / host_ints / host_scal
     int mail_seq[3] = {0, 0, 0};
     unsigned int *mail_ticket = nullptr;   // device: last-workgroup tickets of the two multi-block posters
     bool mailbox = true;
@@ -1371,6 +1372,8 @@ struct as_schur {
     // the coefficients are READ by the kernels straight from the host's buffer, the dot products are WRITTEN there: no copy commands)
     int *meta_pin = nullptr;
     double *small_pin = nullptr, *coef_pin = nullptr;
+    int *meta_pin_d = nullptr;                                // ... and the device's addresses of the three
+    double *small_pin_d = nullptr, *coef_pin_d = nullptr;
     long long refreshes = 0, reused = 0;
     long long rows_extended = 0, rows_solved = 0, drops = 0;   // BQ_AS_TIMING: rows the small factorisation (re)built / orders solved / slots dropped
     bool timing = false;                  // BQ_AS_TIMING: host microseconds spent in ...
@@ -1757,6 +1760,9 @@ static int as_schur_setup(bq_solver *s, as_ws *w) {
     BQ_HIP(hipHostMalloc(&c->small_pin, sizeof(double) * 2 * AS_SCHUR_MAX, AS_MAPPED));
     BQ_HIP(hipHostMalloc(&c->coef_pin, sizeof(double) * AS_SCHUR_MAX, AS_MAPPED));
     memset(c->meta_pin, 0, sizeof(int) * 2 * AS_SCHUR_MAX);
+    c->meta_pin_d = as_dev(c->meta_pin);
+    c->small_pin_d = as_dev(c->small_pin);
+    c->coef_pin_d = as_dev(c->coef_pin);
     c->hpos0.assign((size_t)s->N, -1);
     c->C.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
     c->Lc.assign((size_t)AS_SCHUR_MAX * AS_SCHUR_MAX, 0.0);
@@ -1903,12 +1909,12 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         hmeta[AS_SCHUR_MAX + k] = c->var[k];
     }
     const bool mbx = w->mailbox;
-    const int *meta = mbx ? as_dev(c->meta_pin) : c->meta;
+    const int *meta = mbx ? c->meta_pin_d : c->meta;
     if (!mbx) BQ_HIP(hipMemcpyAsync(c->meta, hmeta, sizeof(int) * 2 * AS_SCHUR_MAX, hipMemcpyHostToDevice, st));
     // where the dot products go and how the host learns that they are there
-    double *dots_out = mbx ? as_dev(c->small_pin) : c->small, *t_out = mbx ? as_dev(c->small_pin) + AS_SCHUR_MAX : c->small + 2 * AS_SCHUR_MAX;
+    double *dots_out = mbx ? c->small_pin_d : c->small, *t_out = mbx ? c->small_pin_d + AS_SCHUR_MAX : c->small + 2 * AS_SCHUR_MAX;
     unsigned int *tk = mbx ? w->mail_ticket : nullptr;
-    int *post = mbx ? as_dev(w->mail) + 1 : nullptr;
+    int *post = mbx ? w->mail_d + 1 : nullptr;
     if (!c->y0_valid) {   // while only base variables reach bounds, b0 and Q00^-1 b0 stay what they were
         as_schur_z_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, c->pos0, w->z);
         BQ_TRY(bq_problem_apply(p, w->z, w->Qz, nullptr));
@@ -1965,15 +1971,15 @@ static int as_schur_solve_t(bq_solver *s, as_ws *w, int computed, bool *good) {
         if (!mbx) BQ_HIP(hipMemcpyAsync(c->small + AS_SCHUR_MAX, coef, sizeof(double) * m, hipMemcpyHostToDevice, st));
     }
     as_tick(w, 3);
-    const double *coef_dev = mbx ? as_dev(c->coef_pin) : c->small + AS_SCHUR_MAX;
+    const double *coef_dev = mbx ? c->coef_pin_d : c->small + AS_SCHUR_MAX;
     as_schur_combine_kernel<<<gb, 1024, 0, st>>>(np0, m, c->y0, c->W, c->cap, coef_dev, c->y);
     as_cand_fill_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, s->lb, s->ub, w->cand, w->ints);
     {
         const int64_t span = n0 > m ? (n0 > 0 ? n0 : 1) : (int64_t)m;
         as_cand_scatter_kernel<<<dim3((unsigned)((span + 255) / 256)), 256, 0, st>>>(n0, m, c->idx0, meta, s->mL, s->mU, s->lb, s->ub,
                                                                                   c->y, coef_dev, w->cand, w->ints,
-                                                                                  mbx ? w->mail_ticket + 1 : nullptr, as_dev(w->host_ints),
-                                                                                  mbx ? as_dev(w->mail) + 2 : nullptr, ++w->mail_seq[2]);
+                                                                                  mbx ? w->mail_ticket + 1 : nullptr, w->host_ints_d,
+                                                                                  mbx ? w->mail_d + 2 : nullptr, ++w->mail_seq[2]);
     }
     BQ_HIP(hipGetLastError());
     if (!mbx) BQ_HIP(hipMemcpyAsync(w->host_ints, w->ints, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
@@ -2301,6 +2307,9 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipHostMalloc(&w->host_scal, sizeof(bq_scal), AS_MAPPED));
     BQ_HIP(hipHostMalloc(&w->mail, sizeof(int) * 16, AS_MAPPED));
     memset(w->mail, 0, sizeof(int) * 16);
+    w->mail_d = as_dev(w->mail);
+    w->host_ints_d = as_dev(w->host_ints);
+    w->host_scal_d = reinterpret_cast<int *>(as_dev(w->host_scal));
     BQ_HIP(hipMalloc(&w->mail_ticket, sizeof(unsigned int) * 2));
     BQ_HIP(hipMemsetAsync(w->mail_ticket, 0, sizeof(unsigned int) * 2, s->p->ctx->stream));
     w->mailbox = !s->as_cg && as_env_on("BQ_AS_MAILBOX");
@@ -2425,8 +2434,8 @@ int bq_as_iterate(bq_solver *s) {
 
     as_launch_compact(s, w, st);
     const bool mbx = w->mailbox;
-    as_top_kernel<<<1, 64, 0, st>>>(s->sc, w->ints, s->stats, (int)N, as_dev(w->host_ints), reinterpret_cast<int *>(as_dev(w->host_scal)),
-                                   mbx ? as_dev(w->mail) : nullptr, mbx ? ++w->mail_seq[0] : 0);
+    as_top_kernel<<<1, 64, 0, st>>>(s->sc, w->ints, s->stats, (int)N, w->host_ints_d, w->host_scal_d,
+                                   mbx ? w->mail_d : nullptr, mbx ? ++w->mail_seq[0] : 0);
     if (!s->host.done) {  // snapshot of the point this record describes
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->x, w->x_eval);
         as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, w->g_eval);
