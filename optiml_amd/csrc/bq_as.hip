@@ -234,6 +234,16 @@ __global__ void as_copy_kernel(int64_t N, const double *__restrict__ src, double
         if (i < N) dst[i] = src[i];
     }
 }
+// the iteration's snapshot of x and g in one launch
+__global__ void as_copy2_kernel(int64_t N, const double *__restrict__ a, double *__restrict__ da, const double *__restrict__ b,
+                                double *__restrict__ db) {
+    VEC_LOOP(i) {
+        if (i < N) {
+            da[i] = a[i];
+            db[i] = b[i];
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // The per-iteration O(N) steps, multi-block (round 2).  Their single-block predecessors walked N elements with 256
@@ -2437,8 +2447,7 @@ int bq_as_iterate(bq_solver *s) {
     as_top_kernel<<<1, 64, 0, st>>>(s->sc, w->ints, s->stats, (int)N, w->host_ints_d, w->host_scal_d,
                                    mbx ? w->mail_d : nullptr, mbx ? ++w->mail_seq[0] : 0);
     if (!s->host.done) {  // snapshot of the point this record describes
-        as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->x, w->x_eval);
-        as_copy_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->g, w->g_eval);
+        as_copy2_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->x, w->x_eval, s->g, w->g_eval);
         s->started = true;
     }
     if (s->as_cg && w->pc) {

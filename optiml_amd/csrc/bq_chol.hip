@@ -587,6 +587,14 @@ __global__ __launch_bounds__(256) void sweep_gemv_kernel(const double *__restric
     }
 }
 
+// the block a sweep starts from, copied aside (the block's product with its inverted diagonal block overwrites it in place):
+// a launch of this instead of a device-to-device copy COMMAND, twice per solve (a copy command costs the host ~3 x a launch and
+// the stream a blit kernel between two barriers)
+__global__ void sweep_copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 int bq_chol_prepare_sweeps(bq_chol_ws *ws, int64_t np) {
     hipStream_t st = ws->ctx->stream;
     const int64_t nbb = (np + BB - 1) / BB;
@@ -628,7 +636,7 @@ static int chol_solve_fast(bq_chol_ws *ws, int64_t np, int64_t first_nonzero, do
             sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->H, ldh, r0, nr, Kb * BB, r0, 0, rhs, rhs + r0, -1.0, t, nullptr);
             in = t;
         } else {
-            BQ_HIP(hipMemcpyAsync(t, rhs + r0, sizeof(double) * nr, hipMemcpyDeviceToDevice, st));
+            sweep_copy_kernel<<<(unsigned)((nr + 255) / 256), 256, 0, st>>>(rhs + r0, t, nr);
             in = t;
         }
         sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->bigM + K * BB * BB, BB, 0, nr, 0, nr, 1, in, nullptr, 1.0, rhs + r0, nullptr);
@@ -640,7 +648,7 @@ static int chol_solve_fast(bq_chol_ws *ws, int64_t np, int64_t first_nonzero, do
         if (K < nbb - 1)
             sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->H, ldh, r0, nr, r0 + BB, np, 0, rhs, rhs + r0, -1.0, t, nullptr);
         else
-            BQ_HIP(hipMemcpyAsync(t, rhs + r0, sizeof(double) * nr, hipMemcpyDeviceToDevice, st));
+            sweep_copy_kernel<<<(unsigned)((nr + 255) / 256), 256, 0, st>>>(rhs + r0, t, nr);
         sweep_gemv_kernel<<<g, 256, 0, st>>>(ws->bigMT + K * BB * BB, BB, 0, nr, 0, nr, 2, t, nullptr, 1.0, rhs + r0,
                                              also ? also + r0 : nullptr);
     }
