@@ -1452,6 +1452,14 @@ __global__ __launch_bounds__(256) void as_schur_dots_kernel(int mode, int k, con
     __shared__ double sh[4], sh1[4];
     const int i = blockIdx.x;
     const double *u = U + (int64_t)i * cap;
+    // the slot table may live in the HOST's (mapped) buffer: thread 0 asks for its four entries before the dot products, not after
+    int ki = 0, vi = 0, kk = 0, vk = 0;
+    if (threadIdx.x == 0) {
+        ki = meta[i];
+        vi = meta[AS_SCHUR_MAX + i];
+        kk = meta[k];
+        vk = meta[AS_SCHUR_MAX + k];
+    }
     double s = 0.0, t = 0.0;
     if (mode == 2) {
         for (int64_t a = threadIdx.x; a < np0; a += 256) {
@@ -1471,9 +1479,7 @@ __global__ __launch_bounds__(256) void as_schur_dots_kernel(int mode, int k, con
     __syncthreads();
     if (threadIdx.x == 0) {
         const double dot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
-        const int ki = meta[i], vi = meta[AS_SCHUR_MAX + i];
         if (mode != 1) {
-            const int kk = meta[k], vk = meta[AS_SCHUR_MAX + k];
             double extra = 0.0;
             if (ki == 1 && kk == 1) extra = bq_q_elem(structure, panel, ldp, packed, n, sgn, diag_add, (int64_t)vi, (int64_t)vk);
             out[i] = extra - dot;
@@ -1500,11 +1506,14 @@ __global__ __launch_bounds__(1024) void as_schur_combine_kernel(int64_t np0, int
                                                                 const double *__restrict__ W, int64_t cap,
                                                                 const double *__restrict__ coef, double *__restrict__ y) {
     __shared__ double part[4][256];
+    __shared__ double cf[AS_SCHUR_MAX];   // the coefficients may live in the HOST's (mapped) buffer: one coalesced read per workgroup,
+    for (int k = threadIdx.x; k < m; k += 1024) cf[k] = coef[k];   // not one uncached trip over PCIe per term of the sum
+    __syncthreads();
     const int r = threadIdx.x & 255, g = threadIdx.x >> 8;
     const int64_t a = (int64_t)blockIdx.x * 256 + r;
     double v = 0.0;
     if (a < np0)
-        for (int k = g; k < m; k += 4) v += __dmul_rn(coef[k], W[(int64_t)k * cap + a]);
+        for (int k = g; k < m; k += 4) v += __dmul_rn(cf[k], W[(int64_t)k * cap + a]);
     part[g][r] = v;
     __syncthreads();
     if (g == 0 && a < np0) y[a] = y0[a] - (((part[0][r] + part[1][r]) + part[2][r]) + part[3][r]);
