@@ -10,12 +10,14 @@
 //     yes:   x = candidate; f, g = evaluate; release the FIRST index of L with g < -1e-12, else the first of U with
 //            g > 1e-12 (Bland), else 'optimal' (:156-189)
 //     no:    ratio step towards the candidate, f = evaluate, move variables that hit a bound into L / U (:195-220)
-// The restricted order |A| changes every iteration, so the host reads two small records per iteration (|A| and
-// {pivot info, feasible}); everything else stays on the stream.  When Q[A,A] is not positive definite the reference
+// The restricted order |A| changes every iteration, so the host reads small records per iteration (|A|, the dot products of a
+// new slot, {pivot info, feasible}) — posted by the kernels into mapped pinned memory, three sequence numbers the host spins on
+// (as_ws::mail: no copy commands, no stream drains); everything else stays on the stream.  f(x) after a ratio step comes from the
+// step's own identity (as_step_min_kernel); a panel product is spent on f only at release iterations.  When Q[A,A] is not positive definite the reference
 // silently switches to scipy's minres on the normal equations (:142-151): here a persistent single-workgroup MINRES
 // kernel (bq_minres.hip) takes over for |A| <= 8192.
 //
-// Factor re-use (default for |A| >= 1024; BQ_AS_SCHUR=0 re-factorises every iteration as the reference does): between
+// Factor re-use (default for every non-empty free set; BQ_AS_SCHUR=0 re-factorises every iteration as the reference does): between
 // two consecutive iterations the free set changes by one or a few indices, so the Cholesky factor of a BASE set A0 is
 // kept and the current restricted system is solved through its Schur complement — variables of A0 that have reached a
 // bound since are pinned by a multiplier row (x_k = bound), variables released since are bordered on:
