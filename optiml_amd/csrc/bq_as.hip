@@ -24,7 +24,7 @@
 //     [ Q00  U ] [y]   [b0]        U = [ Q[A0, added] | e_removed ],  V = [ Q[added, added] 0 ; 0 0 ]
 //     [ U'   V ] [w] = [b1]        C = V - U' Q00^-1 U  (m x m, m <= 96 ... 512),  w = C^-1 (b1 - U' Q00^-1 b0),  y = Q00^-1 (b0 - U w)
 // One new column Q00^-1 u (two triangular sweeps) per changed index and one Q00^-1 b0 per iteration replace the
-// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 96 (|A| < 8 192) to 512 (|A| >= 80 000) changes, when C
+// |A|^3/3 factorisation; C is kept on the host and solved there.  The base is re-factorised after 160 (|A| < 8 192) to 1536 (|A| >= 80 000) changes, when C
 // is numerically singular, or when the classic path is needed (non-positive pivot -> the reference's minres branch).
 //
 // BQ_AS_CG (SURVEY 7 "hard parts": ActiveSet beyond the sizes a dense factor fits): the same outer logic, but the
@@ -1361,7 +1361,9 @@ static int as_schur_limit(int64_t np0) {
     if (const char *e = getenv("BQ_AS_SCHUR_LIMIT")) return std::max(1, std::min(atoi(e), AS_SCHUR_MAX));   // tests
     // (re-tuned in round 2 for the two-launches-per-1024-rows sweeps: a solve is ~4x cheaper, so the n^3/3 of a rebuild is
     // amortised over more iterations: n = 50 000: 0.77 s per rebuild = 3 ms per iteration at 256 carried changes)
-    return np0 < 8192 ? 96 : (np0 < 40000 ? 384 : (np0 < 80000 ? 768 : 1536));
+    // (below |A| = 8 192: 96 through round 4's first half; swept again once every free set went through the kept factor and the
+    // looks became cheap — 48 / 96 / 160 / 256: 11.15 / 10.42 / 10.13 / 10.22 s to 'optimal' at n = 20 000, profiles/r04/as_f_chain.txt)
+    return np0 < 8192 ? 160 : (np0 < 40000 ? 384 : (np0 < 80000 ? 768 : 1536));
 }
 
 struct as_schur {
