@@ -45,6 +45,8 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_MFMA_PEAK_TF = 78.6
 
+LINE_LIMIT = 4096       # bytes of the last stdout line (the driver keeps a 12.8 KB tail of stdout: r04's 25.6 KB line was cut)
+
 SIDE_RECORDS = ('c2', 'c4', 'c5', 'shares', 'collective', 'shares_c4', 'shares_c5', 'fixed_cap', 'fixed_cap_c5', 'as_c2')   # in the order they are measured
 
 CONFIGS = {   # BASELINE.json `configs` (C2 .. C5) and the headline
@@ -99,6 +101,12 @@ def parse(argv=None):
                     help='side records of the default single-GPU line, each measured in a fresh child process after the headline '
                          'record is complete: ' + ','.join(SIDE_RECORDS) + '.  Default: all when no workload flag is given '
                          '(the driver\'s command), none otherwise')
+    ap.add_argument('--line', default='compact', choices=['compact', 'full'],
+                    help='what the LAST stdout line is: compact (default) = the headline record cut to what the driver parses, under '
+                         f'{LINE_LIMIT} bytes, with the complete record written to --records-file; full = the complete record itself '
+                         '(what the child processes of the default line print for their parent)')
+    ap.add_argument('--records-file', default=os.path.join(REPO, 'bench_records.json'),
+                    help='where the complete (uncut) record of this run is written as indented JSON (also one line on stderr)')
     ap.add_argument('--budget-s', type=float, default=400.0,
                     help='wall-clock budget of the whole default line: a side record that would not fit is skipped (and says so)')
     ap.add_argument('--fixed-cap', type=int, default=0, metavar='CAP',
@@ -703,7 +711,7 @@ def _run_child(argv, timeout):
     """One fresh `python bench.py ... --records none` process; (last JSON object on its stdout | None, error text | None,
     seconds).  Its stderr is this process's stderr (progress stays visible).  On expiry exactly that child is killed."""
     t0 = time.perf_counter()
-    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ['--records', 'none'], stdout=subprocess.PIPE,
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ['--records', 'none', '--line', 'full'], stdout=subprocess.PIPE,
                             text=True, cwd=REPO)
     try:
         out, _ = proc.communicate(timeout=timeout)
@@ -852,7 +860,7 @@ def orchestrate(args):
     head['records'] = {'requested': want, 'budget_s': args.budget_s, 'wall_s': timing,
                        'note': 'headline record first (its own process, unchanged command); every side record in a fresh process '
                                'of its own after it, inputs resident in HBM inside each timed region; this parent never touches HIP'}
-    print(json.dumps(head), flush=True)
+    emit(head, args)
 
 
 def fixed_cap(args):
@@ -947,6 +955,143 @@ def collective_floor(args):
                     'allreduce': {'bytes': ln * 8, 'mean_us': a[0], 'min_us': a[1]}}
     ctx.close()
     print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the last stdout line: the headline record cut to what the driver parses
+# ---------------------------------------------------------------------------------------------------------------------
+def _r(v, sig=6):
+    """Floats to `sig` significant digits (the line is a summary: the uncut numbers are in --records-file)."""
+    if isinstance(v, float):
+        return float(f'{v:.{sig}g}') if v == v and abs(v) != float('inf') else None
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _pick(src, keys):
+    return {k: src[k] for k in keys if isinstance(src, dict) and k in src}
+
+
+def compact_line(full, records_file=None):
+    """The record the driver parses: BASELINE's metric on BASELINE's config with `roofline` and `cpu_baseline`, one-number
+    summaries of every side record, nothing else.  Always shorter than LINE_LIMIT: if a summary would push it over, summaries
+    are dropped from the end (and named in `dropped`) — the contract fields never are."""
+    out = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                       'vs_baseline', 'dtype', 'data'))
+    cfg = full.get('config', {})
+    out['config'] = _pick(cfg, ('workload', 'n', 'd', 'dual_dim', 'solver', 'C', 'gamma', 'exchange', 'rccl_ranks', 'sym_exchange',
+                                'rows_per_gpu'))
+    if 'device' in cfg:
+        out['config']['device'] = cfg['device'].split(' [')[0] + (' ' + cfg['device'][cfg['device'].rfind('('):] if '(' in cfg['device'] else '')
+    roof = full.get('roofline') or {}
+    out['roofline'] = _pick(roof, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'avg_launch_ms',
+                                   'launches', 'algorithmic_bytes_per_launch', 'flops_per_launch', 'frac_survey_8d_bytes',
+                                   'measured_stream_read_GBs'))
+    if roof.get('bound') == 'hbm':
+        out['roofline']['bytes_basis'] = 'bytes the kernel moves (lower-triangle tiles of the symmetric panel + partial slab); ' \
+                                         'frac_survey_8d_bytes = same launch priced at n^2*s, never read'
+    cpu = full.get('cpu_baseline')
+    if cpu:
+        c = _pick(cpu, ('value', 'unit', 'kind', 'extrapolated', 'cores', 'cpu_model', 'law', 'fitted_exponent', 'value_fitted_exponent',
+                        'value_range'))
+        if 'samples' in cpu:
+            c['samples'] = [_pick(x, ('n', 'iters', 's_per_iter', 's_per_iteration')) for x in cpu['samples']]
+        c['sample'] = (cpu.get('sample') or '')[:240]
+        sp = cpu.get('streamed_product_full_n')
+        if sp:
+            c['streamed_product_full_n'] = {'n': sp.get('n'), 's_per_product': min(sp['s_per_product']) if sp.get('s_per_product') else None}
+        out['cpu_baseline'] = c
+    else:
+        out['cpu_baseline'] = None
+    for k in ('speedup_vs_cpu_baseline', 'steps_done', 'solver_status', 'gram_build_s', 'exchange_ms_per_product', 'inner_products_per_step'):
+        if k in full:
+            out[k] = full[k]
+    # ---- one-number summaries, in the order they are dropped LAST -> FIRST when the line would be too long
+    extra = []
+    per = full.get('per_rank')
+    if per:
+        extra.append(('per_rank', {k: [p.get(k) for p in per] for k in ('tiles', 'ms_per_step', 'symv_tiles_ms', 'exchange_ms_per_product')}))
+    xc = full.get('exchange_compare')
+    if xc:
+        extra.append(('exchange_compare', xc if 'error' in xc else {m: _pick(v, ('exchange_ms_per_product', 'ms_per_step')) for m, v in xc.items()}))
+    side = {}
+    for name, rec in (full.get('configs') or {}).items():
+        if 'value' in rec:
+            key = 'c5_outer_it_s' if name == 'c5' else f'{name}_iter_s'
+            side[key] = rec['value']
+            side[f'{name}_frac'] = (rec.get('roofline') or {}).get('frac')
+            if 'inner_products_per_step' in rec:
+                side[f'{name}_products_per_outer_it'] = rec['inner_products_per_step']
+        else:
+            side[f'{name}_iter_s'] = rec.get('error') or rec.get('skipped')
+    tab = (full.get('shares') or {}).get('headline') or {}
+    parts = {p['G']: p for p in tab.get('partitions', []) if 'G' in p}
+    if parts:
+        side['predicted_x_at_2_4_8'] = [parts.get(g, {}).get('predicted_speedup_vs_1') for g in (2, 4, 8)]
+        side['predicted_symv_frac_at_2_4_8'] = [parts.get(g, {}).get('min_symv_frac_of_8TBs') for g in (2, 4, 8)]
+        side['predicted_assumed_exchange_us'] = tab.get('assumed_exchange_us')
+    for key, g, name in (('c4_over_4', 4, 'c4_predicted_x_at_4'), ('c5_over_8', 8, 'c5_predicted_x_at_8')):
+        for p in ((full.get('shares') or {}).get(key) or {}).get('partitions', []):
+            if p.get('G') == g:
+                side[name] = p.get('predicted_speedup_vs_1')
+    floor = full.get('collective_floor_us') or {}
+    if 'headline' in floor:
+        side['collective_floor_us'] = {k: floor['headline'][k].get('mean_us') for k in ('gather_8_segments', 'allreduce') if k in floor['headline']}
+    kk = full.get('time_to_kkt') or {}
+    for key, name in (('ip_config3', 'ip_c3_s'), ('as_config2_shape', 'as_c2_s'), ('smo', 'smo_headline_s'), ('c5_projected', 'c5_projected_s')):
+        if key in kk and isinstance(kk[key], dict):
+            side[name] = kk[key].get('value', kk[key].get('error'))
+            fr = (kk[key].get('roofline') or {}).get('frac')
+            if fr is not None:
+                side[name[:-2] + '_frac'] = fr
+    caps = full.get('fixed_cap') or {}
+    fc = {k: [v.get('iterations'), v.get('proj_grad_norm_2'), v.get('wall_s')] for k, v in caps.items() if isinstance(v, dict) and 'iterations' in v}
+    if fc:
+        side['fixed_cap_iters_projgrad_wall_s'] = fc
+    if side:
+        extra.append(('side', side))
+    wall = (full.get('records') or {}).get('wall_s') or {}
+    if wall:
+        extra.append(('wall_s', wall.get('total_s')))
+    if records_file:
+        extra.append(('full_record', os.path.relpath(records_file, REPO) if records_file.startswith(REPO) else records_file))
+    for k, v in extra:
+        out[k] = v
+    out = _r(out)
+    dropped = []   # never reached by the records this file produces today (2.8 KB); the bound holds whatever is added later
+    while len(json.dumps(out)) >= LINE_LIMIT:
+        if isinstance(out.get('side'), dict) and out['side']:
+            dropped.append('side.' + out['side'].popitem()[0])
+        else:
+            victims = [k for k, _ in extra if k in out]
+            if not victims:
+                break
+            out.pop(victims[-1])
+            dropped.append(victims[-1])
+        out['dropped'] = dropped
+    return out
+
+
+def emit(full, args, stream=None):
+    """The complete record to --records-file (indented) and to stderr (one line), then THE line on stdout: the complete record with
+    --line full (children of the default line), the compact one otherwise."""
+    stream = stream or sys.stdout
+    if args.line == 'full':
+        print(json.dumps(full), file=stream, flush=True)
+        return
+    path = args.records_file
+    try:
+        with open(path, 'w') as fh:
+            json.dump(full, fh, indent=1)
+            fh.write('\n')
+    except OSError as exc:   # a read-only checkout must not cost the line
+        print(f'[bench] complete record not written to {path}: {exc!r}', file=sys.stderr, flush=True)
+        path = None
+    print('[bench] complete record: ' + json.dumps(full), file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(full, path)), file=stream, flush=True)
 
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
@@ -1197,7 +1342,7 @@ def main():
                 snapshot['exchange_compare'] = {'error': 'the comparison run did not finish within 90 s', 'stuck_at': stage['at'],
                                                 'sym_exchange': stage.get('mode')}
                 snapshot['cpu_baseline'] = None
-                print(json.dumps(snapshot), file=json_out, flush=True)
+                emit(snapshot, args, json_out)
             os._exit(4)
         watchdog = threading.Timer(90.0, _bail)
         watchdog.daemon = True
@@ -1254,7 +1399,7 @@ def main():
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out), file=json_out, flush=True)
+        emit(out, args, json_out)
     barrier()
     if comm is not None:
         comm.close()

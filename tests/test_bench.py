@@ -11,10 +11,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(REPO, 'bench.py')
 
 
-def _run(args, timeout=600, env=None):
+def _run(args, timeout=600, env=None, line='full'):
+    """`--line full`: the complete record on stdout (what these tests read); `line='compact'` is the driver's view."""
     e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     e.update(env or {})
-    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=REPO)
+    return subprocess.run([sys.executable, BENCH] + args + ['--line', line], capture_output=True, text=True, timeout=timeout, env=e, cwd=REPO)
 
 
 def test_presets_and_argument_checks():
@@ -96,7 +97,7 @@ def test_rccl_that_cannot_be_created_is_an_error_not_a_fallback():
 
 
 @pytest.mark.gpu
-def test_launched_by_torch_distributed_run_like_the_driver():
+def test_launched_by_torch_distributed_run_like_the_driver(tmp_path):
     """The driver's N > 1 command: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...  (two ranks on GPU 0 of this box, host exchange): ONE JSON line on stdout."""
     import socket
@@ -106,16 +107,20 @@ def test_launched_by_torch_distributed_run_like_the_driver():
     e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), BENCH, '--gpus', '2', '--exchange', 'host', '--samples', '5000', '--features', '16',
-           '--steps', '6', '--warmup', '2', '--no-cpu', '--kkt', 'none']
+           '--steps', '6', '--warmup', '2', '--no-cpu', '--kkt', 'none', '--records-file', str(tmp_path / 'full.json')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
-    assert len(lines) == 1, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, r.stdout      # the driver's view: ONE compact line (it keeps a 12.8 KB tail)
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps_done'] == 6 and rec['config']['exchange'] == 'host'
+    assert rec['roofline']['bound'] == 'hbm' and rec['roofline']['frac'] > 0 and rec['cpu_baseline'] is None
+    assert len(rec['per_rank']['symv_tiles_ms']) == 2 and set(rec['exchange_compare']) == {'gather', 'allreduce'}
+    full = json.load(open(tmp_path / 'full.json'))                   # ... and the uncut record beside it
+    assert full['value'] == pytest.approx(rec['value'], rel=1e-5) and [p['rank'] for p in full['per_rank']] == [0, 1]
 
 
-def test_default_line_is_composed_from_child_records(monkeypatch, capsys):
+def test_default_line_is_composed_from_child_records(monkeypatch, capsys, tmp_path):
     """`python bench.py` with no workload flag: the parent composes ONE line from the headline child's record and the side
     records (configs / shares / collective floor), never touching HIP itself; a failing or over-budget side record is reported
     inside the line, not fatal."""
@@ -124,6 +129,8 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys):
     args = bench.parse(['--gpus', '1', '--steps', '20', '--warmup', '5'])
     assert args.default_workload and args.records == 'all' and args.cpu_stream_iters == 1
     assert bench.parse(['--samples', '5000']).records == 'none'
+    assert args.line == 'compact'
+    args.records_file = str(tmp_path / 'bench_records.json')
     calls = []
 
     def share_rec(workload, gs, ms):
@@ -160,8 +167,15 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys):
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
     bench.orchestrate(args)
     lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
-    assert len(lines) == 1
-    rec = json.loads(lines[0])
+    # the LAST stdout line is the compact record and the only one (r04's 25.6 KB line overflowed the driver's 12.8 KB tail)
+    assert len(lines) == 1 and len(lines[-1]) < bench.LINE_LIMIT == 4096
+    line = json.loads(lines[-1])
+    assert line['value'] == 160.0 and line['steps'] == 20 and line['warmup'] == 5 and line['n_gpus'] == 1
+    assert line['roofline']['frac'] == 0.82 and line['cpu_baseline']['value'] == 0.2
+    assert line['side']['c2_iter_s'] == 10.0 and line['side']['c5_products_per_outer_it'] == 10.0 and line['side']['as_c2_s'] == 10.0
+    assert line['side']['predicted_x_at_2_4_8'][2] == pytest.approx(1e3 / (6.0 / 8 + 0.1) / 160.0, rel=1e-5)
+    assert line['side']['collective_floor_us'] == {'gather_8_segments': 5.0, 'allreduce': 4.0}
+    rec = json.load(open(args.records_file))                                      # the complete record, beside the line
     assert calls[0][0] == ['--gpus', '1', '--steps', '20', '--warmup', '5']       # the headline child runs exactly the caller's command
     assert [c[0][:2] for c in calls[1:4]] == [['--config', 'c2'], ['--config', 'c4'], ['--config', 'c5']]
     assert rec['value'] == 160.0 and rec['steps'] == 20 and rec['cpu_baseline'] == {'value': 0.2}   # headline fields untouched
@@ -179,8 +193,33 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys):
     calls.clear()
     args.budget_s = 1.0
     bench.orchestrate(args)
-    rec = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    rec = json.load(open(args.records_file))
     assert len(calls) == 1 and all('skipped' in v for v in rec['configs'].values())
+    assert line['value'] == 160.0 and 'skipped' not in line and all('budget left' in line['side'][f'{c}_iter_s'] for c in ('c2', 'c4', 'c5'))
+
+
+def test_compact_line_stays_under_the_limit_whatever_the_record_holds():
+    """The committed r04 record (25.6 KB: the one the driver could not keep) compacts to < 4 KB with every contract field; a record
+    bloated far beyond it still does (summaries are dropped and named, contract fields never)."""
+    sys.path.insert(0, REPO)
+    import bench
+    full = json.load(open(os.path.join(REPO, 'profiles', 'r04', 'bench_default_line_final.json')))
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full, os.path.join(REPO, 'bench_records.json'))
+    assert len(json.dumps(line)) < 4096 and 'dropped' not in line
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line
+    assert line['config']['workload'] == 'svc_hinge_rbf_pg_dual_n100000_d128'
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'algorithmic_bytes_per_launch', 'bytes_basis'} <= set(line['roofline'])
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(line['cpu_baseline'])
+    assert line['side']['c5_outer_it_s'] == pytest.approx(4.68469) and line['side']['ip_c3_s'] == pytest.approx(37.4363)
+    full['per_rank'] = [{'rank': k, 'tiles': 10 ** 9 + k, 'ms_per_step': 1.2345678 + k, 'symv_tiles_ms': 0.7654321 + k,
+                         'exchange_ms_per_product': 0.0123 + k} for k in range(64)]
+    full['fixed_cap'].update({f'x{k}': {'iterations': k, 'proj_grad_norm_2': 1.5, 'wall_s': 2.5} for k in range(200)})
+    line = bench.compact_line(full, None)
+    assert len(json.dumps(line)) < 4096 and line['dropped'] and line['roofline']['frac'] and line['cpu_baseline']['value']
 
 
 def test_default_line_without_a_gpu_fails_loudly():
