@@ -945,6 +945,7 @@ def collective_floor(args):
     ctx = device.Context(comm=SocketComm(0, 1), exchange='rccl')
     info = ctx.comm_info()
     out = {'what': 'collective_floor', 'unit': 'us', 'rccl_ranks': info['rccl_ranks'], 'device': ctx.name,
+           'rccl_init_stages': info['rccl_init_stages'],
            'note': 'ONE-rank RCCL communicator on one GPU: launch + local-copy floor of the one collective per product, HIP events '
                    'around each of 50 calls on the compute stream; a lower bound of the N > 1 cost over xGMI, not an estimate of it'}
     for key, n in (('headline', 100000), ('c4', 100000), ('c5', 250000)):
@@ -1274,6 +1275,7 @@ def main():
             'config': {'workload': workload, 'n': n, 'd': d, 'dual_dim': N, 'C': 1.0,
                        'gamma': 'scale', 'solver': args.solver, 'exchange': ctx.exchange, 'rccl_ranks': cinfo['rccl_ranks'],
                        'sym_exchange': cinfo['sym_exchange'] if world > 1 else 'none', 'blob_sigma': args.sigma,
+                       'rccl_init_stages': cinfo['rccl_init_stages'],
                        'rows_per_gpu': r1 - r0, 'device': ctx.name,
                        'panel_placement_ms': dev.placement()},
             'roofline': {'bound': 'hbm', 'kernel': 'symv_tiles_kernel (symmetric panel product Q*d)', 'achieved': achieved,

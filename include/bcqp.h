@@ -116,6 +116,10 @@ int bq_ctx_create(int device, bq_ctx **out);
 /* uid: 128-byte RCCL unique id, created on rank 0 by bq_comm_unique_id and broadcast by the caller */
 int bq_comm_unique_id(void *uid128);
 int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_ctx **out);
+/* where the time of RCCL's start-up went in this process so far: "dlopen(librccl.so) 0.41 s; dlsym x8 0.00 s; ncclGetUniqueId ...;
+ * ncclCommInitRank ...; ncclCommCount ..." (empty when RCCL was never loaded).  A stage still running after 5 s also says so on
+ * stderr every 5 s while it runs; BQ_DEBUG_EXCHANGE=1 prints every stage as it ends. */
+int bq_comm_init_report(char *buf, size_t cap);
 int bq_ctx_create_exchange(int device, int rank, int world, bq_exchange_fn fn, void *user, bq_ctx **out);
 /* ONE rank's share of a `world`-way partition with no transport behind it: panels, segments and every kernel of the
  * per-rank iteration are exactly those of rank `rank` of `world`, every collective is a no-op — so products hold this rank's
@@ -149,14 +153,18 @@ int bq_ctx_probe_mfma_f64(bq_ctx *ctx, double seconds, double *tflops);
 int bq_ctx_probe_exchange(bq_ctx *ctx, int kind, int64_t count, int reps, double *mean_us, double *min_us);
 /* Bound the collectives of an RCCL context in time (0: no bound, the default; also BQ_COLLECTIVE_TIMEOUT_S through the Python
  * Context).  RCCL itself never gives up on a collective whose peer does not arrive (a rank-local error, a dead process): with a
- * timeout a watchdog thread aborts the communicator (ncclCommAbort) once the host has waited on the compute stream for longer,
- * the call in progress returns BQ_ERR_RCCL and the context is unusable afterwards.  The callback transport is bounded by the
- * caller's own communicator (and on every context without an RCCL communicator the setting is accepted and does nothing).  Set it
- * from the thread that owns the context, while no call is in progress. */
+ * timeout a watchdog thread aborts the communicator (ncclCommAbort) once the host has waited for longer on a stream that holds a
+ * collective enqueued since it was last seen empty; the call in progress returns BQ_ERR_RCCL and the context is unusable afterwards.
+ * A wait with only this rank's own kernels ahead of it is never cut short.  The callback transport is bounded by the caller's own
+ * communicator (and on every context without an RCCL communicator the setting is accepted and does nothing).  Set it from the thread
+ * that owns the context, while no call is in progress. */
 int bq_ctx_set_collective_timeout(bq_ctx *ctx, double seconds);
 /* occupy the compute stream for `milliseconds` (one lane spinning on the wall clock; it ends by itself) and wait for it through
- * the library's bounded wait: the end-to-end test of the watchdog on one GPU (BQ_ERR_RCCL when it fired) */
-int bq_ctx_probe_stall(bq_ctx *ctx, double milliseconds);
+ * the library's bounded wait.  behind_collective != 0: the context's collective (an all-reduce of one double) is enqueued BEHIND the
+ * occupation first — what a peer that arrives `milliseconds` late looks like from this rank: the end-to-end test of the watchdog on
+ * one GPU (BQ_ERR_RCCL when it fired).  behind_collective == 0: nothing but this rank's own work is ahead of the wait, which the
+ * watchdog must leave alone however long it lasts (a factorisation, a preconditioner rebuild). */
+int bq_ctx_probe_stall(bq_ctx *ctx, double milliseconds, int behind_collective);
 /* row block [begin,end) of an n-row panel owned by `rank` out of `world` (pure arithmetic): equal 128-aligned
  * blocks for dense panels; bq_sym_row_block: the balanced triangular partition (256-aligned) of the symmetric
  * kernel panels, whose ranks stream only the tiles on/below the diagonal */
@@ -237,6 +245,38 @@ int bq_solver_inner_iters(bq_solver *s, int64_t *total);
 #define BQ_COUNT_NO_PRODUCT 4
 int bq_solver_counter(bq_solver *s, int which, int64_t *value);
 int bq_solver_get(bq_solver *s, int what, double *out);
+
+/* ---- checkpoint / resume (SURVEY 5 "checkpoint / resume") -------------------------------------------------------
+ * What the reference's loop holds at the TOP of an iteration, so that a run which was stopped (max_iter, a callback's
+ * StopIteration, a process that has to go) can be continued in a NEW solver: the reference offers `x=` only
+ * (constrained/_base.py:61-65) and keeps the rest as locals — InteriorPoint's multipliers lp / lm (interior_point.py:181-186),
+ * ActiveSet's masks L / U (active_set.py:91-92), FrankWolfe's best lower bound (frank_wolfe.py:90,105-106), self.g_x.
+ *
+ * bq_solver_get_state: the state at the top of the NEXT iteration (iteration `iter`): a step that has been decided but not yet
+ * applied to the device vectors (PG / FW: x + t d, g + t Qd; IP: x + t dx, lp + t dlp, lm + t dlm) is applied to the copies
+ * handed out, with the device's own rounding (one rounded product, one sum).  Vector pointers that are NULL are skipped; `have`
+ * says which of the others were filled (BQ_STATE_*): lp / lm exist for BQ_IP, the masks (1.0 / 0.0 per index) for BQ_AS / BQ_AS_CG.
+ *
+ * bq_solver_set_state: into a solver that has not run yet (same problem, kind, bounds).  x is required; g, lp & lm, the masks are
+ * taken when given (`have`), otherwise formed as the reference forms them at a start point (g = Qx + q by one product, lp / lm
+ * from g, empty masks).  With everything given, InteriorPoint, ProjectedGradient and FrankWolfe continue BIT-IDENTICALLY to the
+ * run that was stopped (every later quantity is a function of this state); ActiveSet continues from the same point and masks with a
+ * freshly built factor (the stopped run's was updated incrementally: same iterates to rounding).
+ * max_iter keeps counting from `iter`. */
+#define BQ_STATE_X 1
+#define BQ_STATE_G 2
+#define BQ_STATE_MULT 4   /* lp and lm */
+#define BQ_STATE_MASKS 8  /* mask_l and mask_u */
+typedef struct bq_solver_snapshot {
+    int64_t iter;      /* iterations completed = index of the next iteration record */
+    int kind;          /* BQ_PG ... (get: filled; set: must match the solver, or -1 = not checked) */
+    int have;          /* BQ_STATE_* bits: which vectors are filled (get) / given (set) */
+    double f;          /* objective of the last record (NaN before the first); informational on set */
+    double best_lb;    /* FrankWolfe: best lower bound so far (-inf before the first record) */
+    double *x, *g, *lp, *lm, *mask_l, *mask_u;   /* dual-dim fp64 host vectors owned by the caller, NULL = absent */
+} bq_solver_snapshot;
+int bq_solver_get_state(bq_solver *s, bq_solver_snapshot *state);
+int bq_solver_set_state(bq_solver *s, const bq_solver_snapshot *state);
 
 /* ---- augmented-Lagrangian dual + first-order update rules ------------------------------------
  * min 1/2 x'Qx + q'x  s.t.  a_eq'x = 0 (optional), lb <= x <= ub (each optional), relaxed into

@@ -28,11 +28,18 @@ RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RUL
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
 COUNT_INNER, COUNT_MINRES, COUNT_REFACTOR, COUNT_REUSED, COUNT_NO_PRODUCT = range(5)
+STATE_X, STATE_G, STATE_MULT, STATE_MASKS = 1, 2, 4, 8
 ABI_VERSION = 1
 
 
 class IterStat(C.Structure):
     _fields_ = [('iter', C.c_int64), ('f', C.c_double), ('r1', C.c_double), ('r2', C.c_double), ('r3', C.c_double)]
+
+
+class SolverState(C.Structure):   # bq_solver_snapshot
+    _fields_ = [('iter', C.c_int64), ('kind', C.c_int), ('have', C.c_int), ('f', C.c_double), ('best_lb', C.c_double),
+                ('x', C.POINTER(C.c_double)), ('g', C.POINTER(C.c_double)), ('lp', C.POINTER(C.c_double)),
+                ('lm', C.POINTER(C.c_double)), ('mask_l', C.POINTER(C.c_double)), ('mask_u', C.POINTER(C.c_double))]
 
 
 class AlParams(C.Structure):
@@ -58,6 +65,7 @@ PROTOTYPES = {
     'bq_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
     'bq_comm_unique_id': (C.c_int, [_vp]),
     'bq_ctx_create_rccl': (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    'bq_comm_init_report': (C.c_int, [C.c_char_p, C.c_size_t]),
     'bq_ctx_create_exchange': (C.c_int, [C.c_int, C.c_int, C.c_int, EXCHANGE_FN, _vp, C.POINTER(_vp)]),
     'bq_ctx_create_share': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     'bq_ctx_destroy': (C.c_int, [_vp]),
@@ -70,7 +78,7 @@ PROTOTYPES = {
     'bq_ctx_probe_mfma_f64': (C.c_int, [_vp, C.c_double, _dp]),
     'bq_ctx_probe_exchange': (C.c_int, [_vp, C.c_int, _i64, C.c_int, _dp, _dp]),
     'bq_ctx_set_collective_timeout': (C.c_int, [_vp, C.c_double]),
-    'bq_ctx_probe_stall': (C.c_int, [_vp, C.c_double]),
+    'bq_ctx_probe_stall': (C.c_int, [_vp, C.c_double, C.c_int]),
     'bq_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_sym_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_problem_create_dense': (C.c_int, [_vp, _i64, _dp, _dp, C.c_int, C.POINTER(_vp)]),
@@ -93,6 +101,8 @@ PROTOTYPES = {
     'bq_solver_set_inner': (C.c_int, [_vp, C.c_double, _i64]),
     'bq_solver_inner_iters': (C.c_int, [_vp, C.POINTER(_i64)]),
     'bq_solver_counter': (C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
+    'bq_solver_get_state': (C.c_int, [_vp, C.POINTER(SolverState)]),
+    'bq_solver_set_state': (C.c_int, [_vp, C.POINTER(SolverState)]),
     'bq_al_solver_create': (C.c_int, [_vp, C.POINTER(AlParams), _dp, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     'bq_al_solver_dual_size': (C.c_int, [_vp, C.POINTER(_i64)]),
     'bq_al_solver_set_schedules': (C.c_int, [_vp, _dp, _dp, _i64]),

@@ -116,8 +116,10 @@ extern "C" int bq_ctx_destroy(bq_ctx *c) {
     }
     hipSetDevice(c->device);
     bq_ctx_register(c, false);
+    // the bounded wait first, the watchdog's end after it: a context closed behind a collective whose peer has gone must not sit
+    // here for ever either; after an abort the stream holds nothing worth waiting for
+    if (c->stream && !c->comm_aborted) (void)bq_ctx_sync(c);
     bq_watchdog_stop(c);
-    if (c->stream && !c->comm_aborted) hipStreamSynchronize(c->stream);
     bq_comm_destroy(c);
     for (auto &slot : c->prof)
         for (auto &pr : slot.pending) {
@@ -448,7 +450,7 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
         return BQ_OK;
     }
     hipSetDevice(p->ctx->device);
-    hipStreamSynchronize(p->ctx->stream);
+    (void)bq_ctx_sync(p->ctx);   // may sit behind a collective: bounded when a collective timeout is set
     if (p->panel_alloc && p->panel_bytes >= ((size_t)1 << 30)) {   // keep one large panel for the next problem (see bq_ctx)
         bq_ctx_cache_put(p->ctx, p->panel_alloc, p->panel_bytes);
         p->panel_alloc = nullptr;
@@ -971,17 +973,24 @@ __global__ void probe_stall_kernel(long long ticks, long long *sink) {
     if (ticks < 0) *sink = t;   // never: keeps the loop
 }
 
-extern "C" int bq_ctx_probe_stall(bq_ctx *c, double milliseconds) {
+extern "C" int bq_ctx_probe_stall(bq_ctx *c, double milliseconds, int behind_collective) {
     BQ_ARG(c != nullptr, "ctx is NULL");
     BQ_ARG(milliseconds > 0.0 && milliseconds <= 5000.0, "milliseconds in (0, 5000]");
     BQ_HIP(hipSetDevice(c->device));
     int rate_khz = 0;
     BQ_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c->device));
     if (rate_khz <= 0) rate_khz = 100000;   // 100 MHz on every part this library is built for
+    double *one = nullptr;
+    if (behind_collective) {
+        BQ_HIP(hipMalloc(&one, sizeof(double)));
+        BQ_HIP(hipMemsetAsync(one, 0, sizeof(double), c->stream));
+    }
     probe_stall_kernel<<<1, 1, 0, c->stream>>>((long long)(milliseconds * (double)rate_khz), nullptr);
-    BQ_HIP(hipGetLastError());
-    BQ_SYNC(c);
-    return BQ_OK;
+    int rc = hipGetLastError() == hipSuccess ? BQ_OK : BQ_ERR_HIP;
+    if (rc == BQ_OK && behind_collective) rc = bq_exchange_sum(c, one, 1);
+    if (rc == BQ_OK) rc = bq_ctx_sync(c);
+    if (one) hipFree(one);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -996,7 +1005,7 @@ static int alloc_vec(bq_solver *s, double **v) {
 extern "C" int bq_solver_destroy(bq_solver *s) {
     if (s == nullptr) return BQ_OK;
     hipSetDevice(s->p->ctx->device);
-    hipStreamSynchronize(s->p->ctx->stream);
+    (void)bq_ctx_sync(s->p->ctx);   // may sit behind a collective: bounded when a collective timeout is set
     for (void *ptr : {(void *)s->x, (void *)s->g, (void *)s->d, (void *)s->Qd, (void *)s->lb, (void *)s->ub,
                       (void *)s->lp, (void *)s->lm, (void *)s->rhs, (void *)s->hd, (void *)s->dlp, (void *)s->dlm,
                       (void *)s->mL, (void *)s->mU, (void *)s->partials, (void *)s->sc, (void *)s->stats})
@@ -1007,6 +1016,7 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
         hipEventDestroy(s->flag_event);
     }
     bq_as_free(s);
+    delete s->resume;
     if (s->al) {
         bq_al_vecs &V = s->al->V;   // x, g, step (= s->d) and Qx (= s->Qd) are owned by the common slots above
         for (void *ptr : {(void *)V.xe, (void *)V.s1, (void *)V.s2, (void *)V.s3, (void *)V.a, (void *)V.llb, (void *)V.lub,
@@ -1261,15 +1271,39 @@ extern "C" int bq_al_solver_dual_size(const bq_solver *s, int64_t *n_dual) {
 
 static int solver_first(bq_solver *s) {
     if (s->kind == BQ_AL) return BQ_OK;   // nothing to prepare: every iteration evaluates Q x afresh
+    bq_solver::resume_t *r = s->resume;
+    const int have = r ? r->have : 0;
+    hipStream_t st = s->p->ctx->stream;
+    auto up = [&](double *dev, const std::vector<double> &src) {
+        return hipMemcpyAsync(dev, src.data(), sizeof(double) * s->N, hipMemcpyHostToDevice, st);
+    };
     switch (s->kind) {
         case BQ_PG:
         case BQ_FW:
-            return bq_pgfw_start(s);
+            // g given: the start product is not needed — (x, g) is the whole state of these two (bq_solver_set_state)
+            if (have & BQ_STATE_G) BQ_HIP(up(s->g, r->g));
+            else BQ_TRY(bq_pgfw_start(s));
+            break;
         case BQ_IP:
-            return bq_ip_start(s);
+            // interior_point.py:180-186 where something is missing; what was given then replaces what the start formed
+            if ((have & (BQ_STATE_G | BQ_STATE_MULT)) != (BQ_STATE_G | BQ_STATE_MULT)) BQ_TRY(bq_ip_start(s));
+            if (have & BQ_STATE_G) BQ_HIP(up(s->g, r->g));
+            if (have & BQ_STATE_MULT) {
+                BQ_HIP(up(s->lp, r->lp));
+                BQ_HIP(up(s->lm, r->lm));
+            }
+            break;
         default:
-            return bq_as_start(s);
+            BQ_TRY(bq_as_start(s));   // takes the masks from s->resume itself (they are allocated there)
+            if (have & BQ_STATE_G) BQ_HIP(up(s->g, r->g));
+            break;
     }
+    if (r) {
+        BQ_SYNC(s->p->ctx);   // the uploads read the vectors about to be released
+        delete r;
+        s->resume = nullptr;
+    }
+    return BQ_OK;
 }
 
 static int solver_iterate(bq_solver *s) {
@@ -1433,6 +1467,116 @@ extern "C" int bq_solver_get(bq_solver *s, int what, double *out) {
     BQ_SYNC(c);
     return BQ_OK;
 }
+
+// ---- checkpoint / resume (bcqp.h) -----------------------------------------------------------------------------
+// v + t dv with the device's rounding: one rounded product, one sum (pg_update_eval_kernel / ip_update_kernel use __dmul_rn).
+#pragma clang fp contract(off)
+static void state_apply_step(std::vector<double> &v, const std::vector<double> &dv, double t) {
+    for (size_t i = 0; i < v.size(); ++i) {
+        const double prod = t * dv[i];
+        v[i] = v[i] + prod;
+    }
+}
+
+extern "C" int bq_solver_get_state(bq_solver *s, bq_solver_snapshot *out) {
+    BQ_ARG(s && out, "NULL argument");
+    BQ_ARG(s->kind != BQ_AL, "the augmented-Lagrangian solver keeps its state in x and BQ_GET_DUAL");
+    bq_ctx *c = s->p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    const size_t N = (size_t)s->N;
+    out->iter = s->host.iter;
+    out->kind = s->as_cg ? BQ_AS_CG : s->kind;
+    out->f = s->host.f;
+    out->best_lb = s->host.best_lb;
+    out->have = 0;
+    // a decided step waits on the device until the next iteration's first kernel applies it — unless the run has ended
+    // (the deciding kernels return before they form one) or has not begun
+    const bool pending = s->started && !s->host.done && s->kind != BQ_AS;
+    const double t = s->kind == BQ_IP ? s->host.step : s->host.t;
+    std::vector<double> v(N), dv(N);
+    auto down = [&](std::vector<double> &dst, const double *src) {
+        return hipMemcpyAsync(dst.data(), src, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream);
+    };
+    auto fetch = [&](double *dst, const double *vec, const double *dvec) -> int {
+        BQ_HIP(down(v, vec));
+        if (pending) BQ_HIP(down(dv, dvec));
+        BQ_SYNC(c);
+        if (pending) state_apply_step(v, dv, t);
+        memcpy(dst, v.data(), sizeof(double) * N);
+        return BQ_OK;
+    };
+    const bool pgfw = s->kind == BQ_PG || s->kind == BQ_FW;
+    if (out->x) {
+        BQ_TRY(fetch(out->x, s->x, s->d));   // d: PG / FW direction, IP dx (ip_vecs)
+        out->have |= BQ_STATE_X;
+    }
+    // the gradient exists once the start-up has run (PG / FW keep it current: g + t Qd; IP and ActiveSet keep the reference's
+    // stale self.g_x: interior_point.py:180, active_set.py:157)
+    if (out->g && s->initialised) {
+        if (pgfw) {
+            BQ_TRY(fetch(out->g, s->g, s->Qd));
+        } else {
+            BQ_HIP(down(v, s->g));
+            BQ_SYNC(c);
+            memcpy(out->g, v.data(), sizeof(double) * N);
+        }
+        out->have |= BQ_STATE_G;
+    }
+    if (s->kind == BQ_IP && out->lp && out->lm && s->initialised) {
+        BQ_TRY(fetch(out->lp, s->lp, s->dlp));
+        BQ_TRY(fetch(out->lm, s->lm, s->dlm));
+        out->have |= BQ_STATE_MULT;
+    }
+    if (s->kind == BQ_AS && out->mask_l && out->mask_u && s->mL && s->mU) {
+        BQ_TRY(bq_solver_get(s, BQ_GET_MASK_L, out->mask_l));
+        BQ_TRY(bq_solver_get(s, BQ_GET_MASK_U, out->mask_u));
+        out->have |= BQ_STATE_MASKS;
+    }
+    return BQ_OK;
+}
+
+extern "C" int bq_solver_set_state(bq_solver *s, const bq_solver_snapshot *in) {
+    BQ_ARG(s && in, "NULL argument");
+    BQ_ARG(s->kind != BQ_AL, "the augmented-Lagrangian solver is resumed through x0 / dual0 of bq_al_solver_create");
+    BQ_ARG(!s->initialised, "the state can only be set before the solver's first run");
+    BQ_ARG(in->kind == -1 || in->kind == (s->as_cg ? BQ_AS_CG : s->kind), "the state was taken from another kind of solver");
+    BQ_ARG((in->have & BQ_STATE_X) && in->x, "a state holds x at least");
+    BQ_ARG(in->iter >= 0, "iter must be >= 0");
+    BQ_ARG(!(in->have & BQ_STATE_G) || in->g, "BQ_STATE_G without g");
+    BQ_ARG(!(in->have & BQ_STATE_MULT) || (s->kind == BQ_IP && in->lp && in->lm), "BQ_STATE_MULT: lp and lm, InteriorPoint only");
+    BQ_ARG(!(in->have & BQ_STATE_MASKS) || (s->kind == BQ_AS && in->mask_l && in->mask_u), "BQ_STATE_MASKS: mask_l and mask_u, ActiveSet only");
+    bq_ctx *c = s->p->ctx;
+    BQ_HIP(hipSetDevice(c->device));
+    const size_t N = (size_t)s->N;
+    delete s->resume;
+    s->resume = new bq_solver::resume_t();
+    bq_solver::resume_t *r = s->resume;
+    r->have = in->have & (BQ_STATE_G | BQ_STATE_MULT | BQ_STATE_MASKS);
+    if (r->have & BQ_STATE_G) r->g.assign(in->g, in->g + N);
+    if (r->have & BQ_STATE_MULT) {
+        r->lp.assign(in->lp, in->lp + N);
+        r->lm.assign(in->lm, in->lm + N);
+    }
+    if (r->have & BQ_STATE_MASKS) {
+        r->mL.resize(N);
+        r->mU.resize(N);
+        for (size_t i = 0; i < N; ++i) {
+            r->mL[i] = in->mask_l[i] != 0.0;
+            r->mU[i] = in->mask_u[i] != 0.0;
+            if (r->mL[i] && r->mU[i]) {
+                bq_set_error("state: index %zu is in both masks (L and U are disjoint: active_set.py:85)", i);
+                return BQ_ERR_BADARG;
+            }
+        }
+    }
+    s->host.iter = in->iter;
+    if (s->kind == BQ_FW && in->best_lb == in->best_lb) s->host.best_lb = in->best_lb;
+    BQ_HIP(hipMemcpyAsync(s->x, in->x, sizeof(double) * N, hipMemcpyHostToDevice, c->stream));
+    BQ_HIP(hipMemcpyAsync(s->sc, &s->host, sizeof(bq_scal), hipMemcpyHostToDevice, c->stream));
+    BQ_SYNC(c);
+    return BQ_OK;
+}
+#pragma clang fp contract(on)
 
 extern "C" int bq_decision_function(bq_ctx *c, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                                     const double *SV, const double *coef, double intercept, int64_t t,

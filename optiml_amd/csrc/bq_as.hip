@@ -2113,7 +2113,7 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
             hipError_t ae = hipMemcpyAsync(s->partials, &failed, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
             int arc = ae == hipSuccess ? bq_exchange_sum(ctx, s->partials, 1) : BQ_ERR_HIP;
             if (arc == BQ_OK) ae = hipMemcpyAsync(&failed, s->partials, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-            if (arc == BQ_OK && ae == hipSuccess) ae = hipStreamSynchronize(ctx->stream);
+            if (arc == BQ_OK && ae == hipSuccess) arc = bq_ctx_sync(ctx);   // behind a collective: the bounded wait
             if (arc != BQ_OK || ae != hipSuccess) {
                 as_pc_free(pc);
                 if (arc == BQ_OK) bq_set_error("agreeing on the preconditioner across ranks failed: %s", hipGetErrorString(ae));
@@ -2133,11 +2133,11 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
                                                                                  pc->Phi, pc->dinv, pc->z);
         hipError_t fe = hipGetLastError();
         if (fe == hipSuccess) fe = hipMemcpyAsync(share.data(), pc->z, sizeof(double) * p->n, hipMemcpyDeviceToHost, ctx->stream);
-        if (fe == hipSuccess) fe = hipStreamSynchronize(ctx->stream);
-        if (fe != hipSuccess) {
+        int frc = fe == hipSuccess ? bq_ctx_sync(ctx) : BQ_OK;
+        if (fe != hipSuccess || frc != BQ_OK) {
             as_pc_free(pc);
-            bq_set_error("building the preconditioner features failed: %s", hipGetErrorString(fe));
-            return BQ_ERR_HIP;
+            if (fe != hipSuccess) bq_set_error("building the preconditioner features failed: %s", hipGetErrorString(fe));
+            return fe != hipSuccess ? BQ_ERR_HIP : frc;
         }
         double lo = 1.0;
         for (double v : share) lo = std::min(lo, v);
@@ -2376,6 +2376,24 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipMalloc(&s->mU, (size_t)s->ldN));
     BQ_HIP(hipMemsetAsync(s->mL, 0, (size_t)s->ldN, ctx->stream));
     BQ_HIP(hipMemsetAsync(s->mU, 0, (size_t)s->ldN, ctx->stream));
+    // bq_solver_set_state: continue from given masks L / U (the reference starts with both empty, active_set.py:91-92).  The host
+    // vectors live until solver_first has synchronised.
+    const bool resumed = s->resume && (s->resume->have & BQ_STATE_MASKS);
+    if (resumed) {
+        BQ_HIP(hipMemcpyAsync(s->mL, s->resume->mL.data(), (size_t)s->N, hipMemcpyHostToDevice, ctx->stream));
+        BQ_HIP(hipMemcpyAsync(s->mU, s->resume->mU.data(), (size_t)s->N, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (w->f_chain && resumed) {
+        // the product-free f of ratio steps needs a point that solves its restricted system and the gradient there: neither is
+        // known for a restored point, so the first run starts at the next release (as_finish_iteration), as after a minres step
+        BQ_HIP(hipMalloc(&w->g0, sizeof(double) * s->ldN));
+        BQ_HIP(hipMemsetAsync(w->g0, 0, sizeof(double) * s->ldN, ctx->stream));
+        static const double one = 1.0;
+        BQ_HIP(hipMemcpyAsync(&s->sc->aux[0], &one, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        w->gref = nullptr;
+        w->chain_ok = false;
+        return eval_f(s, nullptr);
+    }
     if (w->f_chain) {
         // the gradient at x0 rides on the product of f(x0): with every index free, x0 + t d obeys the ratio step's identity from the
         // first iteration on (as_step_min_kernel).  Kept apart from s->g, which the reference does not touch before a release.

@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <thread>
 
 #include "bq_common.h"
@@ -38,26 +39,80 @@ struct rccl_api {
 };
 rccl_api g_rccl;
 
+// ---- where the time of a communicator's creation goes ------------------------------------------------------
+// Round 4 lost > 90 s inside Context.__init__ of a one-rank RCCL context on a cold box and the Python-level dump could not tell
+// dlopen of the 573 MB librccl.so from ncclGetUniqueId from ncclCommInitRank.  Every stage is now clocked: the durations are kept
+// (bq_comm_init_report), a stage that is still running after 5 s says so on stderr every 5 s WHILE it runs (so a hang names its
+// stage), and a stage that took more than 5 s — or any stage under BQ_DEBUG_EXCHANGE=1 — is reported when it ends.
+struct stage_log {
+    std::mutex m;
+    std::string text;   // "dlopen(librccl.so.1) 0.412 s; dlsym x8 0.000 s; ..."
+};
+stage_log g_stages;
+
+struct stage_scope {
+    const char *name;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::mutex m;
+    std::condition_variable cv;
+    bool over = false;
+    std::thread ticker;
+    explicit stage_scope(const char *nm) : name(nm) {
+        ticker = std::thread([this] {
+            std::unique_lock<std::mutex> lk(m);
+            while (!cv.wait_for(lk, std::chrono::seconds(5), [this] { return over; }))
+                fprintf(stderr, "[bcqp] RCCL start-up: still inside %s after %.0f s\n", name, seconds());
+        });
+    }
+    double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    ~stage_scope() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            over = true;
+        }
+        cv.notify_all();
+        ticker.join();
+        const double dt = seconds();
+        static const bool verbose = [] {
+            const char *e = getenv("BQ_DEBUG_EXCHANGE");
+            return e != nullptr && atoi(e) != 0;
+        }();
+        if (dt > 5.0 || verbose) fprintf(stderr, "[bcqp] RCCL start-up: %s took %.3f s\n", name, dt);
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s%s %.3f s", g_stages.text.empty() ? "" : "; ", name, dt);
+        std::lock_guard<std::mutex> lk(g_stages.m);
+        g_stages.text += buf;
+    }
+};
+
 int load_rccl() {
     if (g_rccl.handle) return BQ_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *nm : names) {
-        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    {
+        // RTLD_LAZY: the eight entry points used here are resolved by dlsym below; binding every other function of a 573 MB
+        // library at load time (RTLD_NOW) buys nothing
+        stage_scope st("dlopen(librccl.so)");
+        for (const char *nm : names) {
+            h = dlopen(nm, RTLD_LAZY | RTLD_GLOBAL);
+            if (h) break;
+        }
     }
     if (!h) {
         bq_set_error("cannot load RCCL (librccl.so): %s", dlerror());
         return BQ_ERR_RCCL;
     }
-    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
-    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
-    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
-    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
-    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
-    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
-    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    {
+        stage_scope st("dlsym x8");
+        g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+        g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+        g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
+        g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+        g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+        g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+        g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    }
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.CommCount || !g_rccl.AllGather ||
         !g_rccl.AllReduce) {
         bq_set_error("librccl.so lacks a required symbol");
@@ -125,9 +180,21 @@ extern "C" int bq_comm_unique_id(void *uid128) {
     BQ_ARG(uid128 != nullptr, "uid is NULL");
     BQ_TRY(load_rccl());
     ncclUniqueId id;
-    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    ncclResult_t r;
+    {
+        stage_scope st("ncclGetUniqueId");
+        r = g_rccl.GetUniqueId(&id);
+    }
     if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
     memcpy(uid128, &id, sizeof(id));
+    return BQ_OK;
+}
+
+// "stage seconds; stage seconds; ..." of every RCCL start-up stage this process has gone through so far (empty: RCCL never loaded)
+extern "C" int bq_comm_init_report(char *buf, size_t cap) {
+    BQ_ARG(buf != nullptr && cap > 0, "buf is NULL");
+    std::lock_guard<std::mutex> lk(g_stages.m);
+    snprintf(buf, cap, "%s", g_stages.text.c_str());
     return BQ_OK;
 }
 
@@ -136,10 +203,17 @@ int bq_comm_init_rccl(bq_ctx *ctx, const void *uid128) {
     ncclUniqueId id;
     memcpy(&id, uid128, sizeof(id));
     ncclComm_t comm = nullptr;
-    ncclResult_t r = g_rccl.CommInitRank(&comm, ctx->world, id, ctx->rank);
+    ncclResult_t r;
+    {
+        stage_scope st("ncclCommInitRank");
+        r = g_rccl.CommInitRank(&comm, ctx->world, id, ctx->rank);
+    }
     if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
     int count = 0;
-    r = g_rccl.CommCount(comm, &count);
+    {
+        stage_scope st("ncclCommCount");
+        r = g_rccl.CommCount(comm, &count);
+    }
     if (r != ncclSuccess || count != ctx->world) {
         g_rccl.CommDestroy(comm);
         if (r != ncclSuccess) return rccl_fail("ncclCommCount", r);
@@ -180,8 +254,12 @@ struct bq_watchdog {
     std::condition_variable cv;
     bool stop = false;
     double timeout_s = 0.0;
-    std::atomic<long long> wait_since_ns{0};   // 0: the host is not inside a stream wait
+    std::atomic<long long> wait_since_ns{0};   // 0: the host is not inside a wait that may sit behind a collective
     std::atomic<bool> fired{false};
+    // a collective has been enqueued since the stream was last seen empty: only then can a wait be a wait for a PEER.  A wait with
+    // nothing but this rank's own kernels ahead of it (a factorisation of a replicated solver, a preconditioner rebuild) is never
+    // stamped, however long it lasts
+    std::atomic<bool> collective_pending{false};
 };
 
 namespace {
@@ -208,17 +286,25 @@ void watchdog_loop(bq_ctx *ctx, bq_watchdog *wd) {
     }
 }
 
-struct wait_scope {   // stamps a host wait on the stream; the stamp is cleared under the watchdog's mutex
+struct wait_scope {   // stamps a host wait that has a collective ahead of it; the stamp is cleared under the watchdog's mutex
     bq_watchdog *wd;
     explicit wait_scope(bq_ctx *ctx) : wd(ctx->watchdog) {
+        if (wd && !wd->collective_pending.load()) wd = nullptr;
         if (wd) wd->wait_since_ns.store(now_ns());
     }
-    ~wait_scope() {
+    // drained: the wait that ends was for the whole stream and succeeded, so no collective is outstanding any more
+    void release(bool drained) {
         if (!wd) return;
         std::lock_guard<std::mutex> lk(wd->m);
         wd->wait_since_ns.store(0);
+        if (drained && !wd->fired.load()) wd->collective_pending.store(false);
+        wd = nullptr;
     }
+    ~wait_scope() { release(false); }
 };
+inline void note_collective(bq_ctx *ctx) {
+    if (ctx->watchdog) ctx->watchdog->collective_pending.store(true);
+}
 
 int aborted_error(bq_ctx *ctx) {
     bq_set_error("a collective did not complete within %.1f s (a peer rank stopped taking part?): the communicator of rank %d was "
@@ -234,6 +320,7 @@ int bq_ctx_sync(bq_ctx *ctx) {
     {
         wait_scope scope(ctx);
         e = hipStreamSynchronize(ctx->stream);
+        scope.release(e == hipSuccess);
     }
     if (ctx->comm_aborted) return aborted_error(ctx);
     if (e != hipSuccess) {
@@ -319,6 +406,7 @@ int bq_exchange_gather(bq_ctx *ctx, double *buf, int64_t chunk) {
     prof_scope prof(ctx);
     BQ_TRY(prof.begin());
     if (ctx->comm_kind == BQ_COMM_RCCL) {
+        note_collective(ctx);
         ncclResult_t r = g_rccl.AllGather(buf + (int64_t)ctx->rank * chunk, buf, (size_t)chunk, ncclDouble,
                                           (ncclComm_t)ctx->nccl_comm, ctx->stream);
         if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
@@ -348,6 +436,7 @@ int bq_exchange_sum(bq_ctx *ctx, double *v, int64_t count) {
     prof_scope prof(ctx);
     BQ_TRY(prof.begin());
     if (ctx->comm_kind == BQ_COMM_RCCL) {
+        note_collective(ctx);
         ncclResult_t r = g_rccl.AllReduce(v, v, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)ctx->nccl_comm, ctx->stream);
         if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
     } else {
@@ -388,7 +477,7 @@ extern "C" int bq_ctx_probe_exchange(bq_ctx *ctx, int kind, int64_t count, int r
         if (e == hipSuccess) rc = call();
         if (e == hipSuccess && rc == BQ_OK) e = hipEventRecord(ev[2 * i + 1], ctx->stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && rc == BQ_OK) rc = bq_ctx_sync(ctx);   // behind `reps` collectives: the bounded wait
     double sum = 0.0, mn = 1e300;
     for (int i = 0; e == hipSuccess && rc == BQ_OK && i < reps; ++i) {
         float ms = 0.f;

@@ -217,6 +217,13 @@ struct bq_solver {
     bq_al_state *al = nullptr;
     int *flag_host = nullptr;          // pinned copy of sc->done + its event (lagged polling in bq_solver_run)
     hipEvent_t flag_event = nullptr;
+    // bq_solver_set_state: what the start-up must take instead of forming it (x itself is uploaded at once)
+    struct resume_t {
+        int have = 0;                                 // BQ_STATE_* bits
+        std::vector<double> g, lp, lm;
+        std::vector<unsigned char> mL, mU;
+    };
+    resume_t *resume = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------

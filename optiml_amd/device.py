@@ -166,11 +166,14 @@ class Context:
 
     def comm_info(self):
         """{'kind': 'none'|'rccl'|'callback'|'share', 'rccl_ranks': ncclCommCount of the live communicator (0 without RCCL),
-        'sym_exchange': 'gather'|'allreduce'}"""
+        'sym_exchange': 'gather'|'allreduce', 'rccl_init_stages': 'dlopen(librccl.so) 0.4 s; ...'}"""
         kind, ranks, ar = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.check(self._lib.bq_ctx_comm_info(self.handle, C.byref(kind), C.byref(ranks), C.byref(ar)))
+        buf = C.create_string_buffer(1024)
+        _lib.check(self._lib.bq_comm_init_report(buf, len(buf)))
         return {'kind': ('none', 'rccl', 'callback', 'share')[kind.value], 'rccl_ranks': ranks.value,
-                'sym_exchange': 'allreduce' if ar.value else 'gather'}
+                'sym_exchange': 'allreduce' if ar.value else 'gather',
+                'rccl_init_stages': buf.value.decode()}   # where RCCL's start-up time went in this process ('' without RCCL)
 
     def set_sym_exchange(self, mode):
         """'gather' or 'allreduce' for the products that follow (every rank must switch at the same point)."""
@@ -197,9 +200,10 @@ class Context:
         """Abort the RCCL communicator when a wait on the stream lasts longer than `seconds` (0: never)."""
         _lib.check(self._lib.bq_ctx_set_collective_timeout(self.handle, float(seconds)))
 
-    def probe_stall(self, milliseconds):
-        """Occupy the stream for `milliseconds` and wait for it through the bounded wait (the watchdog's one-GPU test)."""
-        _lib.check(self._lib.bq_ctx_probe_stall(self.handle, float(milliseconds)))
+    def probe_stall(self, milliseconds, behind_collective=False):
+        """Occupy the stream for `milliseconds` and wait for it through the bounded wait; behind_collective: with the context's
+        collective enqueued behind the occupation, i.e. a peer that is that late (the watchdog's one-GPU test)."""
+        _lib.check(self._lib.bq_ctx_probe_stall(self.handle, float(milliseconds), int(bool(behind_collective))))
 
     def probe_exchange(self, kind, count, reps=50):
         """(mean_us, min_us) of this context's closing collective timed on its own: kind 'gather' = the in-place all-gather of

@@ -58,6 +58,38 @@ class _DeviceSolver:
         _lib.check(self._lib.bq_solver_get(self._h, what, _lib.ptr(out)))
         return out
 
+    _STATE_VECS = (('x', _lib.STATE_X), ('g', _lib.STATE_G), ('lp', _lib.STATE_MULT), ('lm', _lib.STATE_MULT),
+                   ('mask_l', _lib.STATE_MASKS), ('mask_u', _lib.STATE_MASKS))
+
+    def get_state(self):
+        """bq_solver_get_state: what the reference's loop holds at the top of the next iteration, as a dict of host arrays and
+        scalars (`kind, iter, f, best_lb, x, g` + `lp, lm` for InteriorPoint, boolean `mask_l, mask_u` for ActiveSet)."""
+        st = _lib.SolverState()
+        bufs = {name: np.empty(self.N) for name, _ in self._STATE_VECS}
+        for name, buf in bufs.items():
+            setattr(st, name, _lib.ptr(buf))
+        _lib.check(self._lib.bq_solver_get_state(self._h, C.byref(st)))
+        out = {'kind': int(st.kind), 'iter': int(st.iter), 'f': float(st.f), 'best_lb': float(st.best_lb)}
+        for name, bit in self._STATE_VECS:
+            if st.have & bit:
+                out[name] = bufs[name] != 0.0 if name.startswith('mask') else bufs[name]
+        return out
+
+    def set_state(self, state):
+        """bq_solver_set_state: continue from a dict made by get_state (or by hand: `x` is required, the rest is formed as at a start
+        point when absent).  Only before the first run."""
+        st = _lib.SolverState()
+        st.iter, st.kind = int(state.get('iter', 0)), int(state.get('kind', -1))
+        st.f, st.best_lb = float(state.get('f', np.nan)), float(state.get('best_lb', np.nan))
+        keep = []
+        for name, bit in self._STATE_VECS:
+            if state.get(name) is not None:
+                buf = _lib.as_f64(np.asarray(state[name], dtype=float), self.N, name)
+                keep.append(buf)
+                setattr(st, name, _lib.ptr(buf))
+                st.have |= bit
+        _lib.check(self._lib.bq_solver_set_state(self._h, C.byref(st)))
+
     def set_inner(self, rtol, max_iter):
         _lib.check(self._lib.bq_solver_set_inner(self._h, float(rtol), int(max_iter)))
 
@@ -120,11 +152,36 @@ class BoxConstrainedQuadraticOptimizer(Optimizer, ABC):
             return getattr(self._callback, '_bq_needs_state', True)
         return False
 
+    # -- checkpoint / resume: the reference can only be restarted from `x=` (constrained/_base.py:61-65) and loses
+    #    InteriorPoint's multipliers (interior_point.py:181-186) and ActiveSet's masks (active_set.py:91-92) -----------------
+    def get_state(self):
+        """The state the last `minimize()` stopped in (max_iter, a callback's StopIteration), to be handed to `set_state` of a
+        new optimizer on the same problem: a dict of NumPy arrays and scalars (picklable).  It describes the top of iteration
+        `state['iter']`: the step decided in the last iteration is applied."""
+        if getattr(self, '_state', None) is None:
+            raise RuntimeError('no state: minimize() has not run')
+        return dict(self._state)
+
+    def set_state(self, state):
+        """Continue where another run stopped: the next `minimize()` starts from `state` (iteration counter included, so `max_iter`
+        keeps its meaning) instead of from `x`."""
+        if 'x' not in state:
+            raise ValueError('a state holds x at least')
+        if state.get('kind', self._kind) != self._kind:
+            raise ValueError('the state was taken from another kind of solver')
+        self._resume = dict(state)
+        self.x = np.array(state['x'], dtype=float)
+        self.iter = int(state.get('iter', 0))
+        return self
+
     def minimize(self):
         dev = self.f.device_problem()
         solver = _DeviceSolver(dev, self._kind, self.lb, self.ub, self.x, self.eps, self.max_iter, self._solver_t())
         self._solver = solver
         self._configure(solver)
+        if getattr(self, '_resume', None) is not None:
+            solver.set_state(self._resume)
+            self._resume = None
         if self.verbose:
             print(self._header, end='')
         step_mode = self._needs_state()
@@ -156,6 +213,7 @@ class BoxConstrainedQuadraticOptimizer(Optimizer, ABC):
                 # value of the last record
                 self.f_x = solver.state()[2]
             self._finalize(solver)
+            self._state = solver.get_state()
         finally:
             solver.close()
             self._solver = None

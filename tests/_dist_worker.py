@@ -159,9 +159,12 @@ def gpu_c4(outdir):
 
 
 def gpu_watchdog(outdir):
-    """One rank, an RCCL communicator of its own, collectives bounded to 0.4 s: short waits pass, a 1.5 s occupation of the stream
-    (bq_ctx_probe_stall: a lane spinning on the wall clock, it ends by itself) trips the watchdog — the communicator is aborted,
-    the call raises ERR_RCCL, later collectives fail at once, closing the context does not hang."""
+    """One rank, an RCCL communicator of its own, collectives bounded to 0.4 s.  Short waits pass; so does a 1.2 s wait with only
+    this rank's own work ahead of it (a long factorisation must never cost the communicator: ADVICE r4); a collective that sits
+    behind a 1.5 s occupation of the stream (bq_ctx_probe_stall(behind_collective): a lane spinning on the wall clock, it ends by
+    itself — what a late peer looks like) trips the watchdog: the communicator is aborted, the call raises ERR_RCCL, later
+    collectives fail at once, closing the context does not hang.  NOT exercised on this one-GPU box: ncclCommAbort ending an RCCL
+    kernel that is really spinning on a peer (the collective here completes by itself once the occupation ends)."""
     import time
     from optiml_amd import _lib, device
     from optiml_amd.datasets import make_blobs
@@ -174,11 +177,15 @@ def gpu_watchdog(outdir):
     quad = KernelQuadratic(X, -np.ones(700), 'svc', gaussian, y=y)
     v = np.random.RandomState(2).standard_normal(700)
     res['matvec'] = quad.device_problem().matvec(v)            # a product with its (one-rank) all-gather: no false alarm
-    ctx.probe_stall(100.0)                                      # a wait shorter than the limit: nothing happens
+    ctx.probe_stall(100.0, behind_collective=True)              # a peer that is late by less than the limit: nothing happens
     res['matvec_again'] = quad.device_problem().matvec(v)
     t0 = time.perf_counter()
+    ctx.probe_stall(1200.0)                                     # three times the limit, but no collective is outstanding
+    res['own_work_s'] = np.array(time.perf_counter() - t0)
+    res['matvec_third'] = quad.device_problem().matvec(v)
+    t0 = time.perf_counter()
     try:
-        ctx.probe_stall(1500.0)
+        ctx.probe_stall(1500.0, behind_collective=True)
         res['stall_error'] = np.array(0)
     except _lib.BcqpError as err:
         res['stall_error'], res['stall_msg'] = np.array(err.code), np.array(str(err))

@@ -291,18 +291,20 @@ def test_row_cut_strips_are_bit_identical(tmp_path, n):
 @pytest.mark.gpu
 def test_collective_watchdog_aborts_a_wait_that_outlasts_the_timeout(tmp_path):
     """bq_ctx_set_collective_timeout on a one-rank RCCL context (a child process: an aborted communicator is the end of its
-    context): normal products and a short occupation of the stream pass; a 1.5 s occupation against a 0.4 s limit makes the
-    watchdog abort the communicator — ERR_RCCL from the call in progress within about its own length, ERR_RCCL at once from
-    the next collective, and closing the context returns."""
+    context): normal products, a collective that is late by less than the limit and a LONG wait for this rank's own work all pass;
+    a collective behind a 1.5 s occupation against a 0.4 s limit makes the watchdog abort the communicator — ERR_RCCL from the call
+    in progress, ERR_RCCL from the next collective, and closing the context returns.  Only error codes and generous upper bounds
+    are asserted (the child also initialises HIP and RCCL on a shared box: ADVICE r4); ncclCommAbort ending a collective that is
+    really waiting for a peer cannot be exercised with one GPU."""
     from optiml_amd import _lib
-    # (generous limit: the first dlopen of the system's librccl.so on a cold box has been seen to take more than 90 s)
     got = _launch('gpu-watchdog', 1, tmp_path, timeout=400)[0]
     assert int(got['rccl_ranks']) == 1
-    assert np.array_equal(got['matvec'], got['matvec_again'])
+    assert np.array_equal(got['matvec'], got['matvec_again']) and np.array_equal(got['matvec'], got['matvec_third'])
+    assert float(got['own_work_s']) >= 1.0                       # the whole occupation was waited for, and nothing fired
     assert int(got['stall_error']) == _lib.ERR_RCCL and 'did not complete within' in str(got['stall_msg'])
-    assert 1.0 < float(got['stall_s']) < 4.0
-    assert int(got['after_error']) == _lib.ERR_RCCL and float(got['after_s']) < 1.0
-    assert int(got['rccl_ranks_after']) == 0 and float(got['close_s']) < 5.0
+    assert float(got['stall_s']) < 0.4 + 1.5 + 10.0              # the limit + the occupation's own length + slack: it did not hang
+    assert int(got['after_error']) == _lib.ERR_RCCL and float(got['after_s']) < 30.0
+    assert int(got['rccl_ranks_after']) == 0 and float(got['close_s']) < 30.0
 
 
 @pytest.mark.gpu
