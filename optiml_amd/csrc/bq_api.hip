@@ -348,8 +348,6 @@ static int problem_alloc_common(bq_problem *p, const double *q_host) {
     const int64_t slen = bq_round_up(std::max(p->blk * c->world, p->nb * BQ_SYM_TILE), BQ_PAD);
     if (p->symmetric) {
         if (!p->streamed) BQ_HIP(hipMalloc(&p->slab, sizeof(double) * p->nb * p->nb * BQ_SYM_TILE));   // streamed: its own scratch
-        if (!p->streamed && bq_symv_wants_split(c, p->I0, p->I1))   // a short grid: its strips are cut by rows (bq_symv.hip)
-            BQ_HIP(hipMalloc(&p->slab2, sizeof(double) * p->nb * p->nb * 2 * BQ_SYM_TILE));
         if (c->comm_kind != BQ_COMM_NONE) {   // the gathered segment vectors of every rank (also a one-rank communicator)
             const size_t gl = sizeof(double) * (size_t)c->world * p->seg_cmax * p->nb * BQ_SYM_TILE;
             BQ_HIP(hipMalloc(&p->gath, gl));
@@ -457,7 +455,7 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
     }
     p->panel = nullptr;
     for (void *ptr : {(void *)p->panel_alloc, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
-                      (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab, (void *)p->slab2, (void *)p->gath})
+                      (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab, (void *)p->gath})
         if (ptr) hipFree(ptr);
     bq_stream_free(p->stream_img);
     bq_ctx *c = p->ctx;
@@ -563,10 +561,10 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
     BQ_HIP(hipEventCreate(&sc.e0));
     BQ_HIP(hipEventCreate(&sc.e1));
     auto time_on = [&](void *panel, double *ms_out) -> int {
-        int rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->slab2, p->s, nullptr);   // warm
+        int rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr);   // warm
         hipEventRecord(sc.e0, c->stream);
         for (int i = 0; rc == BQ_OK && i < 4; ++i)
-            rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->slab2, p->s, nullptr);
+            rc = bq_launch_symv(c, panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr);
         hipEventRecord(sc.e1, c->stream);
         hipError_t he = hipEventSynchronize(sc.e1);
         float ms = 0.f;
@@ -816,7 +814,7 @@ extern "C" int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms) 
         if (p->streamed)
             return bq_stream_sym_product(c, p->stream_img, p->n, p->nb, tab, p->kernel, p->gamma, p->coef0, p->degree, p->add_one, p->w,
                                          p->s, 0, nullptr);
-        return p->symmetric ? bq_launch_symv(c, p->panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->slab2, p->s, nullptr)
+        return p->symmetric ? bq_launch_symv(c, p->panel, p->storage, p->add_one, p->nb, tab, p->w, p->slab, p->s, nullptr)
                             : bq_launch_gemv(c, p->panel, p->storage, p->add_one, p->r1 - p->r0, p->ld, p->w,
                                              p->s + p->r0, nullptr);
     };

@@ -147,7 +147,6 @@ struct bq_problem {
     void *stream_img = nullptr;
     int64_t I0 = 0, I1 = 0, nb = 0;
     double *slab = nullptr;   // nb x nb x 256 partial products
-    double *slab2 = nullptr;  // nb x nb x 2 x 256: second and third column-part entries of row-cut strips (short grids only)
     // canonical segments of the tile rows (bq_sym_segments): this rank owns segments [seg_lo, seg_hi) of seg_count; the
     // per-segment partial products are gathered into gath[world][seg_cmax][nb*256] and summed in segment order
     int seg_count = 0, seg_lo = 0, seg_hi = 0, seg_cmax = 0;
@@ -275,14 +274,12 @@ struct bq_seg_table {
 };
 // tiles of the segments [tab.lo, tab.hi) + their sum in segment order -> out (nb*256)
 struct bq_epilogue;   // bq_epilogue.h: the PG / FW step fused into the kernel that finishes the product (null: none)
-// slab2 (may be null): the second slab of row-cut strips (short grids: bq_symv_wants_split; nb x nb x 2 x 256 doubles)
 int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                   const double *w, double *slab, double *slab2, double *out, const int *done, const bq_epilogue *epi = nullptr);
-bool bq_symv_wants_split(const bq_ctx *ctx, int64_t I0, int64_t I1);
+                   const double *w, double *slab, double *out, const int *done, const bq_epilogue *epi = nullptr);
 // the same with the segment partials written to `gath` (slots of this rank) instead of one summed vector; and the closing
 // sum of all S gathered segment vectors -> out
 int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                            const double *w, double *slab, double *slab2, double *gath, const int *done);
+                            const double *w, double *slab, double *gath, const int *done);
 int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done,
                           const bq_epilogue *epi = nullptr);
 void bq_sym_seg_table(const bq_problem *p, bq_seg_table *tab);

@@ -92,7 +92,6 @@ struct gram_params {
     int64_t ld;              // output pitch (elements)
     int64_t ntiles;          // tiles of this launch (XCD-aware remap bound)
     int rect_rb, rect_sb;    // > 0: 1-D grid walked in XCD-local rectangles of GRAM_RECT_R tile rows x GRAM_RECT_S strips
-    int stagger_mode, stagger_unit;   // start-up phase shift of the first round of workgroups (gram_stagger)
     int tiles_m, strips;
 };
 
@@ -106,28 +105,12 @@ constexpr int GRAM_STRIP = 8;
 // column tile streams through once for 16 consumers, instead of every workgroup re-fetching its row slice for each of its
 // 8 column tiles (round 2: 44 GB of L2 fills per n = 100 000 build for a 0.1 GB operand).  Speed only: any placement is correct.
 constexpr int GRAM_RECT_R = 16, GRAM_RECT_S = 4;
-// Every workgroup of the build does the same thing for the same time: 512 MFMAs per wave, then an epilogue of 64 kernel-map
-// evaluations and 32 stores per lane during which its matrix pipe idles.  Launched together, the two workgroups of a CU — and
-// all 512 of the chip — stay in lockstep: the pipes idle and the stores hit HBM in bursts, chip-wide (VERDICT r3 item 4:
-// 16.3 ms of MFMA + 8 ms of stores that do not overlap).  gram_stagger delays the FIRST round of workgroups (the 2 x CUs that
-// start at t = 0; every later workgroup inherits the phase of the one it replaces) by a phase in {0 .. phases-1} x unit so that
-// co-resident workgroups alternate: one's epilogue under the other's MFMAs.  mode: which bits of the XCD-local slot index pick
-// the phase (the dispatcher's CU assignment is not architected: measured, profiles/r04/gram_stagger.txt).
-__device__ __forceinline__ void gram_stagger(int mode, int unit, int64_t first_round) {
-    if (mode == 0 || (int64_t)blockIdx.x >= first_round) return;
-    const int slot = (int)(blockIdx.x >> 3);   // index inside the XCD (workgroups are dealt round-robin over the 8 XCDs)
-    int phase = 0;
-    if (mode == 1) phase = slot & 1;                    // neighbours in the XCD's dispatch order alternate
-    else if (mode == 2) phase = (slot >> 5) & 1;        // first 32 slots against the second 32 (one per CU, then the second)
-    else if (mode == 3) phase = (slot ^ (slot >> 5)) & 1;
-    else if (mode == 4) phase = slot & 3;               // four phases of a quarter tile
-    for (int i = 0; i < phase * unit; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 clocks ~ 2 us
-}
-
+// (Round 4 tried to break the lockstep of the co-resident workgroups — 512 MFMAs per wave, then 64 map evaluations and 32 stores per
+// lane with the matrix pipe idle, chip-wide in phase — by delaying the first round of workgroups by a phase: five modes x three
+// units measured 25.7 - 26.4 ms against 25.7 - 26.2 ms without, profiles/r04/gram_stagger.txt.  No effect; removed in round 5.)
 template <typename T, int KIND>
 __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    gram_stagger(P.stagger_mode, P.stagger_unit, 512);
     int64_t bx = blockIdx.x, by = blockIdx.y;
     if (P.rect_rb > 0) {
         const int64_t b = blockIdx.x;
@@ -305,7 +288,6 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
                     int storage, int64_t ld, bool lower_only = false) {
     gram_params P;
     P.rect_rb = P.rect_sb = P.tiles_m = P.strips = 0;
-    P.stagger_mode = P.stagger_unit = 0;
     P.lower_only = lower_only ? 1 : 0;
     P.At = A.At;
     P.Bt = B.At;
@@ -355,12 +337,6 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
             P.rect_sb = (int)((strips + GRAM_RECT_S - 1) / GRAM_RECT_S);
             const int64_t nrect = (int64_t)P.rect_rb * P.rect_sb;
             grid = dim3((unsigned)(((nrect + 7) / 8) * 8 * GRAM_RECT_R * GRAM_RECT_S), 1);
-        }
-        {
-            static const int st_mode = [] { const char *e = getenv("BQ_GRAM_STAGGER"); return e ? atoi(e) : 0; }();
-            static const int st_unit = [] { const char *e = getenv("BQ_GRAM_STAGGER_UNIT"); return e ? atoi(e) : 10; }();
-            P.stagger_mode = grid.y == 1 ? st_mode : 0;   // the 1-D (rectangle-ordered) grid only
-            P.stagger_unit = st_unit;
         }
         // one instantiation per kernel map (all of exp / pow / tanh inlined in the 64-element epilogue costs registers)
 #define BQ_GRAM_LAUNCH(KIND)                                                                                           \
@@ -776,7 +752,6 @@ int bq_stream_sym_product(bq_ctx *ctx, void *h, int64_t n, int64_t nb, const bq_
     P.ld = 0;
     P.ntiles = 0;
     P.rect_rb = P.rect_sb = P.tiles_m = P.strips = 0;
-    P.stagger_mode = P.stagger_unit = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1));
     int *skip = nullptr, skip_seq = 0;

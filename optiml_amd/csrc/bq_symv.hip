@@ -59,27 +59,21 @@ __device__ __host__ __forceinline__ int64_t strips_before(int64_t I) {  // sum_{
     return JG * qq * (qq + 1) / 2 + rr * (qq + 1);
 }
 
-// NW = waves per workgroup.  4: one workgroup streams all 256 rows of a strip.  2 (short grids, launch_any): the strip is cut by
-// ROWS into two workgroups of 128 threads — rows [0, 128) and [128, 256) — so that a grid of a few hundred to a few thousand strips
-// fills the chip's workgroup slots twice as finely (a 1/8 share of n = 100 000 is 1 200 strips of 4 MB for 512 slots).  A wave still
-// owns the SAME 64 rows as in the uncut kernel (wave `ow` = 2 h + wv), so the row parts are unchanged; the column part of a tile is
-// ((P0 + P1) + P2) + P3 over the four waves' partial sums: the first half writes E0 = P0 + P1 where the uncut kernel writes the
-// whole sum, the second half writes E1 = P2 and E2 = P3 into a second slab, and the reduction adds (E0 + E1) + E2 — the same
-// association, the same bits.
-template <typename T, bool ADD_ONE, int JG, int SR, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void symv_tiles_kernel(const T *__restrict__ panel, int64_t ld, int64_t I0,
-                                                            int64_t nb, const double *__restrict__ w,
-                                                            double *__restrict__ slab, double *__restrict__ slab2,
-                                                            const int *__restrict__ done,
-                                                            int *__restrict__ skip, int skip_seq) {
+// One workgroup of four waves streams all 256 rows of a strip: wave `wv` owns rows [64 wv, 64 wv + 64).
+// (Round 4 also carried a row-cut variant — two 128-thread workgroups per strip with a three-entry column slab — for short grids: built,
+// bit-identical, measured no faster (1/8 shares 0.796 - 0.885 ms cut against 0.801 - 0.832 ms uncut, profiles/r04/symv_row_cut_strips.txt)
+// and removed in round 5 together with the <4,4> <4,8> <2,8> <2,4> tuning variants: HISTORY.md.)
+template <typename T, bool ADD_ONE, int JG, int SR>
+__global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict__ panel, int64_t I0, int64_t nb,
+                                                          const double *__restrict__ w, double *__restrict__ slab,
+                                                          const int *__restrict__ done, int *__restrict__ skip, int skip_seq) {
     if (done != nullptr && *done) {
         if (skip != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *skip = skip_seq;   // bq_prof_skip_arg: "this launch was no product"
         return;
     }
-    __shared__ double colred[NW][ST];
+    __shared__ double colred[4][ST];
     // decode (I, g) from the linear strip index
-    const int half = NW == 4 ? 0 : (int)(blockIdx.x & 1);
-    const int64_t t = (int64_t)(NW == 4 ? blockIdx.x : blockIdx.x >> 1) + strips_before<JG>(I0);
+    const int64_t t = (int64_t)blockIdx.x + strips_before<JG>(I0);
     int64_t I = (int64_t)sqrt(2.0 * (double)JG * (double)t);
     if (I >= nb) I = nb - 1;
     while (I > 0 && strips_before<JG>(I) > t) --I;
@@ -89,12 +83,10 @@ __global__ __launch_bounds__(NW * 64, 2) void symv_tiles_kernel(const T *__restr
     const int nj = (int)((J0 + JG <= I + 1) ? JG : (I + 1 - J0));  // tiles in this strip (J <= I)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ow = NW == 4 ? wv : 2 * half + wv;   // which 64 rows of the strip: the wave index of the uncut kernel
     // packed symmetric layout: tile row I has pitch (I+1)*256 and starts at bq_sym_off(I) - bq_sym_off(I0)
     const int64_t pitch = bq_sym_pitch(I);
-    const T *rows = panel + (bq_sym_off(I) - bq_sym_off(I0)) + (int64_t)(ow * 64) * pitch + J0 * ST;
-    (void)ld;
-    const double *wI = w + I * ST + ow * 64;
+    const T *rows = panel + (bq_sym_off(I) - bq_sym_off(I0)) + (int64_t)(wv * 64) * pitch + J0 * ST;
+    const double *wI = w + I * ST + wv * 64;
     const int c0 = tile_ld<T>::c0(lane), c1 = tile_ld<T>::c1(lane);
     d2_t wj0[JG], wj1[JG];
     double ca[JG][4];
@@ -105,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, 2) void symv_tiles_kernel(const T *__restr
         wj1[j] = *reinterpret_cast<const d2_t *>(wJ + c1);
         ca[j][0] = ca[j][1] = ca[j][2] = ca[j][3] = 0.0;
     }
-    double *rowout = slab + (I * nb + J0) * ST + ow * 64;
+    double *rowout = slab + (I * nb + J0) * ST + wv * 64;
     const bool b5 = lane & 32, b4 = lane & 16;
 
 #pragma unroll 1
@@ -199,18 +191,7 @@ __global__ __launch_bounds__(NW * 64, 2) void symv_tiles_kernel(const T *__restr
             colred[wv][c1 + 1] = ca[j][3];
             __syncthreads();
             const int64_t entry = (J0 + j) * nb + I;
-            if constexpr (NW == 4) {
-                slab[entry * ST + tid] = ((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid];
-            } else if (half == 0) {   // E0 = P0 + P1
-                slab[entry * ST + tid] = colred[0][tid] + colred[1][tid];
-                slab[entry * ST + tid + 128] = colred[0][tid + 128] + colred[1][tid + 128];
-            } else {                  // E1 = P2, E2 = P3
-                double *e1 = slab2 + (entry * 2) * ST, *e2 = e1 + ST;
-                e1[tid] = colred[0][tid];
-                e1[tid + 128] = colred[0][tid + 128];
-                e2[tid] = colred[1][tid];
-                e2[tid + 128] = colred[1][tid + 128];
-            }
+            slab[entry * ST + tid] = ((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid];
         }
     }
 }
@@ -220,15 +201,8 @@ __global__ __launch_bounds__(NW * 64, 2) void symv_tiles_kernel(const T *__restr
 //   col parts at every b > a inside [c0, c1).
 // 1024 threads: thread (r, q) sums every 4th entry of that fixed entry list (two independent chains each for load-level
 // parallelism); the four partial sums are combined in the fixed order q = 0..3.  Every thread returns the combined value.
-// p2 (null: uncut strips): the second slab of row-cut strips; a column part is then (E0 + E1) + E2 (symv_tiles_kernel, NW = 2)
 template <int JG>
-__device__ __forceinline__ double seg_thread_sum(const double *__restrict__ p, const double *__restrict__ p2, int64_t a, int64_t c0,
-                                                 int64_t c1, int q) {
-    auto col = [&](int64_t b) -> double {
-        const double e0 = p[b * ST];
-        if (p2 == nullptr) return e0;
-        return (e0 + p2[(b * 2) * ST]) + p2[(b * 2 + 1) * ST];
-    };
+__device__ __forceinline__ double seg_thread_sum(const double *__restrict__ p, int64_t a, int64_t c0, int64_t c1, int q) {
     double s0 = 0.0, s1 = 0.0;
     int64_t e = 0;   // running index over the entry list: row parts (b = 0, JG, 2JG, ... <= a) then col parts (b > a)
     if (a >= c0 && a < c1) {
@@ -244,17 +218,17 @@ __device__ __forceinline__ double seg_thread_sum(const double *__restrict__ p, c
     // keep the q-assignment a function of the position in the whole list (row parts first)
     const int64_t shift = (4 - (e & 3)) & 3;
     for (int64_t k = (q + shift) & 3; k < ncol; k += 8) {
-        s0 += col(bs + k);
-        if (k + 4 < ncol) s1 += col(bs + k + 4);
+        s0 += p[(bs + k) * ST];
+        if (k + 4 < ncol) s1 += p[(bs + k + 4) * ST];
     }
     return s0 + s1;   // this thread's share (every 4th entry, q = its phase) of the segment's entry list
 }
 
 // the four phases of a segment's sum combined in the fixed order q = 0..3; every thread returns the combined value
 template <int JG>
-__device__ __forceinline__ double seg_partial(const double *__restrict__ p, const double *__restrict__ p2, int64_t a, int64_t c0,
-                                              int64_t c1, int q, int r, double (*part)[ST]) {
-    part[q][r] = seg_thread_sum<JG>(p, p2, a, c0, c1, q);
+__device__ __forceinline__ double seg_partial(const double *__restrict__ p, int64_t a, int64_t c0, int64_t c1, int q, int r,
+                                              double (*part)[ST]) {
+    part[q][r] = seg_thread_sum<JG>(p, a, c0, c1, q);
     __syncthreads();
     const double v = ((part[0][r] + part[1][r]) + part[2][r]) + part[3][r];
     __syncthreads();
@@ -265,9 +239,8 @@ __device__ __forceinline__ double seg_partial(const double *__restrict__ p, cons
 // the product: the same association whether the segments were summed here (one rank) or gathered from their owners
 // EPI: the PG / FW epilogue of bq_epilogue.h goes on from the summed product (out is still written: other consumers read p->s)
 template <int JG, bool EPI>
-__global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ slab, const double *__restrict__ slab2,
-                                                           int64_t nb, bq_seg_table tab, double *__restrict__ out,
-                                                           const int *__restrict__ done, bq_epilogue epi) {
+__global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, bq_seg_table tab,
+                                                           double *__restrict__ out, const int *__restrict__ done, bq_epilogue epi) {
     if (done != nullptr && *done) return;
     // the phase sums of up to eight segments (all of them on one rank) meet in LDS in ONE round of barriers — one round per segment
     // made sixteen barriers of 1 024 threads, a third of this kernel's length; the association per segment and the segment order
@@ -276,11 +249,10 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
     const int64_t a = blockIdx.x;
     const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
     const double *p = slab + a * nb * ST + r;
-    const double *p2 = slab2 ? slab2 + a * nb * 2 * ST + r : nullptr;
     double acc = 0.0;
     for (int s0 = tab.lo; s0 < tab.hi; s0 += BQ_SYM_SEG) {
         const int ns = tab.hi - s0 < BQ_SYM_SEG ? tab.hi - s0 : BQ_SYM_SEG;
-        for (int k = 0; k < ns; ++k) part[k][q][r] = seg_thread_sum<JG>(p, p2, a, tab.cut[s0 + k], tab.cut[s0 + k + 1], q);
+        for (int k = 0; k < ns; ++k) part[k][q][r] = seg_thread_sum<JG>(p, a, tab.cut[s0 + k], tab.cut[s0 + k + 1], q);
         __syncthreads();
         if (q == 0)
             for (int k = 0; k < ns; ++k) acc += ((part[k][0][r] + part[k][1][r]) + part[k][2][r]) + part[k][3][r];
@@ -295,16 +267,14 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
 
 // the per-segment partial vectors of this rank's segments, each to its slot of the gathered buffer
 template <int JG>
-__global__ __launch_bounds__(1024) void symv_reduce_seg_kernel(const double *__restrict__ slab, const double *__restrict__ slab2,
-                                                               int64_t nb, bq_seg_table tab, double *__restrict__ gath,
-                                                               const int *__restrict__ done) {
+__global__ __launch_bounds__(1024) void symv_reduce_seg_kernel(const double *__restrict__ slab, int64_t nb, bq_seg_table tab,
+                                                               double *__restrict__ gath, const int *__restrict__ done) {
     if (done != nullptr && *done) return;
     __shared__ double part[4][ST];
     const int64_t a = blockIdx.x;
     const int s = tab.lo + (int)blockIdx.y;
     const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
-    const double v = seg_partial<JG>(slab + a * nb * ST + r, slab2 ? slab2 + a * nb * 2 * ST + r : nullptr, a, tab.cut[s],
-                                     tab.cut[s + 1], q, r, part);
+    const double v = seg_partial<JG>(slab + a * nb * ST + r, a, tab.cut[s], tab.cut[s + 1], q, r, part);
     if (q == 0) gath[((int64_t)tab.slot[s] * nb + a) * ST + r] = v;
 }
 
@@ -333,15 +303,14 @@ static hipError_t launch_timed(bq_ctx *ctx, bool ext, hipEvent_t e0, hipEvent_t 
     return hipGetLastError();
 }
 
-template <int JG, int SR, int NW>
+template <int JG, int SR>
 static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
-                        const double *w, double *slab, double *slab2, const int *done) {
+                        const double *w, double *slab, const int *done) {
     static const bool bracket = [] {
         const char *e = getenv("BQ_PROF_BRACKET");
         return e && atoi(e) != 0;
     }();
     const int64_t nstrips = strips_before<JG>(I1) - strips_before<JG>(I0);
-    const int64_t ld = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1, bracket));
     if (nstrips <= 0) {
@@ -354,18 +323,18 @@ static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_on
     int *skip = nullptr, skip_seq = 0;
     if (done != nullptr) bq_prof_skip_arg(ctx, e0, &skip, &skip_seq);
     const bool ext = !bracket && e0 != nullptr;
-    const dim3 grid((unsigned)(NW == 4 ? nstrips : 2 * nstrips)), block(NW * 64);
+    const dim3 grid((unsigned)nstrips), block(256);
     hipError_t err;
     if (storage == BQ_F64) {
         if (add_one)
-            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<double, true, JG, SR, NW>, grid, block, (const double *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<double, true, JG, SR>, grid, block, (const double *)panel, I0, nb, w, slab, done, skip, skip_seq);
         else
-            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<double, false, JG, SR, NW>, grid, block, (const double *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<double, false, JG, SR>, grid, block, (const double *)panel, I0, nb, w, slab, done, skip, skip_seq);
     } else {
         if (add_one)
-            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<float, true, JG, SR, NW>, grid, block, (const float *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<float, true, JG, SR>, grid, block, (const float *)panel, I0, nb, w, slab, done, skip, skip_seq);
         else
-            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<float, false, JG, SR, NW>, grid, block, (const float *)panel, ld, I0, nb, w, slab, slab2, done, skip, skip_seq);
+            err = launch_timed(ctx, ext, e0, e1, symv_tiles_kernel<float, false, JG, SR>, grid, block, (const float *)panel, I0, nb, w, slab, done, skip, skip_seq);
     }
     if (err != hipSuccess) {
         bq_prof_drop(ctx, e0, e1);
@@ -376,88 +345,50 @@ static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_on
 }
 
 // mode 0: tiles + the sum over this launch's segments -> out (nb*256);  mode 1: tiles + one vector per segment -> gath slots
-// split: the strips are cut by rows into two workgroups each (NW = 2) and the reduction reads the three-entry column parts
-template <int JG, int SR>
+template <int SR>
 static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                          const double *w, double *slab, double *slab2, bool split, double *out, int mode, const int *done,
-                          const bq_epilogue *epi) {
-    if (split)
-        BQ_TRY((launch_tiles<JG, SR, 2>(ctx, panel, storage, add_one, tab.cut[tab.lo], tab.cut[tab.hi], nb, w, slab, slab2, done)));
-    else
-        BQ_TRY((launch_tiles<JG, SR, 4>(ctx, panel, storage, add_one, tab.cut[tab.lo], tab.cut[tab.hi], nb, w, slab, slab2, done)));
-    const double *s2 = split ? slab2 : nullptr;
+                          const double *w, double *slab, double *out, int mode, const int *done, const bq_epilogue *epi) {
+    constexpr int JG = JG_DEFAULT;
+    BQ_TRY((launch_tiles<JG, SR>(ctx, panel, storage, add_one, tab.cut[tab.lo], tab.cut[tab.hi], nb, w, slab, done)));
     if (mode == 0 && epi != nullptr)
-        symv_reduce_kernel<JG, true><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, s2, nb, tab, out, done, *epi);
+        symv_reduce_kernel<JG, true><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, *epi);
     else if (mode == 0)
-        symv_reduce_kernel<JG, false><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, s2, nb, tab, out, done, bq_epilogue{});
+        symv_reduce_kernel<JG, false><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, bq_epilogue{});
     else if (tab.hi > tab.lo)
-        symv_reduce_seg_kernel<JG><<<dim3((unsigned)nb, (unsigned)(tab.hi - tab.lo)), 1024, 0, ctx->stream>>>(slab, s2, nb, tab, out, done);
+        symv_reduce_seg_kernel<JG><<<dim3((unsigned)nb, (unsigned)(tab.hi - tab.lo)), 1024, 0, ctx->stream>>>(slab, nb, tab, out, done);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
 
-// Cutting the strips of a short grid by rows (symv_tiles_kernel, NW = 2) was VERDICT r3's item 5 ("split strips by rows when strips
-// < 4 x slots").  Built, bit-identical (tests/test_distributed.py::test_row_cut_strips_are_bit_identical; the whole GPU suite ran
-// with it on for every small problem) — and measured: the eight 1/8 shares of the n = 100 000 panel 0.796 - 0.885 ms cut against
-// 0.801 - 0.832 ms uncut, BASELINE config 2 0.269 against 0.271 ms (profiles/r04/symv_row_cut_strips.txt): half-size workgroups
-// do not drain the last round any faster (the same waves, the same loads in flight per wave), and the column parts cost three slab
-// entries instead of one.  So it is OFF unless BQ_SYMV_SPLIT=1 asks for it.
-bool bq_symv_wants_split(const bq_ctx *ctx, int64_t I0, int64_t I1) {
+static int launch_any(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
+                      const double *w, double *slab, double *out, int mode, const int *done, const bq_epilogue *epi = nullptr) {
+    // Rows per step (loads in flight per wave).  fp32 tiles are half as wide in bytes: 8 rows per step keep the same bytes in
+    // flight per lane.  fp64: 4 rows per step, except on short grids whose LAST round of workgroups is sparsely filled (two
+    // workgroups per CU = 512 slots on this chip; a 1/8 share of n = 100 000 is ~1 200 strips = 2.3 rounds): there 8 rows per
+    // step keep HBM busy while that round drains.  Measured (profiles/r03/symv_rows_per_step.txt): 1 200 strips 0.85 -> 0.81 ms,
+    // 1 650 strips (n = 40 000) 1.07 -> 1.02 ms; grids whose last round is well filled are 2-6 % faster with 4, long grids do not
+    // care.  The rows of a step are independent sums and the lane butterfly pairs the same lanes in the same order: the bits do
+    // not depend on the choice (tests/test_distributed.py::test_rows_per_step_variants_are_bit_identical).
     static const int force = [] {
-        const char *e = getenv("BQ_SYMV_SPLIT");
+        const char *e = getenv("BQ_SYMV_ROWS_PER_STEP");   // 4 or 8: no heuristic (the bit-identity test switches it)
         return e ? atoi(e) : 0;
     }();
-    (void)ctx;
-    return force == 1 && strips_before<JG_DEFAULT>(I1) > strips_before<JG_DEFAULT>(I0);
-}
-
-static int launch_any(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                      const double *w, double *slab, double *slab2, double *out, int mode, const int *done,
-                      const bq_epilogue *epi = nullptr) {
-    const bool split = slab2 != nullptr && bq_symv_wants_split(ctx, tab.cut[tab.lo], tab.cut[tab.hi]);
-    // BQ_SYMV_VARIANT=<tiles per strip><rows per step> selects a tuning variant (benchmarking only)
-    static const int variant = [] {
-        const char *e = getenv("BQ_SYMV_VARIANT");
-        return e ? atoi(e) : 84;
-    }();
-    switch (variant) {
-        case 44: return launch_variant<4, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, split, out, mode, done, epi);
-        case 48: return launch_variant<4, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, split, out, mode, done, epi);
-        case 28: return launch_variant<2, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, split, out, mode, done, epi);
-        case 24: return launch_variant<2, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, split, out, mode, done, epi);
-        case 88: return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, split, out, mode, done, epi);
-        default: {
-            // fp32 tiles are half as wide in bytes: 8 rows per step keep the same bytes in flight per lane.  fp64: 4 rows per
-            // step, except on short grids whose LAST round of workgroups is sparsely filled (two workgroups per CU = 512 slots
-            // on this chip; a 1/8 share of n = 100 000 is ~1 200 strips = 2.3 rounds): there 8 rows per step — twice the loads in
-            // flight per wave — keep HBM busy while that round drains.  Measured (r03, `profiles/r03/symv_rows_per_step.txt`):
-            // 1 200 strips 0.85 -> 0.81 ms, 1 650 strips (n = 40 000) 1.07 -> 1.02 ms; grids whose last round is well filled
-            // are 2-6 % faster with 4 (n = 30 000: 1.86 rounds, 1/4 shares: 4.7 rounds), long grids do not care.  The rows of a
-            // step are independent sums and the lane butterfly pairs the same lanes in the same order: the bits do not depend
-            // on the choice (tests/test_distributed.py::test_rows_per_step_variants_are_bit_identical).
-            static const int force = [] {
-                const char *e = getenv("BQ_SYMV_ROWS_PER_STEP");   // 4 or 8: no heuristic
-                return e ? atoi(e) : 0;
-            }();
-            // (work items and slots of the launch: a row-cut strip is two items for twice as many 128-thread slots)
-            const int64_t strips = (strips_before<JG_DEFAULT>(tab.cut[tab.hi]) - strips_before<JG_DEFAULT>(tab.cut[tab.lo])) * (split ? 2 : 1);
-            const int64_t slots = (split ? 4 : 2) * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256);
-            const bool sparse_tail = strips >= slots && strips < 8 * slots && 2 * (strips % slots) < slots;
-            const bool eight = force == 8 || (force != 4 && (storage == BQ_F32 || sparse_tail));
-            if (eight) return launch_variant<8, 8>(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, split, out, mode, done, epi);
-            return launch_variant<JG_DEFAULT, 4>(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, split, out, mode, done, epi);
-        }
-    }
+    const int64_t strips = strips_before<JG_DEFAULT>(tab.cut[tab.hi]) - strips_before<JG_DEFAULT>(tab.cut[tab.lo]);
+    const int64_t slots = 2 * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256);
+    const bool sparse_tail = strips >= slots && strips < 8 * slots && 2 * (strips % slots) < slots;
+    const bool eight = force == 8 || (force != 4 && (storage == BQ_F32 || sparse_tail));
+    if (eight) return launch_variant<8>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
+    return launch_variant<4>(ctx, panel, storage, add_one, nb, tab, w, slab, out, mode, done, epi);
 }
 
 int bq_launch_symv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                   const double *w, double *slab, double *slab2, double *out, const int *done, const bq_epilogue *epi) {
-    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, out, 0, done, epi);
+                   const double *w, double *slab, double *out, const int *done, const bq_epilogue *epi) {
+    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, out, 0, done, epi);
 }
 
 int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nb, const bq_seg_table &tab,
-                            const double *w, double *slab, double *slab2, double *gath, const int *done) {
-    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, slab2, gath, 1, done);
+                            const double *w, double *slab, double *gath, const int *done) {
+    return launch_any(ctx, panel, storage, add_one, nb, tab, w, slab, gath, 1, done);
 }
 
 int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done,

@@ -164,13 +164,13 @@ int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *do
         bq_seg_table tab;
         bq_sym_seg_table(p, &tab);
         if (ctx->comm_kind == BQ_COMM_NONE) {
-            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->slab2, p->s, done, epi));
+            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->s, done, epi));
             if (fused) *fused = epi != nullptr;
         } else if (ctx->sym_allreduce) {   // rank partials meet in one all-reduce(sum): association depends on the transport
-            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->slab2, p->s, done));
+            BQ_TRY(bq_launch_symv(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->s, done));
             BQ_TRY(bq_exchange_sum(ctx, p->s, p->nb * BQ_SYM_TILE));
         } else {   // default: all-gather of the segment vectors, summed in segment order on every rank (bit-identical for any world)
-            BQ_TRY(bq_launch_symv_segments(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->slab2, p->gath, done));
+            BQ_TRY(bq_launch_symv_segments(ctx, p->panel, p->storage, add_one, p->nb, tab, w, p->slab, p->gath, done));
             BQ_TRY(bq_exchange_gather(ctx, p->gath, (int64_t)p->seg_cmax * p->nb * BQ_SYM_TILE));
             BQ_TRY(bq_launch_symv_segsum(ctx, p->nb, tab, p->gath, p->s, done, epi));
             if (fused) *fused = epi != nullptr;

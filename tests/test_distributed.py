@@ -272,23 +272,6 @@ def test_rows_per_step_variants_are_bit_identical(tmp_path, one_rank):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n', ['700', '2100'])
-def test_row_cut_strips_are_bit_identical(tmp_path, n):
-    """Short grids cut every strip of the symmetric product by rows into two half-size workgroups (round 4; the column part of a
-    tile then arrives as three slab entries, E0 = P0 + P1, E1 = P2, E2 = P3, which the reduction adds in the uncut kernel's order).
-    Forced off and forced on — one rank and two ranks, fp64 — every product and every solver run has the same bits."""
-    keys = ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_f', 'ascg_kernel_x', 'ascg_kernel_f')
-    env = {'BQ_TEST_DIST_N': n}
-    uncut = _launch('gpu-host', 1, tmp_path / 'uncut', extra_env=dict(env, BQ_SYMV_SPLIT='0'))[0]
-    cut = _launch('gpu-host', 1, tmp_path / 'cut', extra_env=dict(env, BQ_SYMV_SPLIT='1'))[0]
-    cut2 = _launch('gpu-host', 2, tmp_path / 'cut2', extra_env=dict(env, BQ_SYMV_SPLIT='1'))
-    for key in keys:
-        assert np.array_equal(cut[key], uncut[key]), key
-        for r in cut2:
-            assert np.array_equal(r[key], uncut[key]), key
-
-
-@pytest.mark.gpu
 def test_collective_watchdog_aborts_a_wait_that_outlasts_the_timeout(tmp_path):
     """bq_ctx_set_collective_timeout on a one-rank RCCL context (a child process: an aborted communicator is the end of its
     context): normal products, a collective that is late by less than the limit and a LONG wait for this rank's own work all pass;
