@@ -961,46 +961,58 @@ __global__ __launch_bounds__(256) void as_pc_class_kernel(int64_t n, int64_t d, 
     }
 }
 
-// Phi (feature-major) and 1 / D_i, D_i = Q_ii - |Phi_i|^2 (floored at 1e-8 Q_ii: P only has to be positive definite).
-// One thread per sample.  RBF:
+// Phi (feature-major).  One thread per sample.  RBF:
 //   family 1 (d + 1 columns): y e^{-g|x|^2} [1, sqrt(2g) x]                    the order-0/1 terms of e^{2g x.x'}
-//   family 2 (d columns, BQ_SVC): 2g |a| e^{-g|x|^2} (x - m0 - y a)               the cross term 2 (y y' |a|^2)(e.e') of the order-2
-//       term (2g x.x')^2 / 2 with x = m0 + y a + e split into class means and deviation: d more directions whose eigenvalues
-//       grow like n (at BASELINE config 5 they sit at ~0.4 of family 1's)
+//   family 2, BQ_SVC panels — the directions of the ORDER-2 term (2g x.x')^2 / 2 = 2g^2 <x x', x' x''> whose eigenvalues grow like
+//   n |class mean|^2 (the rest of that term is a flat bulk of d (d + 1) / 2 directions no low-rank model captures:
+//   tools/pc_nystrom_study.py, tools/pc_order2_cpu_study.py):
+//     fam2 == 2 (2d columns, round 5): the EXACT projection of the order-2 feature sqrt(2) g y e vec(x x') onto the span of
+//       U_{c,k} = m_c e_k' + e_k m_c' (c = the two class means, k < d) — raw coordinates f_{c,k} = <x x', U_{c,k}> = 2 (x.m_c) x_k
+//       (as_pc_raw_kernel), orthonormalised by the inverse Cholesky factor of the 2d x 2d Gram matrix of the U's
+//       (as_pc_project_kernel).  A projection of a positive semi-definite term: P = D + Phi Phi' never over-counts Q.
+//     fam2 == 1 (d columns, rounds 3-4; kept for d too large for 3d + 2 features): 2g |a| e (x - m0 - y a), the cross term
+//       2 (y y' |a|^2)(e.e') under the assumption m0 ~ 0 — not a projection (it over-counts when m0 is not small): measured against
+//       fam2 == 2 at d = 64, n = 20 000: 39 against 23 conjugate-gradient iterations to 1e-8 (profiles/r05/pc_projected_study.txt)
+// share[i] <- Q_ii and, for fam2 != 2, the sum of squares of the stored features in s1[i]; as_pc_diag_kernel turns them into 1 / D.
 __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t ld, const double *__restrict__ X,
-                                      const double *__restrict__ sgn, const double *__restrict__ cls, double gamma,
-                                      int add_one, double diag_add, int m, float *__restrict__ Phi, double *__restrict__ dinv,
-                                      double *__restrict__ share) {
+                                      const double *__restrict__ sgn, const double *__restrict__ cls, int fam2, double gamma,
+                                      int add_one, double diag_add, int m, float *__restrict__ Phi, double *__restrict__ qdiag,
+                                      double *__restrict__ raw) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ld) return;
     if (i >= n) {
         for (int j = 0; j < m; ++j) Phi[(int64_t)j * ld + i] = 0.f;
-        dinv[i] = 0.0;
-        share[i] = 1.0;
+        qdiag[i] = 0.0;
+        if (raw != nullptr) raw[i] = raw[ld + i] = raw[2 * ld + i] = 0.0;
         return;
     }
     const double y = sgn ? sgn[i] : 1.0;
     const double *x = X + i * d;
     double sq = 0.0;
     for (int64_t k = 0; k < d; ++k) sq = fma(x[k], x[k], sq);
-    double s = 0.0, qii;
+    double qii;
     int col = 0;
-    // every feature is rounded to fp32 where it is stored, and D is what THOSE values leave of the diagonal
-    auto put = [&](int64_t j, double v) {
-        const float vf = (float)v;
-        Phi[j * ld + i] = vf;
-        s = fma((double)vf, (double)vf, s);
-    };
+    auto put = [&](int64_t j, double v) { Phi[j * ld + i] = (float)v; };   // D is what the STORED (fp32) values leave of the diagonal
     if (kernel == BQ_KERNEL_RBF) {
         const double e = exp(-gamma * sq);
         const double c0 = y * e, c1 = c0 * sqrt(2.0 * gamma);
         put(0, c0);
         for (int64_t k = 0; k < d; ++k) put(1 + k, c1 * x[k]);
         col = (int)d + 1;
-        if (cls != nullptr) {
+        if (fam2 == 1) {
             const double c2 = 2.0 * gamma * cls[2 * d] * e;
             for (int64_t k = 0; k < d; ++k) put(col + k, c2 * (x[k] - cls[d + k] - y * cls[k]));
             col += (int)d;
+        } else if (fam2 == 2) {   // the columns are written by as_pc_project_kernel from these three per-sample numbers
+            double sp = 0.0, sm = 0.0;
+            for (int64_t k = 0; k < d; ++k) {
+                sp = fma(x[k], cls[d + k] + cls[k], sp);   // x . m_+,  m_+ = m0 + a
+                sm = fma(x[k], cls[d + k] - cls[k], sm);   // x . m_-,  m_- = m0 - a
+            }
+            raw[i] = 2.0 * sp;
+            raw[ld + i] = 2.0 * sm;
+            raw[2 * ld + i] = sqrt(2.0) * gamma * c0;      // sqrt(2 g^2) y e
+            col += 2 * (int)d;
         }
         qii = 1.0;
     } else {   // linear: exact features (up to their fp32 rounding)
@@ -1012,9 +1024,80 @@ __global__ void as_pc_features_kernel(int kernel, int64_t n, int64_t d, int64_t 
         put(col, y);
         qii += 1.0;
     }
-    qii += diag_add;
+    qdiag[i] = qii + diag_add;
+}
+
+// family 2, fam2 == 2: Phi[col0 + j][i] = scale_i * sum_{l <= j} F[i][l] Rinv[l][j],  F[i][c d + k] = (2 x_i.m_c) x_ik — a
+// (samples x 2d) x (2d x 2d upper triangular) product, 64 x 64 output tiles, 4 x 4 per thread, fp64 accumulation, once per solver.
+__global__ __launch_bounds__(256) void as_pc_project_kernel(int64_t n, int64_t d, int64_t ld, const double *__restrict__ X,
+                                                            const double *__restrict__ raw, const double *__restrict__ Rinv,
+                                                            int col0, float *__restrict__ Phi) {
+    __shared__ double As[16][65], Bs[16][65];
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int j0 = (int)blockIdx.y * 64, n2 = 2 * (int)d;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double acc[4][4] = {};
+    const int kend = j0 + 64 < n2 ? j0 + 64 : n2;   // Rinv is upper triangular: rows beyond the tile's last column are zero
+    for (int k0 = 0; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + q * 256, kk = e & 15, ii = e >> 4;   // consecutive threads: consecutive k of one sample (row-major X)
+            const int64_t i = i0 + ii;
+            const int l = k0 + kk;
+            double v = 0.0;
+            if (i < n && l < n2) v = raw[(l >= d ? ld : 0) + i] * X[i * d + (l >= d ? l - d : l)];
+            As[kk][ii] = v;
+            const int jj = e & 63, kb = e >> 6;
+            Bs[kb][jj] = (k0 + kb < n2 && j0 + jj < n2) ? Rinv[(int64_t)(k0 + kb) * n2 + j0 + jj] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = As[kk][ty * 4 + r];
+                b[r] = Bs[kk][tx * 4 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + ty * 4 + r;
+        if (i >= n) continue;
+        const double sc = raw[2 * ld + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = j0 + tx * 4 + c;
+            if (j < n2) Phi[(int64_t)(col0 + j) * ld + i] = (float)(sc * acc[r][c]);
+        }
+    }
+}
+
+// 1 / D_i and the share of the diagonal the features leave, D_i = Q_ii - |Phi_i|^2 over the STORED features (floored at 1e-8 Q_ii: P
+// only has to be positive definite).  qdiag_share: Q_ii in, share out.
+__global__ void as_pc_diag_kernel(int64_t n, int64_t ld, int m, const float *__restrict__ Phi, double *__restrict__ dinv,
+                                  double *__restrict__ qdiag_share) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ld) return;
+    if (i >= n) {
+        dinv[i] = 0.0;
+        qdiag_share[i] = 1.0;
+        return;
+    }
+    double s = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const double v = (double)Phi[(int64_t)j * ld + i];
+        s = fma(v, v, s);
+    }
+    const double qii = qdiag_share[i];
     dinv[i] = 1.0 / fmax(qii - s, 1e-8 * qii);
-    share[i] = (qii - s) / qii;   // what the features leave of the diagonal: the host refuses a model that leaves too little
+    qdiag_share[i] = (qii - s) / qii;   // what the features leave of the diagonal: the host refuses a model that leaves too little
 }
 
 // Gpart[slice][a][b] = sum over the slice's FREE samples of Phi[a][i] Phi[b][i] / D_i, lower tiles (b-tile <= a-tile)
@@ -2065,14 +2148,21 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
     if (p->X == nullptr || (p->structure != BQ_PLAIN && p->structure != BQ_SVC)) return BQ_OK;
     if (p->kernel != BQ_KERNEL_RBF && !(p->kernel == BQ_KERNEL_LINEAR && p->diag_add > 0.0)) return BQ_OK;
     bq_ctx *ctx = p->ctx;
-    bool classes = p->kernel == BQ_KERNEL_RBF && p->structure == BQ_SVC && as_env_on("BQ_AS_CG_PC_CLASS");
+    // family 2 of the RBF features on BQ_SVC panels: 2 = projected order-2 directions (2d columns), 1 = the class-mean cross term of
+    // rounds 3-4 (d columns), 0 = none.  BQ_AS_CG_PC_CLASS=0|1|2 caps it (tests compare them); a family that does not fit PC_MAX_M
+    // features, or whose model leaves a sample too little of its diagonal, steps down.
+    int fam2 = 0;
+    if (p->kernel == BQ_KERNEL_RBF && p->structure == BQ_SVC) {
+        const char *e = getenv("BQ_AS_CG_PC_CLASS");
+        fam2 = e ? std::max(0, std::min(atoi(e), 2)) : 2;
+    }
     std::vector<double> share((size_t)p->n);
-    for (int attempt = 0; attempt < 2; ++attempt) {   // with the class-interaction family, then without it
-        int m = p->kernel == BQ_KERNEL_RBF ? (int)p->d + 1 + (classes ? (int)p->d : 0) : (int)p->d;
+    for (; fam2 >= 0; --fam2) {
+        const bool classes = fam2 > 0;
+        int m = p->kernel == BQ_KERNEL_RBF ? (int)p->d + 1 + fam2 * (int)p->d : (int)p->d;
         if (p->add_one) m += 1;
         if (m > PC_MAX_M) {   // the apply kernel keeps the coefficients of all features in LDS
-            if (!classes) return BQ_OK;
-            classes = false;
+            if (fam2 == 0) return BQ_OK;
             continue;
         }
         as_pc *pc = new as_pc();
@@ -2124,16 +2214,83 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
             as_pc_free(pc);
             return BQ_OK;
         }
+        double *raw = nullptr, *rinv_d = nullptr;   // fam2 == 2: per-sample numbers and the orthonormalising factor (setup only)
+        hipError_t fe = hipSuccess;
+        int frc = BQ_OK;
         if (classes) {
             unsigned int *ticket = (unsigned int *)(pc->cls + 2 * p->d + 1);   // the spare slot, zeroed above
             as_pc_class_kernel<<<(unsigned)p->d, 256, 0, ctx->stream>>>(p->n, p->d, p->X, p->sgn, pc->cls, ticket);
+            fe = hipGetLastError();
         }
-        as_pc_features_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->kernel, p->n, p->d, s->ldN, p->X, p->sgn, pc->cls,
-                                                                                 p->gamma, p->add_one ? 1 : 0, p->diag_add, m,
-                                                                                 pc->Phi, pc->dinv, pc->z);
-        hipError_t fe = hipGetLastError();
-        if (fe == hipSuccess) fe = hipMemcpyAsync(share.data(), pc->z, sizeof(double) * p->n, hipMemcpyDeviceToHost, ctx->stream);
-        int frc = fe == hipSuccess ? bq_ctx_sync(ctx) : BQ_OK;
+        if (fam2 == 2 && fe == hipSuccess) {
+            // the 2d x 2d Gram matrix of U_{c,k} = m_c e_k' + e_k m_c' (Frobenius): <U_{c,k}, U_{c',l}> = 2 (m_c.m_c') [k == l] + 2 m_c[l] m_c'[k],
+            // its Cholesky factor R (columns whose pivot falls below 1e-8 of their diagonal are dropped: m_- = -m_+ leaves d directions)
+            // and Rinv — on the host, from the class means (deterministic: the same on every rank)
+            const int d = (int)p->d, n2 = 2 * d;
+            std::vector<double> cls((size_t)n2 + 2), mc((size_t)n2);
+            fe = hipMemcpyAsync(cls.data(), pc->cls, sizeof(double) * (n2 + 1), hipMemcpyDeviceToHost, ctx->stream);
+            if (fe == hipSuccess) frc = bq_ctx_sync(ctx);
+            if (fe == hipSuccess && frc == BQ_OK) {
+                for (int k = 0; k < d; ++k) {
+                    mc[k] = cls[d + k] + cls[k];
+                    mc[d + k] = cls[d + k] - cls[k];
+                }
+                double dots[2][2] = {{0, 0}, {0, 0}};
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        for (int k = 0; k < d; ++k) dots[a][b] += mc[a * d + k] * mc[b * d + k];
+                auto gram = [&](int i, int j) {
+                    const int a = i / d, k = i % d, b = j / d, l = j % d;
+                    return 2.0 * ((k == l ? dots[a][b] : 0.0) + mc[a * d + l] * mc[b * d + k]);
+                };
+                std::vector<double> R((size_t)n2 * n2, 0.0), Rinv((size_t)n2 * n2, 0.0);
+                std::vector<int> kept;
+                std::vector<double> c((size_t)n2);
+                for (int j = 0; j < n2; ++j) {   // up-looking Cholesky over the kept columns
+                    double piv = gram(j, j);
+                    const double gjj = piv;
+                    for (size_t a = 0; a < kept.size(); ++a) {
+                        const int ia = kept[a];
+                        double v = gram(ia, j);
+                        for (size_t b = 0; b < a; ++b) v -= R[(size_t)kept[b] * n2 + ia] * c[b];
+                        c[a] = v / R[(size_t)ia * n2 + ia];
+                        piv -= c[a] * c[a];
+                    }
+                    if (!(piv > 1e-8 * gjj) || !(gjj > 0.0)) continue;   // (numerically) inside the span of the kept ones
+                    for (size_t a = 0; a < kept.size(); ++a) R[(size_t)kept[a] * n2 + j] = c[a];
+                    R[(size_t)j * n2 + j] = sqrt(piv);
+                    kept.push_back(j);
+                }
+                for (size_t b = 0; b < kept.size(); ++b) {   // Rinv over the kept set by back substitution, column by column
+                    const int jb = kept[b];
+                    Rinv[(size_t)jb * n2 + jb] = 1.0 / R[(size_t)jb * n2 + jb];
+                    for (size_t a = b; a-- > 0;) {
+                        const int ia = kept[a];
+                        double v = 0.0;
+                        for (size_t q = a + 1; q <= b; ++q) v += R[(size_t)ia * n2 + kept[q]] * Rinv[(size_t)kept[q] * n2 + jb];
+                        Rinv[(size_t)ia * n2 + jb] = -v / R[(size_t)ia * n2 + ia];
+                    }
+                }
+                fe = hipMalloc(&raw, sizeof(double) * 3 * s->ldN);
+                if (fe == hipSuccess) fe = hipMalloc(&rinv_d, sizeof(double) * (size_t)n2 * n2);
+                if (fe == hipSuccess) fe = hipMemcpyAsync(rinv_d, Rinv.data(), sizeof(double) * (size_t)n2 * n2, hipMemcpyHostToDevice, ctx->stream);
+                if (fe == hipSuccess) frc = bq_ctx_sync(ctx);   // Rinv leaves this scope
+            }
+        }
+        if (fe == hipSuccess && frc == BQ_OK) {
+            as_pc_features_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->kernel, p->n, p->d, s->ldN, p->X, p->sgn, pc->cls, fam2,
+                                                                                     p->gamma, p->add_one ? 1 : 0, p->diag_add, m,
+                                                                                     pc->Phi, pc->z, raw);
+            if (fam2 == 2)
+                as_pc_project_kernel<<<dim3((unsigned)(s->ldN / 64), (unsigned)((2 * p->d + 63) / 64)), 256, 0, ctx->stream>>>(
+                    p->n, p->d, s->ldN, p->X, raw, rinv_d, (int)p->d + 1, pc->Phi);
+            as_pc_diag_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->n, s->ldN, m, pc->Phi, pc->dinv, pc->z);
+            fe = hipGetLastError();
+        }
+        if (fe == hipSuccess && frc == BQ_OK) fe = hipMemcpyAsync(share.data(), pc->z, sizeof(double) * p->n, hipMemcpyDeviceToHost, ctx->stream);
+        if (fe == hipSuccess && frc == BQ_OK) frc = bq_ctx_sync(ctx);
+        if (raw) hipFree(raw);
+        if (rinv_d) hipFree(rinv_d);
         if (fe != hipSuccess || frc != BQ_OK) {
             as_pc_free(pc);
             if (fe != hipSuccess) bq_set_error("building the preconditioner features failed: %s", hipGetErrorString(fe));
@@ -2145,9 +2302,7 @@ static int as_pc_create(bq_solver *s, as_pc **out) {
             *out = pc;
             return BQ_OK;
         }
-        as_pc_free(pc);
-        if (!classes) break;
-        classes = false;
+        as_pc_free(pc);   // the model leaves some sample too little of its diagonal: the next smaller family
     }
     return BQ_OK;
 }

@@ -798,6 +798,34 @@ def test_active_set_cg_on_kernel_panels_against_the_oracle(amd, kind, n, d, stor
     quad.release()
 
 
+@pytest.mark.parametrize('n,d,sigma', [(3000, 24, 6.0), (2500, 40, 8.0)])
+def test_active_set_cg_feature_families_agree_and_the_projected_one_is_the_cheapest(amd, monkeypatch, n, d, sigma):
+    """The preconditioner's second feature family on RBF / SVC panels (csrc/bq_as.hip as_pc_features_kernel): none (0), the class-mean
+    cross term of rounds 3-4 (1), the exact projection of the order-2 Taylor term onto the 2d class-mean directions (2, the default of
+    round 5).  A preconditioner changes how many inner iterations a restricted solve takes, never what it converges to: the three
+    runs follow the oracle's trajectory alike; the projected family needs the fewest inner iterations (a projection never
+    over-counts Q; family 1 does when the classes' mid point is not at the origin)."""
+    from oracle import svm_oracle as so, bcqp_oracle as bo
+    from optiml_amd.datasets import make_blobs
+    from optiml_amd.opti import KernelQuadratic
+    from optiml_amd.ml.svm.kernels import GaussianKernel
+    X, y = make_blobs(n, d, seed=n + d, sigma=sigma)
+    K = so.gram('rbf', X, None, 'scale', 0.0, 3)
+    Q = K * np.outer(y, y) + np.outer(y, y) + 0.5 * np.eye(n)
+    ref = bo.active_set(Q, -np.ones(n), np.full(n, np.inf), x0=np.ones(n), max_iter=30)
+    inner = {}
+    for fam in ('0', '1', '2'):
+        monkeypatch.setenv('BQ_AS_CG_PC_CLASS', fam)
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', GaussianKernel('scale'), y=y, diag=0.5)
+        opt = _solvers()['ascg'](quad=quad, ub=np.full(n, np.inf), x=np.ones(n), max_iter=30).minimize()
+        assert opt.iter == ref['iter'] and opt.status == ref['status']
+        np.testing.assert_allclose(opt.x, ref['x'], rtol=1e-6, atol=1e-6 * np.abs(ref['x']).max())
+        np.testing.assert_allclose(opt.f_x, ref['f_x'], rtol=1e-9)
+        inner[fam] = opt.inner_iters
+        quad.release()
+    assert inner['2'] <= inner['1'] <= inner['0'], inner
+
+
 def test_active_set_singular_system_uses_minres(amd, as_factor_mode):
     """Linear kernel, n > d + 1: Q[A,A] is singular, the reference's Cholesky raises and it falls back to scipy's
     minres on the normal equations (active_set.py:142-151).  The device path takes the same branch (persistent MINRES
