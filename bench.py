@@ -847,6 +847,8 @@ def orchestrate(args):
             caps[name] = rec
     if caps:
         head['fixed_cap'] = caps
+    if isinstance(side.get('c5'), dict) and side['c5'].get('time_to_kkt_projected'):
+        head.setdefault('time_to_kkt', {})['c5_projected'] = side['c5']['time_to_kkt_projected']
     if 'as_c2' in side:
         rec = side['as_c2']
         keep = ('value', 'unit', 'iterations', 'status', 'f', 'n_sv', 's_per_iteration', 'stop_test', 'includes', 'route', 'config', 'roofline',
@@ -1339,8 +1341,12 @@ def main():
         if ascg:
             out['inner_products_per_step'] = inner / max(done, 1)
             out['inner_tol'] = args.inner_tol
+            fam = os.environ.get('BQ_AS_CG_PC_CLASS', '2')
             out['inner_preconditioner'] = 'none (BQ_AS_CG_PC=0)' if os.environ.get('BQ_AS_CG_PC') == '0' else \
-                'diagonal + first-order Taylor features of the RBF kernel (d + 2 columns), Woodbury'
+                'diagonal + Taylor features of the RBF kernel through Woodbury: orders 0-1 (d + 2 columns)' + \
+                {'2': ' + the order-2 term projected onto the 2d class-mean directions (3d + 2 columns in all)',
+                 '1': ' + the class-mean cross term of rounds 3-4 (2d + 2 columns in all)'}.get(fam, '')
+            out['time_to_kkt_projected'] = c5_projection(n, d, 1e3 * elapsed / max(done, 1))
             out['inner_warm_start'] = os.environ.get('BQ_AS_CG_WARM') != '0'
             out['products_per_sec'] = mv_cnt / elapsed
         traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
@@ -1443,6 +1449,32 @@ def main():
     barrier()
     if comm is not None:
         comm.close()
+
+
+def c5_projection(n, d, ms_per_outer_iteration):
+    """Config 5 cannot be run to 'optimal' inside a bench (the reference algorithm moves about one index per outer iteration: of the
+    order of n of them).  Projection: the iterations / n the SAME workload needed to 'optimal' at the sizes tools/c5_scaling.py ran
+    (committed: profiles/rNN/c5_outer_iterations_scaling.json, largest n) x this n x the seconds per outer iteration measured here.
+    None when no scaling file is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', 'c5_outer_iterations_scaling.json'))):
+        try:
+            rec = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        runs = [r for r in rec.get('runs', []) if r.get('status') == 'optimal' and rec.get('d') == d]
+        if runs:
+            best = (max(runs, key=lambda r: r['n']), os.path.relpath(path, REPO))
+    if best is None:
+        return None
+    run, src = best
+    iters = run['iterations_per_n'] * n
+    return {'value': iters * ms_per_outer_iteration * 1e-3, 'unit': 's', 'kind': 'projected, not measured',
+            'outer_iterations_projected': iters, 'iterations_per_n': run['iterations_per_n'], 'from_n': run['n'], 'source': src,
+            'ms_per_outer_iteration': ms_per_outer_iteration,
+            'note': 'iterations / n of the same workload run to its stop test at a size that finishes, times n, times the measured time per '
+                    'outer iteration at this n (which grows with the free set shrinking: an upper estimate of the rate, a projection of the time)'}
 
 
 def measured_traffic(workload, world):
