@@ -231,15 +231,19 @@ __global__ __launch_bounds__(256) void as_absorb_mb_kernel(int64_t N, unsigned c
     VEC_LOOP(i) {
         if (i < N && !(mL[i] | mU[i])) {
             bool hit = false;
+            bool off = false;   // absorbed within the tolerance but NOT exactly on the bound (the reference does not snap x either)
             if (x[i] <= lb[i] + ACT_TOL) {
                 mL[i] = 1;
                 ++nl;
                 hit = true;
+                off = x[i] != lb[i];
             } else if (x[i] >= ub[i] - ACT_TOL) {
                 mU[i] = 1;
                 ++nu;
                 hit = true;
+                off = x[i] != ub[i];
             }
+            if (off) __hip_atomic_store(&ints[30], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every writer stores 1
             if (hit) {
                 const int slot = atomicAdd(&ints[26], 1);
                 if (slot < 16) ints[9 + slot] = (int)i;
@@ -270,6 +274,10 @@ __global__ __launch_bounds__(256) void as_absorb_mb_kernel(int64_t N, unsigned c
         ints[6] = tu;
         ints[8] = __hip_atomic_load(&ints[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ints[26], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ints[29]: THIS step bound a variable that sits off its bound by up to 1e-12 — the product-free f of the following ratio
+        // steps assumes bound variables ON their bounds (as_step_min_kernel), so the host ends the run (as_finish_iteration)
+        ints[29] = __hip_atomic_load(&ints[30], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ints[30], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long row = sc->iter - sc->stat_base;
         if (row >= 0 && row < sc->stat_cap) {
             stats[row].r2 = 0.0;
@@ -381,6 +389,10 @@ int as_finish_iteration(bq_solver *s, as_ws *w, hipStream_t st, bool exact) {
         w->gref = s->g;
         w->chain_len = 0;
     } else {
+        // a variable absorbed OFF its bound in the previous step (|x - bound| <= 1e-12, not 0): Q_AA d_A = -g_A(x) then carries an
+        // O(1e-12 |Q_AB|) error per such index until x is replaced by a feasible candidate — the run ends here, f is formed by products
+        // until the next release re-anchors it (host_ints: this iteration's top record, i.e. the state the previous body left)
+        if (w->host_ints[29]) w->chain_ok = false;
         const bool run = w->chain_ok && exact;          // the run's identity holds for this step
         const bool chain = run && w->chain_len < 64;    // ... and f is taken from it (every 64th step of a run: from a product)
         as_launch_step(s, w, st, chain ? 1 : (run ? 2 : 0));

@@ -191,35 +191,46 @@ __global__ __launch_bounds__(1024) void as_schur_combine_kernel(int64_t np0, int
 // to the pivoted elimination below (and from there to a fresh base factor).
 // The host's share of a kept-factor iteration is this O(m^2) work between two waits on the stream (the device idles meanwhile:
 // profiles/r04/as_n20k_stream_idle_*.txt), so it is compiled a second time for AVX2 + FMA hosts and picked at load time
-// (function multi-versioning; the device pass of hipcc does not know the attribute).  The sums may be re-associated by the
-// vectoriser: the small system's solution moves in its last bits with the host's vector width, as it would with another BLAS.
+// (function multi-versioning; the device pass of hipcc does not know the attribute).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BQ_HOST_SIMD
 #else
 #define BQ_HOST_SIMD __attribute__((target_clones("arch=x86-64-v3", "default")))
 #endif
 
+// The three loops below are compiled twice (AVX2 and baseline x86-64) and must give the SAME bits in both: the small system's
+// solution feeds the 1e-12 feasibility decision of the iteration, and a trajectory must not depend on the host's vector width
+// (ADVICE r4).  So the association is written out — eight independent partial sums over j mod 8, combined in one fixed tree — and
+// contraction is off (the AVX2 clone has fused multiply-add, the baseline has not: a fused product rounds once, a separate one
+// twice).  The vectoriser needs no licence to re-associate for this shape.
+#pragma clang fp contract(off)
 // sum_j a[j] * b[j]
 BQ_HOST_SIMD static double as_dot4(const double *__restrict__ a, const double *__restrict__ b, int n) {
-#pragma clang fp reassociate(on)
-    double s = 0.0;
-#pragma clang loop vectorize(enable) interleave_count(4)
-    for (int j = 0; j < n; ++j) s += a[j] * b[j];
-    return s;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int j = 0;
+    for (; j + 8 <= n; j += 8)
+        for (int l = 0; l < 8; ++l) acc[l] += a[j + l] * b[j + l];
+    for (int l = 0; j < n; ++j, ++l) acc[l] += a[j] * b[j];
+    return ((acc[0] + acc[4]) + (acc[2] + acc[6])) + ((acc[1] + acc[5]) + (acc[3] + acc[7]));
 }
 // sum_j |a[j] * b[j]|
 BQ_HOST_SIMD static double as_absdot(const double *__restrict__ a, const double *__restrict__ b, int n) {
-#pragma clang fp reassociate(on)
-    double s = 0.0;
-#pragma clang loop vectorize(enable) interleave_count(4)
-    for (int j = 0; j < n; ++j) s += std::fabs(a[j] * b[j]);
-    return s;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int j = 0;
+    for (; j + 8 <= n; j += 8)
+        for (int l = 0; l < 8; ++l) acc[l] += std::fabs(a[j + l] * b[j + l]);
+    for (int l = 0; j < n; ++j, ++l) acc[l] += std::fabs(a[j] * b[j]);
+    return ((acc[0] + acc[4]) + (acc[2] + acc[6])) + ((acc[1] + acc[5]) + (acc[3] + acc[7]));
 }
 // y[0:n) -= l[0:n) * w
 BQ_HOST_SIMD static void as_axpy_neg(double *__restrict__ y, const double *__restrict__ l, double w, int n) {
 #pragma clang loop vectorize(enable) interleave_count(4)
-    for (int j = 0; j < n; ++j) y[j] -= l[j] * w;
+    for (int j = 0; j < n; ++j) {
+        const double prod = l[j] * w;
+        y[j] -= prod;
+    }
 }
+#pragma clang fp contract(on)
 
 // C = L D L' of the m x m Schur complement, kept on the host and grown by one row per new slot (O(m^2)); C is symmetric
 // quasi-definite — minus a positive definite block for the pinned variables, a positive definite one for the freed —
