@@ -231,17 +231,20 @@ __global__ __launch_bounds__(256) void as_absorb_mb_kernel(int64_t N, unsigned c
     VEC_LOOP(i) {
         if (i < N && !(mL[i] | mU[i])) {
             bool hit = false;
-            bool off = false;   // absorbed within the tolerance but NOT exactly on the bound (the reference does not snap x either)
+            // absorbed within the 1e-12 tolerance but further from the bound than the rounding of the step that brought it there (a
+            // blocking variable lands on its bound to an ulp or two: 1e-14 relative is that, with room) — a NEAR-TIE of the ratio test.
+            // The reference does not snap x to the bound either (active_set.py:208-217), so neither does this kernel; see ints[29].
+            bool off = false;
             if (x[i] <= lb[i] + ACT_TOL) {
                 mL[i] = 1;
                 ++nl;
                 hit = true;
-                off = x[i] != lb[i];
+                off = fabs(x[i] - lb[i]) > 1e-14 * fmax(1.0, fabs(lb[i]));
             } else if (x[i] >= ub[i] - ACT_TOL) {
                 mU[i] = 1;
                 ++nu;
                 hit = true;
-                off = x[i] != ub[i];
+                off = fabs(x[i] - ub[i]) > 1e-14 * fmax(1.0, fabs(ub[i]));
             }
             if (off) __hip_atomic_store(&ints[30], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every writer stores 1
             if (hit) {
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void as_absorb_mb_kernel(int64_t N, unsigned c
         ints[6] = tu;
         ints[8] = __hip_atomic_load(&ints[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ints[26], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ints[29]: THIS step bound a variable that sits off its bound by up to 1e-12 — the product-free f of the following ratio
+        // ints[29]: THIS step bound a variable that sits off its bound by 1e-14 .. 1e-12 — the product-free f of the following ratio
         // steps assumes bound variables ON their bounds (as_step_min_kernel), so the host ends the run (as_finish_iteration)
         ints[29] = __hip_atomic_load(&ints[30], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ints[30], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -389,8 +392,8 @@ int as_finish_iteration(bq_solver *s, as_ws *w, hipStream_t st, bool exact) {
         w->gref = s->g;
         w->chain_len = 0;
     } else {
-        // a variable absorbed OFF its bound in the previous step (|x - bound| <= 1e-12, not 0): Q_AA d_A = -g_A(x) then carries an
-        // O(1e-12 |Q_AB|) error per such index until x is replaced by a feasible candidate — the run ends here, f is formed by products
+        // a variable absorbed OFF its bound in the previous step (1e-14 < |x - bound| <= 1e-12: a near-tie of the ratio test):
+        // Q_AA d_A = -g_A(x) then carries an O(1e-12 |Q_AB|) error per such index until x is replaced by a feasible candidate — the run ends here, f is formed by products
         // until the next release re-anchors it (host_ints: this iteration's top record, i.e. the state the previous body left)
         if (w->host_ints[29]) w->chain_ok = false;
         const bool run = w->chain_ok && exact;          // the run's identity holds for this step
