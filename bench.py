@@ -1235,7 +1235,7 @@ def main():
                                tune_placement=not args.no_placement)
         a_eq = np.hstack((np.ones(n), -np.ones(n)))
     N = quad.ndim
-    ctx.profile(os.environ.get('BQ_BENCH_NOPROF', '0') != '1')   # HIP-event timing of the dominant kernel (roofline)
+    ctx.profile(True)   # timing of the dominant kernel by its own dispatch timestamps (roofline)
     t0 = time.perf_counter()
     dev = quad.device_problem(ctx)
     t_gram_total = time.perf_counter() - t0

@@ -118,7 +118,7 @@ int bq_comm_unique_id(void *uid128);
 int bq_ctx_create_rccl(int device, int rank, int world, const void *uid128, bq_ctx **out);
 /* where the time of RCCL's start-up went in this process so far: "dlopen(librccl.so) 0.41 s; dlsym x8 0.00 s; ncclGetUniqueId ...;
  * ncclCommInitRank ...; ncclCommCount ..." (empty when RCCL was never loaded).  A stage still running after 5 s also says so on
- * stderr every 5 s while it runs; BQ_DEBUG_EXCHANGE=1 prints every stage as it ends. */
+ * stderr every 5 s while it runs; NCCL_DEBUG=INFO prints every stage as it ends. */
 int bq_comm_init_report(char *buf, size_t cap);
 int bq_ctx_create_exchange(int device, int rank, int world, bq_exchange_fn fn, void *user, bq_ctx **out);
 /* ONE rank's share of a `world`-way partition with no transport behind it: panels, segments and every kernel of the

@@ -393,21 +393,7 @@ static int problem_layout(bq_problem *p, int64_t n, int64_t N) {
     const size_t elems = p->symmetric ? (size_t)(bq_sym_off(p->I1) - bq_sym_off(p->I0))
                                       : (size_t)(rows > 0 ? rows : 1) * (size_t)p->ld;
     size_t bytes = (elems > 0 ? elems : 1) * esz;
-    // BQ_PLACE_OFFSETS (experiment): room behind the panel so that place_panel can try the SAME allocation at several offsets
-    static const size_t slack = [] {
-        const char *e = getenv("BQ_PLACE_OFFSETS");
-        size_t mx = 0;
-        for (const char *q = e; q && *q;) {
-            char *end = nullptr;
-            const unsigned long long v = strtoull(q, &end, 10);
-            if (end == q) break;
-            mx = std::max(mx, (size_t)v);
-            q = *end == ',' ? end + 1 : end;
-        }
-        return mx;
-    }();
     const size_t data_bytes = bytes;
-    if (p->symmetric && bytes >= ((size_t)1 << 30)) bytes += slack;
     hipError_t e = hipSuccess;
     size_t cached = 0;
     if (void *kept = bq_ctx_cache_take(c, bytes, &cached)) {
@@ -537,9 +523,8 @@ extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, co
 static int place_panel(bq_problem *p, double first_alloc_ms) {
     bq_ctx *c = p->ctx;
     if (!p->symmetric || p->streamed || p->panel == nullptr || p->panel_bytes < ((size_t)1 << 30) || p->I1 <= p->I0) return BQ_OK;
-    const char *e = getenv("BQ_PANEL_CANDIDATES");
-    const int want = e ? std::max(1, std::min(atoi(e), 4)) : 3;
-    e = getenv("BQ_PANEL_GOOD_GBS");
+    const int want = 3;   // allocations tried at most (a 4th never won in round 4's sweeps: profiles/r04/placement_*.txt)
+    const char *e = getenv("BQ_PANEL_GOOD_GBS");
     const double good_gbs = e ? atof(e) : 6500.0;
     e = getenv("BQ_PLACE_BUDGET_MS");
     const double budget_ms = e ? atof(e) : 200.0;
@@ -578,28 +563,6 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
     };
     std::vector<void *> losers;
     double best = 0.0;
-    if (const char *offs = getenv("BQ_PLACE_OFFSETS")) {
-        // diagnostic (tools/placement_offsets.py): the launch time of the product on this ONE allocation at a list of byte offsets
-        // (problem_layout left zero-filled room behind the panel); the fastest offset is kept
-        int rc = BQ_OK;
-        size_t best_off = 0;
-        p->place_tried = 0;
-        for (const char *q = offs; q && *q && rc == BQ_OK && p->place_tried < 32;) {
-            char *end = nullptr;
-            const size_t off = (size_t)strtoull(q, &end, 10) & ~(size_t)4095;
-            if (end == q) break;
-            q = *end == ',' ? end + 1 : end;
-            double t = 0.0;
-            rc = time_on((char *)p->panel_alloc + off, &t);
-            p->place_ms[p->place_tried++] = t;
-            if (p->place_tried == 1 || t < best) {
-                best = t;
-                best_off = off;
-            }
-        }
-        p->panel = (char *)p->panel_alloc + best_off;
-        return rc;
-    }
     int rc = time_on(p->panel, &best);
     p->place_tried = 1;
     p->place_ms[0] = best;

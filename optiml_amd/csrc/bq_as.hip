@@ -436,7 +436,9 @@ int bq_as_start(bq_solver *s) {
     BQ_HIP(hipMemsetAsync(w->mail_ticket, 0, sizeof(unsigned int) * 2, s->p->ctx->stream));
     w->mailbox = !s->as_cg && as_env_on("BQ_AS_MAILBOX");
     w->f_chain = !s->as_cg && as_env_on("BQ_AS_F_CHAIN");
-    if (const char *e = getenv("BQ_AS_TIMING")) w->timing = atoi(e) != 0;
+#ifdef BQ_AS_TIMING   // diagnostic build (BQ_EXTRA_CXXFLAGS=-DBQ_AS_TIMING): where the host's time goes per iteration, printed by bq_as_free
+    w->timing = true;
+#endif
     BQ_HIP(hipHostMalloc(&w->host_info, sizeof(int) * 8));
     BQ_HIP(hipHostMalloc(&w->host_cg, sizeof(as_cg_scal)));
     memset(w->host_ints, 0, sizeof(int) * 32);

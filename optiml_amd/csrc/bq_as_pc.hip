@@ -706,10 +706,7 @@ void as_pc_free(as_pc *pc) {
 int as_pc_apply(bq_solver *s, as_ws *w, int first) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
-    static const int tslices = [] {
-        const char *e = getenv("BQ_AS_PC_TSLICES");
-        return e ? std::max(1, std::min(atoi(e), PC_TSLICES_MAX)) : 1;
-    }();
+    constexpr int tslices = 1;   // feature slices of the t kernel (2 and 4 measured no faster at m = 514: HISTORY 10)
     as_pc_tphi_kernel<<<dim3(vgrid(s->ldN).x, (unsigned)tslices), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, pc->mp, s->N, s->ldN, pc->Phi, pc->dinv, w->r,
                                                                                         pc->tpart, pc->ws->rhs, pc->tticket, w->cg);
     as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(pc->m8, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ws->rhs, w->cg);

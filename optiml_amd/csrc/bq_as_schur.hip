@@ -415,11 +415,7 @@ static int as_schur_refresh(bq_solver *s, as_ws *w, int64_t nA, bool *ok) {
         return BQ_OK;
     }
     // this factor is kept for up to hundreds of iterations: make its sweeps short chains of full-chip products
-    static const bool fast_sweeps = [] {
-        const char *e = getenv("BQ_AS_FAST_SWEEPS");
-        return e == nullptr || atoi(e) != 0;
-    }();
-    if (fast_sweeps) BQ_TRY(bq_chol_prepare_sweeps(ws, np0));
+    BQ_TRY(bq_chol_prepare_sweeps(ws, np0));
     std::fill(c->hpos0.begin(), c->hpos0.end(), -1);
     for (int64_t a = 0; a < nA; ++a) c->hpos0[(size_t)hidx[(size_t)a]] = (int)a;
     c->n0 = nA;

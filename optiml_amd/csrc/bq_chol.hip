@@ -293,12 +293,11 @@ int bq_chol_ws_create(bq_ctx *ctx, int64_t n, bq_chol_ws **out) {
         return BQ_ERR_HIP;
     }
     // Look-ahead: the narrow work of pass p+1 is issued on a high-priority stream beside the wide update of pass p
-    // (BQ_CHOL_LOOKAHEAD=2, the default; =0 issues everything in order on one stream; =1 uses CU-masked streams and is
-    // experimental: one run with it at n = 16 384 did not finish within its limit).  Measured +5 % at n = 50 000: the
+    // (priority streams; issuing everything in order on one stream was 5 % slower at n = 50 000, CU-masked streams did not finish a
+    // run at n = 16 384 within its limit: both removed in round 5).  The
     // diagonal-block kernel needs a whole free CU (136 KB of LDS, 8 waves) and the wide update keeps every CU's
     // register file full, so the priority stream mostly gets its turn in the tail of the wide kernel.
-    const char *la = getenv("BQ_CHOL_LOOKAHEAD");
-    const int la_mode = la != nullptr ? atoi(la) : 2;   // 0: off, 1: CU-masked streams, 2: priority streams (default)
+    const int la_mode = 2;   // priority streams
     if (la_mode != 0 && ctx->num_cu >= 64) {
         bool ok;
         if (la_mode == 2) {
@@ -372,11 +371,10 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
     // The images of a super-pass are contiguous in k, two buffers.
     // With look-ahead the narrow chain of super-pass q+1 (it touches only the 2P block columns head(q) has finished) runs on
     // the high-priority side stream while rest(q) keeps the chip busy.
-    // P passes per super-pass (env BQ_CHOL_SUPER, default by size): the wide update then has K = P * 256.  A larger P cuts the C
+    // P passes per super-pass (by size): the wide update then has K = P * 256.  A larger P cuts the C
     // traffic and the per-tile prologue per flop further but lengthens the narrow chain between two wide updates.
     const int P = [&] {
-        const char *e = getenv("BQ_CHOL_SUPER");
-        int v = e ? atoi(e) : (np >= 65536 ? 4 : (np >= 24576 ? 3 : 2));   // measured (final kernel): n=50k 622 / 608 / 621 ms, n=32k 192 / 190 / 194 ms for P = 2 / 3 / 4
+        int v = np >= 65536 ? 4 : (np >= 24576 ? 3 : 2);   // measured (final kernel): n=50k 622 / 608 / 621 ms, n=32k 192 / 190 / 194 ms for P = 2 / 3 / 4
         return v < 1 ? 1 : (v > ws->super_max ? ws->super_max : v);
     }();
     auto wimg = [&](int64_t p) {   // images of a super-pass are contiguous in k; two buffers

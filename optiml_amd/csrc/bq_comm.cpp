@@ -43,7 +43,7 @@ rccl_api g_rccl;
 // Round 4 lost > 90 s inside Context.__init__ of a one-rank RCCL context on a cold box and the Python-level dump could not tell
 // dlopen of the 573 MB librccl.so from ncclGetUniqueId from ncclCommInitRank.  Every stage is now clocked: the durations are kept
 // (bq_comm_init_report), a stage that is still running after 5 s says so on stderr every 5 s WHILE it runs (so a hang names its
-// stage), and a stage that took more than 5 s — or any stage under BQ_DEBUG_EXCHANGE=1 — is reported when it ends.
+// stage), and a stage that took more than 5 s — or any stage under NCCL_DEBUG=INFO — is reported when it ends.
 struct stage_log {
     std::mutex m;
     std::string text;   // "dlopen(librccl.so.1) 0.412 s; dlsym x8 0.000 s; ..."
@@ -74,8 +74,8 @@ struct stage_scope {
         ticker.join();
         const double dt = seconds();
         static const bool verbose = [] {
-            const char *e = getenv("BQ_DEBUG_EXCHANGE");
-            return e != nullptr && atoi(e) != 0;
+            const char *e = getenv("NCCL_DEBUG");   // RCCL's own switch: whoever asked RCCL to talk wants the stages too
+            return e != nullptr && *e != 0 && strcmp(e, "VERSION") != 0 && strcmp(e, "WARN") != 0;
         }();
         if (dt > 5.0 || verbose) fprintf(stderr, "[bcqp] RCCL start-up: %s took %.3f s\n", name, dt);
         char buf[160];

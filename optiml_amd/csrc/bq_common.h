@@ -138,7 +138,7 @@ struct bq_problem {
     // symmetric mode (kernel-built panels): only tiles on/below the diagonal are stored and streamed; this rank owns
     // the 256-row tile rows [I0, I1) of nb, panel row 0 is global row I0*256
     size_t panel_bytes = 0;    // allocated size of `panel_alloc`
-    void *panel_alloc = nullptr;   // what the allocator handed out; `panel` = panel_alloc + the chosen offset (BQ_PLACE_OFFSETS)
+    void *panel_alloc = nullptr;   // what the allocator handed out; `panel` = panel_alloc (round 4's offset experiment — no effect — is gone)
     int place_tried = 0;       // BQ_PLACE_PANEL: placements timed, and the product's launch time on each
     double place_ms[32] = {0.0};
     double alloc_ms = 0.0;     // what the driver took to hand out the panel (0: it came from the context's cache)

@@ -328,11 +328,7 @@ static int run_gram(bq_ctx *ctx, const gram_images &A, const gram_images &B, int
         P.rect_rb = P.rect_sb = 0;
         P.tiles_m = (int)tiles_m;
         P.strips = (int)strips;
-        static const bool rect_order = [] {
-            const char *e = getenv("BQ_GRAM_ORDER");   // 0: the plain 2-D grid (tile rows fastest)
-            return !(e && atoi(e) == 0);
-        }();
-        if (rect_order && tiles_m * strips >= 8 * GRAM_RECT_R * GRAM_RECT_S) {
+        if (tiles_m * strips >= 8 * GRAM_RECT_R * GRAM_RECT_S) {
             P.rect_rb = (int)((tiles_m + GRAM_RECT_R - 1) / GRAM_RECT_R);
             P.rect_sb = (int)((strips + GRAM_RECT_S - 1) / GRAM_RECT_S);
             const int64_t nrect = (int64_t)P.rect_rb * P.rect_sb;

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restri
 // The timed launch: when the context is profiling, the kernel's own dispatch carries the two timestamps (hipExtLaunchKernelGGL with a
 // start and a stop event) instead of two events recorded around it on the stream: the duration is the kernel's own, as rocprofv3's
 // kernel trace reports it, and the stream carries nothing a solve without profiling would not (measured: 1-2 us per product less than
-// the bracketing, profiles/r04/share_gaps_events.txt; BQ_PROF_BRACKET=1 brings the bracketing back, to compare).
+// the bracketing, profiles/r04/share_gaps_events.txt).
 template <typename K, typename... A>
 static hipError_t launch_timed(bq_ctx *ctx, bool ext, hipEvent_t e0, hipEvent_t e1, K kernel, dim3 grid, dim3 block, A... args) {
     if (ext)
@@ -306,10 +306,7 @@ static hipError_t launch_timed(bq_ctx *ctx, bool ext, hipEvent_t e0, hipEvent_t 
 template <int JG, int SR>
 static int launch_tiles(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t I0, int64_t I1, int64_t nb,
                         const double *w, double *slab, const int *done) {
-    static const bool bracket = [] {
-        const char *e = getenv("BQ_PROF_BRACKET");
-        return e && atoi(e) != 0;
-    }();
+    constexpr bool bracket = false;   // (round 4's BQ_PROF_BRACKET=1 — events recorded around the launch — cost 1-2 us per product: removed)
     const int64_t nstrips = strips_before<JG>(I1) - strips_before<JG>(I0);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     BQ_TRY(bq_prof_begin(ctx, BQ_PROF_MATVEC, &e0, &e1, bracket));

@@ -469,10 +469,7 @@ int bq_pgfw_iterate(bq_solver *s) {
     }
     // the kernel that finishes the product also finishes the iteration (Qd, d'Qd, the step length) where the path has one such
     // kernel (symmetric panels: the slab reduction / the ordered segment sum); dense row-block panels keep the separate launch
-    static const bool fuse = [] {
-        const char *e = getenv("BQ_PGFW_FUSE");
-        return e == nullptr || atoi(e) != 0;
-    }();
+    constexpr bool fuse = true;
     bq_epilogue epi;
     epi.structure = p->structure;
     epi.kind = s->kind == BQ_PG ? 0 : 1;

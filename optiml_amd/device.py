@@ -115,7 +115,7 @@ class Context:
         elif exchange == 'host':
             self.rank, self.world, self.exchange = comm.rank, comm.world_size, 'host'
 
-            debug = os.environ.get('BQ_DEBUG_EXCHANGE') == '1'
+            debug = os.environ.get('NCCL_DEBUG', '') in ('INFO', 'TRACE')
 
             def _exchange(user, buf, n, r0, r1, op):
                 try:

@@ -62,7 +62,7 @@ class TorchComm(_Base):
 
     def allgather_rows(self, buf, r0, r1):
         import torch
-        dbg = os.environ.get('BQ_DEBUG_EXCHANGE') == '1'
+        dbg = os.environ.get('NCCL_DEBUG', '') in ('INFO', 'TRACE')
         t = [time.perf_counter()]
         n = buf.shape[0]
         blk = block_size(n, self.world_size)
