@@ -1344,7 +1344,9 @@ def main():
             fam = os.environ.get('BQ_AS_CG_PC_CLASS', '2')
             out['inner_preconditioner'] = 'none (BQ_AS_CG_PC=0)' if os.environ.get('BQ_AS_CG_PC') == '0' else \
                 'diagonal + Taylor features of the RBF kernel through Woodbury: orders 0-1 (d + 2 columns)' + \
-                {'2': ' + the order-2 term projected onto the 2d class-mean directions (3d + 2 columns in all)',
+                {'2': ' + the order-2 term projected onto the 2d class-mean directions (3d + 2 columns in all)' +
+                      (', the rest of the order-2 term applied without features behind a degree-1 Chebyshev polynomial' if n >= 65536 and 'BQ_AS_CG_PC_CLASS' not in os.environ else ''),
+                 '3': ' + the order-2 term projected onto the 2d class-mean directions + its implicit remainder (forced)',
                  '1': ' + the class-mean cross term of rounds 3-4 (2d + 2 columns in all)'}.get(fam, '')
             out['time_to_kkt_projected'] = c5_projection(n, d, 1e3 * elapsed / max(done, 1))
             out['inner_warm_start'] = os.environ.get('BQ_AS_CG_WARM') != '0'

@@ -70,6 +70,11 @@ struct as_pc {
     long long rebuilds = 0;
     double *cls = nullptr;   // class statistics (as_pc_class_kernel), BQ_SVC + RBF only
     bq_chol_ws *ws = nullptr;
+    // the implicit order-2 remainder behind a degree-1 Chebyshev polynomial (bq_as_pc2.hip); null: the explicit model alone
+    struct as_pc2 *r2 = nullptr;
+    int top0 = 0, ntop = 0;       // the Phi_top columns (the projected order-2 directions) of the explicit model
+    double *y1 = nullptr, *v2 = nullptr, *z2 = nullptr, *ones = nullptr;   // ldN each: y = P1^-1 r, R y, P1^-1 R y; weights 1
+    double *ttop = nullptr;       // mp: Phi_top' y
 };
 
 struct as_ws {
@@ -352,7 +357,17 @@ int as_finish_iteration(bq_solver *s, as_ws *w, hipStream_t st, bool exact);
 int as_cg_create(bq_solver *s, as_ws *w);      // buffers, switches and the preconditioner of a BQ_AS_CG solver (bq_as_start)
 int as_cg_iterate(bq_solver *s, as_ws *w);     // the body of one outer iteration once the top record has been read
 
-// ---- preconditioner (bq_as_pc.hip) ----------------------------------------------------------------------------
+// ---- preconditioner (bq_as_pc.hip, bq_as_pc2.hip) ------------------------------------------------------------
+constexpr int PC_MAX_M = 1024;   // features the apply kernels keep in LDS
+typedef float as_f4 __attribute__((ext_vector_type(4)));
+int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out);
+void as_pc2_free(as_pc2 *r);
+int as_pc2_bpart(bq_solver *s, as_pc2 *r, const double *y, const as_cg_scal *cg);
+const double *as_pc2_ypart(const as_pc2 *r, int *tiles);
+const double *as_pc2_c(const as_pc2 *r);
+double as_pc2_lambda(const as_pc2 *r);
+void as_pc2_set_lambda(as_pc2 *r, double lambda);
+void as_pc2_coefs(const as_pc2 *r, double *alpha, double *beta);
 int as_pc_create(bq_solver *s, as_pc **out);
 void as_pc_free(as_pc *pc);
 void as_pc_track(bq_solver *s, as_ws *w, hipStream_t st);   // which samples entered / left the free set since G^-1 was brought up to date

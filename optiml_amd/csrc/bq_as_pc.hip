@@ -5,7 +5,6 @@
 // ---------------------------------------------------------------------------------------------------------------
 // the diagonal + low-rank preconditioner of the inner iteration (struct as_pc)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int PC_MAX_M = 1024;   // features the apply kernel keeps in LDS
 constexpr int PC_T = 32, PC_C = 64, PC_SLICES = 8;
 
 // class statistics of the samples (BQ_SVC panels): cls[k] = a_k = (mean_+ - mean_-)_k / 2, cls[d + k] = m0_k = (mean_+ + mean_-)_k / 2,
@@ -165,8 +164,10 @@ __global__ __launch_bounds__(256) void as_pc_project_kernel(int64_t n, int64_t d
 
 // 1 / D_i and the share of the diagonal the features leave, D_i = Q_ii - |Phi_i|^2 over the STORED features (floored at 1e-8 Q_ii: P
 // only has to be positive definite).  qdiag_share: Q_ii in, share out.
+// With the implicit order-2 remainder R = B - Phi_top Phi_top' (bq_as_pc2.hip) the model is P = D + Phi Phi' + R: D also gives up
+// R's diagonal, bdiag_i - |Phi_top,i|^2 (bdiag: the diagonal of B; top0 / ntop: the Phi_top columns; null / 0: no remainder).
 __global__ void as_pc_diag_kernel(int64_t n, int64_t ld, int m, const float *__restrict__ Phi, double *__restrict__ dinv,
-                                  double *__restrict__ qdiag_share) {
+                                  double *__restrict__ qdiag_share, const double *__restrict__ bdiag, int top0, int ntop) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ld) return;
     if (i >= n) {
@@ -176,9 +177,11 @@ __global__ void as_pc_diag_kernel(int64_t n, int64_t ld, int m, const float *__r
     }
     double s = 0.0;
     for (int j = 0; j < m; ++j) {
+        if (bdiag != nullptr && j >= top0 && j < top0 + ntop) continue;   // Phi_top Phi_top' + R = B on these directions
         const double v = (double)Phi[(int64_t)j * ld + i];
         s = fma(v, v, s);
     }
+    if (bdiag != nullptr) s += bdiag[i];
     const double qii = qdiag_share[i];
     dinv[i] = 1.0 / fmax(qii - s, 1e-8 * qii);
     qdiag_share[i] = (qii - s) / qii;   // what the features leave of the diagonal: the host refuses a model that leaves too little
@@ -379,7 +382,6 @@ __global__ __launch_bounds__(1024) void as_pc_sm_kernel(int m, int64_t mp, int64
     }
 }
 
-typedef float as_f4 __attribute__((ext_vector_type(4)));
 constexpr int PC_FG = 8;   // features per butterfly group of the t kernel
 
 // t[j] = sum_i Phi[j][i] r_i / D_i   (r vanishes outside the free set).  One workgroup per block of 1024 samples: a lane keeps
@@ -474,7 +476,8 @@ __global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int
                                                           const double *__restrict__ dinv, const unsigned char *__restrict__ mL,
                                                           const unsigned char *__restrict__ mU, const double *__restrict__ r,
                                                           const double *__restrict__ u, double *__restrict__ z, double *part,
-                                                          int64_t nblk, as_cg_scal *cg, int first) {
+                                                          int64_t nblk, as_cg_scal *cg, int first, int fin) {
+    // fin == 0: z only (an inner application of P1^-1 inside the polynomial of the order-2 remainder: as_pc_apply)
     if (cg->done) return;
     __shared__ double us[PC_MAX_M];
     __shared__ double sh[4];
@@ -506,6 +509,7 @@ __global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int
         }
         z[i] = zi;
     }
+    if (!fin) return;
     s = as_block_sum(s, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
     if (as_last_block(&cg->ticket[0])) {
@@ -519,6 +523,78 @@ __global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int
     }
 }
 
+
+// v_i = c_i (the column tiles' partials of x_i' M x_i, added in tile order) - Phi_top[:, i] . t   on the free set, 0 elsewhere:
+// v = R y, R = B - Phi_top Phi_top' (bq_as_pc2.hip formed the B part, as_pc_tphi_kernel t = Phi_top' y)
+__global__ __launch_bounds__(256) void as_pc_r_finish_kernel(int64_t N, int64_t ld, int tiles, int ncols, const float *__restrict__ Phitop,
+                                                             const double *__restrict__ c, const double *__restrict__ ypart,
+                                                             const double *__restrict__ t, const unsigned char *__restrict__ mL,
+                                                             const unsigned char *__restrict__ mU, double *__restrict__ v, const as_cg_scal *cg) {
+    if (cg->done) return;
+    __shared__ double ts[PC_MAX_M];
+    for (int j = threadIdx.x; j < ncols; j += 256) ts[j] = t[j];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + 4 * threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < ncols; ++j) {
+        const as_f4 f = *reinterpret_cast<const as_f4 *>(Phitop + (int64_t)j * ld + base);
+        const double tj = ts[j];
+        acc[0] = fma((double)f.x, tj, acc[0]);
+        acc[1] = fma((double)f.y, tj, acc[1]);
+        acc[2] = fma((double)f.z, tj, acc[2]);
+        acc[3] = fma((double)f.w, tj, acc[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k;
+        double r = 0.0;
+        if (i < N && !(mL[i] | mU[i])) {
+            double b = 0.0;
+            for (int ct = 0; ct < tiles; ++ct) b += ypart[(int64_t)ct * ld + i];
+            r = c[i] * b - acc[k];
+        }
+        v[i] = r;
+    }
+}
+
+// z = alpha y - beta z2 (both vanish outside the free set);  rz = r'z and beta of the conjugate gradients, as as_pc_apply_kernel does
+__global__ __launch_bounds__(256) void as_pc_combine_kernel(int64_t N, double alpha, double beta, const double *__restrict__ r,
+                                                            const double *__restrict__ y, const double *__restrict__ z2,
+                                                            double *__restrict__ z, double *part, int64_t nblk, as_cg_scal *cg, int first) {
+    if (cg->done) return;
+    __shared__ double sh[4];
+    double s = 0.0;
+    VEC_LOOP(i) {
+        double zi = 0.0;
+        if (i < N) {
+            zi = alpha * y[i] - beta * z2[i];
+            s += __dmul_rn(r[i], zi);
+        }
+        z[i] = zi;
+    }
+    s = as_block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (as_last_block(&cg->ticket[0])) {
+        const double rz = as_final_sum(part, nblk, sh);
+        if (threadIdx.x == 0) {
+            cg->ticket[0] = 0;
+            cg->beta = (first || !(cg->rz > 0.0)) ? 0.0 : rz / cg->rz;
+            cg->rz = rz;
+            if (!(rz > 0.0) || !isfinite(rz)) cg->info = 2;
+        }
+    }
+}
+
+__global__ void as_pc_fill_kernel(int64_t ld, double value, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < ld) out[i] = value;
+}
+// v = 1 on the free set, 0 elsewhere (start vector of the power iteration)
+__global__ void as_pc_mask_ones_kernel(int64_t N, int64_t ld, const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                       double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < ld) out[i] = (i < N && !(mL[i] | mU[i])) ? 1.0 : 0.0;
+}
 
 // The model P = D + Phi Phi' is only used when it leaves every sample a diagonal share D_i / Q_ii of at least this much: a
 // feature set that explains (or over-explains: D_i <= 0) the whole diagonal of some sample is a Taylor expansion outside its
@@ -536,11 +612,17 @@ int as_pc_create(bq_solver *s, as_pc **out) {
     bq_ctx *ctx = p->ctx;
     // family 2 of the RBF features on BQ_SVC panels: 2 = projected order-2 directions (2d columns), 1 = the class-mean cross term of
     // rounds 3-4 (d columns), 0 = none.  BQ_AS_CG_PC_CLASS=0|1|2 caps it (tests compare them); a family that does not fit PC_MAX_M
-    // features, or whose model leaves a sample too little of its diagonal, steps down.
+    // features, or whose model leaves a sample too little of its diagonal, steps down.  With family 2 the REST of the order-2 term is
+    // applied without features behind a degree-1 Chebyshev polynomial (bq_as_pc2.hip) where its bulk stands out of the diagonal —
+    // n >= 65 536 (its eigenvalues grow like n / (d (d + 1) / 2); below, it costs more launches than it saves products) or
+    // BQ_AS_CG_PC_CLASS=3 (tests).
     int fam2 = 0;
+    bool want_r2 = false;
     if (p->kernel == BQ_KERNEL_RBF && p->structure == BQ_SVC) {
         const char *e = getenv("BQ_AS_CG_PC_CLASS");
-        fam2 = e ? std::max(0, std::min(atoi(e), 2)) : 2;
+        const int v = e ? std::max(0, std::min(atoi(e), 3)) : 2;
+        fam2 = std::min(v, 2);
+        want_r2 = v == 3 || (e == nullptr && p->n >= 65536);
     }
     std::vector<double> share((size_t)p->n);
     for (; fam2 >= 0; --fam2) {
@@ -557,8 +639,9 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         int rc = bq_chol_ws_create(ctx, pc->mp, &pc->ws);
         hipError_t e = hipSuccess;
         pc->m8 = bq_round_up(m, PC_FG);
-        if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(float) * (size_t)pc->m8 * s->ldN);
-        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->Phi, 0, sizeof(float) * (size_t)pc->m8 * s->ldN, ctx->stream);
+        // (PC_FG spare zero rows: the t kernel walks feature groups of PC_FG from any first column — the Phi_top block of the remainder)
+        if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(float) * (size_t)(pc->m8 + PC_FG) * s->ldN);
+        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->Phi, 0, sizeof(float) * (size_t)(pc->m8 + PC_FG) * s->ldN, ctx->stream);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->tpart, sizeof(double) * (size_t)s->nblk * pc->mp);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->tticket, sizeof(unsigned int));
         if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->tticket, 0, sizeof(unsigned int), ctx->stream);
@@ -583,8 +666,28 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         // that fell back to plain conjugate gradients alone — or returned an error alone — would leave the others waiting in the
         // next collective for ever.  So the outcome is agreed on (one all-reduce of a flag) and, if any rank has no room, every rank
         // runs unpreconditioned.
-        double failed = (rc != BQ_OK || e != hipSuccess) ? 1.0 : 0.0;
-        if (failed != 0.0) (void)hipGetLastError();
+        // the implicit order-2 remainder (family 2 only): its images and buffers — a rank without room for them drops IT on every rank
+        // (the 1e-3 digit of the agreed flag), not the explicit model
+        double *bdiag = nullptr;
+        if (rc == BQ_OK && e == hipSuccess && fam2 == 2 && want_r2) {
+            hipError_t re = hipMalloc(&bdiag, sizeof(double) * s->ldN);
+            for (double **v : {&pc->y1, &pc->v2, &pc->z2, &pc->ones})
+                if (re == hipSuccess) re = hipMalloc(v, sizeof(double) * s->ldN);
+            if (re == hipSuccess) re = hipMalloc(&pc->ttop, sizeof(double) * pc->mp);
+            if (re == hipSuccess && as_pc2_create(s, bdiag, &pc->r2) != BQ_OK) re = hipErrorOutOfMemory;
+            if (re == hipSuccess && pc->r2 != nullptr) {
+                as_pc_fill_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(s->ldN, 1.0, pc->ones);
+                pc->top0 = (int)p->d + 1;
+                pc->ntop = 2 * (int)p->d;
+            } else {
+                (void)hipGetLastError();
+                as_pc2_free(pc->r2);
+                pc->r2 = nullptr;
+            }
+        }
+        const bool r2_missing = fam2 == 2 && want_r2 && pc->r2 == nullptr;
+        double failed = ((rc != BQ_OK || e != hipSuccess) ? 1.0 : 0.0) + (r2_missing ? 1e-3 : 0.0);
+        if (failed >= 0.5) (void)hipGetLastError();
         if (ctx->world > 1 && ctx->comm_kind != BQ_COMM_SHARE) {
             hipError_t ae = hipMemcpyAsync(s->partials, &failed, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
             int arc = ae == hipSuccess ? bq_exchange_sum(ctx, s->partials, 1) : BQ_ERR_HIP;
@@ -596,9 +699,14 @@ int as_pc_create(bq_solver *s, as_pc **out) {
                 return arc != BQ_OK ? arc : BQ_ERR_HIP;
             }
         }
-        if (failed != 0.0) {   // no room for the features on some rank: all ranks run plain conjugate gradients
+        if (failed >= 0.5) {   // no room for the features on some rank: all ranks run plain conjugate gradients
+            if (bdiag) hipFree(bdiag);
             as_pc_free(pc);
             return BQ_OK;
+        }
+        if (failed > 1e-6 && pc->r2 != nullptr) {   // some rank has no room for the remainder: nobody uses it
+            as_pc2_free(pc->r2);
+            pc->r2 = nullptr;
         }
         double *raw = nullptr, *rinv_d = nullptr;   // fam2 == 2: per-sample numbers and the orthonormalising factor (setup only)
         hipError_t fe = hipSuccess;
@@ -670,13 +778,15 @@ int as_pc_create(bq_solver *s, as_pc **out) {
             if (fam2 == 2)
                 as_pc_project_kernel<<<dim3((unsigned)(s->ldN / 64), (unsigned)((2 * p->d + 63) / 64)), 256, 0, ctx->stream>>>(
                     p->n, p->d, s->ldN, p->X, raw, rinv_d, (int)p->d + 1, pc->Phi);
-            as_pc_diag_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->n, s->ldN, m, pc->Phi, pc->dinv, pc->z);
+            as_pc_diag_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(p->n, s->ldN, m, pc->Phi, pc->dinv, pc->z,
+                                                                                 pc->r2 ? bdiag : nullptr, pc->top0, pc->ntop);
             fe = hipGetLastError();
         }
         if (fe == hipSuccess && frc == BQ_OK) fe = hipMemcpyAsync(share.data(), pc->z, sizeof(double) * p->n, hipMemcpyDeviceToHost, ctx->stream);
         if (fe == hipSuccess && frc == BQ_OK) frc = bq_ctx_sync(ctx);
         if (raw) hipFree(raw);
         if (rinv_d) hipFree(rinv_d);
+        if (bdiag) hipFree(bdiag);
         if (fe != hipSuccess || frc != BQ_OK) {
             as_pc_free(pc);
             if (fe != hipSuccess) bq_set_error("building the preconditioner features failed: %s", hipGetErrorString(fe));
@@ -696,23 +806,62 @@ int as_pc_create(bq_solver *s, as_pc **out) {
 void as_pc_free(as_pc *pc) {
     if (!pc) return;
     if (pc->ws) bq_chol_ws_destroy(pc->ws);
+    as_pc2_free(pc->r2);
+    for (void *ptr : {(void *)pc->y1, (void *)pc->v2, (void *)pc->z2, (void *)pc->ones, (void *)pc->ttop})
+        if (ptr) hipFree(ptr);
     for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls, (void *)pc->Ginv,
                       (void *)pc->u, (void *)pc->sm_fail, (void *)pc->prev, (void *)pc->chg, (void *)pc->tpart, (void *)pc->tticket})
         if (ptr) hipFree(ptr);
     delete pc;
 }
 
-// z = P_AA^-1 r (+ r'z and beta on the device)
+// out = P1_AA^-1 in (in vanishes outside the free set); fin: also r'z and beta of the conjugate gradients (in is their residual)
+static void as_pc_solve1(bq_solver *s, as_ws *w, const double *in, double *out, int first, int fin) {
+    as_pc *pc = w->pc;
+    hipStream_t st = s->p->ctx->stream;
+    const dim3 g1(vgrid(s->ldN).x, 1);
+    as_pc_tphi_kernel<<<g1, BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, pc->mp, s->N, s->ldN, pc->Phi, pc->dinv, in, pc->tpart, pc->ws->rhs, pc->tticket, w->cg);
+    as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(pc->m8, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ws->rhs, w->cg);
+    as_pc_gemv_kernel<<<(unsigned)((pc->mp + 3) / 4), 256, 0, st>>>(pc->mp, pc->Ginv, pc->ws->rhs, pc->u, w->cg);   // u = G^-1 t
+    as_pc_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, s->N, s->ldN, pc->Phi, pc->dinv, s->mL, s->mU, in, pc->u, out,
+                                                               s->partials, s->nblk, w->cg, first, fin);
+}
+
+// v2 = R y1 on the free set, R = B - Phi_top Phi_top' (y1 vanishes outside the free set)
+static int as_pc_r_apply(bq_solver *s, as_ws *w) {
+    as_pc *pc = w->pc;
+    hipStream_t st = s->p->ctx->stream;
+    BQ_TRY(as_pc2_bpart(s, pc->r2, pc->y1, w->cg));
+    const float *Phitop = pc->Phi + (int64_t)pc->top0 * s->ldN;
+    const int64_t m8t = bq_round_up(pc->ntop, PC_FG);   // (Phi carries PC_FG spare zero rows behind its last feature)
+    as_pc_tphi_kernel<<<dim3(vgrid(s->ldN).x, 1), BQ_VEC_BLOCK, 0, st>>>(pc->ntop, m8t, pc->mp, s->N, s->ldN, Phitop, pc->ones, pc->y1, pc->tpart,
+                                                                         pc->ttop, pc->tticket, w->cg);
+    as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(m8t, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ttop, w->cg);
+    int tiles = 0;
+    const double *ypart = as_pc2_ypart(pc->r2, &tiles);
+    as_pc_r_finish_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->ldN, tiles, pc->ntop, Phitop, as_pc2_c(pc->r2), ypart, pc->ttop, s->mL,
+                                                                  s->mU, pc->v2, w->cg);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
+// z = P_AA^-1 r (+ r'z and beta on the device).  Explicit model: one Woodbury application.  With the order-2 remainder:
+// z = alpha y - beta P1^-1 (R y), y = P1^-1 r — the degree-1 Chebyshev polynomial of bq_as_pc2.hip (alpha = 1, beta = 0 until the
+// spectrum bound has been estimated).
 int as_pc_apply(bq_solver *s, as_ws *w, int first) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
-    constexpr int tslices = 1;   // feature slices of the t kernel (2 and 4 measured no faster at m = 514: HISTORY 10)
-    as_pc_tphi_kernel<<<dim3(vgrid(s->ldN).x, (unsigned)tslices), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, pc->mp, s->N, s->ldN, pc->Phi, pc->dinv, w->r,
-                                                                                        pc->tpart, pc->ws->rhs, pc->tticket, w->cg);
-    as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(pc->m8, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ws->rhs, w->cg);
-    as_pc_gemv_kernel<<<(unsigned)((pc->mp + 3) / 4), 256, 0, st>>>(pc->mp, pc->Ginv, pc->ws->rhs, pc->u, w->cg);   // u = G^-1 t
-    as_pc_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, s->N, s->ldN, pc->Phi, pc->dinv, s->mL, s->mU, w->r,
-                                                               pc->u, pc->z, s->partials, s->nblk, w->cg, first);
+    double alpha = 1.0, beta = 0.0;
+    if (pc->r2) as_pc2_coefs(pc->r2, &alpha, &beta);
+    if (pc->r2 == nullptr || beta == 0.0) {
+        as_pc_solve1(s, w, w->r, pc->z, first, 1);
+        return BQ_OK;
+    }
+    as_pc_solve1(s, w, w->r, pc->y1, first, 0);
+    BQ_TRY(as_pc_r_apply(s, w));
+    as_pc_solve1(s, w, pc->v2, pc->z2, first, 0);
+    as_pc_combine_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, alpha, beta, w->r, pc->y1, pc->z2, pc->z, s->partials, s->nblk, w->cg, first);
+    BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
 
@@ -752,6 +901,29 @@ int as_pc_update(bq_solver *s, as_ws *w) {
         pc->rebuilds += 1;
     } else {
         as_pc_sm_kernel<<<1, 1024, 0, st>>>(pc->m, pc->mp, s->ldN, pc->Phi, pc->dinv, pc->chg, pc->Ginv, pc->sm_fail);
+    }
+    if (pc->r2 && rebuild && as_pc2_lambda(pc->r2) < 0.0) {
+        // lambda_max of P1^-1 R on this free set by a power iteration from the all-ones vector (six applications, two norms on the
+        // host; once per solver: restricting to a smaller free set later only lowers it).  Every rank computes the same bits.
+        // A spectrum bound that cannot be formed (a solve that was over before it began: the kernels return on `done`) is retried
+        // at the next rebuild; until then the explicit model alone is used.
+        std::vector<double> a((size_t)N), b((size_t)N);
+        as_pc_mask_ones_kernel<<<(unsigned)(s->ldN / 256), 256, 0, st>>>(N, s->ldN, s->mL, s->mU, pc->y1);
+        double lam = -1.0;
+        for (int it = 0; it < 6; ++it) {
+            if (it == 5) BQ_HIP(hipMemcpyAsync(a.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+            BQ_TRY(as_pc_r_apply(s, w));
+            as_pc_solve1(s, w, pc->v2, pc->y1, 1, 0);
+        }
+        BQ_HIP(hipMemcpyAsync(b.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        BQ_TRY(bq_ctx_sync(s->p->ctx));
+        double na = 0.0, nb = 0.0;
+        for (int64_t i = 0; i < N; ++i) {
+            na += a[(size_t)i] * a[(size_t)i];
+            nb += b[(size_t)i] * b[(size_t)i];
+        }
+        if (na > 0.0 && std::isfinite(na) && std::isfinite(nb)) lam = sqrt(nb / na);
+        if (lam >= 0.0 && std::isfinite(lam)) as_pc2_set_lambda(pc->r2, 1.15 * lam);   // a power iteration comes from below
     }
     return BQ_OK;
 }
