@@ -923,7 +923,10 @@ int as_pc_update(bq_solver *s, as_ws *w) {
             nb += b[(size_t)i] * b[(size_t)i];
         }
         if (na > 0.0 && std::isfinite(na) && std::isfinite(nb)) lam = sqrt(nb / na);
-        if (lam >= 0.0 && std::isfinite(lam)) as_pc2_set_lambda(pc->r2, 1.15 * lam);   // a power iteration comes from below
+#ifndef BQ_PC2_LAMBDA_SCALE
+#define BQ_PC2_LAMBDA_SCALE 1.15   // a power iteration comes from below (swept at config 5: profiles/r05/c5_lambda_scale.txt)
+#endif
+        if (lam >= 0.0 && std::isfinite(lam)) as_pc2_set_lambda(pc->r2, BQ_PC2_LAMBDA_SCALE * lam);
     }
     return BQ_OK;
 }

@@ -67,13 +67,15 @@ __global__ __launch_bounds__(256) void pc2_scale_kernel(int64_t ld, int64_t dp, 
     }
 }
 
-// Mpart[s] (tile ta, tb) = Xp[slice s]' W[slice s]: blockIdx.x = tile (ta * T + tb), blockIdx.y = slice
+// Mpart[s] (tile ta, tb) = Xp[slice s]' W[slice s], tb <= ta only (M is symmetric: the reduction mirrors): blockIdx.x = the tile's
+// index in the lower triangle, blockIdx.y = slice
 __global__ __launch_bounds__(256, 2) void pc2_moment_kernel(int64_t dp, int64_t kc, const double *__restrict__ Xp, const double *__restrict__ W,
                                                             double *__restrict__ Mpart, const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
-    const int64_t T = dp / BQ_GT;
-    const int64_t ta = blockIdx.x / T, tb = blockIdx.x % T;
+    int64_t ta = 0;
+    while ((ta + 1) * (ta + 2) / 2 <= (int64_t)blockIdx.x) ++ta;
+    const int64_t tb = (int64_t)blockIdx.x - ta * (ta + 1) / 2;
     const int64_t k0 = (int64_t)blockIdx.y * kc;
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
@@ -85,8 +87,10 @@ __global__ __launch_bounds__(256, 2) void pc2_moment_kernel(int64_t dp, int64_t 
 __global__ __launch_bounds__(256) void pc2_moment_reduce_kernel(int64_t dp, int64_t S, const double *__restrict__ Mpart, double *__restrict__ M,
                                                                 const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= dp * dp) return;
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= dp * dp) return;
+    const int64_t ra = o / dp, rb = o % dp;
+    const int64_t e = (ra / BQ_GT >= rb / BQ_GT) ? o : rb * dp + ra;   // tiles above the diagonal: the mirrored element
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four interleaved chains (loads in flight), combined in a fixed order
     int64_t s = 0;
     for (; s + 4 <= S; s += 4) {
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void pc2_moment_reduce_kernel(int64_t dp, int6
         a3 += Mpart[(s + 3) * dp * dp + e];
     }
     for (; s < S; ++s) a0 += Mpart[s * dp * dp + e];
-    M[e] = (a0 + a1) + (a2 + a3);
+    M[o] = (a0 + a1) + (a2 + a3);
 }
 
 // ypart[ct][i] = sum over the 128 columns b of column tile ct of (X M)[i][b] X[i][b]: blockIdx.x = sample tile, blockIdx.y = ct
@@ -171,7 +175,7 @@ int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out) {
     r->ld = s->ldN;
     const int64_t T = r->dp / BQ_GT;
     // slices of the moment matrix: about two workgroups per CU in all, at least 256 samples each
-    int64_t S = std::max<int64_t>(1, 512 / (T * T));
+    int64_t S = std::max<int64_t>(1, 512 / (T * (T + 1) / 2));
     S = std::min<int64_t>(S, std::max<int64_t>(1, r->ld / 256));
     r->kc = bq_round_up((r->ld + S - 1) / S, BQ_GK);
     r->S = (r->ld + r->kc - 1) / r->kc;
@@ -204,7 +208,7 @@ int as_pc2_bpart(bq_solver *s, as_pc2 *r, const double *y, const as_cg_scal *cg)
     hipStream_t st = s->p->ctx->stream;
     const int64_t T = r->dp / BQ_GT;
     pc2_scale_kernel<<<(unsigned)((r->ld + 3) / 4), 256, 0, st>>>(r->ld, r->dp, r->Xp, r->c, y, r->W, cg);
-    pc2_moment_kernel<<<dim3((unsigned)(T * T), (unsigned)r->S), 256, 0, st>>>(r->dp, r->kc, r->Xp, r->W, r->Mpart, cg);
+    pc2_moment_kernel<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)r->S), 256, 0, st>>>(r->dp, r->kc, r->Xp, r->W, r->Mpart, cg);
     pc2_moment_reduce_kernel<<<(unsigned)((r->dp * r->dp + 255) / 256), 256, 0, st>>>(r->dp, r->S, r->Mpart, r->M, cg);
     pc2_bilinear_kernel<<<dim3((unsigned)(r->ld / BQ_GT), (unsigned)T), 256, 0, st>>>(r->dp, r->ld, r->Xt, r->Xp, r->M, r->ypart, cg);
     BQ_HIP(hipGetLastError());
