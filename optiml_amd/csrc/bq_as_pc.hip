@@ -903,15 +903,18 @@ int as_pc_update(bq_solver *s, as_ws *w) {
         as_pc_sm_kernel<<<1, 1024, 0, st>>>(pc->m, pc->mp, s->ldN, pc->Phi, pc->dinv, pc->chg, pc->Ginv, pc->sm_fail);
     }
     if (pc->r2 && rebuild && as_pc2_lambda(pc->r2) < 0.0) {
-        // lambda_max of P1^-1 R on this free set by a power iteration from the all-ones vector (six applications, two norms on the
+        // lambda_max of P1^-1 R on this free set by a power iteration from the all-ones vector (twelve applications, two norms on the
         // host; once per solver: restricting to a smaller free set later only lowers it).  Every rank computes the same bits.
+        // The polynomial stays positive up to 1 + the assumed bound, so an estimate from BELOW must be widened, never trusted: at
+        // config 5 six applications x 1.15 still gave 5.0 products per outer iteration, x 0.85 gave 8.0 and x 0.6 36 (the operator
+        // turns indefinite); x 1.6 is as good as x 1.15 (profiles/r05/c5_lambda_scale.txt) — wide is cheap, narrow is not.
         // A spectrum bound that cannot be formed (a solve that was over before it began: the kernels return on `done`) is retried
         // at the next rebuild; until then the explicit model alone is used.
         std::vector<double> a((size_t)N), b((size_t)N);
         as_pc_mask_ones_kernel<<<(unsigned)(s->ldN / 256), 256, 0, st>>>(N, s->ldN, s->mL, s->mU, pc->y1);
         double lam = -1.0;
-        for (int it = 0; it < 6; ++it) {
-            if (it == 5) BQ_HIP(hipMemcpyAsync(a.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        for (int it = 0; it < 12; ++it) {
+            if (it == 11) BQ_HIP(hipMemcpyAsync(a.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
             BQ_TRY(as_pc_r_apply(s, w));
             as_pc_solve1(s, w, pc->v2, pc->y1, 1, 0);
         }
@@ -924,7 +927,7 @@ int as_pc_update(bq_solver *s, as_ws *w) {
         }
         if (na > 0.0 && std::isfinite(na) && std::isfinite(nb)) lam = sqrt(nb / na);
 #ifndef BQ_PC2_LAMBDA_SCALE
-#define BQ_PC2_LAMBDA_SCALE 1.15   // a power iteration comes from below (swept at config 5: profiles/r05/c5_lambda_scale.txt)
+#define BQ_PC2_LAMBDA_SCALE 1.5   // a power iteration comes from below (swept at config 5: profiles/r05/c5_lambda_scale.txt)
 #endif
         if (lam >= 0.0 && std::isfinite(lam)) as_pc2_set_lambda(pc->r2, BQ_PC2_LAMBDA_SCALE * lam);
     }
