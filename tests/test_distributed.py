@@ -272,6 +272,21 @@ def test_rows_per_step_variants_are_bit_identical(tmp_path, one_rank):
 
 
 @pytest.mark.gpu
+def test_order2_remainder_of_the_preconditioner_is_replicated_bitwise(tmp_path):
+    """The implicit order-2 remainder of ActiveSetCG's preconditioner (csrc/bq_as_pc2.hip: two MFMA products with a split-K sum, a
+    power-iteration spectrum bound, a Chebyshev polynomial) runs replicated on every rank like the rest of the preconditioner: forced on
+    (BQ_AS_CG_PC_CLASS=3), one rank and two ranks give the same bits — and the same outer trajectory as without it."""
+    env = {'BQ_AS_CG_PC_CLASS': '3'}
+    one = _launch('gpu-host', 1, tmp_path / 'one', extra_env=env)[0]
+    two = _launch('gpu-host', 2, tmp_path / 'two', extra_env=env)
+    plain = _launch('gpu-host', 1, tmp_path / 'plain', extra_env={'BQ_AS_CG_PC_CLASS': '2'})[0]
+    for key in ('ascg_kernel_x', 'ascg_kernel_f'):
+        for r in two:
+            assert np.array_equal(r[key], one[key]), key
+    np.testing.assert_allclose(one['ascg_kernel_x'], plain['ascg_kernel_x'], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.gpu
 def test_collective_watchdog_aborts_a_wait_that_outlasts_the_timeout(tmp_path):
     """bq_ctx_set_collective_timeout on a one-rank RCCL context (a child process: an aborted communicator is the end of its
     context): normal products, a collective that is late by less than the limit and a LONG wait for this rank's own work all pass;
