@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
         s1 += __shfl_xor(s1, 4, 64);
         s1 += __shfl_xor(s1, 2, 64);
         s1 += __shfl_xor(s1, 1, 64);
-        if ((lane & (64 / SR - 1)) == 0) rowout[step * SR + rho] = s1;
+        if ((lane & (64 / SR - 1)) == 0) __builtin_nontemporal_store(s1, &rowout[step * SR + rho]);
     }
     // column parts of every off-diagonal tile of the strip
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
             colred[wv][c1 + 1] = ca[j][3];
             __syncthreads();
             const int64_t entry = (J0 + j) * nb + I;
-            slab[entry * ST + tid] = ((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid];
+            __builtin_nontemporal_store(((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid], &slab[entry * ST + tid]);
         }
     }
 }
@@ -205,22 +205,38 @@ template <int JG>
 __device__ __forceinline__ double seg_thread_sum(const double *__restrict__ p, int64_t a, int64_t c0, int64_t c1, int q) {
     double s0 = 0.0, s1 = 0.0;
     int64_t e = 0;   // running index over the entry list: row parts (b = 0, JG, 2JG, ... <= a) then col parts (b > a)
+    // Two chains (s0: entries k, k + 8, ...; s1: k + 4, k + 12, ...), each added in its own order — but the LOADS of four turns are
+    // issued together (round 5): written as one load per turn the loop was a chain of L2 round trips (~11 of them at nb = 79, ~50 at
+    // nb = 391: most of this kernel's 7 us on short grids); the association, and with it every bit, is what it was.
+    auto walk = [&](const double *base, int64_t first, int64_t count, int64_t stride) {
+        int64_t k = first;
+        for (; k + 28 < count; k += 32) {   // four turns of both chains: all eight entries exist
+            const double a0 = base[(k) * stride], b0 = base[(k + 4) * stride], a1 = base[(k + 8) * stride], b1 = base[(k + 12) * stride];
+            const double a2 = base[(k + 16) * stride], b2 = base[(k + 20) * stride], a3 = base[(k + 24) * stride], b3 = base[(k + 28) * stride];
+            s0 += a0;
+            s1 += b0;
+            s0 += a1;
+            s1 += b1;
+            s0 += a2;
+            s1 += b2;
+            s0 += a3;
+            s1 += b3;
+        }
+        for (; k < count; k += 8) {
+            s0 += base[k * stride];
+            if (k + 4 < count) s1 += base[(k + 4) * stride];
+        }
+    };
     if (a >= c0 && a < c1) {
         const int64_t nrow = a / JG + 1;
-        for (int64_t k = q; k < nrow; k += 8) {
-            s0 += p[(k * JG) * ST];
-            if (k + 4 < nrow) s1 += p[((k + 4) * JG) * ST];
-        }
+        walk(p, q, nrow, (int64_t)JG * ST);
         e = nrow;
     }
     const int64_t bs = (a + 1 > c0) ? a + 1 : c0;
     const int64_t ncol = c1 > bs ? c1 - bs : 0;
     // keep the q-assignment a function of the position in the whole list (row parts first)
     const int64_t shift = (4 - (e & 3)) & 3;
-    for (int64_t k = (q + shift) & 3; k < ncol; k += 8) {
-        s0 += p[(bs + k) * ST];
-        if (k + 4 < ncol) s1 += p[(bs + k + 4) * ST];
-    }
+    walk(p + bs * ST, (q + shift) & 3, ncol, ST);
     return s0 + s1;   // this thread's share (every 4th entry, q = its phase) of the segment's entry list
 }
 
@@ -285,7 +301,15 @@ __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restri
     if (done != nullptr && *done) return;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // len = nb * 256: always in range
     double acc = 0.0;
-    for (int s = 0; s < tab.count; ++s) acc += gath[(int64_t)tab.slot[s] * len + i];
+    int s = 0;
+    for (; s + 8 <= tab.count; s += 8) {   // the canonical eight segments: eight loads in flight, added in segment order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gath[(int64_t)tab.slot[s + u] * len + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < tab.count; ++s) acc += gath[(int64_t)tab.slot[s] * len + i];
     out[i] = acc;
     if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, acc), gridDim.x);
 }
