@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
         s1 += __shfl_xor(s1, 4, 64);
         s1 += __shfl_xor(s1, 2, 64);
         s1 += __shfl_xor(s1, 1, 64);
-        if ((lane & (64 / SR - 1)) == 0) __builtin_nontemporal_store(s1, &rowout[step * SR + rho]);
+        if ((lane & (64 / SR - 1)) == 0) rowout[step * SR + rho] = s1;
     }
     // column parts of every off-diagonal tile of the strip
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void symv_tiles_kernel(const T *__restrict_
             colred[wv][c1 + 1] = ca[j][3];
             __syncthreads();
             const int64_t entry = (J0 + j) * nb + I;
-            __builtin_nontemporal_store(((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid], &slab[entry * ST + tid]);
+            slab[entry * ST + tid] = ((colred[0][tid] + colred[1][tid]) + colred[2][tid]) + colred[3][tid];
         }
     }
 }
