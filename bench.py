@@ -1175,7 +1175,7 @@ def main():
             prefetch_rccl()
         # rendezvous / barrier / max-over-ranks: torch.distributed (gloo) when torch is importable, else the package's own
         # TCP communicator (BQ_RENDEZVOUS=socket forces it) — the data path is RCCL either way
-        from optiml_amd.dist import from_env
+        from bench_rendezvous import from_env
         comm = from_env(timeout=600.0)
         # RCCL over xGMI is the data path.  A communicator that cannot be created on EVERY rank ends the run with exit code
         # 3 — a scaling number must never silently be a host-transport number — unless --allow-host-exchange asks for the

@@ -1,9 +1,10 @@
 """Host-side communicators used to bootstrap multi-GPU runs (rendezvous only — the data path is RCCL).
 
 A communicator provides: rank, world_size, broadcast_bytes(data, src), allgather_rows(buf, r0, r1),
-allreduce_sum(buf), barrier(), max_float(x).  `TorchComm` rides on an initialised torch.distributed process group (gloo on the host; the
-launcher `python -m torch.distributed.run` sets RANK/WORLD_SIZE/MASTER_*); `SocketComm` is a dependency-free
-TCP star for environments without torch (loopback by default, HMAC hello handshake, raw length-bounded frames).  torch is plumbing here, never on the compute path.
+allreduce_sum(buf), barrier(), max_float(x).  `SocketComm` is a dependency-free TCP star (loopback by default, HMAC hello handshake,
+raw length-bounded frames); `ThreadComm` joins the threads of one process.  Nothing in this package imports torch: the communicator that
+rides on a torch.distributed (gloo) process group — what `bench.py` and the tests use under `python -m torch.distributed.run` — lives
+outside it, in `bench_rendezvous.py` at the repository root (round 5).
 """
 import hashlib
 import hmac
@@ -14,7 +15,7 @@ import time
 
 import numpy as np
 
-__all__ = ['TorchComm', 'SocketComm', 'ThreadComm', 'from_env', 'block_size']
+__all__ = ['SocketComm', 'ThreadComm', 'from_env', 'block_size']
 
 
 def block_size(n, world):
@@ -39,69 +40,6 @@ class _Base:
     def allgather_float(self, x):
         """[x of rank 0, x of rank 1, ...] on every rank (control plane: one max per rank)."""
         return [self.max_float(float(x) if self.rank == k else float('-inf')) for k in range(self.world_size)]
-
-
-class TorchComm(_Base):
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError('torch.distributed is not initialised')
-        self._dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world_size = dist.get_world_size(group)
-
-    def broadcast_bytes(self, data, src=0):
-        import torch
-        n = len(data)
-        t = torch.zeros(n, dtype=torch.uint8)
-        if self.rank == src:
-            t = torch.frombuffer(bytearray(data), dtype=torch.uint8).clone()
-        self._dist.broadcast(t, src=src, group=self.group)
-        return bytes(t.numpy().tobytes())
-
-    def allgather_rows(self, buf, r0, r1):
-        import torch
-        dbg = os.environ.get('NCCL_DEBUG', '') in ('INFO', 'TRACE')
-        t = [time.perf_counter()]
-        n = buf.shape[0]
-        blk = block_size(n, self.world_size)
-        send = torch.zeros(blk, dtype=torch.float64)
-        if r1 > r0:
-            send[:r1 - r0] = torch.from_numpy(np.array(buf[r0:r1], copy=True))
-        t.append(time.perf_counter())
-        parts = [torch.zeros(blk, dtype=torch.float64) for _ in range(self.world_size)]
-        self._dist.all_gather(parts, send, group=self.group)
-        t.append(time.perf_counter())
-        for r, part in enumerate(parts):
-            b, e = self.rows_of(n, r)
-            if e > b:
-                buf[b:e] = part[:e - b].numpy()
-        t.append(time.perf_counter())
-        if dbg and self.rank == 0:
-            import sys
-            print('[allgather_rows] read %.3f ms, all_gather %.3f ms, write %.3f ms' % tuple(1e3 * (b - a) for a, b in zip(t, t[1:])),
-                  file=sys.stderr, flush=True)
-
-    def allreduce_sum(self, buf):
-        import torch
-        t = torch.from_numpy(np.array(buf, copy=True))
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-        buf[:] = t.numpy()
-
-    def barrier(self):
-        self._dist.barrier(group=self.group)
-
-    def max_float(self, x):
-        import torch
-        t = torch.tensor([float(x)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
-        return float(t.item())
-
-    def close(self):
-        if getattr(self, '_owns_group', False) and self._dist.is_initialized():
-            self._dist.destroy_process_group()
-            self._owns_group = False
 
 
 # Wire format of SocketComm: a fixed 16-byte header (magic, kind, payload length) followed by raw bytes — byte strings and
@@ -316,31 +254,14 @@ class ThreadComm(_Base):
         self._s['barrier'].abort()
 
 
-def from_env(prefer_torch=True, timeout=600.0):
-    """Communicator for the current launcher environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT): torch.distributed
-    (gloo) when torch is importable, otherwise — or with BQ_RENDEZVOUS=socket — the dependency-free SocketComm on
-    MASTER_PORT + 33.  BQ_RENDEZVOUS=torch insists on torch."""
+def from_env(timeout=600.0):
+    """Communicator for the current launcher environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT): the dependency-free
+    SocketComm on MASTER_PORT + 33.  (bench_rendezvous.from_env at the repository root prefers torch.distributed's gloo group when
+    torch is importable.)"""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world == 1:
         return SocketComm(0, 1)
-    mode = os.environ.get('BQ_RENDEZVOUS', '')
-    if mode not in ('', 'torch', 'socket'):
-        raise ValueError(f"BQ_RENDEZVOUS='{mode}' (use 'torch' or 'socket')")
-    if (prefer_torch and mode != 'socket') or mode == 'torch':
-        try:
-            import datetime
-            import torch.distributed as dist
-            owns = not dist.is_initialized()
-            if owns:
-                dist.init_process_group(backend='gloo', rank=rank, world_size=world,
-                                        timeout=datetime.timedelta(seconds=timeout))
-            comm = TorchComm()
-            comm._owns_group = owns
-            return comm
-        except ImportError:
-            if mode == 'torch':
-                raise
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(os.environ.get('MASTER_PORT', '29500')) + 33
     return SocketComm(rank, world, addr, port, timeout=timeout)

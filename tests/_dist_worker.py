@@ -18,7 +18,8 @@ sys.path.insert(0, REPO)
 def make_comm(kind):
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     if kind == 'fromenv-socket':   # what bench.py does on a host without torch (BQ_RENDEZVOUS=socket forces it)
-        from optiml_amd.dist import SocketComm, from_env
+        from optiml_amd.dist import SocketComm
+        from bench_rendezvous import from_env
         os.environ['BQ_RENDEZVOUS'] = 'socket'
         comm = from_env(timeout=60.0)
         assert isinstance(comm, SocketComm)
@@ -29,7 +30,7 @@ def make_comm(kind):
                           int(os.environ['MASTER_PORT']) + 1)
     import torch.distributed as dist
     dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-    from optiml_amd.dist import TorchComm
+    from bench_rendezvous import TorchComm
     return TorchComm()
 
 

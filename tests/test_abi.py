@@ -289,3 +289,21 @@ def test_collective_timeout_is_inert_without_an_rccl_communicator():
     r, c = ctx.probe_bandwidth(1 << 26, 2)
     assert r > 0 and c > 0
     ctx.close()
+
+
+def test_the_product_package_imports_no_torch():
+    """BASELINE's north star: Python host code over ctypes, no PyTorch.  The one torch user of earlier rounds — the gloo rendezvous of
+    launcher-started ranks — lives outside the package since round 5 (bench_rendezvous.py); optiml_amd itself names torch nowhere."""
+    import re
+    pkg = os.path.join(REPO, 'optiml_amd')
+    pat = re.compile(r'^\s*(import|from)\s+torch\b', re.M)
+    hits = []
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py') and pat.search(open(os.path.join(root, f)).read()):
+                hits.append(os.path.join(root, f))
+    assert hits == []
+    import subprocess
+    import sys
+    code = 'import sys; import optiml_amd, optiml_amd.dist, optiml_amd.opti.constrained, optiml_amd.ml.svm; assert "torch" not in sys.modules'
+    assert subprocess.run([sys.executable, '-c', code], cwd=REPO).returncode == 0

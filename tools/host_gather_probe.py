@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from optiml_amd.dist import from_env
+from bench_rendezvous import from_env
 comm = from_env(timeout=60.0)
 w, r = comm.world_size, comm.rank
 chunk = 60416
