@@ -101,6 +101,30 @@ __global__ __launch_bounds__(256, 2) void barrier_kernel(bar_state *b, int reps,
     if (acc == -1.0) sink[0] = acc;
 }
 
+// the library's "last block closes" pattern without any waiting: per block one store, a fence, one agent-scope atomic on a shared ticket;
+// the block that takes the last ticket reads every block's value.  How long is a launch of G such blocks?
+__global__ __launch_bounds__(256) void ticket_kernel(double *part, unsigned int *ticket, double *out, int k) {
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = (double)(blockIdx.x + k);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double a = 0.0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) a += part[i];
+    if (threadIdx.x == 0) {
+        out[0] = a;
+        *ticket = 0;
+    }
+}
+// the same blocks without the ticket (what the launch costs by itself at this grid size)
+__global__ __launch_bounds__(256) void noticket_kernel(double *part, int k) {
+    if (threadIdx.x == 0) part[blockIdx.x] = (double)(blockIdx.x + k);
+}
+
 __global__ void empty_kernel(double *sink, int k) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && k < 0) sink[0] = 1.0;
 }
@@ -157,6 +181,31 @@ int main() {
                 if (h.timeout) break;
             }
         }
+    }
+    // a launch of G blocks that meet in a ticket against the same launch without one
+    {
+        unsigned int *ticket;
+        CK(hipMalloc(&ticket, sizeof(unsigned int)));
+        CK(hipMemsetAsync(ticket, 0, sizeof(unsigned int), st));
+        for (int g : {32, 128, 512, 1024, 2048, 4096}) {
+            for (int kind = 0; kind < 2; ++kind)
+                for (int pass = 0; pass < 2; ++pass) {
+                    CK(hipEventRecord(e0, st));
+                    for (int k = 0; k < reps; ++k) {
+                        if (kind == 0)
+                            ticket_kernel<<<g, 256, 0, st>>>(sink, ticket, sink + 8192, k);
+                        else
+                            noticket_kernel<<<g, 256, 0, st>>>(sink, k);
+                    }
+                    CK(hipEventRecord(e1, st));
+                    CK(hipStreamSynchronize(st));
+                    float ms = 0.f;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (pass == 1)
+                        printf("%-8s grid %4d x 256: %7.3f us per dependent launch\n", kind == 0 ? "ticket" : "noticket", g, 1e3 * ms / reps);
+                }
+        }
+        CK(hipFree(ticket));
     }
     // the kernel boundary it would replace
     for (int kind = 0; kind < 2; ++kind) {
