@@ -969,7 +969,7 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
     (void)bq_ctx_sync(s->p->ctx);   // may sit behind a collective: bounded when a collective timeout is set
     for (void *ptr : {(void *)s->x, (void *)s->g, (void *)s->d, (void *)s->Qd, (void *)s->lb, (void *)s->ub,
                       (void *)s->lp, (void *)s->lm, (void *)s->rhs, (void *)s->hd, (void *)s->dlp, (void *)s->dlm,
-                      (void *)s->mL, (void *)s->mU, (void *)s->partials, (void *)s->sc, (void *)s->stats, (void *)s->tix})
+                      (void *)s->mL, (void *)s->mU, (void *)s->partials, (void *)s->sc, (void *)s->stats})
         if (ptr) hipFree(ptr);
     if (s->chol) bq_chol_ws_destroy(s->chol);
     if (s->flag_host) {
@@ -1047,11 +1047,8 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
     }
     if (e == hipSuccess) e = hipMalloc(&s->partials, sizeof(double) * BQ_MAX_PARTIAL_Q * s->nblk);
     if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_scal));
-    if (e == hipSuccess) e = hipMalloc(&s->tix, sizeof(unsigned int) * BQ_TICK_WORDS);
-    if (e == hipSuccess) e = hipMemsetAsync(s->tix, 0, sizeof(unsigned int) * BQ_TICK_WORDS, c->stream);
     if (e == hipSuccess) {
         memset(&s->host, 0, sizeof(bq_scal));
-        s->host.gtick = s->tix;
         s->host.max_iter = max_iter;
         s->host.eps = eps;
         s->host.fw_t = fw_t;

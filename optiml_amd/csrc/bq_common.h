@@ -178,43 +178,7 @@ struct bq_scal {
     unsigned int ticket[2], pad1[2];           // last-block tickets of the fused reduce-and-decide kernels (PG / FW)
     long long al_last;                         // the epoch test fired: the gradient of the last record is still due
     double aux[8];
-    unsigned int *gtick;                       // two-level ticket arena of this solver (bq_last_block2), device memory
 };
-
-// "The last workgroup to finish closes the launch" with TWO levels of tickets (round 5).  One shared ticket costs ~20 ns per
-// arriving workgroup — the agent-scope atomics on one address serialise: a launch of 128 / 512 / 1 024 / 4 096 workgroups that meet in
-// one ticket takes 5.6 / 13.0 / 23.6 / 85.0 us against 3.0 us without (tools/barrier_probe.hip, profiles/r05/barrier_probe.txt) — so the
-// 391 workgroups of the ordered segment sum at n = 100 000 paid 8 us for it.  Here a workgroup takes a ticket of its GROUP of 32
-// (counters 128 bytes apart: different lines, different atomic units, in parallel), the last of a group one of the root: ~32 + G / 32
-// serialised atomics instead of G.  Fences on both sides of both atomics: what every workgroup wrote before its ticket is visible to
-// the one that closes.  The counters are back at zero when the launch ends (the last of a group resets its group, the closer the
-// root), so consecutive launches of one stream share the arena.  Which workgroup closes has never mattered (fixed-order sums).
-constexpr int BQ_TICK_GROUP = 32, BQ_TICK_GROUPS_MAX = 256, BQ_TICK_WORDS = (1 + BQ_TICK_GROUPS_MAX) * 32;
-__device__ __forceinline__ bool bq_last_block2(unsigned int *arena, unsigned int block, unsigned int nblocks) {
-    __shared__ int bq_last2;
-    if (threadIdx.x == 0) {
-        unsigned int ngroups = (nblocks + BQ_TICK_GROUP - 1) / BQ_TICK_GROUP;
-        if (ngroups > BQ_TICK_GROUPS_MAX) ngroups = BQ_TICK_GROUPS_MAX;   // (more than 8 192 workgroups: the last group is larger)
-        unsigned int g = block / BQ_TICK_GROUP;
-        if (g >= ngroups) g = ngroups - 1;
-        const unsigned int members = g + 1 < ngroups ? BQ_TICK_GROUP : nblocks - BQ_TICK_GROUP * (ngroups - 1);
-        unsigned int *gc = arena + 32 * (1 + g);
-        int l = 0;
-        __threadfence();
-        if (atomicAdd(gc, 1u) == members - 1) {
-            *gc = 0u;
-            __threadfence();
-            if (atomicAdd(arena, 1u) == ngroups - 1) {
-                *arena = 0u;
-                l = 1;
-            }
-        }
-        bq_last2 = l;
-    }
-    __syncthreads();
-    if (bq_last2) __threadfence();
-    return bq_last2 != 0;
-}
 
 struct bq_chol_ws;
 
@@ -250,7 +214,6 @@ struct bq_solver {
     double inner_rtol = 1e-13;
     long long inner_max = 0;           // 0: 2 |A| + 50
     bq_al_state *al = nullptr;
-    unsigned int *tix = nullptr;       // the two-level ticket arena sc->gtick points at (BQ_TICK_WORDS words, zero between launches)
     int *flag_host = nullptr;          // pinned copy of sc->done + its event (lagged polling in bq_solver_run)
     hipEvent_t flag_event = nullptr;
     // bq_solver_set_state: what the start-up must take instead of forming it (x itself is uploaded at once)

@@ -57,15 +57,21 @@ __device__ __forceinline__ double bq_epi_element(const bq_epilogue &e, long long
 // block partial -> part[a]; the last block of the grid turns the partials into the step length and closes the iteration
 __device__ __forceinline__ void bq_epi_finish(const bq_epilogue &e, long long a, long long nblocks, double c, unsigned int nwg) {
     __shared__ double sh[4];
+    __shared__ int last;
     const int tid = threadIdx.x;
     if (tid < 256) {
         c = bq_epi_wsum(c);
         if ((tid & 63) == 0) sh[tid >> 6] = c;
     }
     __syncthreads();
-    if (tid == 0) e.part[a] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
-    // two-level ticket (bq_common.h): the 391 workgroups of this kernel at n = 100 000 spent ~8 us serialising on one counter
-    if (!bq_last_block2(e.sc->gtick, blockIdx.x, nwg)) return;
+    if (tid == 0) {
+        e.part[a] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        __threadfence();   // this block's partial sum is visible device-wide before the ticket is taken
+        last = atomicAdd(&e.sc->ticket[1], 1u) == nwg - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
     double acc = 0.0;
     if (tid < 256)
         for (long long k = tid; k < nblocks; k += 256) acc += e.part[k];
@@ -89,5 +95,6 @@ __device__ __forceinline__ void bq_epi_finish(const bq_epilogue &e, long long a,
                 e.stats[row].r3 = t;
         }
         sc->iter += 1;
+        sc->ticket[1] = 0;
     }
 }

@@ -299,7 +299,10 @@ __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
         part[2 * nblk + blockIdx.x] = br.c;
         part[3 * nblk + blockIdx.x] = br.m;
     }
-    if (bq_last_block2(sc->gtick, blockIdx.x, gridDim.x)) pg_decide_body(sc, part, nblk, stats);
+    if (last_block(&sc->ticket[0])) {
+        pg_decide_body(sc, part, nblk, stats);
+        if (threadIdx.x == 0) sc->ticket[0] = 0;
+    }
 }
 
 __device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
@@ -379,7 +382,10 @@ __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
         part[1 * nblk + blockIdx.x] = br.b;
         part[2 * nblk + blockIdx.x] = br.c;
     }
-    if (bq_last_block2(sc->gtick, blockIdx.x, gridDim.x)) fw_decide_body(sc, part, nblk, stats);
+    if (last_block(&sc->ticket[0])) {
+        fw_decide_body(sc, part, nblk, stats);
+        if (threadIdx.x == 0) sc->ticket[0] = 0;
+    }
 }
 
 __device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
