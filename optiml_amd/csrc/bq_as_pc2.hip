@@ -197,7 +197,10 @@ int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out) {
     pc2_pad_kernel<<<dim3((unsigned)((r->rows + 31) / 32), (unsigned)((r->dp + 31) / 32)), 256, 0, st>>>(p->X, p->n, p->d, r->dp, r->rows, r->ld,
                                                                                                       r->Xp, r->Xt);
     pc2_coef_kernel<<<(unsigned)(r->ld / 256), 256, 0, st>>>(p->n, p->d, r->ld, p->X, p->sgn, p->gamma, r->c, bdiag_out);
-    BQ_HIP(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {   // a launch that cannot be made: the explicit model alone
+        as_pc2_free(r);
+        return BQ_OK;
+    }
     *out = r;
     return BQ_OK;
 }
