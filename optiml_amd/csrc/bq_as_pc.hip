@@ -585,6 +585,32 @@ __global__ __launch_bounds__(256) void as_pc_combine_kernel(int64_t N, double al
     }
 }
 
+#ifdef BQ_PC2_STEPS
+// one step of the Chebyshev recurrence on the vectors (mode 0: d = c2 res, z = d;  mode 1: res -= d + z2, d = c1 d + c2 res, z += d)
+__global__ void as_pc_cheb_kernel(int64_t N, int mode, double c1, double c2, double *__restrict__ res, const double *__restrict__ z2,
+                                  double *__restrict__ d, double *__restrict__ z, const as_cg_scal *cg) {
+    if (cg->done) return;
+    VEC_LOOP(i) {
+        if (i < N) {
+            if (mode == 0) {
+                const double dv = c2 * res[i];
+                d[i] = dv;
+                z[i] = dv;
+            } else {
+                const double rv = res[i] - d[i] - z2[i];
+                const double dv = c1 * d[i] + c2 * rv;
+                res[i] = rv;
+                d[i] = dv;
+                z[i] += dv;
+            }
+        } else {
+            d[i] = 0.0;
+            z[i] = 0.0;
+        }
+    }
+}
+#endif
+
 __global__ void as_pc_fill_kernel(int64_t ld, double value, double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < ld) out[i] = value;
@@ -671,7 +697,7 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         double *bdiag = nullptr;
         if (rc == BQ_OK && e == hipSuccess && fam2 == 2 && want_r2) {
             hipError_t re = hipMalloc(&bdiag, sizeof(double) * s->ldN);
-            for (double **v : {&pc->y1, &pc->v2, &pc->z2, &pc->ones})
+            for (double **v : {&pc->y1, &pc->v2, &pc->z2, &pc->ones, &pc->d1, &pc->za})
                 if (re == hipSuccess) re = hipMalloc(v, sizeof(double) * s->ldN);
             if (re == hipSuccess) re = hipMalloc(&pc->ttop, sizeof(double) * pc->mp);
             if (re == hipSuccess && as_pc2_create(s, bdiag, &pc->r2) != BQ_OK) re = hipErrorOutOfMemory;
@@ -807,7 +833,7 @@ void as_pc_free(as_pc *pc) {
     if (!pc) return;
     if (pc->ws) bq_chol_ws_destroy(pc->ws);
     as_pc2_free(pc->r2);
-    for (void *ptr : {(void *)pc->y1, (void *)pc->v2, (void *)pc->z2, (void *)pc->ones, (void *)pc->ttop})
+    for (void *ptr : {(void *)pc->y1, (void *)pc->v2, (void *)pc->z2, (void *)pc->ones, (void *)pc->ttop, (void *)pc->d1, (void *)pc->za})
         if (ptr) hipFree(ptr);
     for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls, (void *)pc->Ginv,
                       (void *)pc->u, (void *)pc->sm_fail, (void *)pc->prev, (void *)pc->chg, (void *)pc->tpart, (void *)pc->tticket})
@@ -827,14 +853,14 @@ static void as_pc_solve1(bq_solver *s, as_ws *w, const double *in, double *out, 
                                                                s->partials, s->nblk, w->cg, first, fin);
 }
 
-// v2 = R y1 on the free set, R = B - Phi_top Phi_top' (y1 vanishes outside the free set)
-static int as_pc_r_apply(bq_solver *s, as_ws *w) {
+// v2 = R y on the free set, R = B - Phi_top Phi_top' (y vanishes outside the free set)
+static int as_pc_r_apply(bq_solver *s, as_ws *w, const double *y) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
-    BQ_TRY(as_pc2_bpart(s, pc->r2, pc->y1, w->cg));
+    BQ_TRY(as_pc2_bpart(s, pc->r2, y, w->cg));
     const float *Phitop = pc->Phi + (int64_t)pc->top0 * s->ldN;
     const int64_t m8t = bq_round_up(pc->ntop, PC_FG);   // (Phi carries PC_FG spare zero rows behind its last feature)
-    as_pc_tphi_kernel<<<dim3(vgrid(s->ldN).x, 1), BQ_VEC_BLOCK, 0, st>>>(pc->ntop, m8t, pc->mp, s->N, s->ldN, Phitop, pc->ones, pc->y1, pc->tpart,
+    as_pc_tphi_kernel<<<dim3(vgrid(s->ldN).x, 1), BQ_VEC_BLOCK, 0, st>>>(pc->ntop, m8t, pc->mp, s->N, s->ldN, Phitop, pc->ones, y, pc->tpart,
                                                                          pc->ttop, pc->tticket, w->cg);
     as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(m8t, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ttop, w->cg);
     int tiles = 0;
@@ -857,8 +883,27 @@ int as_pc_apply(bq_solver *s, as_ws *w, int first) {
         as_pc_solve1(s, w, w->r, pc->z, first, 1);
         return BQ_OK;
     }
+#ifdef BQ_PC2_STEPS   // experiment (build macro): BQ_PC2_STEPS Chebyshev steps = BQ_PC2_STEPS - 1 applications of R per call (2 = the default path below)
+    if (BQ_PC2_STEPS > 2) {
+        const double lam = as_pc2_lambda(pc->r2), theta = 1.0 + 0.5 * lam, delta = 0.5 * lam, sigma = theta / delta;
+        double rho = 1.0 / sigma;
+        as_pc_solve1(s, w, w->r, pc->y1, first, 0);                                                  // res = P1^-1 r
+        as_pc_cheb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, 0, 0.0, 1.0 / theta, pc->y1, pc->v2, pc->d1, pc->za, w->cg);   // d = res / theta, z = d
+        for (int k = 1; k < BQ_PC2_STEPS; ++k) {
+            BQ_TRY(as_pc_r_apply(s, w, pc->d1));
+            as_pc_solve1(s, w, pc->v2, pc->z2, first, 0);
+            const double rho1 = 1.0 / (2.0 * sigma - rho);
+            // res -= d + z2;  d = rho1 rho d + (2 rho1 / delta) res;  z += d
+            as_pc_cheb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, 1, rho1 * rho, 2.0 * rho1 / delta, pc->y1, pc->z2, pc->d1, pc->za, w->cg);
+            rho = rho1;
+        }
+        as_pc_combine_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, 1.0, 0.0, w->r, pc->za, pc->z2, pc->z, s->partials, s->nblk, w->cg, first);
+        BQ_HIP(hipGetLastError());
+        return BQ_OK;
+    }
+#endif
     as_pc_solve1(s, w, w->r, pc->y1, first, 0);
-    BQ_TRY(as_pc_r_apply(s, w));
+    BQ_TRY(as_pc_r_apply(s, w, pc->y1));
     as_pc_solve1(s, w, pc->v2, pc->z2, first, 0);
     as_pc_combine_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, alpha, beta, w->r, pc->y1, pc->z2, pc->z, s->partials, s->nblk, w->cg, first);
     BQ_HIP(hipGetLastError());
@@ -915,7 +960,7 @@ int as_pc_update(bq_solver *s, as_ws *w) {
         double lam = -1.0;
         for (int it = 0; it < 12; ++it) {
             if (it == 11) BQ_HIP(hipMemcpyAsync(a.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
-            BQ_TRY(as_pc_r_apply(s, w));
+            BQ_TRY(as_pc_r_apply(s, w, pc->y1));
             as_pc_solve1(s, w, pc->v2, pc->y1, 1, 0);
         }
         BQ_HIP(hipMemcpyAsync(b.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
