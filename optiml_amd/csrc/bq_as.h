@@ -75,7 +75,6 @@ struct as_pc {
     int top0 = 0, ntop = 0;       // the Phi_top columns (the projected order-2 directions) of the explicit model
     double *y1 = nullptr, *v2 = nullptr, *z2 = nullptr, *ones = nullptr;   // ldN each: y = P1^-1 r, R y, P1^-1 R y; weights 1
     double *ttop = nullptr;       // mp: Phi_top' y
-    double *d1 = nullptr, *za = nullptr;   // ldN each: direction and sum of a longer Chebyshev recurrence (BQ_PC2_STEPS experiment)
 };
 
 struct as_ws {

@@ -585,32 +585,6 @@ __global__ __launch_bounds__(256) void as_pc_combine_kernel(int64_t N, double al
     }
 }
 
-#ifdef BQ_PC2_STEPS
-// one step of the Chebyshev recurrence on the vectors (mode 0: d = c2 res, z = d;  mode 1: res -= d + z2, d = c1 d + c2 res, z += d)
-__global__ void as_pc_cheb_kernel(int64_t N, int mode, double c1, double c2, double *__restrict__ res, const double *__restrict__ z2,
-                                  double *__restrict__ d, double *__restrict__ z, const as_cg_scal *cg) {
-    if (cg->done) return;
-    VEC_LOOP(i) {
-        if (i < N) {
-            if (mode == 0) {
-                const double dv = c2 * res[i];
-                d[i] = dv;
-                z[i] = dv;
-            } else {
-                const double rv = res[i] - d[i] - z2[i];
-                const double dv = c1 * d[i] + c2 * rv;
-                res[i] = rv;
-                d[i] = dv;
-                z[i] += dv;
-            }
-        } else {
-            d[i] = 0.0;
-            z[i] = 0.0;
-        }
-    }
-}
-#endif
-
 __global__ void as_pc_fill_kernel(int64_t ld, double value, double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < ld) out[i] = value;
@@ -697,7 +671,7 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         double *bdiag = nullptr;
         if (rc == BQ_OK && e == hipSuccess && fam2 == 2 && want_r2) {
             hipError_t re = hipMalloc(&bdiag, sizeof(double) * s->ldN);
-            for (double **v : {&pc->y1, &pc->v2, &pc->z2, &pc->ones, &pc->d1, &pc->za})
+            for (double **v : {&pc->y1, &pc->v2, &pc->z2, &pc->ones})
                 if (re == hipSuccess) re = hipMalloc(v, sizeof(double) * s->ldN);
             if (re == hipSuccess) re = hipMalloc(&pc->ttop, sizeof(double) * pc->mp);
             if (re == hipSuccess && as_pc2_create(s, bdiag, &pc->r2) != BQ_OK) re = hipErrorOutOfMemory;
@@ -833,7 +807,7 @@ void as_pc_free(as_pc *pc) {
     if (!pc) return;
     if (pc->ws) bq_chol_ws_destroy(pc->ws);
     as_pc2_free(pc->r2);
-    for (void *ptr : {(void *)pc->y1, (void *)pc->v2, (void *)pc->z2, (void *)pc->ones, (void *)pc->ttop, (void *)pc->d1, (void *)pc->za})
+    for (void *ptr : {(void *)pc->y1, (void *)pc->v2, (void *)pc->z2, (void *)pc->ones, (void *)pc->ttop})
         if (ptr) hipFree(ptr);
     for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls, (void *)pc->Ginv,
                       (void *)pc->u, (void *)pc->sm_fail, (void *)pc->prev, (void *)pc->chg, (void *)pc->tpart, (void *)pc->tticket})
@@ -873,7 +847,9 @@ static int as_pc_r_apply(bq_solver *s, as_ws *w, const double *y) {
 
 // z = P_AA^-1 r (+ r'z and beta on the device).  Explicit model: one Woodbury application.  With the order-2 remainder:
 // z = alpha y - beta P1^-1 (R y), y = P1^-1 r — the degree-1 Chebyshev polynomial of bq_as_pc2.hip (alpha = 1, beta = 0 until the
-// spectrum bound has been estimated).
+// spectrum bound has been estimated).  More Chebyshev steps were measured at config 5 (two and three applications of R per call): the
+// outer iteration still takes 5.0 products and gets 7 / 18 ms longer (profiles/r05/c5_chebyshev_steps.txt) — the order-2 MODEL is the
+// limit, not how exactly it is inverted; the CPU study said the same (18 / 18 / 17 iterations).
 int as_pc_apply(bq_solver *s, as_ws *w, int first) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
@@ -883,25 +859,6 @@ int as_pc_apply(bq_solver *s, as_ws *w, int first) {
         as_pc_solve1(s, w, w->r, pc->z, first, 1);
         return BQ_OK;
     }
-#ifdef BQ_PC2_STEPS   // experiment (build macro): BQ_PC2_STEPS Chebyshev steps = BQ_PC2_STEPS - 1 applications of R per call (2 = the default path below)
-    if (BQ_PC2_STEPS > 2) {
-        const double lam = as_pc2_lambda(pc->r2), theta = 1.0 + 0.5 * lam, delta = 0.5 * lam, sigma = theta / delta;
-        double rho = 1.0 / sigma;
-        as_pc_solve1(s, w, w->r, pc->y1, first, 0);                                                  // res = P1^-1 r
-        as_pc_cheb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, 0, 0.0, 1.0 / theta, pc->y1, pc->v2, pc->d1, pc->za, w->cg);   // d = res / theta, z = d
-        for (int k = 1; k < BQ_PC2_STEPS; ++k) {
-            BQ_TRY(as_pc_r_apply(s, w, pc->d1));
-            as_pc_solve1(s, w, pc->v2, pc->z2, first, 0);
-            const double rho1 = 1.0 / (2.0 * sigma - rho);
-            // res -= d + z2;  d = rho1 rho d + (2 rho1 / delta) res;  z += d
-            as_pc_cheb_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, 1, rho1 * rho, 2.0 * rho1 / delta, pc->y1, pc->z2, pc->d1, pc->za, w->cg);
-            rho = rho1;
-        }
-        as_pc_combine_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, 1.0, 0.0, w->r, pc->za, pc->z2, pc->z, s->partials, s->nblk, w->cg, first);
-        BQ_HIP(hipGetLastError());
-        return BQ_OK;
-    }
-#endif
     as_pc_solve1(s, w, w->r, pc->y1, first, 0);
     BQ_TRY(as_pc_r_apply(s, w, pc->y1));
     as_pc_solve1(s, w, pc->v2, pc->z2, first, 0);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/c5_macro_sweep.sh OUT MACRO value...: BASELINE config 5 with bq_as_pc.hip rebuilt on the box with -DMACRO=value for every value
-# (BQ_PC2_LAMBDA_SCALE: widening of the order-2 remainder's spectrum bound; BQ_PC2_STEPS: Chebyshev steps per preconditioner call);
+# (BQ_PC2_LAMBDA_SCALE: widening of the order-2 remainder's spectrum bound);
 # the default library is restored at the end
 out=$1; macro=$2; shift 2
 mkdir -p "$out"
