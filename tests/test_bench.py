@@ -267,3 +267,21 @@ def test_products_that_returned_on_the_done_flag_are_not_counted():
     assert rec['steps_done'] == 6 and inner > 6
     # (a start product that is really needed — more than 16 variables bound at once — is a product too: none or one here)
     assert round(inner) <= rec['roofline']['launches'] <= round(inner) + 2, (rec['roofline']['launches'], inner)
+
+
+def test_c5_projection_reads_the_committed_scaling():
+    """time_to_kkt.c5_projected: iterations / n of config 5's workload run to 'optimal' at the largest committed size
+    (profiles/rNN/c5_outer_iterations_scaling.json, tools/c5_scaling.py) x n x the measured time per outer iteration — labelled a
+    projection; the compact line carries it as side.c5_projected_s."""
+    sys.path.insert(0, REPO)
+    import bench
+    rec = bench.c5_projection(250000, 256, 112.0)
+    assert rec['kind'].startswith('projected') and rec['from_n'] >= 40000 and 0.9 < rec['iterations_per_n'] < 1.0
+    assert rec['outer_iterations_projected'] == pytest.approx(rec['iterations_per_n'] * 250000)
+    assert rec['value'] == pytest.approx(rec['outer_iterations_projected'] * 0.112)
+    assert bench.c5_projection(250000, 17, 112.0) is None          # no scaling run for another d
+    full = json.load(open(os.path.join(REPO, 'profiles', 'r05', 'bench_default_records.json')))
+    line = bench.compact_line(full, None)
+    assert line['side']['c5_projected_s'] == pytest.approx(full['time_to_kkt']['c5_projected']['value'], rel=1e-5)
+    assert line['side']['c5_products_per_outer_it'] <= 5.5 and line['side']['c5_outer_it_s'] > 8.0
+    assert len(json.dumps(line)) < 4096
