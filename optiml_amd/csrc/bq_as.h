@@ -359,12 +359,22 @@ int as_cg_iterate(bq_solver *s, as_ws *w);     // the body of one outer iteratio
 
 // ---- preconditioner (bq_as_pc.hip, bq_as_pc2.hip) ------------------------------------------------------------
 constexpr int PC_MAX_M = 1024;   // features the apply kernels keep in LDS
+// the sample segments of the sharded order-2 remainder (bq_as_pc2.hip): segment k = sample blocks [blk[k], blk[k + 1]) of 1024 samples,
+// this rank owns [lo, hi); gathered buffers hold world * cmax slots of maxlen blocks (a kernel argument: plain data)
+struct as_pc_part {
+    int S, lo, hi, cmax;
+    int slot[BQ_SYM_SEG_MAX];
+    long long blk[BQ_SYM_SEG_MAX + 1];
+    long long maxlen;
+};
 typedef float as_f4 __attribute__((ext_vector_type(4)));
 int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out);
 void as_pc2_free(as_pc2 *r);
 int as_pc2_bpart(bq_solver *s, as_pc2 *r, const double *y, const as_cg_scal *cg);
 const double *as_pc2_ypart(const as_pc2 *r, int *tiles);
 const double *as_pc2_c(const as_pc2 *r);
+const as_pc_part *as_pc2_part(const as_pc2 *r);
+double *as_pc2_vg(const as_pc2 *r);
 double as_pc2_lambda(const as_pc2 *r);
 void as_pc2_set_lambda(as_pc2 *r, double lambda);
 void as_pc2_coefs(const as_pc2 *r, double *alpha, double *beta);

@@ -525,16 +525,22 @@ __global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int
 
 
 // v_i = c_i (the column tiles' partials of x_i' M x_i, added in tile order) - Phi_top[:, i] . t   on the free set, 0 elsewhere:
-// v = R y, R = B - Phi_top Phi_top' (bq_as_pc2.hip formed the B part, as_pc_tphi_kernel t = Phi_top' y)
-__global__ __launch_bounds__(256) void as_pc_r_finish_kernel(int64_t N, int64_t ld, int tiles, int ncols, const float *__restrict__ Phitop,
-                                                             const double *__restrict__ c, const double *__restrict__ ypart,
-                                                             const double *__restrict__ t, const unsigned char *__restrict__ mL,
-                                                             const unsigned char *__restrict__ mU, double *__restrict__ v, const as_cg_scal *cg) {
+// v = R y, R = B - Phi_top Phi_top' (bq_as_pc2.hip formed the B part for THIS RANK's samples, as_pc_tphi_kernel t = Phi_top' y).
+// blockIdx.x = a block of this rank's samples (block0 on); written in the gathered layout (slot of the block's segment).
+__global__ __launch_bounds__(256) void as_pc_r_finish_kernel(int64_t N, int64_t ld, int64_t block0, as_pc_part part, int tiles, int ncols,
+                                                             const float *__restrict__ Phitop, const double *__restrict__ c,
+                                                             const double *__restrict__ ypart, const double *__restrict__ t,
+                                                             const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                                             double *__restrict__ vg, const as_cg_scal *cg) {
     if (cg->done) return;
     __shared__ double ts[PC_MAX_M];
     for (int j = threadIdx.x; j < ncols; j += 256) ts[j] = t[j];
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + 4 * threadIdx.x;
+    const int64_t blk = block0 + blockIdx.x;
+    int k = part.lo;
+    while (k + 1 < part.hi && blk >= part.blk[k + 1]) ++k;
+    double *dst = vg + ((int64_t)part.slot[k] * part.maxlen + (blk - part.blk[k])) * BQ_VEC_TILE + 4 * threadIdx.x;
+    const int64_t base = blk * BQ_VEC_TILE + 4 * threadIdx.x;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int j = 0; j < ncols; ++j) {
         const as_f4 f = *reinterpret_cast<const as_f4 *>(Phitop + (int64_t)j * ld + base);
@@ -545,16 +551,29 @@ __global__ __launch_bounds__(256) void as_pc_r_finish_kernel(int64_t N, int64_t 
         acc[3] = fma((double)f.w, tj, acc[3]);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int64_t i = base + k;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + q;
         double r = 0.0;
         if (i < N && !(mL[i] | mU[i])) {
             double b = 0.0;
             for (int ct = 0; ct < tiles; ++ct) b += ypart[(int64_t)ct * ld + i];
-            r = c[i] * b - acc[k];
+            r = c[i] * b - acc[q];
         }
-        v[i] = r;
+        dst[q] = r;
     }
+}
+// v (contiguous, every sample) from the gathered layout
+__global__ __launch_bounds__(256) void as_pc_unpack_kernel(int64_t ld, as_pc_part part, const double *__restrict__ vg, double *__restrict__ v,
+                                                           const as_cg_scal *cg) {
+    if (cg->done) return;
+    const int64_t blk = blockIdx.x;
+    int k = 0;
+    while (k + 1 < part.S && blk >= part.blk[k + 1]) ++k;
+    const double *src = vg + ((int64_t)part.slot[k] * part.maxlen + (blk - part.blk[k])) * BQ_VEC_TILE;
+    double *dst = v + blk * BQ_VEC_TILE;
+#pragma unroll
+    for (int q = 0; q < BQ_VEC_ITEMS; ++q) dst[threadIdx.x + q * BQ_VEC_BLOCK] = src[threadIdx.x + q * BQ_VEC_BLOCK];
+    (void)ld;
 }
 
 // z = alpha y - beta z2 (both vanish outside the free set);  rz = r'z and beta of the conjugate gradients, as as_pc_apply_kernel does
@@ -839,8 +858,15 @@ static int as_pc_r_apply(bq_solver *s, as_ws *w, const double *y) {
     as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(m8t, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ttop, w->cg);
     int tiles = 0;
     const double *ypart = as_pc2_ypart(pc->r2, &tiles);
-    as_pc_r_finish_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, s->ldN, tiles, pc->ntop, Phitop, as_pc2_c(pc->r2), ypart, pc->ttop, s->mL,
-                                                                  s->mU, pc->v2, w->cg);
+    const as_pc_part pt = *as_pc2_part(pc->r2);
+    double *vg = as_pc2_vg(pc->r2);
+    const int64_t b0 = pt.blk[pt.lo], b1 = pt.blk[pt.hi];   // this rank's sample blocks
+    if (b1 > b0)
+        as_pc_r_finish_kernel<<<(unsigned)(b1 - b0), BQ_VEC_BLOCK, 0, st>>>(s->N, s->ldN, b0, pt, tiles, pc->ntop, Phitop, as_pc2_c(pc->r2), ypart,
+                                                                          pc->ttop, s->mL, s->mU, vg, w->cg);
+    BQ_HIP(hipGetLastError());
+    BQ_TRY(bq_exchange_gather(s->p->ctx, vg, (int64_t)pt.cmax * pt.maxlen * BQ_VEC_TILE));
+    as_pc_unpack_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->ldN, pt, vg, pc->v2, w->cg);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

@@ -14,17 +14,28 @@
 //      P^-1 r  ~  alpha y - beta P1^-1 (R y),   y = P1^-1 r            (a fixed symmetric positive definite operator: plain PCG)
 // tools/pc_projected_cpu_study.py (d = 64, n = 20 000): 23 -> 18 conjugate-gradient iterations, the exact order-2 model needs 17.
 //
-// Everything is a fixed-order sum: the same bits on every rank (the operator is replicated, like the rest of the preconditioner).
+// Everything is a fixed-order sum.  The two products are sums over SAMPLES and are sharded like the panel product (round 5): the
+// sample blocks are cut into the canonical segments of bq_sym_segments(world) (8 up to 8 ranks), a rank owns a run of them and forms
+// their slices of M, the per-segment sums are gathered (8 x d^2 doubles: 4 MB at d = 256) and added in segment order on every rank;
+// x_i' M x_i and v = R y are formed for the rank's own samples and v is gathered (n doubles).  Two collectives per application, the
+// same bits for any rank count (and the same association on one rank).  The explicit model P1 stays replicated.
 #include "bq_as.h"
 #include "bq_mfma_tile.h"
 
 struct as_pc2 {
     int64_t n = 0, d = 0, dp = 0, ld = 0;   // samples, features, features padded to 128, vector pitch (s->ldN)
-    int64_t S = 0, kc = 0, rows = 0;        // split-K of M: S slices of kc samples, rows = S * kc >= ld
+    int64_t rows = 0;                       // rows of Xp / W (= ld)
+    // the sample segments (in blocks of 1024 samples) and their slices (<= 2 blocks each: the split-K of M)
+    as_pc_part part;
+    int nsl = 0, own_sl_lo = 0, own_sl_hi = 0;   // slices in all; this rank's (its segments are a contiguous run)
+    long long *sl_row = nullptr, *sl_k = nullptr; // device: first row and length (samples) of slice s
+    int *sl_first = nullptr;                      // device: first slice of segment k (k = S: nsl)
+    double *Mg = nullptr;     // (world * cmax) x dp x dp: the per-segment sums, gathered
+    double *vg = nullptr;     // (world * cmax) x maxlen x 1024: v in the gathered layout
     double *Xp = nullptr;     // rows x dp, row-major, zero padded: the k-major image of X with k = sample
     double *Xt = nullptr;     // dp x ld: the k-major image with k = feature
     double *W = nullptr;      // rows x dp: diag(w) Xp, w = c o y
-    double *Mpart = nullptr;  // S x dp x dp
+    double *Mpart = nullptr;  // nsl x dp x dp (this rank fills its own slices)
     double *M = nullptr;      // dp x dp
     double *ypart = nullptr;  // (dp / 128) x ld: x_i' M x_i, one partial per column tile
     double *c = nullptr;      // ld: sqrt(2) g y e
@@ -51,11 +62,12 @@ __global__ void pc2_pad_kernel(const double *__restrict__ X, int64_t n, int64_t 
 }
 
 // W[i][:] = (c_i y_i) Xp[i][:]  (y vanishes outside the free set: so does W)
-__global__ __launch_bounds__(256) void pc2_scale_kernel(int64_t ld, int64_t dp, const double *__restrict__ Xp, const double *__restrict__ c,
-                                                        const double *__restrict__ y, double *__restrict__ W, const as_cg_scal *cg) {
+__global__ __launch_bounds__(256) void pc2_scale_kernel(int64_t row0, int64_t row1, int64_t dp, const double *__restrict__ Xp,
+                                                        const double *__restrict__ c, const double *__restrict__ y, double *__restrict__ W,
+                                                        const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // a wave per sample row
-    if (i >= ld) return;
+    const int64_t i = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // a wave per sample row, this rank's rows
+    if (i >= row1) return;
     const double w = c[i] * y[i];
     const double *src = Xp + i * dp;
     double *dst = W + i * dp;
@@ -69,47 +81,60 @@ __global__ __launch_bounds__(256) void pc2_scale_kernel(int64_t ld, int64_t dp, 
 
 // Mpart[s] (tile ta, tb) = Xp[slice s]' W[slice s], tb <= ta only (M is symmetric: the reduction mirrors): blockIdx.x = the tile's
 // index in the lower triangle, blockIdx.y = slice
-__global__ __launch_bounds__(256, 2) void pc2_moment_kernel(int64_t dp, int64_t kc, const double *__restrict__ Xp, const double *__restrict__ W,
-                                                            double *__restrict__ Mpart, const as_cg_scal *cg) {
+__global__ __launch_bounds__(256, 2) void pc2_moment_kernel(int64_t dp, int sl0, const long long *__restrict__ sl_row,
+                                                            const long long *__restrict__ sl_k, const double *__restrict__ Xp,
+                                                            const double *__restrict__ W, double *__restrict__ Mpart, const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     int64_t ta = 0;
     while ((ta + 1) * (ta + 2) / 2 <= (int64_t)blockIdx.x) ++ta;
     const int64_t tb = (int64_t)blockIdx.x - ta * (ta + 1) / 2;
-    const int64_t k0 = (int64_t)blockIdx.y * kc;
+    const int sl = sl0 + (int)blockIdx.y;
+    const int64_t k0 = sl_row[sl], kc = sl_k[sl];
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
     bq_mfma_tile_128(Xp + k0 * dp, dp, ta * BQ_GT, W + k0 * dp, dp, tb * BQ_GT, kc, sm, acc);
-    bq_tile_store(acc, Mpart + ((int64_t)blockIdx.y * dp + ta * BQ_GT) * dp + tb * BQ_GT, dp);
+    bq_tile_store(acc, Mpart + ((int64_t)sl * dp + ta * BQ_GT) * dp + tb * BQ_GT, dp);
 }
 
-// M = the slices added in slice order
-__global__ __launch_bounds__(256) void pc2_moment_reduce_kernel(int64_t dp, int64_t S, const double *__restrict__ Mpart, double *__restrict__ M,
-                                                                const as_cg_scal *cg) {
+// Mg[slot(k)] = the slices of segment k added in slice order (blockIdx.y = k - first own segment); tiles above the diagonal mirrored
+__global__ __launch_bounds__(256) void pc2_moment_seg_kernel(int64_t dp, as_pc_part part, const int *__restrict__ sl_first,
+                                                             const double *__restrict__ Mpart, double *__restrict__ Mg, const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= dp * dp) return;
+    const int k = part.lo + (int)blockIdx.y;
     const int64_t ra = o / dp, rb = o % dp;
-    const int64_t e = (ra / BQ_GT >= rb / BQ_GT) ? o : rb * dp + ra;   // tiles above the diagonal: the mirrored element
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four interleaved chains (loads in flight), combined in a fixed order
-    int64_t s = 0;
-    for (; s + 4 <= S; s += 4) {
-        a0 += Mpart[(s + 0) * dp * dp + e];
-        a1 += Mpart[(s + 1) * dp * dp + e];
-        a2 += Mpart[(s + 2) * dp * dp + e];
-        a3 += Mpart[(s + 3) * dp * dp + e];
+    const int64_t e = (ra / BQ_GT >= rb / BQ_GT) ? o : rb * dp + ra;
+    double a0 = 0.0, a1 = 0.0;   // two interleaved chains, combined in a fixed order (a segment has at most a few dozen slices)
+    int sl = sl_first[k];
+    const int end = sl_first[k + 1];
+    for (; sl + 2 <= end; sl += 2) {
+        a0 += Mpart[(int64_t)sl * dp * dp + e];
+        a1 += Mpart[(int64_t)(sl + 1) * dp * dp + e];
     }
-    for (; s < S; ++s) a0 += Mpart[s * dp * dp + e];
-    M[o] = (a0 + a1) + (a2 + a3);
+    if (sl < end) a0 += Mpart[(int64_t)sl * dp * dp + e];
+    Mg[(int64_t)part.slot[k] * dp * dp + o] = a0 + a1;
+}
+// M = the gathered per-segment sums added in segment order (every rank: the same bits)
+__global__ __launch_bounds__(256) void pc2_moment_final_kernel(int64_t dp, as_pc_part part, const double *__restrict__ Mg, double *__restrict__ M,
+                                                               const as_cg_scal *cg) {
+    if (cg != nullptr && cg->done) return;
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= dp * dp) return;
+    double a = 0.0;
+    for (int k = 0; k < part.S; ++k) a += Mg[(int64_t)part.slot[k] * dp * dp + o];
+    M[o] = a;
 }
 
 // ypart[ct][i] = sum over the 128 columns b of column tile ct of (X M)[i][b] X[i][b]: blockIdx.x = sample tile, blockIdx.y = ct
-__global__ __launch_bounds__(256, 2) void pc2_bilinear_kernel(int64_t dp, int64_t ld, const double *__restrict__ Xt, const double *__restrict__ Xp,
-                                                              const double *__restrict__ M, double *__restrict__ ypart, const as_cg_scal *cg) {
+__global__ __launch_bounds__(256, 2) void pc2_bilinear_kernel(int64_t dp, int64_t ld, int64_t tile0, const double *__restrict__ Xt,
+                                                              const double *__restrict__ Xp, const double *__restrict__ M,
+                                                              double *__restrict__ ypart, const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
     __shared__ double half[2][BQ_GT];
-    const int64_t i0 = (int64_t)blockIdx.x * BQ_GT, b0 = (int64_t)blockIdx.y * BQ_GT;
+    const int64_t i0 = (tile0 + (int64_t)blockIdx.x) * BQ_GT, b0 = (int64_t)blockIdx.y * BQ_GT;
     bq_d4 acc[4][4];
     bq_tile_zero(acc);
     // acc[row = sample][col = b] = sum_k Xt[k][i0 + row] M[k][b0 + col]   (M is symmetric: its rows are its k-major image)
@@ -158,7 +183,8 @@ __global__ void pc2_coef_kernel(int64_t n, int64_t d, int64_t ld, const double *
 
 void as_pc2_free(as_pc2 *r) {
     if (!r) return;
-    for (void *p : {(void *)r->Xp, (void *)r->Xt, (void *)r->W, (void *)r->Mpart, (void *)r->M, (void *)r->ypart, (void *)r->c})
+    for (void *p : {(void *)r->Xp, (void *)r->Xt, (void *)r->W, (void *)r->Mpart, (void *)r->M, (void *)r->ypart, (void *)r->c, (void *)r->sl_row,
+                    (void *)r->sl_k, (void *)r->sl_first, (void *)r->Mg, (void *)r->vg})
         if (p) hipFree(p);
     delete r;
 }
@@ -174,16 +200,54 @@ int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out) {
     r->dp = bq_round_up(p->d, BQ_GT);
     r->ld = s->ldN;
     const int64_t T = r->dp / BQ_GT;
-    // slices of the moment matrix: about two workgroups per CU in all, at least 256 samples each
-    int64_t S = std::max<int64_t>(1, 512 / (T * (T + 1) / 2));
-    S = std::min<int64_t>(S, std::max<int64_t>(1, r->ld / 256));
-    r->kc = bq_round_up((r->ld + S - 1) / S, BQ_GK);
-    r->S = (r->ld + r->kc - 1) / r->kc;
-    r->rows = r->S * r->kc;
+    r->rows = r->ld;
+    // the canonical sample segments (as many as the panel's: 8 up to 8 ranks), in blocks of 1024 samples, this rank's run of them
+    // and the slot of every segment in the gathered buffers; slices of at most two blocks (2 048 samples: ~3 x 123 workgroups at
+    // config 5) inside every segment
+    bq_ctx *ctx = p->ctx;
+    as_pc_part &pt = r->part;
+    const int64_t nblk = r->ld / BQ_VEC_TILE;
+    pt.S = bq_sym_segments(ctx->world);
+    pt.lo = bq_sym_seg_first(ctx->rank, ctx->world, pt.S);
+    pt.hi = bq_sym_seg_first(ctx->rank + 1, ctx->world, pt.S);
+    pt.cmax = (pt.S + ctx->world - 1) / ctx->world;
+    pt.maxlen = 0;
+    for (int k = 0; k <= pt.S; ++k) pt.blk[k] = (long long)((int64_t)k * nblk / pt.S);
+    for (int k = 0; k < pt.S; ++k) pt.maxlen = std::max(pt.maxlen, pt.blk[k + 1] - pt.blk[k]);
+    for (int q = 0; q < ctx->world; ++q) {
+        const int lo = bq_sym_seg_first(q, ctx->world, pt.S), hi = bq_sym_seg_first(q + 1, ctx->world, pt.S);
+        for (int k = lo; k < hi; ++k) pt.slot[k] = q * pt.cmax + (k - lo);
+    }
+    std::vector<long long> sl_row, sl_k;
+    std::vector<int> sl_first((size_t)pt.S + 1, 0);
+    for (int k = 0; k < pt.S; ++k) {
+        sl_first[(size_t)k] = (int)sl_row.size();
+        if (k == pt.lo) r->own_sl_lo = (int)sl_row.size();
+        for (long long b = pt.blk[k]; b < pt.blk[k + 1]; b += 2) {
+            sl_row.push_back(b * BQ_VEC_TILE);
+            sl_k.push_back(std::min<long long>(2, pt.blk[k + 1] - b) * BQ_VEC_TILE);
+        }
+        if (k + 1 == pt.hi) r->own_sl_hi = (int)sl_row.size();
+    }
+    sl_first[(size_t)pt.S] = (int)sl_row.size();
+    if (pt.hi <= pt.lo) r->own_sl_lo = r->own_sl_hi = 0;
+    r->nsl = (int)sl_row.size();
+    const size_t nsl1 = (size_t)std::max(r->nsl, 1);
     hipError_t e = hipMalloc(&r->Xp, sizeof(double) * r->rows * r->dp);
+    if (e == hipSuccess) e = hipMalloc(&r->sl_row, sizeof(long long) * nsl1);
+    if (e == hipSuccess) e = hipMalloc(&r->sl_k, sizeof(long long) * nsl1);
+    if (e == hipSuccess) e = hipMalloc(&r->sl_first, sizeof(int) * ((size_t)pt.S + 1));
+    if (e == hipSuccess) e = hipMalloc(&r->Mg, sizeof(double) * (size_t)ctx->world * pt.cmax * r->dp * r->dp);
+    if (e == hipSuccess) e = hipMemsetAsync(r->Mg, 0, sizeof(double) * (size_t)ctx->world * pt.cmax * r->dp * r->dp, st);
+    if (e == hipSuccess) e = hipMalloc(&r->vg, sizeof(double) * (size_t)ctx->world * pt.cmax * pt.maxlen * BQ_VEC_TILE);
+    if (e == hipSuccess) e = hipMemsetAsync(r->vg, 0, sizeof(double) * (size_t)ctx->world * pt.cmax * pt.maxlen * BQ_VEC_TILE, st);
+    if (e == hipSuccess && r->nsl > 0) e = hipMemcpyAsync(r->sl_row, sl_row.data(), sizeof(long long) * r->nsl, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && r->nsl > 0) e = hipMemcpyAsync(r->sl_k, sl_k.data(), sizeof(long long) * r->nsl, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->sl_first, sl_first.data(), sizeof(int) * ((size_t)pt.S + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // the three tables leave this scope
     if (e == hipSuccess) e = hipMalloc(&r->Xt, sizeof(double) * r->dp * r->ld);
     if (e == hipSuccess) e = hipMalloc(&r->W, sizeof(double) * r->rows * r->dp);
-    if (e == hipSuccess) e = hipMalloc(&r->Mpart, sizeof(double) * r->S * r->dp * r->dp);
+    if (e == hipSuccess) e = hipMalloc(&r->Mpart, sizeof(double) * nsl1 * r->dp * r->dp);
     if (e == hipSuccess) e = hipMalloc(&r->M, sizeof(double) * r->dp * r->dp);
     if (e == hipSuccess) e = hipMalloc(&r->ypart, sizeof(double) * T * r->ld);
     if (e == hipSuccess) e = hipMalloc(&r->c, sizeof(double) * r->ld);
@@ -208,15 +272,29 @@ int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out) {
 // the B part of v = R y:  ypart[ct][i] = the column tile's share of x_i' M x_i, M = sum_j (c_j y_j) x_j x_j'  (y: zero outside the free set);
 // bq_as_pc.hip (as_pc_r_apply) adds the tiles, scales by c_i and takes Phi_top Phi_top' y off
 int as_pc2_bpart(bq_solver *s, as_pc2 *r, const double *y, const as_cg_scal *cg) {
-    hipStream_t st = s->p->ctx->stream;
+    bq_ctx *ctx = s->p->ctx;
+    hipStream_t st = ctx->stream;
     const int64_t T = r->dp / BQ_GT;
-    pc2_scale_kernel<<<(unsigned)((r->ld + 3) / 4), 256, 0, st>>>(r->ld, r->dp, r->Xp, r->c, y, r->W, cg);
-    pc2_moment_kernel<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)r->S), 256, 0, st>>>(r->dp, r->kc, r->Xp, r->W, r->Mpart, cg);
-    pc2_moment_reduce_kernel<<<(unsigned)((r->dp * r->dp + 255) / 256), 256, 0, st>>>(r->dp, r->S, r->Mpart, r->M, cg);
-    pc2_bilinear_kernel<<<dim3((unsigned)(r->ld / BQ_GT), (unsigned)T), 256, 0, st>>>(r->dp, r->ld, r->Xt, r->Xp, r->M, r->ypart, cg);
+    const as_pc_part &pt = r->part;
+    const int64_t row0 = pt.blk[pt.lo] * BQ_VEC_TILE, row1 = pt.blk[pt.hi] * BQ_VEC_TILE;   // this rank's samples
+    const int own_sl = r->own_sl_hi - r->own_sl_lo, own_seg = pt.hi - pt.lo;
+    const unsigned ge = (unsigned)((r->dp * r->dp + 255) / 256);
+    if (row1 > row0) pc2_scale_kernel<<<(unsigned)((row1 - row0 + 3) / 4), 256, 0, st>>>(row0, row1, r->dp, r->Xp, r->c, y, r->W, cg);
+    if (own_sl > 0)
+        pc2_moment_kernel<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)own_sl), 256, 0, st>>>(r->dp, r->own_sl_lo, r->sl_row, r->sl_k, r->Xp, r->W,
+                                                                                            r->Mpart, cg);
+    if (own_seg > 0) pc2_moment_seg_kernel<<<dim3(ge, (unsigned)own_seg), 256, 0, st>>>(r->dp, pt, r->sl_first, r->Mpart, r->Mg, cg);
+    BQ_HIP(hipGetLastError());
+    BQ_TRY(bq_exchange_gather(ctx, r->Mg, (int64_t)pt.cmax * r->dp * r->dp));
+    pc2_moment_final_kernel<<<ge, 256, 0, st>>>(r->dp, pt, r->Mg, r->M, cg);
+    if (row1 > row0)
+        pc2_bilinear_kernel<<<dim3((unsigned)((row1 - row0) / BQ_GT), (unsigned)T), 256, 0, st>>>(r->dp, r->ld, row0 / BQ_GT, r->Xt, r->Xp, r->M,
+                                                                                               r->ypart, cg);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }
+const as_pc_part *as_pc2_part(const as_pc2 *r) { return &r->part; }
+double *as_pc2_vg(const as_pc2 *r) { return r->vg; }
 const double *as_pc2_ypart(const as_pc2 *r, int *tiles) {
     *tiles = (int)(r->dp / BQ_GT);
     return r->ypart;

@@ -274,14 +274,16 @@ def test_rows_per_step_variants_are_bit_identical(tmp_path, one_rank):
 @pytest.mark.gpu
 def test_order2_remainder_of_the_preconditioner_is_replicated_bitwise(tmp_path):
     """The implicit order-2 remainder of ActiveSetCG's preconditioner (csrc/bq_as_pc2.hip: two MFMA products with a split-K sum, a
-    power-iteration spectrum bound, a Chebyshev polynomial) runs replicated on every rank like the rest of the preconditioner: forced on
-    (BQ_AS_CG_PC_CLASS=3), one rank and two ranks give the same bits — and the same outer trajectory as without it."""
+    power-iteration spectrum bound, a Chebyshev polynomial) is sharded by sample segments — a rank forms the moment slices and the
+    x'Mx values of its own samples, the per-segment sums and v are gathered and added in segment order: forced on
+    (BQ_AS_CG_PC_CLASS=3), one, two and three ranks give the same bits — and the same outer trajectory as without it."""
     env = {'BQ_AS_CG_PC_CLASS': '3'}
     one = _launch('gpu-host', 1, tmp_path / 'one', extra_env=env)[0]
     two = _launch('gpu-host', 2, tmp_path / 'two', extra_env=env)
+    three = _launch('gpu-host', 3, tmp_path / 'three', extra_env=env)     # uneven runs of the eight sample segments: 2 / 3 / 3
     plain = _launch('gpu-host', 1, tmp_path / 'plain', extra_env={'BQ_AS_CG_PC_CLASS': '2'})[0]
     for key in ('ascg_kernel_x', 'ascg_kernel_f'):
-        for r in two:
+        for r in two + three:
             assert np.array_equal(r[key], one[key]), key
     np.testing.assert_allclose(one['ascg_kernel_x'], plain['ascg_kernel_x'], rtol=1e-7, atol=1e-9)
 
