@@ -884,10 +884,15 @@ def orchestrate(args):
                         # panel's placement moves it by +-3 % from process to process: a difference of two processes' numbers is
                         # noise); the share run contributes only what a product costs beside its tile kernel (slab reduction, O(n))
                         p1 = one['roofline']['avg_launch_ms'] + (g1['slowest_share_ms_per_step'] - g1['slowest_share_symv_tiles_ms'])
-                        repl = one['ms_per_step'] - prods * p1
+                        # ... of which the implicit order-2 remainder of the preconditioner is sharded by samples (round 5): it costs
+                        # 1 / G of its one-GPU time (HIP events around it in the c5 record) + two more collectives per application
+                        shard = one.get('preconditioner_sharded_ms_per_step', 0.0)
+                        calls = one.get('preconditioner_sharded_calls_per_step', 0.0)
+                        repl = one['ms_per_step'] - prods * p1 - shard
                         share_ms = part['slowest_share_ms_per_step'] + tab['assumed_exchange_us'] * 1e-3
-                        part['ascg_outer_iteration_ms_predicted'] = prods * share_ms + repl
+                        part['ascg_outer_iteration_ms_predicted'] = prods * share_ms + repl + shard / part['G'] + 2 * calls * tab['assumed_exchange_us'] * 1e-3
                         part['ascg_replicated_ms_per_outer_iteration'] = repl
+                        part['ascg_sample_sharded_ms_per_outer_iteration_one_gpu'] = shard
                         part['ascg_one_gpu_product_step_ms'] = p1
                         part['predicted_speedup_vs_1'] = one['ms_per_step'] / part['ascg_outer_iteration_ms_predicted']
                 else:
@@ -1258,6 +1263,7 @@ def main():
     rows, status = solver.run(max(args.warmup, 1))      # includes the start-up gradient product
     ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     ctx.profile_read(_lib.PROF_EXCH, reset=True)
+    ctx.profile_read(_lib.PROF_PCSHARD, reset=True)
     inner0 = solver.inner_iters() if ascg else 0
     barrier()
     t0 = time.perf_counter()
@@ -1270,6 +1276,7 @@ def main():
     done = len(rows)
     mv_ms, mv_cnt = ctx.profile_read(_lib.PROF_MATVEC, reset=True)
     ex_ms, ex_cnt = ctx.profile_read(_lib.PROF_EXCH, reset=True)
+    pcs_ms, pcs_cnt = ctx.profile_read(_lib.PROF_PCSHARD, reset=True) if ascg else (0.0, 0)
     inner = (solver.inner_iters() - inner0) if ascg else 0
     per_rank = None
     if comm is not None:   # every rank's share and timings in the one line rank 0 prints
@@ -1351,6 +1358,10 @@ def main():
             out['time_to_kkt_projected'] = c5_projection(n, d, 1e3 * elapsed / max(done, 1))
             out['inner_warm_start'] = os.environ.get('BQ_AS_CG_WARM') != '0'
             out['products_per_sec'] = mv_cnt / elapsed
+            # the sample-sharded part of the preconditioner (the implicit order-2 remainder: moment slices, x'Mx, v of a rank's own
+            # samples): HIP events around it; on G ranks it costs 1/G of this + two more collectives per application
+            out['preconditioner_sharded_ms_per_step'] = pcs_ms / max(done, 1)
+            out['preconditioner_sharded_calls_per_step'] = pcs_cnt / max(done, 1)
         traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
         if traffic:
             out['roofline']['traffic'] = traffic['hbm_bytes']

@@ -135,7 +135,8 @@ int bq_ctx_comm_info(const bq_ctx *ctx, int *kind, int *comm_ranks, int *sym_all
  * partials + ordered sum (default), 1 = all-reduce(sum) */
 int bq_ctx_set_sym_allreduce(bq_ctx *ctx, int on);
 /* HIP-event timing of the dominant kernels (on the stream they run on).  which: 0 = Q*v panel
- * product, 1 = Gram build, 2 = Cholesky factorisation, 3 = row-block exchange. */
+ * product, 1 = Gram build, 2 = Cholesky factorisation, 3 = row-block exchange, 4 = the sample-sharded part of ActiveSetCG's
+ * preconditioner (the implicit order-2 remainder: what divides by the rank count; bench.py's prediction for config 5 over 8). */
 int bq_ctx_profile(bq_ctx *ctx, int enable);
 int bq_ctx_profile_read(bq_ctx *ctx, int which, double *total_ms, int64_t *launches, int reset);
 /* measured HBM ceilings of this GPU on a scratch buffer of `bytes`: a read-only streaming sweep and a

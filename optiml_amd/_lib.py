@@ -26,7 +26,7 @@ PLACE_PANEL = 64
 SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS, SMO_STATS = range(4)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
-PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH = range(4)
+PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH, PROF_PCSHARD = range(5)
 COUNT_INNER, COUNT_MINRES, COUNT_REFACTOR, COUNT_REUSED, COUNT_NO_PRODUCT = range(5)
 STATE_X, STATE_G, STATE_MULT, STATE_MASKS = 1, 2, 4, 8
 ABI_VERSION = 1

@@ -850,6 +850,8 @@ static void as_pc_solve1(bq_solver *s, as_ws *w, const double *in, double *out, 
 static int as_pc_r_apply(bq_solver *s, as_ws *w, const double *y) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;   // profiling: the part of the preconditioner that is sharded by samples (BQ_PROF_PCSHARD)
+    BQ_TRY(bq_prof_begin(s->p->ctx, BQ_PROF_PCSHARD, &pe0, &pe1));
     BQ_TRY(as_pc2_bpart(s, pc->r2, y, w->cg));
     const float *Phitop = pc->Phi + (int64_t)pc->top0 * s->ldN;
     const int64_t m8t = bq_round_up(pc->ntop, PC_FG);   // (Phi carries PC_FG spare zero rows behind its last feature)
@@ -868,7 +870,7 @@ static int as_pc_r_apply(bq_solver *s, as_ws *w, const double *y) {
     BQ_TRY(bq_exchange_gather(s->p->ctx, vg, (int64_t)pt.cmax * pt.maxlen * BQ_VEC_TILE));
     as_pc_unpack_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->ldN, pt, vg, pc->v2, w->cg);
     BQ_HIP(hipGetLastError());
-    return BQ_OK;
+    return bq_prof_end(s->p->ctx, BQ_PROF_PCSHARD, pe0, pe1);
 }
 
 // z = P_AA^-1 r (+ r'z and beta on the device).  Explicit model: one Woodbury application.  With the order-2 remainder:

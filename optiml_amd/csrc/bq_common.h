@@ -63,7 +63,7 @@ constexpr int BQ_MAX_PARTIAL_Q = 8;               // reduced quantities per kern
 
 static inline int64_t bq_round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
 
-enum { BQ_PROF_MATVEC = 0, BQ_PROF_GRAM = 1, BQ_PROF_CHOL = 2, BQ_PROF_EXCH = 3, BQ_PROF_COUNT = 4 };
+enum { BQ_PROF_MATVEC = 0, BQ_PROF_GRAM = 1, BQ_PROF_CHOL = 2, BQ_PROF_EXCH = 3, BQ_PROF_PCSHARD = 4, BQ_PROF_COUNT = 5 };
 // BQ_COMM_SHARE: one rank's share of a `world`-way partition with NO transport behind it — every collective is a no-op, so the
 // products hold this rank's contributions only.  It exists to time and inspect a share on a single GPU (bq_ctx_create_share).
 enum { BQ_COMM_NONE = 0, BQ_COMM_RCCL = 1, BQ_COMM_CALLBACK = 2, BQ_COMM_SHARE = 3 };
