@@ -29,9 +29,37 @@ int main(int argc, char **argv) {
         if (bq_solver_get(s, BQ_GET_X_NOW, x) != BQ_OK) return 25;
         if (x[0] < 0.4999 || x[0] > 0.5001 || x[1] < 0.9999 || x[1] > 1.0001) return 26;
         bq_solver_destroy(s);
+        {
+            /* checkpoint / resume through the plain-C struct: InteriorPoint stopped after 3 iterations continues in a NEW solver and
+             * ends bit for bit where an uninterrupted one ends (bq_solver_get_state / bq_solver_set_state) */
+            double xa[2], xb[2], sx[2], sg[2], slp[2], slm[2];
+            bq_solver_snapshot st;
+            bq_solver *a = NULL, *b2 = NULL, *c2 = NULL;
+            if (bq_solver_create(p, BQ_IP, NULL, ub, NULL, 1e-10, 1000, 0.0, &a) != BQ_OK) return 30;
+            if (bq_solver_run(a, 64, rows, 64, &n, &status) != BQ_OK || status != BQ_STATUS_OPTIMAL) return 31;
+            if (bq_solver_get(a, BQ_GET_X_NOW, xa) != BQ_OK) return 32;
+            if (bq_solver_create(p, BQ_IP, NULL, ub, NULL, 1e-10, 3, 0.0, &b2) != BQ_OK) return 33;
+            if (bq_solver_run(b2, 8, rows, 64, &n, &status) != BQ_OK || status != BQ_STATUS_STOPPED) return 34;
+            memset(&st, 0, sizeof(st));
+            st.x = sx;
+            st.g = sg;
+            st.lp = slp;
+            st.lm = slm;
+            if (bq_solver_get_state(b2, &st) != BQ_OK || st.iter != 3 || st.kind != BQ_IP) return 35;
+            if ((st.have & (BQ_STATE_X | BQ_STATE_G | BQ_STATE_MULT)) != (BQ_STATE_X | BQ_STATE_G | BQ_STATE_MULT)) return 36;
+            if (bq_solver_create(p, BQ_IP, NULL, ub, NULL, 1e-10, 1000, 0.0, &c2) != BQ_OK) return 37;
+            if (bq_solver_set_state(c2, &st) != BQ_OK) return 38;
+            if (bq_solver_run(c2, 64, rows, 64, &n, &status) != BQ_OK || status != BQ_STATUS_OPTIMAL) return 39;
+            if (bq_solver_get(c2, BQ_GET_X_NOW, xb) != BQ_OK) return 40;
+            if (memcmp(xa, xb, sizeof(xa)) != 0) return 41;
+            if (bq_solver_set_state(c2, &st) != BQ_ERR_BADARG) return 42;   /* only before the first run */
+            bq_solver_destroy(a);
+            bq_solver_destroy(b2);
+            bq_solver_destroy(c2);
+        }
         bq_problem_destroy(p);
         bq_ctx_destroy(ctx);
-        printf("c abi gpu ok: x = (%.6f, %.6f) after %lld records\n", x[0], x[1], (long long)n);
+        printf("c abi gpu ok: x = (%.6f, %.6f) after %lld records; InteriorPoint resumed bit for bit\n", x[0], x[1], (long long)n);
     }
     printf("c abi ok\n");
     return 0;
