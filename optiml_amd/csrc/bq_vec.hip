@@ -245,27 +245,11 @@ __global__ void grad_init_kernel(int64_t N, vecs V) {
     }
 }
 
-// The block that takes the last ticket of a launch finishes the reduction over the per-block partial sums and takes the
-// iteration's scalar decisions in the same kernel (one launch and one dependent-kernel gap less per reduction; the
-// fixed-order final sum is the same code as before, so results do not depend on which block is last).
-__device__ __forceinline__ bool last_block(unsigned int *ticket) {
-    __shared__ int last;
-    if (threadIdx.x == 0) {
-        __threadfence();   // this block's partial sums are visible device-wide before the ticket is taken
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (last) __threadfence();   // and the other blocks' partial sums are visible to this one
-    return last != 0;
-}
-
-__device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
-__device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats);
-
-// apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and its reductions; the last
-// block finalises them: objective, |d|, record, stop tests (projected_gradient.py:81-110)
+// apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and the per-block partial sums of its
+// reductions (projected_gradient.py:81-98); they are summed, and the iteration's decisions taken (objective, |d|, record, stop
+// tests: :99-110), by the last block of the kernel that closes the product (bq_epi_finish): one pass, no ticket
 __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
-                                      const double *__restrict__ sgn, double *__restrict__ w_out, bq_iter_stat *stats) {
+                                      const double *__restrict__ sgn, double *__restrict__ w_out) {
     if (sc->done) return;
     __shared__ double sh4[4][4];
     const double t = do_update ? sc->t : 0.0;
@@ -299,40 +283,6 @@ __global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
         part[2 * nblk + blockIdx.x] = br.c;
         part[3 * nblk + blockIdx.x] = br.m;
     }
-    if (last_block(&sc->ticket[0])) {
-        pg_decide_body(sc, part, nblk, stats);
-        if (threadIdx.x == 0) sc->ticket[0] = 0;
-    }
-}
-
-__device__ __forceinline__ void pg_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh4[4][4];
-    const red4 fr = final_reduce4(part + 0 * nblk, part + 1 * nblk, part + 2 * nblk, part + 3 * nblk, nblk, sh4);
-    const double sd2 = fr.a, sgd = fr.b, sxg = fr.c, rmin = fr.m;
-    if (threadIdx.x == 0) {
-        const double f = 0.5 * sxg, ng = sqrt(sd2);
-        sc->f = f;
-        sc->ng = ng;
-        sc->gd = sgd;
-        sc->max_t = rmin;
-        const long long row = sc->iter - sc->stat_base;
-        if (row >= 0 && row < sc->stat_cap) {
-            bq_iter_stat st;
-            st.iter = sc->iter;
-            st.f = f;
-            st.r1 = ng;
-            st.r2 = NAN;
-            st.r3 = rmin;
-            stats[row] = st;
-        }
-        if (ng <= sc->eps) {
-            sc->status = BQ_STATUS_OPTIMAL;
-            sc->done = 1;
-        } else if (sc->iter >= sc->max_iter) {
-            sc->status = BQ_STATUS_STOPPED;
-            sc->done = 1;
-        }
-    }
 }
 
 // finish (gathered panel output -> Q d) fused with the partial sums of d'Qd and the step length: the stand-alone form of the
@@ -347,7 +297,7 @@ __global__ __launch_bounds__(256) void finish_den_kernel(const double *__restric
 
 // FW: apply pending step, pick the vertex, form the (optionally trust-clipped) direction
 __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
-                                      const double *__restrict__ sgn, double *__restrict__ w_out, bq_iter_stat *stats) {
+                                      const double *__restrict__ sgn, double *__restrict__ w_out) {
     if (sc->done) return;
     __shared__ double sh4[4][4];
     const double a = do_update ? sc->t : 0.0;
@@ -381,43 +331,6 @@ __global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal 
         part[0 * nblk + blockIdx.x] = br.a;
         part[1 * nblk + blockIdx.x] = br.b;
         part[2 * nblk + blockIdx.x] = br.c;
-    }
-    if (last_block(&sc->ticket[0])) {
-        fw_decide_body(sc, part, nblk, stats);
-        if (threadIdx.x == 0) sc->ticket[0] = 0;
-    }
-}
-
-__device__ __forceinline__ void fw_decide_body(bq_scal *sc, const double *part, int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh4[4][4];
-    const red4 fr = final_reduce4(part + 0 * nblk, part + 1 * nblk, part + 2 * nblk, nullptr, nblk, sh4);
-    const double sgy = fr.a, sgd = fr.b, sxg = fr.c;
-    if (threadIdx.x == 0) {
-        const double f = 0.5 * sxg;
-        const double low = f + sgy;
-        if (low > sc->best_lb) sc->best_lb = low;
-        const double gap = (f - sc->best_lb) / fmax(fabs(f), 1.0);
-        sc->f = f;
-        sc->low = low;
-        sc->gap = gap;
-        sc->gd = sgd;
-        const long long row = sc->iter - sc->stat_base;
-        if (row >= 0 && row < sc->stat_cap) {
-            bq_iter_stat st;
-            st.iter = sc->iter;
-            st.f = f;
-            st.r1 = sc->best_lb;
-            st.r2 = gap;
-            st.r3 = NAN;
-            stats[row] = st;
-        }
-        if (gap <= sc->eps) {
-            sc->status = BQ_STATUS_OPTIMAL;
-            sc->done = 1;
-        } else if (sc->iter >= sc->max_iter) {
-            sc->status = BQ_STATUS_STOPPED;
-            sc->done = 1;
-        }
     }
 }
 
@@ -453,11 +366,9 @@ int bq_pgfw_iterate(bq_solver *s) {
     const double *sgn = fused_w ? p->sgn : nullptr;
     double *w_out = fused_w ? p->w : nullptr;
     if (s->kind == BQ_PG) {
-        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out,
-                                                                         s->stats);
+        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
     } else {
-        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out,
-                                                                         s->stats);
+        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
     }
     s->started = true;
     const double *w = s->d;   // BQ_PLAIN: the direction itself (same padded length as the panel width)
@@ -480,8 +391,11 @@ int bq_pgfw_iterate(bq_solver *s) {
     epi.sgn = p->sgn;
     epi.Qd = s->Qd;
     epi.sc = s->sc;
-    epi.part = s->partials;
+    epi.part = s->partials + 4 * s->nblk;   // [0, 4 nblk): the update / evaluation kernel's partial sums, still to be read
     epi.stats = s->stats;
+    epi.dec = s->partials;
+    epi.nblk = s->nblk;
+    static_assert(BQ_MAX_PARTIAL_Q >= 8, "4 nblk decision sums + up to 4 nblk (= n / 256) blocks of d'Qd");
     bool fused = false;
     BQ_TRY(bq_panel_product(p, p->add_one, w, done, fuse ? &epi : nullptr, &fused));
     if (!fused) finish_den_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(p->s, epi);
