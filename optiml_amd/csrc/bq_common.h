@@ -59,7 +59,7 @@ constexpr int64_t BQ_PAD = 1024;
 constexpr int BQ_VEC_BLOCK = 256;                 // threads per block in the O(n) kernels
 constexpr int BQ_VEC_ITEMS = 4;                   // elements per thread
 constexpr int BQ_VEC_TILE = BQ_VEC_BLOCK * BQ_VEC_ITEMS;  // 1024 elements per block == BQ_PAD
-constexpr int BQ_MAX_PARTIAL_Q = 8;               // reduced quantities per kernel
+constexpr int BQ_MAX_PARTIAL_Q = 20;              // reduced quantities per block of 1024 elements (PG / FW: five per block of 256 rows)
 
 static inline int64_t bq_round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
 

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
     }
     if (q == 0) out[a * ST + r] = acc;
     if constexpr (EPI) {
-        const double c = q == 0 ? bq_epi_element(epi, a * ST + r, acc) : 0.0;
+        const bq_epi_sums c = q == 0 ? bq_epi_element(epi, a * ST + r, acc, epi.sc->fw_t) : bq_epi_zero();
         bq_epi_finish(epi, a, nb, c, gridDim.x);
     }
 }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restri
     }
     for (; s < tab.count; ++s) acc += gath[(int64_t)tab.slot[s] * len + i];
     out[i] = acc;
-    if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, acc), gridDim.x);
+    if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, acc, epi.sc->fw_t), gridDim.x);
 }
 
 // The timed launch: when the context is profiling, the kernel's own dispatch carries the two timestamps (hipExtLaunchKernelGGL with a

@@ -245,93 +245,35 @@ __global__ void grad_init_kernel(int64_t N, vecs V) {
     }
 }
 
-// apply the pending step (x += t d, g += t Qd), then evaluate the projected direction and the per-block partial sums of its
-// reductions (projected_gradient.py:81-98); they are summed, and the iteration's decisions taken (objective, |d|, record, stop
-// tests: :99-110), by the last block of the kernel that closes the product (bq_epi_finish): one pass, no ticket
-__global__ void pg_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
-                                      const double *__restrict__ sgn, double *__restrict__ w_out) {
-    if (sc->done) return;
-    __shared__ double sh4[4][4];
-    const double t = do_update ? sc->t : 0.0;
-    double sd2 = 0.0, sgd = 0.0, sxg = 0.0, rmin = INFINITY;
+// An iteration's update (projected_gradient.py:81-98, frank_wolfe.py:96-110): x += t d, g += t Qd, the new direction, and — BQ_SVC —
+// the panel-product input w = y o d.  One elementwise pass, no sums: they are taken, with the decisions, by the kernel that closes
+// the product (bq_epilogue.h).
+__global__ void pgfw_update_kernel(bq_epilogue e, double *__restrict__ w_out) {
+    if (e.sc->done) return;
+    double t, tr;
+    bq_epi_scalars(e, t, tr);
+    const bool upd = e.do_update != 0;
     VEC_LOOP(i) {
-        if (i < N) {
-            double xi = V.x[i], gi = V.g[i];
-            if (do_update) {
-                xi = xi + __dmul_rn(t, V.d[i]);
-                gi = gi + __dmul_rn(t, V.Qd[i]);
-                V.x[i] = xi;
-                V.g[i] = gi;
+        if (i < e.N) {
+            const bq_pgfw_elem el = bq_pgfw_element(e, i, upd, t, tr);
+            if (upd) {
+                e.x[i] = el.x;
+                e.g[i] = el.g;
             }
-            const double ubi = V.ub[i], lbi = V.lb[i];
-            double di = -gi;
-            if (ubi - xi <= ACT_TOL && di > 0.0) di = 0.0;
-            if (xi - lbi <= ACT_TOL && di < 0.0) di = 0.0;
-            V.d[i] = di;
-            if (w_out != nullptr) w_out[i] = sgn[i] * di;   // fused panel-product input of the SVC structure
-            sd2 += di * di;
-            sgd += gi * di;
-            sxg += xi * (gi + V.q[i]);
-            if (di > 0.0) rmin = fmin(rmin, (ubi - xi) / di);
-            if (di < 0.0) rmin = fmin(rmin, (lbi - xi) / di);
+            e.d[i] = el.d;
+            if (w_out != nullptr) w_out[i] = e.sgn[i] * el.d;
         }
-    }
-    const red4 br = block_reduce4(sd2, sgd, sxg, rmin, sh4);
-    if (threadIdx.x == 0) {
-        part[0 * nblk + blockIdx.x] = br.a;
-        part[1 * nblk + blockIdx.x] = br.b;
-        part[2 * nblk + blockIdx.x] = br.c;
-        part[3 * nblk + blockIdx.x] = br.m;
     }
 }
 
-// finish (gathered panel output -> Q d) fused with the partial sums of d'Qd and the step length: the stand-alone form of the
-// epilogue (bq_epilogue.h) for the paths whose product has no closing kernel of its own to carry it (dense row-block panels, the
-// one-rank streamed product, BQ_SYM_EXCHANGE=allreduce).  One workgroup per 256 rows, exactly as inside symv_reduce_kernel /
-// symv_segsum_kernel: d'Qd — and with it the step length — has the same bits whichever kernel closed the product.
+// The stand-alone closing kernel of an iteration (bq_epilogue.h) for the paths whose product has no closing kernel of its own to
+// carry it (dense row-block panels, the one-rank streamed product, BQ_SYM_EXCHANGE=allreduce).  One workgroup per 256 rows, exactly
+// as inside symv_reduce_kernel / symv_segsum_kernel: the sums — and with them the step length — have the same bits whichever
+// kernel closed the product.
 __global__ __launch_bounds__(256) void finish_den_kernel(const double *__restrict__ sv, bq_epilogue epi) {
     if (epi.sc->done) return;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, i < epi.n ? sv[i] : 0.0), gridDim.x);
-}
-
-// FW: apply pending step, pick the vertex, form the (optionally trust-clipped) direction
-__global__ void fw_update_eval_kernel(int64_t N, int do_update, vecs V, bq_scal *sc, double *part, int64_t nblk,
-                                      const double *__restrict__ sgn, double *__restrict__ w_out) {
-    if (sc->done) return;
-    __shared__ double sh4[4][4];
-    const double a = do_update ? sc->t : 0.0;
-    const double tr = sc->fw_t;
-    double sgy = 0.0, sgd = 0.0, sxg = 0.0;
-    VEC_LOOP(i) {
-        if (i < N) {
-            double xi = V.x[i], gi = V.g[i];
-            if (do_update) {
-                xi = xi + __dmul_rn(a, V.d[i]);
-                gi = gi + __dmul_rn(a, V.Qd[i]);
-                V.x[i] = xi;
-                V.g[i] = gi;
-            }
-            const double ubi = V.ub[i], lbi = V.lb[i];
-            double yi = (gi < 0.0) ? ubi : lbi;
-            sgy += gi * (yi - xi);
-            if (tr > 0.0) {
-                const double rad = tr * (ubi - lbi);
-                yi = fmin(fmax(yi, xi - rad), xi + rad);
-            }
-            const double di = yi - xi;
-            V.d[i] = di;
-            if (w_out != nullptr) w_out[i] = sgn[i] * di;
-            sgd += gi * di;
-            sxg += xi * (gi + V.q[i]);
-        }
-    }
-    const red4 br = block_reduce4(sgy, sgd, sxg, INFINITY, sh4);
-    if (threadIdx.x == 0) {
-        part[0 * nblk + blockIdx.x] = br.a;
-        part[1 * nblk + blockIdx.x] = br.b;
-        part[2 * nblk + blockIdx.x] = br.c;
-    }
+    bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, i < epi.n ? sv[i] : 0.0, epi.sc->fw_t), gridDim.x);
 }
 
 static vecs solver_vecs(bq_solver *s) {
@@ -358,46 +300,38 @@ int bq_pgfw_start(bq_solver *s) {
 int bq_pgfw_iterate(bq_solver *s) {
     hipStream_t st = s->p->ctx->stream;
     const int *done = &s->sc->done;
-    const int upd = s->started ? 1 : 0;
-    vecs V = solver_vecs(s);
     bq_problem *p = s->p;
-    // SVC structure: the update/eval kernel also writes the panel-product input w = y o d (saves the prep launch)
-    const bool fused_w = p->structure == BQ_SVC;
-    const double *sgn = fused_w ? p->sgn : nullptr;
-    double *w_out = fused_w ? p->w : nullptr;
-    if (s->kind == BQ_PG) {
-        pg_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
-    } else {
-        fw_update_eval_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, upd, V, s->sc, s->partials, s->nblk, sgn, w_out);
-    }
+    bq_epilogue epi;
+    epi.structure = p->structure;
+    epi.kind = s->kind == BQ_PG ? 0 : 1;
+    epi.do_update = s->started ? 1 : 0;
+    epi.n = p->n;
+    epi.N = p->N;
+    epi.diag_add = p->diag_add;
+    epi.x = s->x;
+    epi.g = s->g;
+    epi.d = s->d;
+    epi.q = p->q;
+    epi.lb = s->lb;
+    epi.ub = s->ub;
+    epi.sgn = p->sgn;
+    epi.Qd = s->Qd;
+    epi.sc = s->sc;
+    epi.part = s->partials;
+    epi.stats = s->stats;
+    static_assert(BQ_MAX_PARTIAL_Q >= 20, "five sums per block of 256 rows = 20 per block of 1024");
     s->started = true;
     const double *w = s->d;   // BQ_PLAIN: the direction itself (same padded length as the panel width)
+    // BQ_SVC: the update kernel also writes the panel-product input w = y o d (saves the prep launch)
+    pgfw_update_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(epi, p->structure == BQ_SVC ? p->w : nullptr);
     if (p->structure == BQ_SVC) {
         w = p->w;
     } else if (p->structure == BQ_SVR) {
         prep_kernel<<<vec_grid(p->ld), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, s->d, p->sgn, p->w, done);
         w = p->w;
     }
-    // the kernel that finishes the product also finishes the iteration (Qd, d'Qd, the step length) where the path has one such
-    // kernel (symmetric panels: the slab reduction / the ordered segment sum); dense row-block panels keep the separate launch
-    constexpr bool fuse = true;
-    bq_epilogue epi;
-    epi.structure = p->structure;
-    epi.kind = s->kind == BQ_PG ? 0 : 1;
-    epi.n = p->n;
-    epi.N = p->N;
-    epi.diag_add = p->diag_add;
-    epi.d = s->d;
-    epi.sgn = p->sgn;
-    epi.Qd = s->Qd;
-    epi.sc = s->sc;
-    epi.part = s->partials + 4 * s->nblk;   // [0, 4 nblk): the update / evaluation kernel's partial sums, still to be read
-    epi.stats = s->stats;
-    epi.dec = s->partials;
-    epi.nblk = s->nblk;
-    static_assert(BQ_MAX_PARTIAL_Q >= 8, "4 nblk decision sums + up to 4 nblk (= n / 256) blocks of d'Qd");
     bool fused = false;
-    BQ_TRY(bq_panel_product(p, p->add_one, w, done, fuse ? &epi : nullptr, &fused));
+    BQ_TRY(bq_panel_product(p, p->add_one, w, done, &epi, &fused));
     if (!fused) finish_den_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(p->s, epi);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
