@@ -1430,7 +1430,7 @@ extern "C" int bq_solver_get(bq_solver *s, int what, double *out) {
 }
 
 // ---- checkpoint / resume (bcqp.h) -----------------------------------------------------------------------------
-// v + t dv with the device's rounding: one rounded product, one sum (pg_update_eval_kernel / ip_update_kernel use __dmul_rn).
+// v + t dv with the device's rounding: one rounded product, one sum (pgfw_update_kernel / ip_update_kernel use __dmul_rn).
 #pragma clang fp contract(off)
 static void state_apply_step(std::vector<double> &v, const std::vector<double> &dv, double t) {
     for (size_t i = 0; i < v.size(); ++i) {

@@ -106,31 +106,47 @@ struct bq_epi_sums {
 };
 __device__ __forceinline__ bq_epi_sums bq_epi_zero() { return bq_epi_sums{0.0, 0.0, 0.0, 0.0, INFINITY}; }
 
+// what an output row's epilogue reads that does not depend on the product: loaded by the closing kernels BEFORE they sum the product
+// (the loads then overlap the slab walk / the gathered segment loads instead of following them: one round trip less per iteration)
+struct bq_epi_pre {
+    bq_pgfw_raw r0, r1;   // the element(s) of row i: u0 = i, and u1 = n + i for BQ_SVR (else u1 = u0: the same lines)
+    double q0, q1, sg, tr;
+    bool live;
+};
+__device__ __forceinline__ bq_epi_pre bq_epi_preload(const bq_epilogue &e, long long i, bool active) {
+    bq_epi_pre p;
+    p.live = active && i < e.n;
+    const long long u0 = p.live ? i : 0, u1 = e.structure == BQ_SVR ? e.n + u0 : u0;
+    p.r0 = bq_pgfw_load(e, u0, false);
+    p.r1 = bq_pgfw_load(e, u1, false);
+    p.q0 = e.q[u0];
+    p.q1 = e.q[u1];
+    p.sg = e.structure == BQ_SVC ? e.sgn[u0] : 1.0;
+    p.tr = e.sc->fw_t;
+    return p;
+}
+
 // one output row: i = a * 256 + r of the n-vector s (both halves for BQ_SVR): Qd and the element's contributions to the sums
-__device__ __forceinline__ bq_epi_sums bq_epi_element(const bq_epilogue &e, long long i, double sv, double tr) {
+__device__ __forceinline__ bq_epi_sums bq_epi_element(const bq_epilogue &e, const bq_epi_pre &p, long long i, double sv) {
     bq_epi_sums c = bq_epi_zero();
-    if (i >= e.n) return c;
+    if (!p.live) return c;
     const bool two = e.structure == BQ_SVR;
-    const long long u0 = i, u1 = two ? e.n + i : i;
-    const bq_pgfw_raw r0 = bq_pgfw_load(e, u0, false), r1 = bq_pgfw_load(e, u1, false);   // (u1 == u0 unless BQ_SVR: the same lines)
-    const double q0 = e.q[u0], q1 = e.q[u1];
-    const double sg = e.structure == BQ_SVC ? e.sgn[u0] : 1.0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 0 || two) {
-            const long long u = h == 0 ? u0 : u1;
-            const bq_pgfw_raw &in = h == 0 ? r0 : r1;
-            const bq_pgfw_elem el = bq_pgfw_compute(e.kind, in, false, 0.0, tr);   // d as the update kernel stored it, and FW's y0
+            const long long u = h == 0 ? i : e.n + i;
+            const bq_pgfw_raw &in = h == 0 ? p.r0 : p.r1;
+            const bq_pgfw_elem el = bq_pgfw_compute(e.kind, in, false, 0.0, p.tr);   // d as the update kernel stored it, and FW's y0
             double r;
             if (two)
                 r = h == 0 ? sv : -sv;
             else
-                r = e.structure == BQ_SVC ? sg * sv : sv;
+                r = e.structure == BQ_SVC ? p.sg * sv : sv;
             if (e.diag_add != 0.0) r += e.diag_add * el.d;
             e.Qd[u] = r;
             c.den += el.d * r;
             c.gd += el.g * el.d;
-            c.xg += el.x * (el.g + (h == 0 ? q0 : q1));
+            c.xg += el.x * (el.g + (h == 0 ? p.q0 : p.q1));
             if (e.kind == 0) {
                 c.a += el.d * el.d;
                 if (el.d > 0.0) c.rmin = fmin(c.rmin, (in.ub - el.x) / el.d);

@@ -265,6 +265,8 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
     const int64_t a = blockIdx.x;
     const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
     const double *p = slab + a * nb * ST + r;
+    bq_epi_pre pre;
+    if constexpr (EPI) pre = bq_epi_preload(epi, a * ST + r, q == 0);   // in flight while the slab is walked
     double acc = 0.0;
     for (int s0 = tab.lo; s0 < tab.hi; s0 += BQ_SYM_SEG) {
         const int ns = tab.hi - s0 < BQ_SYM_SEG ? tab.hi - s0 : BQ_SYM_SEG;
@@ -276,8 +278,7 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
     }
     if (q == 0) out[a * ST + r] = acc;
     if constexpr (EPI) {
-        const bq_epi_sums c = q == 0 ? bq_epi_element(epi, a * ST + r, acc, epi.sc->fw_t) : bq_epi_zero();
-        bq_epi_finish(epi, a, nb, c, gridDim.x);
+        bq_epi_finish(epi, a, nb, bq_epi_element(epi, pre, a * ST + r, acc), gridDim.x);
     }
 }
 
@@ -300,6 +301,8 @@ __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restri
                                                           double *__restrict__ out, const int *__restrict__ done, bq_epilogue epi) {
     if (done != nullptr && *done) return;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // len = nb * 256: always in range
+    bq_epi_pre pre;
+    if constexpr (EPI) pre = bq_epi_preload(epi, i, true);
     double acc = 0.0;
     int s = 0;
     for (; s + 8 <= tab.count; s += 8) {   // the canonical eight segments: eight loads in flight, added in segment order
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restri
     }
     for (; s < tab.count; ++s) acc += gath[(int64_t)tab.slot[s] * len + i];
     out[i] = acc;
-    if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, acc, epi.sc->fw_t), gridDim.x);
+    if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, pre, i, acc), gridDim.x);
 }
 
 // The timed launch: when the context is profiling, the kernel's own dispatch carries the two timestamps (hipExtLaunchKernelGGL with a

@@ -273,7 +273,8 @@ __global__ void pgfw_update_kernel(bq_epilogue e, double *__restrict__ w_out) {
 __global__ __launch_bounds__(256) void finish_den_kernel(const double *__restrict__ sv, bq_epilogue epi) {
     if (epi.sc->done) return;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, i, i < epi.n ? sv[i] : 0.0, epi.sc->fw_t), gridDim.x);
+    const bq_epi_pre pre = bq_epi_preload(epi, i, true);
+    bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, pre, i, i < epi.n ? sv[i] : 0.0), gridDim.x);
 }
 
 static vecs solver_vecs(bq_solver *s) {
