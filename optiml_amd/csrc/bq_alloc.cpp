@@ -37,6 +37,35 @@ void bq_ctx_drop_cache(bq_ctx *c) {
     drop_cache_locked(c);
 }
 
+// the allocations a placement choice did not keep (bq_ctx::held)
+static bool release_held_locked(bq_ctx *c, const void *owner) {
+    bool any = false;
+    int dev = 0;
+    hipGetDevice(&dev);
+    for (size_t k = 0; k < c->held.size();) {
+        if (owner == nullptr || c->held[k].owner == owner) {
+            hipSetDevice(c->device);
+            hipFree(c->held[k].ptr);
+            c->held.erase(c->held.begin() + (long)k);
+            any = true;
+        } else {
+            ++k;
+        }
+    }
+    if (any) hipSetDevice(dev);
+    return any;
+}
+
+void bq_ctx_hold(bq_ctx *c, void *ptr, size_t bytes, const void *owner) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    c->held.push_back({ptr, bytes, owner});
+}
+
+void bq_ctx_release_held(bq_ctx *c, const void *owner) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    release_held_locked(c, owner);
+}
+
 // the cached panel if it holds `bytes` with at most 25 % to spare; the caller owns it afterwards
 void *bq_ctx_cache_take(bq_ctx *c, size_t bytes, size_t *cap) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -67,7 +96,7 @@ hipError_t bq_device_malloc(void **ptr, size_t bytes) {
     bool simulated = false;
     if (fail_above >= 0 && (long long)bytes > fail_above) {
         std::lock_guard<std::mutex> lk(g_mu);
-        for (bq_ctx *c : g_live) simulated = simulated || c->panel_cache != nullptr;
+        for (bq_ctx *c : g_live) simulated = simulated || c->panel_cache != nullptr || !c->held.empty();
     }
     // (hipExtMallocWithFlags(hipDeviceMallocContiguous) for the panels was tried in round 4: the launch-time spread of the panel
     // product is the same with it — profiles/r04/placement_contiguous_flag.txt)
@@ -79,11 +108,13 @@ hipError_t bq_device_malloc(void **ptr, size_t bytes) {
     bool dropped = false;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        for (bq_ctx *c : g_live)
+        for (bq_ctx *c : g_live) {
             if (c->panel_cache) {
                 drop_cache_locked(c);
                 dropped = true;
             }
+            if (release_held_locked(c, nullptr)) dropped = true;
+        }
     }
     // a failed hipMalloc leaves its error pending: the next hipGetLastError() of an unrelated call would report "out of
     // memory" (seen: after a panel that does not fit, the next — small — problem failed once).  The caller gets the code.

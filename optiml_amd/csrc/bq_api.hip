@@ -130,6 +130,7 @@ extern "C" int bq_ctx_destroy(bq_ctx *c) {
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->pinned) hipHostFree(c->pinned);
     bq_ctx_drop_cache(c);
+    bq_ctx_release_held(c, nullptr);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return BQ_OK;
@@ -440,6 +441,7 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
         p->panel_alloc = nullptr;
     }
     p->panel = nullptr;
+    bq_ctx_release_held(p->ctx, p);
     for (void *ptr : {(void *)p->panel_alloc, (void *)p->q, (void *)p->sgn, (void *)p->X, (void *)p->w, (void *)p->s,
                       (void *)p->va, (void *)p->vb, (void *)p->partials, (void *)p->scal, (void *)p->slab, (void *)p->gath})
         if (ptr) hipFree(ptr);
@@ -508,7 +510,8 @@ extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, co
 
 // BQ_PLACE_PANEL (bcqp.h): time the product kernel on the freshly allocated, zeroed panel; while it streams below the "good" rate,
 // the device can hold one more panel and the TIME BUDGET allows it, allocate another candidate and time it; keep the fastest,
-// release the rest at the end (released earlier, the allocator would hand the same memory back as the next candidate).
+// HOLD the rest until the problem is destroyed or an allocation fails (released earlier, the allocator would hand the same memory
+// back as the next candidate; released at the end — rounds 4-5 — the release itself slowed the solve that followed: bq_ctx::held).
 //
 // What a slow placement is (round 4, profiles/r04/placement_*.txt): a property of the physical region the driver handed out, stable
 // for the life of the allocation (6.04 ... 6.50 ms in clusters) — NOT of the base address (the same allocation at 8 - 20 byte
@@ -598,7 +601,8 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
             losers.push_back(cand);
         }
     }
-    for (void *l : losers) hipFree(l);
+    // not released here: a large hipFree is followed by a transient in which the whole process streams slower (bq_ctx::held)
+    for (void *l : losers) bq_ctx_hold(c, l, p->panel_bytes, p);
     return rc;
 }
 

@@ -107,6 +107,16 @@ struct bq_ctx {
     // library fails (bq_device_malloc, which every hipMalloc here is routed through) and with the context.
     void *panel_cache = nullptr;
     size_t panel_cache_bytes = 0;
+    // Allocations the placement choice did not keep (place_panel), HELD until their problem goes: hipFree of a large allocation is
+    // followed by a transient — ~0.5 s after 3 GB, longer after 40 GB — during which every kernel of the process streams 1.5 - 4.5 %
+    // slower (round 5, profiles/r05/placement_release_transient.txt: the driver clears what was released), i.e. exactly while the
+    // solve that the choice was made for runs.  Given back earlier when ANY device allocation of the library fails (bq_alloc.cpp).
+    struct held_t {
+        void *ptr;
+        size_t bytes;
+        const void *owner;
+    };
+    std::vector<held_t> held;
     // problems alive on this context; a context destroyed while some are is only marked and goes with the last of them
     int refs = 0;
     bool zombie = false;
@@ -245,6 +255,8 @@ void bq_ctx_register(bq_ctx *c, bool alive);   // bq_alloc.cpp: the contexts who
 void bq_ctx_drop_cache(bq_ctx *ctx);   // give the cached panel back to the driver
 void *bq_ctx_cache_take(bq_ctx *ctx, size_t bytes, size_t *cap);   // the cached panel if it fits `bytes` (<= 25 % spare), else null
 void bq_ctx_cache_put(bq_ctx *ctx, void *panel, size_t bytes);
+void bq_ctx_hold(bq_ctx *ctx, void *ptr, size_t bytes, const void *owner);   // keep an unused allocation until bq_ctx_release_held
+void bq_ctx_release_held(bq_ctx *ctx, const void *owner);                    // owner's blocks (null: all) go back to the driver
 
 // bq_symv.hip: symmetric tile product over tile rows [I0, I1) -> out (nb*256 partial sums)
 constexpr int64_t BQ_SYM_TILE = 256;
