@@ -43,6 +43,9 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# `value` is a steady-state rate (iterations per second, set-up reported separately): the panel placement choice is told
+# that many products follow, so that it may spend its maximum (5 s) instead of SVC.fit's 2 % of max_iter products (config.placement_budget)
+STEADY_STATE_PRODUCTS = 1e9
 FP64_MFMA_PEAK_TF = 78.6
 
 LINE_LIMIT = 4096       # bytes of the last stdout line (the driver keeps a 12.8 KB tail of stdout: r04's 25.6 KB line was cut)
@@ -651,7 +654,7 @@ def share_timing(args):
         for k in range(G):
             ctx = device.Context(share=(k, G)) if G > 1 else device.Context()
             name = name or ctx.name
-            quad = KernelQuadratic(X, q, struct, kern, y=yy, storage=args.storage, tune_placement=not args.no_placement)
+            quad = KernelQuadratic(X, q, struct, kern, y=yy, storage=args.storage, tune_placement=not args.no_placement, expected_products=STEADY_STATE_PRODUCTS)
             ctx.profile(True)
             dev = quad.device_problem(ctx)
             gram_ms, _ = ctx.profile_read(_lib.PROF_GRAM, reset=True)
@@ -1232,12 +1235,12 @@ def main():
     if args.task == 'svc':
         X, y = make_blobs(n, d, seed=0, sigma=args.sigma)
         quad = KernelQuadratic(X, -np.ones(n), 'svc', kern, y=y, storage=args.storage, rank_one=not al,
-                               diag=0.5 if ascg else 0.0, tune_placement=not args.no_placement)
+                               diag=0.5 if ascg else 0.0, tune_placement=not args.no_placement, expected_products=STEADY_STATE_PRODUCTS)
         a_eq = y
     else:   # eps-insensitive SVR dual: 2n variables on one n x n panel (BASELINE config 4 shape)
         X, y = make_regression(n, d, seed=0)
         quad = KernelQuadratic(X, np.hstack((-y, y)) + 0.1, 'svr', kern, storage=args.storage, rank_one=not al,
-                               tune_placement=not args.no_placement)
+                               tune_placement=not args.no_placement, expected_products=STEADY_STATE_PRODUCTS)
         a_eq = np.hstack((np.ones(n), -np.ones(n)))
     N = quad.ndim
     ctx.profile(True)   # timing of the dominant kernel by its own dispatch timestamps (roofline)
@@ -1324,7 +1327,8 @@ def main():
                        'sym_exchange': cinfo['sym_exchange'] if world > 1 else 'none', 'blob_sigma': args.sigma,
                        'rccl_init_stages': cinfo['rccl_init_stages'],
                        'rows_per_gpu': r1 - r0, 'device': ctx.name,
-                       'panel_placement_ms': dev.placement()},
+                       'panel_placement_ms': dev.placement(),
+                       'placement_budget': 'off' if args.no_placement else 'steady state: up to 5 s (SVC.fit: 2 % of max_iter products, 0.2 s at least)'},
             'roofline': {'bound': 'hbm', 'kernel': 'symv_tiles_kernel (symmetric panel product Q*d)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'traffic_source': None, 'avg_launch_ms': avg_ms, 'launches': mv_cnt,

@@ -71,8 +71,9 @@ enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian 
  * 6.50 ms per product, each reproducible to 0.005 ms; NOT of its base address, nor of the contiguity the API can ask for:
  * profiles/r04/placement_*.txt): with this flag the product kernel is timed on the freshly allocated (still empty) panel and, if
  * it streams below ~6.5 TB/s, further allocations are tried while they fit a time budget (BQ_PLACE_BUDGET_MS, default 200 ms; at
- * most BQ_PANEL_CANDIDATES = 3; a candidate is priced at what the first allocation cost) and the fastest is kept (the others are
- * released; skipped when the device cannot hold a second panel).  For the product-bound solvers (PG, FW, ActiveSetCG, the
+ * most 3; a candidate is priced at what the first allocation cost; bq_ctx_set_placement_budget lets the budget grow with the work
+ * the caller expects) and the fastest is kept (the others are held until the problem is destroyed; skipped when a panel takes 40 %
+ * of the device).  For the product-bound solvers (PG, FW, ActiveSetCG, the
  * augmented-Lagrangian rules), whose every iteration streams the panel — SVC / SVR.fit set it for those; pointless for
  * InteriorPoint / ActiveSet / SMO.  Per rank, before the first collective. */
 #define BQ_PLACE_PANEL 64
@@ -210,6 +211,14 @@ int bq_problem_time_matvec(bq_problem *p, int reps, double *mean_ms);
 /* BQ_PLACE_PANEL: how many placements of the panel were timed (0: the flag was not given or did not apply) and the product's
  * launch time on each, in the order tried (ms[0 .. min(*tried, cap))); the panel kept is the fastest of them */
 int bq_problem_placement(const bq_problem *p, int *tried, double *ms, int cap);
+/* Budget of the BQ_PLACE_PANEL choice for the problems created on this context from now on.  A slow placement costs ~5 % of every
+ * product of the solve that follows, so the choice may spend up to 2 % of the products the caller EXPECTS to run
+ * (expected_products x the product's measured time), never less than min_ms (< 0: BQ_PLACE_BUDGET_MS, default 200) and never
+ * more than max_ms.  SVC / SVR.fit pass their max_iter (svm/_base.py:187-240: the optimizer's iteration cap), a steady-state
+ * measurement passes a large number; expected_products = 0 (the default) keeps the fixed min_ms budget.  Candidates that were
+ * not kept stay allocated until their problem is destroyed or a device allocation of the library fails (releasing them before
+ * the solve slowed it down: profiles/r05/placement_release_transient.txt). */
+int bq_ctx_set_placement_budget(bq_ctx *ctx, double min_ms, double max_ms, double expected_products);
 
 /* ---- solvers (optiml/opti/constrained/, the four .py files) --------------------------------------------------- */
 /* lb/ub/x0: dual-dim fp64 host vectors (lb, x0 may be NULL: 0 and mid-box, constrained/_base.py:61-65).

@@ -78,6 +78,7 @@ PROTOTYPES = {
     'bq_ctx_probe_mfma_f64': (C.c_int, [_vp, C.c_double, _dp]),
     'bq_ctx_probe_exchange': (C.c_int, [_vp, C.c_int, _i64, C.c_int, _dp, _dp]),
     'bq_ctx_set_collective_timeout': (C.c_int, [_vp, C.c_double]),
+    'bq_ctx_set_placement_budget': (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
     'bq_ctx_probe_stall': (C.c_int, [_vp, C.c_double, C.c_int]),
     'bq_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_sym_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -530,7 +530,8 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
     const char *e = getenv("BQ_PANEL_GOOD_GBS");
     const double good_gbs = e ? atof(e) : 6500.0;
     e = getenv("BQ_PLACE_BUDGET_MS");
-    const double budget_ms = e ? atof(e) : 200.0;
+    const double budget_min = c->place_min_ms >= 0.0 ? c->place_min_ms : (e ? atof(e) : 200.0);
+    double budget_ms = budget_min;   // grows with the work the caller expects once the product's time is known (below)
     const auto t_start = std::chrono::steady_clock::now();
     auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     bq_seg_table tab;
@@ -572,12 +573,18 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
     // a panel that came from the context's cache (a destroyed problem of the same size left it: fit loops) was chosen when IT was
     // allocated, and a fresh allocation right after that release is the slow kind: it is kept as it is
     if (first_alloc_ms <= 0.0) return rc;
+    // bq_ctx_set_placement_budget: a slow placement costs ~5 % of every product, so up to 2 % of the products the caller expects to
+    // run may be spent on finding a better one (within [min, max]): SVC.fit passes its max_iter, a steady-state measurement "many"
+    if (c->place_products > 0.0 && c->place_max_ms > budget_min)
+        budget_ms = std::min(c->place_max_ms, std::max(budget_min, 0.02 * c->place_products * best));
     // what one more candidate costs: an allocation like the first one + clearing it + five products on it
     const double cand_ms = first_alloc_ms + (double)p->panel_bytes / 4.0e9 + 6.0 * best;
     while (rc == BQ_OK && p->place_tried < want && (double)p->panel_bytes / (best * 1e-3) / 1e9 < good_gbs &&
            elapsed_ms() + cand_ms <= budget_ms) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < p->panel_bytes + p->panel_bytes / 16) break;
+        // the losers are held while the problem lives (bq_ctx::held): no second copy of a panel that takes 40 % of the device
+        if (2 * p->panel_bytes + p->panel_bytes / 4 > total_b) break;
         void *cand = nullptr;
         if (hipMalloc(&cand, p->panel_bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -604,6 +611,15 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
     // not released here: a large hipFree is followed by a transient in which the whole process streams slower (bq_ctx::held)
     for (void *l : losers) bq_ctx_hold(c, l, p->panel_bytes, p);
     return rc;
+}
+
+extern "C" int bq_ctx_set_placement_budget(bq_ctx *c, double min_ms, double max_ms, double expected_products) {
+    BQ_ARG(c != nullptr, "ctx is NULL");
+    BQ_ARG(expected_products >= 0.0, "expected_products must be >= 0");
+    c->place_min_ms = min_ms;      // < 0: BQ_PLACE_BUDGET_MS / 200 ms
+    c->place_max_ms = max_ms;
+    c->place_products = expected_products;
+    return BQ_OK;
 }
 
 extern "C" int bq_problem_placement(const bq_problem *p, int *tried, double *ms, int cap) {

@@ -111,6 +111,8 @@ struct bq_ctx {
     // followed by a transient — ~0.5 s after 3 GB, longer after 40 GB — during which every kernel of the process streams 1.5 - 4.5 %
     // slower (round 5, profiles/r05/placement_release_transient.txt: the driver clears what was released), i.e. exactly while the
     // solve that the choice was made for runs.  Given back earlier when ANY device allocation of the library fails (bq_alloc.cpp).
+    // budget of the placement choice (bq_ctx_set_placement_budget): min / max ms and the products the caller expects to run
+    double place_min_ms = -1.0, place_max_ms = -1.0, place_products = 0.0;
     struct held_t {
         void *ptr;
         size_t bytes;

@@ -196,6 +196,11 @@ class Context:
         _lib.check(self._lib.bq_ctx_probe_bandwidth(self.handle, int(nbytes), int(reps), C.byref(r), C.byref(c)))
         return r.value, c.value
 
+    def set_placement_budget(self, expected_products=0., min_ms=-1., max_ms=5000.):
+        """Budget of the panel placement choice (`KernelQuadratic(tune_placement=True)`) for problems created from now on: up to 2 %
+        of `expected_products` products of the panel, within [min_ms (default: BQ_PLACE_BUDGET_MS / 200 ms), max_ms]."""
+        _lib.check(self._lib.bq_ctx_set_placement_budget(self.handle, float(min_ms), float(max_ms), float(expected_products)))
+
     def set_collective_timeout(self, seconds):
         """Abort the RCCL communicator when a wait on the stream lasts longer than `seconds` (0: never)."""
         _lib.check(self._lib.bq_ctx_set_collective_timeout(self.handle, float(seconds)))

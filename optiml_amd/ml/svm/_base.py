@@ -247,7 +247,7 @@ class SVC(ClassifierMixin, SVM):
             sq = self.loss == SquaredHinge   # Q += I/(2C), no upper bound (svm/_base.py:727-730, :778-794)
             obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage,
                                   diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept,
-                                  tune_placement=self._streams_panel())
+                                  tune_placement=self._streams_panel(), expected_products=self.max_iter)
             self._run_lagrangian(obj, None if self.reg_intercept else y, None if sq else np.ones(n) * self.C)
         else:
             self._check_bcqp()
@@ -257,7 +257,7 @@ class SVC(ClassifierMixin, SVM):
             if self.loss != Hinge:
                 raise TypeError(f'{self.loss} is not an allowed loss')
             obj = KernelQuadratic(X, -np.ones(n), 'svc', self.kernel, y=y, storage=self.storage,
-                                  tune_placement=self._streams_panel())
+                                  tune_placement=self._streams_panel(), expected_products=self.max_iter)
             self._run(obj, np.ones(n) * self.C)
 
         sv = self.alphas_ > 1e-6
@@ -324,7 +324,7 @@ class SVR(RegressorMixin, SVM):
             sq = self.loss == SquaredEpsilonInsensitive   # Q += I/(2C), no upper bound (svm/_base.py:1279-1283, :1332-1348)
             obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage,
                                   diag=1. / (2 * self.C) if sq else 0., rank_one=self.reg_intercept,
-                                  tune_placement=self._streams_panel())
+                                  tune_placement=self._streams_panel(), expected_products=self.max_iter)
             e = np.hstack((np.ones(n), -np.ones(n)))   # equality row
             self._run_lagrangian(obj, None if self.reg_intercept else e, None if sq else np.ones(2 * n) * self.C)
         else:
@@ -335,7 +335,7 @@ class SVR(RegressorMixin, SVM):
                                           'optimizers')
             if self.loss != EpsilonInsensitive:
                 raise TypeError(f'{self.loss} is not an allowed loss')
-            obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage, tune_placement=self._streams_panel())
+            obj = KernelQuadratic(X, q, 'svr', self.kernel, storage=self.storage, tune_placement=self._streams_panel(), expected_products=self.max_iter)
             self._run(obj, np.ones(2 * n) * self.C)
 
         alphas_p, alphas_n = np.split(self.alphas_, 2)

@@ -201,7 +201,9 @@ class KernelQuadratic(Quadratic):
     `rank_one=False` leaves out the yy' / ee' term of the regularised intercept: the reg_intercept=False duals
     Q = K*yy' and [[K,-K],[-K,K]] (:552-555, :1096-1099) that the augmented-Lagrangian path solves with an equality row.
     `.Q` materialises the dense matrix from the device panel on demand (inspection / small problems only).
-    `tune_placement=True` lets the library pick the fastest of up to three allocations of the panel (`bq_problem_placement`).
+    `tune_placement=True` lets the library pick the fastest of up to three allocations of the panel (`bq_problem_placement`);
+    `expected_products` (the iteration cap of the solve that follows; `SVC` / `SVR.fit` pass their `max_iter`) lets the time that
+    choice may take grow with the work ahead (`bq_ctx_set_placement_budget`: 2 % of it, 200 ms at least, 5 s at most).
     `storage='stream'` keeps NO panel: every product recomputes the Gram tiles on the MFMA (for n^2 beyond HBM; first-order
     solvers only, no `.Q`).
     """
@@ -209,7 +211,7 @@ class KernelQuadratic(Quadratic):
     _STRUCT = {'plain': _lib.PLAIN, 'svc': _lib.SVC, 'svr': _lib.SVR}
 
     def __init__(self, X, q, structure, kernel, y=None, diag=0.0, storage='f64', rank_one=True, full_panel=False,
-                 tune_placement=False):
+                 tune_placement=False, expected_products=0):
         X = np.ascontiguousarray(X, dtype=float)
         if structure not in self._STRUCT:
             raise ValueError(f'unknown structure {structure}')
@@ -233,6 +235,7 @@ class KernelQuadratic(Quadratic):
         # BQ_PLACE_PANEL: time the product on the fresh panel and try up to two more allocations if it streams slowly (panels of
         # >= 1 GB; for solvers whose every iteration streams the panel)
         self.tune_placement = bool(tune_placement)
+        self.expected_products = float(expected_products or 0)
         self.storage = storage
         self.kind, self.gamma, self.coef0, self.degree = kernel.device_spec(X)
         self._dev = None
@@ -241,6 +244,8 @@ class KernelQuadratic(Quadratic):
         lib = _lib.load()
         h = C.c_void_p()
         n, d = self.X.shape
+        if self.tune_placement:
+            ctx.set_placement_budget(self.expected_products)
         _lib.check(lib.bq_problem_create_kernel(
             ctx.handle, self._STRUCT[self.structure] | (0 if self.rank_one else _lib.NO_RANK_ONE) |
             (_lib.FULL_PANEL if self.full_panel else 0) | (_lib.PLACE_PANEL if self.tune_placement else 0), n, d, _lib.ptr(self.X), _lib.ptr(self.y), self.kind,

@@ -156,6 +156,20 @@ def test_panel_placement_selection(amd, monkeypatch):
     assert np.array_equal(cached.device_problem().matvec(v), ref)
     for quad in (cached, tuned, plain):
         quad.release()
+    # bq_ctx_set_placement_budget: the budget grows with the products the caller expects (2 % of them, between the fixed budget and
+    # the maximum) — with no time by default, a caller that expects many products still gets all three candidates; one that expects
+    # a handful does not; the losers stay allocated until their problem goes (releasing them slowed the solve that followed)
+    monkeypatch.setenv('BQ_PLACE_BUDGET_MS', '0')
+    patient = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True, expected_products=1e9)
+    brief = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True, expected_products=3)
+    assert len(patient.device_problem().placement()) in (1, 3)      # 1: its panel came from the context's cache
+    assert len(brief.device_problem().placement()) == 1
+    assert np.array_equal(patient.device_problem().matvec(v), ref) and np.array_equal(brief.device_problem().matvec(v), ref)
+    from optiml_amd import _lib, device
+    with pytest.raises(_lib.BcqpError):
+        device.get_context().set_placement_budget(expected_products=-1.)
+    patient.release()
+    brief.release()
     small = KernelQuadratic(X[:2000], -np.ones(2000), 'svc', gaussian, y=y[:2000], tune_placement=True)
     assert small.device_problem().placement() == []
     small.release()
