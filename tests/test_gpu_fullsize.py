@@ -1,6 +1,8 @@
 """Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot hold an n x n matrix at
 n = 100 000): linearity and symmetry of the Hessian product, spot rows against the oracle's kernel, consistency of the
 objective/gradient pair, descent and feasibility of the solver iterates, record bookkeeping."""
+import os
+
 import numpy as np
 import pytest
 
@@ -440,7 +442,9 @@ def test_config5_squared_hinge_active_set_cg_at_full_size():
     assert opt.iter == 3 and opt.status == 'stopped' and len(rec) == 4 and opt.inner_iters > 0
     # one cold solve from x0 = 1 and two warm ones: 22 inner iterations with round 5's preconditioner (the order-2 term: its 2d large
     # directions as features, the rest implicitly), 32 without the implicit part, 40 with rounds 3-4's features (tools/c5_first_iterations.py)
-    assert opt.inner_iters <= 26, opt.inner_iters
+    # (the suite is also run with the older feature families forced, profiles/rNN/pytest_gpu_shortcuts_off.log: their own counts then)
+    bound = {'0': 80, '1': 44, '2': 35}.get(os.environ.get('BQ_AS_CG_PC_CLASS', ''), 26)
+    assert opt.inner_iters <= bound, opt.inner_iters
     f = [r['f'] for r in rec]
     assert all(b <= a for a, b in zip(f, f[1:]))
     none = np.zeros(n, dtype=bool)
