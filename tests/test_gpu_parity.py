@@ -341,6 +341,39 @@ def test_reference_unit_problems(amd, tag, s):
         assert np.allclose(opt.x, 0.0)
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+@pytest.mark.parametrize('storage', ['kernel', 'dense'])
+def test_pg_converges_to_the_reference_alpha(amd, tag, storage):
+    """north_star: "alpha matching reference to rtol = 1e-6" — for ProjectedGradient, the headline solver, TO CONVERGENCE: two RBF SVC
+    duals on which the reference's own stop test fires (eps = 1e-8: 'optimal' after 471 / 364 iterations; tools/gen_golden.py
+    gen_pg_converged).  The iterates leave the reference's after k ~ 300 (test_pg_is_sensitive_to_rounding), the converged alpha does
+    not depend on the path: status, alpha (rtol 1e-6), the support set and the objective (rtol 1e-10) must agree; the iteration count
+    within 20 %.  Both through the kernel-built packed panel (the headline's path) and a dense Quadratic."""
+    from optiml_amd.ml.svm.kernels import GaussianKernel
+    from optiml_amd.opti import KernelQuadratic, Quadratic
+    from optiml_amd.opti.constrained import ProjectedGradient
+    from oracle import svm_oracle as so
+    g = load_golden('pg_converged.npz')
+    X, y, C, gamma = g[f'{tag}_X'], g[f'{tag}_y'], float(g[f'{tag}_C']), float(g[f'{tag}_gamma'])
+    n = len(y)
+    if storage == 'kernel':
+        quad = KernelQuadratic(X, -np.ones(n), 'svc', GaussianKernel(gamma=gamma), y=y)
+    else:
+        Q, q, _ = so.svc_dual(so.gram('rbf', X, None, gamma), y, C)
+        quad = Quadratic(Q, q)
+    hist = []
+    opt = ProjectedGradient(quad=quad, ub=np.full(n, C), eps=float(g[f'{tag}_eps']), max_iter=20000,
+                            callback=lambda o: hist.append(o.f_x)).minimize()
+    ref_x, ref_iter = g[f'{tag}_x'], int(g[f'{tag}_iter'])
+    assert opt.status == 'optimal' == str(g[f'{tag}_status'])
+    assert abs(opt.iter - ref_iter) <= 0.2 * ref_iter, (opt.iter, ref_iter)
+    np.testing.assert_allclose(opt.x, ref_x, rtol=1e-6, atol=1e-7 * C)
+    np.testing.assert_allclose(opt.f_x, float(g[f'{tag}_f_x']), rtol=1e-10)
+    assert np.array_equal(opt.x > 1e-6, ref_x > 1e-6)
+    k = min(100, len(hist), len(g[f'{tag}_f_hist']))     # and the early history step for step (before rounding separates the paths)
+    np.testing.assert_allclose(hist[:k], g[f'{tag}_f_hist'][:k], rtol=1e-9, atol=1e-11)
+
+
 @pytest.mark.parametrize('s,prefix,kw', [('pg', 'pg', {}), ('fw', 'fw', {}), ('fw', 'fwt', {'t': 0.1})])
 def test_trajectory_svc_dense(amd, s, prefix, kw):
     from optiml_amd.opti import Quadratic

@@ -172,6 +172,22 @@ def test_cfg1_linear_pg_n2000(golden):
     np.testing.assert_allclose(res['x'], g['pg_alphas'], rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_pg_converged_svc_duals(golden, tag):
+    """ProjectedGradient run by the reference to ITS OWN stop test (eps = 1e-8, 'optimal' after 471 / 364 iterations) on two RBF SVC
+    duals conditioned well enough for the method to get there: the converged alpha does not depend on the path, so the oracle is held
+    to it at rtol 1e-6 although its iterates have long left the reference's (test_pg_is_sensitive_to_rounding)."""
+    g = golden('pg_converged.npz')
+    X, y, C, gamma = g[f'{tag}_X'], g[f'{tag}_y'], float(g[f'{tag}_C']), float(g[f'{tag}_gamma'])
+    Q, q, ub = so.svc_dual(so.gram('rbf', X, None, gamma), y, C)
+    res = bo.SOLVERS['pg'](Q, q, ub, eps=float(g[f'{tag}_eps']), max_iter=20000)
+    assert res['status'] == 'optimal' == str(g[f'{tag}_status'])
+    assert abs(res['iter'] - int(g[f'{tag}_iter'])) <= 0.2 * int(g[f'{tag}_iter'])
+    np.testing.assert_allclose(res['x'], g[f'{tag}_x'], rtol=1e-6, atol=1e-7 * C)
+    np.testing.assert_allclose(res['f_hist'][-1], float(g[f'{tag}_f_x']), rtol=1e-10)
+    assert np.array_equal(res['x'] > 1e-6, g[f'{tag}_x'] > 1e-6)
+
+
 def test_pg_is_sensitive_to_rounding(golden):
     """Evidence for the PG parity policy: the reference formulation itself is chaotic.  A 1e-15 relative
     perturbation of the start changes the iterates by > 1e-6 within 500 iterations (and the stopping iteration),

@@ -274,6 +274,27 @@ def gen_trajectories(out):
     np.savez_compressed(os.path.join(out, 'traj_svr_poly_n128.npz'), **data)
 
 
+def gen_pg_converged(out):
+    """ProjectedGradient run by the reference to its own stop test (|d| <= eps, status 'optimal') on two RBF SVC duals whose Hessian is
+    well enough conditioned for the method to get there (the n = 256 trajectory problem is not: beyond k ~ 300 the reference's iterates
+    depend on rounding): the converged alpha is path-independent, so it can be held to rtol 1e-6 — svm/_base.py:552-559, 628-629,
+    projected_gradient.py:76-143.  eps = 1e-8: 471 and 364 iterations; at 1e-9 the reference itself never stops (rounding keeps |d| near 1e-8)."""
+    data = {}
+    for tag, (n, d, sigma, gamma, C) in {'a': (300, 6, 6.0, 0.5, 0.1), 'b': (500, 8, 3.0, 2.0, 1.0)}.items():
+        X, y = make_blobs(n, d, seed=300 + n, sigma=sigma)
+        K = GaussianKernel(gamma=gamma)(X)
+        Q = K * np.outer(y, y)
+        Q += np.outer(y, y)
+        q = -np.ones(n)
+        ub = np.ones(n) * C
+        r = run_solver(ProjectedGradient, Q, q, ub, eps=1e-8, max_iter=20000)
+        print(f'  pg converged {tag}: n={n} gamma={gamma} C={C}: iter={r["iter"]} status={r["status"]} f={r["f_x"]:.12f} '
+              f'nsv={(r["x"] > 1e-6).sum()} at ub={(r["x"] > C - 1e-9).sum()}')
+        data.update({f'{tag}_X': X, f'{tag}_y': y, f'{tag}_gamma': gamma, f'{tag}_C': C, f'{tag}_eps': 1e-8})
+        data.update(flat(tag, r))
+    np.savez_compressed(os.path.join(out, 'pg_converged.npz'), **data)
+
+
 def _fit_record(est, Xtest):
     opt = est.optimizer
     rec = {'alphas': np.asarray(est.alphas_, dtype=float), 'support': np.asarray(est.support_),
@@ -608,7 +629,7 @@ def main():
     ap.add_argument('--only', default=None, help='run a single generator, e.g. gen_kernels_more')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    for fn in (gen_unit_problems, gen_x_star, gen_kernels, gen_kernels_more, gen_trajectories, gen_fits, gen_cfg5, gen_cfg1, gen_lagrangian, gen_smo):
+    for fn in (gen_unit_problems, gen_x_star, gen_kernels, gen_kernels_more, gen_trajectories, gen_pg_converged, gen_fits, gen_cfg5, gen_cfg1, gen_lagrangian, gen_smo):
         if args.only and fn.__name__ != args.only:
             continue
         print(fn.__name__)
