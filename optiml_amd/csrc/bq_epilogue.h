@@ -114,9 +114,10 @@ struct bq_epi_pre {
     bool live;
 };
 __device__ __forceinline__ bq_epi_pre bq_epi_preload(const bq_epilogue &e, long long i, bool active) {
-    bq_epi_pre p;
+    bq_epi_pre p = {};
     p.live = active && i < e.n;
-    const long long u0 = p.live ? i : 0, u1 = e.structure == BQ_SVR ? e.n + u0 : u0;
+    if (!p.live) return p;   // (symv_reduce_kernel: three of a block's four 256-thread groups carry no row)
+    const long long u0 = i, u1 = e.structure == BQ_SVR ? e.n + u0 : u0;
     p.r0 = bq_pgfw_load(e, u0, false);
     p.r1 = bq_pgfw_load(e, u1, false);
     p.q0 = e.q[u0];
