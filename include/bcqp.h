@@ -72,8 +72,8 @@ enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian 
  * profiles/r04/placement_*.txt): with this flag the product kernel is timed on the freshly allocated (still empty) panel and, if
  * it streams below ~6.5 TB/s, further allocations are tried while they fit a time budget (BQ_PLACE_BUDGET_MS, default 200 ms; at
  * most 3; a candidate is priced at what the first allocation cost; bq_ctx_set_placement_budget lets the budget grow with the work
- * the caller expects) and the fastest is kept (the others are held until the problem is destroyed; skipped when a panel takes 40 %
- * of the device).  For the product-bound solvers (PG, FW, ActiveSetCG, the
+ * the caller expects) and the fastest is kept (the others are held until the problem is destroyed; a candidate is only tried while a
+ * tenth of the device stays free beside it).  For the product-bound solvers (PG, FW, ActiveSetCG, the
  * augmented-Lagrangian rules), whose every iteration streams the panel — SVC / SVR.fit set it for those; pointless for
  * InteriorPoint / ActiveSet / SMO.  Per rank, before the first collective. */
 #define BQ_PLACE_PANEL 64

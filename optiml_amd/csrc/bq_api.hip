@@ -583,8 +583,9 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
            elapsed_ms() + cand_ms <= budget_ms) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < p->panel_bytes + p->panel_bytes / 16) break;
-        // the losers are held while the problem lives (bq_ctx::held): no second copy of a panel that takes 40 % of the device
-        if (2 * p->panel_bytes + p->panel_bytes / 4 > total_b) break;
+        // the losers are held while the problem lives (bq_ctx::held): a second copy only if a tenth of the device stays free beside
+        // the two (config 5's 125 GB panel on 288 GB: yes, once; a failing allocation later gives the held one back: bq_alloc.cpp)
+        if (2 * p->panel_bytes + total_b / 10 > total_b || free_b < p->panel_bytes + total_b / 10) break;
         void *cand = nullptr;
         if (hipMalloc(&cand, p->panel_bytes) != hipSuccess) {
             (void)hipGetLastError();
