@@ -4,8 +4,10 @@
 // elements [1024 b, 1024 (b+1)), lane t the elements b*1024 + j*256 + t.  Reductions are two-stage with a fixed
 // order (4 items per lane -> shuffle tree -> 4 waves -> partials[b] -> one block sums the partials strided by
 // 256 + the same tree), so the iterates are bit-identical for any GPU count.  The scalar state of a solver lives
-// in one device struct (bq_scal); "decide"/"step" kernels are single-block and keep the host out of the loop:
-// once `done` is set every later kernel of the run returns immediately.
+// in one device struct (bq_scal) and the decisions are taken on the device: once `done` is set every later kernel
+// of the run returns immediately.  PG / FW: the update before the product is one elementwise pass
+// (pgfw_update_kernel); every sum and decision of the iteration belongs to the kernel that closes the product
+// (bq_epilogue.h: per 256-row block, the same tree in every closing kernel).
 //
 // Reference sites: projected_gradient.py:82-129, frank_wolfe.py:96-151, interior_point.py:180-267
 // (all under optiml/opti/constrained/), objective/gradient optiml/opti/_base.py:282,291.
@@ -15,17 +17,10 @@
 #include <cmath>
 #include <cstdlib>
 
-#define ACT_TOL 1e-12
-#define CURV_TOL 1e-16
 
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double wmin(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
     return v;
 }
 // all threads of a 256-thread block get the result
@@ -37,63 +32,11 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ double block_min(double v, double *sh) {
-    v = wmin(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double r = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
-    __syncthreads();
-    return r;
-}
-// three sums and a minimum of a 256-thread block in ONE round of barriers (each quantity through exactly the tree of block_sum /
-// block_min: the same bits; four separate calls cost eight barriers in a kernel whose length is its chain of dependent steps)
-struct red4 {
-    double a, b, c, m;
-};
-__device__ __forceinline__ red4 block_reduce4(double a, double b, double c, double m, double (*sh4)[4]) {
-    a = wsum(a);
-    b = wsum(b);
-    c = wsum(c);
-    m = wmin(m);
-    if ((threadIdx.x & 63) == 0) {
-        const int w = threadIdx.x >> 6;
-        sh4[0][w] = a;
-        sh4[1][w] = b;
-        sh4[2][w] = c;
-        sh4[3][w] = m;
-    }
-    __syncthreads();
-    red4 r;
-    r.a = ((sh4[0][0] + sh4[0][1]) + sh4[0][2]) + sh4[0][3];
-    r.b = ((sh4[1][0] + sh4[1][1]) + sh4[1][2]) + sh4[1][3];
-    r.c = ((sh4[2][0] + sh4[2][1]) + sh4[2][2]) + sh4[2][3];
-    r.m = fmin(fmin(sh4[3][0], sh4[3][1]), fmin(sh4[3][2], sh4[3][3]));
-    __syncthreads();
-    return r;
-}
-// ... and the same over the per-block partial sums of a launch (the strided accumulation of final_sum / final_min, then the tree)
-__device__ __forceinline__ red4 final_reduce4(const double *pa, const double *pb, const double *pc, const double *pm, int64_t nblk,
-                                              double (*sh4)[4]) {
-    double a = 0.0, b = 0.0, c = 0.0, m = INFINITY;
-    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) {
-        a += pa[i];
-        b += pb[i];
-        c += pc[i];
-        if (pm != nullptr) m = fmin(m, pm[i]);
-    }
-    return block_reduce4(a, b, c, m, sh4);
-}
 __device__ __forceinline__ double final_sum(const double *part, int64_t nblk, double *sh) {
     double a = 0.0;
     for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) a += part[i];
     return block_sum(a, sh);
 }
-__device__ __forceinline__ double final_min(const double *part, int64_t nblk, double *sh) {
-    double a = INFINITY;
-    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) a = fmin(a, part[i]);
-    return block_min(a, sh);
-}
-
 #define VEC_LOOP(i)                                                             \
     const int64_t _base = (int64_t)blockIdx.x * BQ_VEC_TILE + threadIdx.x;      \
     _Pragma("unroll") for (int _j = 0; _j < BQ_VEC_ITEMS; ++_j)                 \
