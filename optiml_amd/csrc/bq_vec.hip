@@ -191,22 +191,36 @@ __global__ void grad_init_kernel(int64_t N, vecs V) {
 // An iteration's update (projected_gradient.py:81-98, frank_wolfe.py:96-110): x += t d, g += t Qd, the new direction, and — BQ_SVC —
 // the panel-product input w = y o d.  One elementwise pass, no sums: they are taken, with the decisions, by the kernel that closes
 // the product (bq_epilogue.h).
-__global__ void pgfw_update_kernel(bq_epilogue e, double *__restrict__ w_out) {
+__global__ __launch_bounds__(256) void pgfw_update_kernel(bq_epilogue e, double *__restrict__ w_out) {
     if (e.sc->done) return;
     double t, tr;
     bq_epi_scalars(e, t, tr);
     const bool upd = e.do_update != 0;
-    VEC_LOOP(i) {
-        if (i < e.N) {
-            const bq_pgfw_elem el = bq_pgfw_element(e, i, upd, t, tr);
-            if (upd) {
-                e.x[i] = el.x;
-                e.g[i] = el.g;
-            }
-            e.d[i] = el.d;
-            if (w_out != nullptr) w_out[i] = e.sgn[i] * el.d;
-        }
+    // one panel column per thread — its dual element, or its two (BQ_SVR: i and n + i) — so the kernel is one round trip long and
+    // writes the product's input w itself for every structure (prep_kernel's map: y o d, d+ - d-, or d)
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= e.n) return;
+    const bool two = e.structure == BQ_SVR;
+    const bq_pgfw_raw r0 = bq_pgfw_load(e, i, upd), r1 = bq_pgfw_load(e, two ? e.n + i : i, upd);
+    const bq_pgfw_elem a = bq_pgfw_compute(e.kind, r0, upd, t, tr);
+    if (upd) {
+        e.x[i] = a.x;
+        e.g[i] = a.g;
     }
+    e.d[i] = a.d;
+    double w = a.d;
+    if (two) {
+        const bq_pgfw_elem b = bq_pgfw_compute(e.kind, r1, upd, t, tr);
+        if (upd) {
+            e.x[e.n + i] = b.x;
+            e.g[e.n + i] = b.g;
+        }
+        e.d[e.n + i] = b.d;
+        w = a.d - b.d;
+    } else if (e.structure == BQ_SVC) {
+        w = e.sgn[i] * a.d;
+    }
+    if (w_out != nullptr) w_out[i] = w;
 }
 
 // The stand-alone closing kernel of an iteration (bq_epilogue.h) for the paths whose product has no closing kernel of its own to
@@ -265,15 +279,9 @@ int bq_pgfw_iterate(bq_solver *s) {
     epi.stats = s->stats;
     static_assert(BQ_MAX_PARTIAL_Q >= 20, "five sums per block of 256 rows = 20 per block of 1024");
     s->started = true;
-    const double *w = s->d;   // BQ_PLAIN: the direction itself (same padded length as the panel width)
-    // BQ_SVC: the update kernel also writes the panel-product input w = y o d (saves the prep launch)
-    pgfw_update_kernel<<<vec_grid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(epi, p->structure == BQ_SVC ? p->w : nullptr);
-    if (p->structure == BQ_SVC) {
-        w = p->w;
-    } else if (p->structure == BQ_SVR) {
-        prep_kernel<<<vec_grid(p->ld), BQ_VEC_BLOCK, 0, st>>>(p->structure, p->n, s->d, p->sgn, p->w, done);
-        w = p->w;
-    }
+    // BQ_PLAIN: the product's input is the direction itself (same padded length as the panel width); else the kernel writes it
+    const double *w = p->structure == BQ_PLAIN ? s->d : p->w;
+    pgfw_update_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(epi, p->structure == BQ_PLAIN ? nullptr : p->w);
     bool fused = false;
     BQ_TRY(bq_panel_product(p, p->add_one, w, done, &epi, &fused));
     if (!fused) finish_den_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(p->s, epi);
