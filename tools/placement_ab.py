@@ -1,11 +1,21 @@
-import os, sys, time
+#!/usr/bin/env python3
+"""What the panel placement choice leaves behind (profiles/r05/placement_release_transient.txt): config 2's panel (1.6 GB) built
+plain, with profiling switched on first, or with the placement choice; then `time_matvec` (50 products by events) three times.
+
+    python tools/placement_ab.py plain|profile_first|tuned
+"""
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, '/root/repo' if os.path.isdir('/root/repo/optiml_amd') else os.getcwd())
-from optiml_amd import _lib, device
-from optiml_amd.datasets import make_blobs
-from optiml_amd.ml.svm.kernels import gaussian
-from optiml_amd.opti import KernelQuadratic
-mode = sys.argv[1]
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optiml_amd import device  # noqa: E402
+from optiml_amd.datasets import make_blobs  # noqa: E402
+from optiml_amd.ml.svm.kernels import gaussian  # noqa: E402
+from optiml_amd.opti import KernelQuadratic  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else 'plain'
 n, d = 20000, 64
 ctx = device.get_context()
 if mode == 'profile_first':
