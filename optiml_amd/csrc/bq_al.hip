@@ -29,18 +29,31 @@ __device__ __forceinline__ double al_wsum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
-__device__ __forceinline__ double al_bsum(double v, double *sh) {
-    v = al_wsum(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+// NQ block sums in ONE round of barriers, and the NQ final sums over a launch's per-block partials (quantity q at part + q * nblk)
+// likewise: each quantity through the tree the one-quantity helpers of rounds 2-4 used (wave tree, four waves in order: same bits); NQ separate calls were 2 NQ barriers in kernels
+// whose length is their chain of dependent steps (round 5; config-2-sized AdaGrad: 42 -> 38 us beside the product)
+template <int NQ>
+__device__ __forceinline__ void al_bsum_n(double (&v)[NQ], double (*sh)[4]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = al_wsum(v[q]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) sh[q][threadIdx.x >> 6] = v[q];
+    }
     __syncthreads();
-    double r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = ((sh[q][0] + sh[q][1]) + sh[q][2]) + sh[q][3];
     __syncthreads();
-    return r;
 }
-__device__ __forceinline__ double al_fsum(const double *part, int64_t nblk, double *sh) {
-    double a = 0.0;
-    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) a += part[i];
-    return al_bsum(a, sh);
+template <int NQ>
+__device__ __forceinline__ void al_fsum_n(const double *part, int64_t nblk, double (&v)[NQ], double (*sh)[4]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = 0.0;
+    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] += part[q * nblk + i];
+    }
+    al_bsum_n<NQ>(v, sh);
 }
 
 // the block that takes the last ticket of a launch finishes the reduction and takes the scalar decisions in the same
@@ -79,7 +92,6 @@ __global__ void al_jump_kernel(int64_t N, bq_al_vecs V, double mom_const, const 
 __global__ void al_eval_kernel(int64_t N, bq_al_vecs V, bq_scal *sc, double *part, int64_t nblk, bq_al_params prm,
                                int has_eq, bq_iter_stat *stats) {
     if (sc->done) return;
-    __shared__ double sh[4];
     double xqx = 0.0, qx = 0.0, ax = 0.0, dc = 0.0, cl = 0.0;
     VEC_LOOP(i) {
         if (i < N) {
@@ -99,17 +111,12 @@ __global__ void al_eval_kernel(int64_t N, bq_al_vecs V, bq_scal *sc, double *par
             }
         }
     }
-    xqx = al_bsum(xqx, sh);
-    qx = al_bsum(qx, sh);
-    ax = al_bsum(ax, sh);
-    dc = al_bsum(dc, sh);
-    cl = al_bsum(cl, sh);
+    __shared__ double sh5[5][4];
+    double v5[5] = {xqx, qx, ax, dc, cl};
+    al_bsum_n<5>(v5, sh5);
     if (threadIdx.x == 0) {
-        part[0 * nblk + blockIdx.x] = xqx;
-        part[1 * nblk + blockIdx.x] = qx;
-        part[2 * nblk + blockIdx.x] = ax;
-        part[3 * nblk + blockIdx.x] = dc;
-        part[4 * nblk + blockIdx.x] = cl;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) part[q * nblk + blockIdx.x] = v5[q];
     }
     if (al_last_block(&sc->ticket[0])) {
         al_record_body(sc, prm, has_eq, part, nblk, stats);
@@ -120,12 +127,10 @@ __global__ void al_eval_kernel(int64_t N, bq_al_vecs V, bq_scal *sc, double *par
 // last block of al_eval_kernel: value, primal value, iteration record, epoch test     (adagrad.py:85-101 and the like)
 __device__ __forceinline__ void al_record_body(bq_scal *sc, const bq_al_params &prm, int has_eq, const double *part,
                                                int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh[4];
-    const double xqx = al_fsum(part + 0 * nblk, nblk, sh);
-    const double qx = al_fsum(part + 1 * nblk, nblk, sh);
-    const double ax = al_fsum(part + 2 * nblk, nblk, sh);
-    const double dc = al_fsum(part + 3 * nblk, nblk, sh);
-    const double cl = al_fsum(part + 4 * nblk, nblk, sh);
+    __shared__ double sh5[5][4];
+    double v5[5];
+    al_fsum_n<5>(part, nblk, v5, sh5);
+    const double xqx = v5[0], qx = v5[1], ax = v5[2], dc = v5[3], cl = v5[4];
     if (threadIdx.x == 0) {
         const double pf = 0.5 * xqx + qx;
         double dual_c = dc, sq = cl;
@@ -160,7 +165,6 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
                                  int has_eq, int has_rows, bq_iter_stat *stats) {
     const bool last = sc->al_last != 0;   // 'stopped' at this evaluation: write its gradient, take no step
     if (sc->done && !last) return;
-    __shared__ double sh[4];
     const double ax = sc->al_ax, mu = sc->al_mu, rho = prm.rho;
     const double lr = al_sched(V.lr_sched, V.sched_len, sc->iter, prm.step_size);
     const double mom = al_sched(V.mom_sched, V.sched_len, sc->iter, prm.momentum);
@@ -290,10 +294,13 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
         }
         return;
     }
-    axn = al_bsum(axn, sh);
-    cn = al_bsum(cn, sh);
-    dl = al_bsum(dl, sh);
-    dx = al_bsum(dx, sh);
+    __shared__ double sh4[4][4];
+    double v4[4] = {axn, cn, dl, dx};
+    al_bsum_n<4>(v4, sh4);
+    axn = v4[0];
+    cn = v4[1];
+    dl = v4[2];
+    dx = v4[3];
     if (threadIdx.x == 0) {
         part[0 * nblk + blockIdx.x] = axn;
         part[1 * nblk + blockIdx.x] = cn;
@@ -310,11 +317,11 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
 // (optiml/opti/_base.py:129-146)
 __device__ __forceinline__ void al_check_body(bq_scal *sc, const bq_al_params &prm, int has_eq, int has_rows,
                                               const double *part, int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh[4];
-    const double axn = al_fsum(part + 0 * nblk, nblk, sh);
-    double cn = al_fsum(part + 1 * nblk, nblk, sh);
-    double dl = al_fsum(part + 2 * nblk, nblk, sh);
-    const double dx = al_fsum(part + 3 * nblk, nblk, sh);
+    __shared__ double sh4[4][4];
+    double v4[4];
+    al_fsum_n<4>(part, nblk, v4, sh4);
+    const double axn = v4[0], dx = v4[3];
+    double cn = v4[1], dl = v4[2];
     if (threadIdx.x == 0) {
         if (has_eq) {
             const double dmu = prm.rho * axn;
