@@ -1162,6 +1162,9 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))   # before anything in this process touches HIP
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    # the host driver of this pool supports dmabuf IPC only: without it RCCL's cross-process buffer sharing fails with
+    # `hipIpcGetMemHandle: invalid argument` (set before anything loads the HIP runtime in this process; a launcher's own value wins)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}')
     # stdout carries ONE JSON line and nothing else: gloo and RCCL (NCCL_DEBUG) write to fd 1 from C++, so fd 1 is pointed at
