@@ -72,7 +72,7 @@ enum { BQ_PLAIN = 0, BQ_SVC = 1, BQ_SVR = 2 };                       /* Hessian 
  * profiles/r04/placement_*.txt): with this flag the product kernel is timed on the freshly allocated (still empty) panel and, if
  * it streams below ~6.5 TB/s, further allocations are tried while they fit a time budget (BQ_PLACE_BUDGET_MS, default 200 ms; at
  * most 3; a candidate is priced at what the first allocation cost; bq_ctx_set_placement_budget lets the budget grow with the work
- * the caller expects) and the fastest is kept (the others are held until the problem is destroyed; a candidate is only tried while a
+ * the caller expects) and the fastest is kept (the others are held until the solve is over: bq_ctx_set_placement_budget; a candidate is only tried while a
  * tenth of the device stays free beside it).  For the product-bound solvers (PG, FW, ActiveSetCG, the
  * augmented-Lagrangian rules), whose every iteration streams the panel — SVC / SVR.fit set it for those; pointless for
  * InteriorPoint / ActiveSet / SMO.  Per rank, before the first collective. */
@@ -216,8 +216,8 @@ int bq_problem_placement(const bq_problem *p, int *tried, double *ms, int cap);
  * (expected_products x the product's measured time), never less than min_ms (< 0: BQ_PLACE_BUDGET_MS, default 200) and never
  * more than max_ms.  SVC / SVR.fit pass their max_iter (svm/_base.py:187-240: the optimizer's iteration cap), a steady-state
  * measurement passes a large number; expected_products = 0 (the default) keeps the fixed min_ms budget.  Candidates that were
- * not kept stay allocated until their problem is destroyed or a device allocation of the library fails (releasing them before
- * the solve slowed it down: profiles/r05/placement_release_transient.txt). */
+ * not kept stay allocated until the first solver created on the problem is destroyed (or the problem, or a device allocation of
+ * the library fails): releasing them before the solve slowed it down (profiles/r05/placement_release_transient.txt). */
 int bq_ctx_set_placement_budget(bq_ctx *ctx, double min_ms, double max_ms, double expected_products);
 
 /* ---- solvers (optiml/opti/constrained/, the four .py files) --------------------------------------------------- */

@@ -510,7 +510,7 @@ extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, co
 
 // BQ_PLACE_PANEL (bcqp.h): time the product kernel on the freshly allocated, zeroed panel; while it streams below the "good" rate,
 // the device can hold one more panel and the TIME BUDGET allows it, allocate another candidate and time it; keep the fastest,
-// HOLD the rest until the problem is destroyed or an allocation fails (released earlier, the allocator would hand the same memory
+// HOLD the rest until the first solver on the problem is destroyed (or the problem, or an allocation fails: released earlier, the allocator would hand the same memory
 // back as the next candidate; released at the end — rounds 4-5 — the release itself slowed the solve that followed: bq_ctx::held).
 //
 // What a slow placement is (round 4, profiles/r04/placement_*.txt): a property of the physical region the driver handed out, stable
@@ -1008,6 +1008,8 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
     }
     bq_problem *p = s->p;
     delete s;
+    // the solve the placement choice was made for is over: what it held back to keep this solve undisturbed can go now (bq_ctx::held)
+    bq_ctx_release_held(p->ctx, p);
     bq_problem_unref(p);
     return BQ_OK;
 }

@@ -107,7 +107,7 @@ struct bq_ctx {
     // library fails (bq_device_malloc, which every hipMalloc here is routed through) and with the context.
     void *panel_cache = nullptr;
     size_t panel_cache_bytes = 0;
-    // Allocations the placement choice did not keep (place_panel), HELD until their problem goes: hipFree of a large allocation is
+    // Allocations the placement choice did not keep (place_panel), HELD until a solver of their problem (or the problem) goes: hipFree of a large allocation is
     // followed by a transient — ~0.5 s after 3 GB, longer after 40 GB — during which every kernel of the process streams 1.5 - 4.5 %
     // slower (round 5, profiles/r05/placement_release_transient.txt: the driver clears what was released), i.e. exactly while the
     // solve that the choice was made for runs.  Given back earlier when ANY device allocation of the library fails (bq_alloc.cpp).
