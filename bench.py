@@ -143,6 +143,10 @@ def parse(argv=None):
     ap.add_argument('--exchange-us', type=float, default=50.0,
                     help='--emulate-shares: ASSUMED duration of the one collective per product (not measurable on one GPU); the '
                          'prediction is printed with it and with 0')
+    ap.add_argument('--dense', action='store_true',
+                    help='dense Quadratic(Q, q) of --samples variables (optiml/opti/_base.py:228-300; a banded symmetric Q whose product '
+                         'is known in closed form): the product and ProjectedGradient iterations on the packed lower-triangle copy the '
+                         'library keeps when Q == Q\' exactly, and on the row blocks it keeps otherwise (forced), each with its roofline')
     ap.add_argument('--cpu-study', action='store_true',
                     help='CPU only (SURVEY 8d): the oracle timed at three sizes to check the n^2 (PG) / n^3 (Cholesky) laws '
                          'behind the extrapolated baseline, plus a blocked Gram-streaming product at the full n')
@@ -706,6 +710,96 @@ def share_timing(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# dense Quadratic(Q, q): packed lower triangle (Q == Q' exactly) against row blocks
+# ---------------------------------------------------------------------------------------------------------------------
+DENSE_BANDS = ((0, 4.0), (1, -1.0), (257, 0.5), (4099, 0.25))   # offset, value: symmetric, strictly diagonally dominant
+
+
+def dense_band_matrix(n):
+    """n x n fp64 host matrix with a few symmetric bands.  np.zeros maps its pages lazily, so only the pages a band touches (and
+    what the upload reads) ever become resident: the n = 100 000 matrix is 80 GB of address space, not of host memory writes."""
+    Q = np.zeros((n, n))
+    flat = Q.reshape(-1)
+    for off, val in DENSE_BANDS:
+        if off < n:
+            flat[off:(n - off) * n:n + 1] = val          # (i, i + off)
+            flat[off * n::n + 1] = val                    # (i + off, i)
+    return Q
+
+
+def dense_band_product(n, v):
+    out = np.zeros(n)
+    for off, val in DENSE_BANDS:
+        if off == 0:
+            out += val * v
+        elif off < n:
+            out[:n - off] += val * v[off:]
+            out[off:] += val * v[:n - off]
+    return out
+
+
+def dense_record(args):
+    """--dense: one JSON record with the two layouts of a dense symmetric Hessian side by side."""
+    from optiml_amd import _lib, device
+    from optiml_amd.opti import Quadratic
+    from optiml_amd.opti.constrained._base import _DeviceSolver
+    ctx = device.get_context()
+    n = args.n
+    t0 = time.perf_counter()
+    Q = dense_band_matrix(n)
+    rs = np.random.RandomState(0)
+    q = rs.standard_normal(n)
+    v = rs.standard_normal(n)
+    ref = dense_band_product(n, v)
+    out = {'what': 'dense_quadratic', 'metric': 'dual_qp_iterations_per_sec', 'unit': 'iter/s', 'n': n, 'dtype': 'f64', 'device': ctx.name,
+           'host_matrix_s': time.perf_counter() - t0,
+           'hessian': 'banded symmetric (offsets %s), handed over as a full n x n row-major fp64 host array' % ', '.join(str(o) for o, _ in DENSE_BANDS),
+           'reference': 'Quadratic(Q, q): optiml/opti/_base.py:228-300 (Q @ x at :282, :291)', 'layouts': {}}
+    T = 256
+    nb = -(-n // T)
+    tiles = nb * (nb + 1) // 2
+    ld = -(-n // 1024) * 1024
+    for name, sym, place in (('packed', None, not args.no_placement), ('rows', False, False)):
+        quad = Quadratic(Q, q, symmetric=sym, tune_placement=place, expected_products=STEADY_STATE_PRODUCTS)
+        ctx.profile(True)
+        t0 = time.perf_counter()
+        dev = quad.device_problem(ctx)
+        setup = time.perf_counter() - t0
+        lay = dev.layout()
+        assert lay['packed'] == (name == 'packed'), lay
+        err = float(np.abs(dev.matvec(v) - ref).max())
+        solver = _DeviceSolver(dev, _lib.PG, np.zeros(n), np.ones(n), np.ones(n) / 2, -1.0, 10 ** 9)
+        solver.run(max(args.warmup, 1))
+        ctx.profile_read(_lib.PROF_MATVEC, reset=True)
+        t0 = time.perf_counter()
+        rows, _ = solver.run(args.steps)
+        dt = time.perf_counter() - t0
+        mv_ms, mv_cnt = ctx.profile_read(_lib.PROF_MATVEC, reset=True)
+        avg = mv_ms / max(mv_cnt, 1)
+        if name == 'packed':
+            alg = tiles * (T * T * 8 + T * 8) + (tiles // 8 + nb) * T * 8 + 2 * n * 8
+            kern = 'symv_tiles_kernel<double, false, 8, SR>'
+        else:
+            alg = n * ld * 8 + 3 * n * 8
+            kern = 'gemv_rows_kernel'
+        gbs = alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        out['layouts'][name] = {
+            'value': len(rows) / dt, 'ms_per_step': 1e3 * dt / max(len(rows), 1), 'steps': len(rows), 'upload_s': setup,
+            'panel_GB': lay['panel_bytes'] / 1e9, 'panel_placement_ms': dev.placement(), 'product_max_abs_error_vs_closed_form': err,
+            'roofline': {'bound': 'hbm', 'kernel': kern, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                         'traffic': None, 'avg_launch_ms': avg, 'launches': mv_cnt, 'algorithmic_bytes_per_launch': alg}}
+        print(f'[dense] n={n} {name}: product {avg:.3f} ms ({gbs:.0f} GB/s), {len(rows) / dt:.1f} iter/s, upload {setup:.1f} s, '
+              f'|error| {err:.2e}', file=sys.stderr, flush=True)
+        solver.close()
+        quad.release()
+        ctx.release_held_memory()
+    pk, rw = out['layouts']['packed'], out['layouts']['rows']
+    out['value'] = pk['value']
+    out['packed_vs_rows_product_time'] = pk['roofline']['avg_launch_ms'] / rw['roofline']['avg_launch_ms'] if rw['roofline']['avg_launch_ms'] else None
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # the default line: headline record + side records, each measured in a fresh child process (this parent never touches HIP)
 # ---------------------------------------------------------------------------------------------------------------------
 SIDE_COMMANDS = {   # name -> (arguments of the child, its time cap in seconds)
@@ -1145,6 +1239,8 @@ def main():
     args = parse()
     if args.cpu_study:
         return cpu_study(args)
+    if args.dense:
+        return dense_record(args)
     if args.emulate_shares:
         return share_timing(args)
     if args.collective_floor:

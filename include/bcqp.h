@@ -22,9 +22,10 @@
  *     symmetric panels are split into tile rows with equal shares of the lower triangle
  *     (bq_sym_row_block: runs of 8 canonical segments) and end in an all-gather of the per-segment
  *     partial vectors, which every rank adds in segment order — bit-identical iterates for 1/2/4/8
- *     ranks (BQ_SYM_EXCHANGE=allreduce: one all-reduce(sum) instead); dense and streamed panels are
- *     split into equal row blocks (bq_row_block) and end in an all-gather.  Solvers that factorise
- *     the Hessian (InteriorPoint, ActiveSet) and SMO need a single-rank context.
+ *     ranks (BQ_SYM_EXCHANGE=allreduce: one all-reduce(sum) instead); a dense Q that equals its transpose
+ *     exactly is stored and split the same way; any other dense Q is split into equal row blocks
+ *     (bq_row_block) and ends in an all-gather.  Solvers that factorise the Hessian (InteriorPoint,
+ *     ActiveSet) and SMO need a single-rank context.
  */
 #ifndef BCQP_H
 #define BCQP_H
@@ -44,7 +45,9 @@ extern "C" {
 #define BQ_ERR_BADARG (-5)
 #define BQ_ERR_NOMEM (-6)
 
-#define BQ_ABI_VERSION 1
+/* 2 (round 6): bq_ctx_probe_stall takes behind_collective, bq_problem_create_dense takes layout flags, bq_problem_layout,
+ * bq_ctx_release_held and the state snapshot were added: a consumer built against version 1 must be rebuilt */
+#define BQ_ABI_VERSION 2
 
 typedef struct bq_ctx bq_ctx;
 typedef struct bq_problem bq_problem;
@@ -174,7 +177,19 @@ int bq_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end);
 int bq_sym_row_block(int64_t n, int rank, int world, int64_t *begin, int64_t *end);
 
 /* ---- the quadratic ("Quadratic", optiml/opti/_base.py:228-300) ------------------------------- */
-/* dense Q (n x n row-major fp64) and q: replaces the host copy at optiml/opti/_base.py:243 */
+/* dense Q (n x n row-major fp64) and q: replaces the host copy at optiml/opti/_base.py:243.
+ * Layout of the resident copy (bq_problem_layout tells which one was taken):
+ *   - Q == Q' exactly (every pair of elements compared as stored, on the device, while the rows are uploaded; on a multi-rank
+ *     context the ranks agree with one all-reduce, so the call is collective there): the packed lower-triangular 256-tile rows of
+ *     the kernel-built panels — half the HBM and half the bytes per product (40 GB and ~6 ms instead of 80 GB and ~12 ms at
+ *     n = 100 000), sharded by the canonical segments, bit-identical products for any rank count;
+ *   - any other Q (the reference never checks symmetry, opti/_base.py:249-256, and computes `Q @ x`): whole row blocks.
+ * OR-ed into `storage`:  BQ_DENSE_ROWS   row blocks whatever Q is (the layout of rounds 1-5; what a comparison needs);
+ *                        BQ_DENSE_LOWER  the caller vouches for symmetry: only the lower triangle of the host matrix is read
+ *                                        (LAPACK's uplo = 'L'), nothing is compared, half the PCIe traffic;
+ *                        BQ_PLACE_PANEL  as for kernel problems (packed layout only). */
+#define BQ_DENSE_ROWS 256
+#define BQ_DENSE_LOWER 512
 int bq_problem_create_dense(bq_ctx *ctx, int64_t n, const double *Q, const double *q, int storage,
                             bq_problem **out);
 /* kernel-structured Hessian built on the device from X (n x d row-major fp64):
@@ -192,6 +207,9 @@ int bq_problem_create_kernel(bq_ctx *ctx, int structure, int64_t n, int64_t d, c
 int bq_problem_destroy(bq_problem *p);
 int bq_problem_dims(const bq_problem *p, int64_t *n_dual, int64_t *n_rows, int64_t *row_begin,
                     int64_t *row_end);
+/* how the Hessian is resident on this rank: *packed = 1 for the packed lower tile rows (kernel-built panels; a dense Q == Q'),
+ * 0 for row blocks; *streamed = 1 for BQ_STREAM (no panel); *panel_bytes = the size of this rank's panel allocation */
+int bq_problem_layout(const bq_problem *p, int *packed, int *streamed, int64_t *panel_bytes);
 /* out = Q v (dual dim; every rank gets the full vector)       optiml/opti/_base.py:291 (minus q) */
 int bq_problem_matvec(bq_problem *p, const double *v, double *out);
 /* f = 1/2 x'Qx + q'x and (optionally, g != NULL) g = Qx + q   optiml/opti/_base.py:282, 291 */
@@ -219,6 +237,11 @@ int bq_problem_placement(const bq_problem *p, int *tried, double *ms, int cap);
  * not kept stay allocated until the first solver created on the problem is destroyed (or the problem, or a device allocation of
  * the library fails): releasing them before the solve slowed it down (profiles/r05/placement_release_transient.txt). */
 int bq_ctx_set_placement_budget(bq_ctx *ctx, double min_ms, double max_ms, double expected_products);
+/* give the allocations the placement choice is holding back (all of them on this context: up to two panel-sized blocks per problem
+ * whose choice tried candidates) to the driver NOW — for a caller that needs the memory for something this library does not see
+ * (another allocator in the process, a communicator about to be created).  *bytes (optional): what was released.  The ~0.5 s
+ * transient that follows a large release (everything streams 1.5 - 4.5 % slower) is then the caller's. */
+int bq_ctx_release_held_memory(bq_ctx *ctx, int64_t *bytes);
 
 /* ---- solvers (optiml/opti/constrained/, the four .py files) --------------------------------------------------- */
 /* lb/ub/x0: dual-dim fp64 host vectors (lb, x0 may be NULL: 0 and mid-box, constrained/_base.py:61-65).

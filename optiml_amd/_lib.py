@@ -23,13 +23,14 @@ GET_X, GET_G, GET_LP, GET_LM, GET_D, GET_MASK_L, GET_MASK_U, GET_X_NOW, GET_G_NO
 NO_RANK_ONE = 16
 FULL_PANEL = 32
 PLACE_PANEL = 64
+DENSE_ROWS, DENSE_LOWER = 256, 512   # OR-ed into the storage of bq_problem_create_dense
 SMO_ALPHAS, SMO_ERRORS, SMO_SCALARS, SMO_STATS = range(4)
 RULE_SGD, RULE_ADAM, RULE_AMSGRAD, RULE_ADAMAX, RULE_ADAGRAD, RULE_ADADELTA, RULE_RMSPROP = range(7)
 MOM = {'none': 0, 'polyak': 1, 'nesterov': 2}
 PROF_MATVEC, PROF_GRAM, PROF_CHOL, PROF_EXCH, PROF_PCSHARD = range(5)
 COUNT_INNER, COUNT_MINRES, COUNT_REFACTOR, COUNT_REUSED, COUNT_NO_PRODUCT = range(5)
 STATE_X, STATE_G, STATE_MULT, STATE_MASKS = 1, 2, 4, 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class IterStat(C.Structure):
@@ -79,6 +80,7 @@ PROTOTYPES = {
     'bq_ctx_probe_exchange': (C.c_int, [_vp, C.c_int, _i64, C.c_int, _dp, _dp]),
     'bq_ctx_set_collective_timeout': (C.c_int, [_vp, C.c_double]),
     'bq_ctx_set_placement_budget': (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
+    'bq_ctx_release_held_memory': (C.c_int, [_vp, C.POINTER(_i64)]),
     'bq_ctx_probe_stall': (C.c_int, [_vp, C.c_double, C.c_int]),
     'bq_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     'bq_sym_row_block': (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -87,6 +89,7 @@ PROTOTYPES = {
                                            C.c_int, C.c_double, _dp, C.c_int, C.POINTER(_vp)]),
     'bq_problem_destroy': (C.c_int, [_vp]),
     'bq_problem_dims': (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'bq_problem_layout': (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     'bq_problem_matvec': (C.c_int, [_vp, _dp, _dp]),
     'bq_problem_eval': (C.c_int, [_vp, _dp, _dp, _dp]),
     'bq_problem_x_star': (C.c_int, [_vp, _dp, C.POINTER(C.c_int), C.POINTER(_i64)]),

@@ -66,6 +66,19 @@ void bq_ctx_release_held(bq_ctx *c, const void *owner) {
     release_held_locked(c, owner);
 }
 
+extern "C" int bq_ctx_release_held_memory(bq_ctx *c, int64_t *bytes) {
+    if (c == nullptr) {
+        bq_set_error("bad argument: ctx is NULL");
+        return BQ_ERR_BADARG;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int64_t total = 0;
+    for (const auto &h : c->held) total += (int64_t)h.bytes;
+    release_held_locked(c, nullptr);
+    if (bytes) *bytes = total;
+    return BQ_OK;
+}
+
 // the cached panel if it holds `bytes` with at most 25 % to spare; the caller owns it afterwards
 void *bq_ctx_cache_take(bq_ctx *c, size_t bytes, size_t *cap) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -330,14 +330,6 @@ extern "C" int bq_sym_row_block(int64_t n, int rank, int world, int64_t *begin, 
 // ---------------------------------------------------------------------------------------------
 // the quadratic
 // ---------------------------------------------------------------------------------------------
-__global__ void f64_to_f32_rows_kernel(const double *__restrict__ src, int64_t rows, int64_t n, float *__restrict__ dst,
-                                       int64_t ld) {
-    const int64_t r = blockIdx.y;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
-        dst[r * ld + j] = (float)src[r * n + j];
-    (void)rows;
-}
-
 static int problem_alloc_common(bq_problem *p, const double *q_host) {
     bq_ctx *c = p->ctx;
     const int64_t nblk = p->ldN / BQ_VEC_TILE;
@@ -456,54 +448,66 @@ extern "C" int bq_problem_destroy(bq_problem *p) {
     return BQ_OK;
 }
 
-extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, const double *q, int storage,
-                                       bq_problem **out) {
-    BQ_ARG(c && Q && q && out, "NULL argument");
-    BQ_ARG(n >= 2, "Q is too small");  // optiml/opti/_base.py:249-250
-    BQ_ARG(storage == BQ_F64 || storage == BQ_F32, "storage");
-    BQ_HIP(hipSetDevice(c->device));
+static int place_panel(bq_problem *p, double first_alloc_ms);
+
+static int dense_new(bq_ctx *c, int64_t n, const double *q, int storage, bool symmetric, bool place, bq_problem **out) {
     bq_problem *p = new bq_problem();
     p->ctx = c;
     c->refs += 1;
     p->structure = BQ_PLAIN;
     p->storage = storage;
+    p->symmetric = symmetric;
     int rc = problem_layout(p, n, n);
     if (rc == BQ_OK) rc = problem_alloc_common(p, q);
+    if (rc == BQ_OK && place && symmetric) rc = place_panel(p, p->alloc_ms);
     if (rc != BQ_OK) {
         bq_problem_destroy(p);
         return rc;
     }
-    const int64_t rows = p->r1 - p->r0;
-    if (rows > 0) {
-        if (storage == BQ_F64) {
-            hipError_t e = hipMemcpy2DAsync(p->panel, p->ld * 8, Q + p->r0 * n, n * 8, n * 8, rows,
-                                            hipMemcpyHostToDevice, c->stream);
-            if (e != hipSuccess) {
-                bq_set_error("panel upload failed: %s", hipGetErrorString(e));
-                bq_problem_destroy(p);
-                return BQ_ERR_HIP;
-            }
-        } else {
-            const int64_t chunk = std::max<int64_t>(1, (int64_t)(256ll << 20) / (n * 8));
-            double *tmp = nullptr;
-            hipError_t e = hipMalloc(&tmp, sizeof(double) * chunk * n);
-            for (int64_t r = 0; e == hipSuccess && r < rows; r += chunk) {
-                const int64_t cr = std::min(chunk, rows - r);
-                e = hipMemcpyAsync(tmp, Q + (p->r0 + r) * n, sizeof(double) * cr * n, hipMemcpyHostToDevice, c->stream);
-                if (e != hipSuccess) break;
-                dim3 grid((unsigned)std::min<int64_t>((n + 255) / 256, 1024), (unsigned)cr);
-                f64_to_f32_rows_kernel<<<grid, 256, 0, c->stream>>>(tmp, cr, n, (float *)p->panel + r * p->ld, p->ld);
-                e = hipStreamSynchronize(c->stream);
-            }
-            if (tmp) hipFree(tmp);
-            if (e != hipSuccess) {
-                bq_set_error("panel upload failed: %s", hipGetErrorString(e));
-                bq_problem_destroy(p);
-                return BQ_ERR_HIP;
-            }
+    *out = p;
+    return BQ_OK;
+}
+
+// Quadratic(Q, q) (optiml/opti/_base.py:228-256).  A Q that equals its transpose exactly goes into the packed lower tile rows of
+// the kernel-built panels (half the HBM, half the bytes per product: symv_tiles_kernel); any other Q keeps whole row blocks and
+// NumPy's `Q @ x` (gemv_rows_kernel).  bq_dense.hip has the upload and the check.
+extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, const double *q, int storage,
+                                       bq_problem **out) {
+    BQ_ARG(c && Q && q && out, "NULL argument");
+    BQ_ARG(n >= 2, "Q is too small");  // optiml/opti/_base.py:249-250
+    const bool force_rows = (storage & BQ_DENSE_ROWS) != 0, trust_lower = (storage & BQ_DENSE_LOWER) != 0;
+    const bool place = (storage & BQ_PLACE_PANEL) != 0;
+    storage &= ~(BQ_DENSE_ROWS | BQ_DENSE_LOWER | BQ_PLACE_PANEL);
+    BQ_ARG(storage == BQ_F64 || storage == BQ_F32, "storage");
+    BQ_ARG(!(force_rows && trust_lower), "BQ_DENSE_ROWS and BQ_DENSE_LOWER exclude each other");
+    BQ_HIP(hipSetDevice(c->device));
+    bq_problem *p = nullptr;
+    // every rank is handed the same Q, so the look at the host matrix sends them all the same way
+    bool try_sym = !force_rows && (trust_lower || bq_dense_host_spot_symmetric(Q, n));
+    if (try_sym) {
+        BQ_TRY(dense_new(c, n, q, storage, true, place, &p));
+        int is_sym = 1;
+        int rc = bq_dense_upload_sym(p, Q, !trust_lower, &is_sym);
+        if (rc == BQ_OK) rc = bq_ctx_sync(c);
+        if (rc != BQ_OK) {
+            bq_problem_destroy(p);
+            return rc;
         }
+        if (is_sym) {
+            *out = p;
+            return BQ_OK;
+        }
+        bq_problem_destroy(p);   // not symmetric after all: row blocks
+        bq_ctx_drop_cache(c);    // (the packed panel is half the size the row blocks need: nothing to keep it for)
+        p = nullptr;
     }
-    BQ_SYNC(c);
+    BQ_TRY(dense_new(c, n, q, storage, false, false, &p));
+    int rc = bq_dense_upload_rows(p, Q);
+    if (rc == BQ_OK) rc = bq_ctx_sync(c);
+    if (rc != BQ_OK) {
+        bq_problem_destroy(p);
+        return rc;
+    }
     *out = p;
     return BQ_OK;
 }
@@ -700,6 +704,14 @@ extern "C" int bq_problem_dims(const bq_problem *p, int64_t *n_dual, int64_t *n_
     if (n_rows) *n_rows = p->n;
     if (rb) *rb = p->r0;
     if (re) *re = p->r1;
+    return BQ_OK;
+}
+
+extern "C" int bq_problem_layout(const bq_problem *p, int *packed, int *streamed, int64_t *panel_bytes) {
+    BQ_ARG(p != nullptr, "problem is NULL");
+    if (packed) *packed = p->symmetric ? 1 : 0;
+    if (streamed) *streamed = p->streamed ? 1 : 0;
+    if (panel_bytes) *panel_bytes = (int64_t)p->panel_bytes;
     return BQ_OK;
 }
 

@@ -301,6 +301,12 @@ void bq_sym_seg_table(const bq_problem *p, bq_seg_table *tab);
 int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *done, const bq_epilogue *epi = nullptr,
                      bool *fused = nullptr);
 
+// bq_dense.hip: a dense host Hessian into the resident panel — packed lower tile rows when Q == Q' exactly (checked on the device
+// while uploading, agreed across ranks), else row blocks
+bool bq_dense_host_spot_symmetric(const double *Q, int64_t n);
+int bq_dense_upload_sym(bq_problem *p, const double *Q, bool check, int *symmetric);
+int bq_dense_upload_rows(bq_problem *p, const double *Q);
+
 // bq_gemv.hip: s[r0 + i] = sum_j elem(panel[i][j]) * w[j], i in [0, nrows)
 int bq_launch_gemv(bq_ctx *ctx, const void *panel, int storage, bool add_one, int64_t nrows, int64_t ld,
                    const double *w, double *s_rows, const int *done_flag);

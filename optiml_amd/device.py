@@ -201,6 +201,13 @@ class Context:
         of `expected_products` products of the panel, within [min_ms (default: BQ_PLACE_BUDGET_MS / 200 ms), max_ms]."""
         _lib.check(self._lib.bq_ctx_set_placement_budget(self.handle, float(min_ms), float(max_ms), float(expected_products)))
 
+    def release_held_memory(self):
+        """Give the panel-sized allocations the placement choice is holding back (until the solve they were tried for is over) to
+        the driver now; returns the bytes released.  For callers that need the memory for something the library does not see."""
+        n = C.c_int64(0)
+        _lib.check(self._lib.bq_ctx_release_held_memory(self.handle, C.byref(n)))
+        return n.value
+
     def set_collective_timeout(self, seconds):
         """Abort the RCCL communicator when a wait on the stream lasts longer than `seconds` (0: never)."""
         _lib.check(self._lib.bq_ctx_set_collective_timeout(self.handle, float(seconds)))

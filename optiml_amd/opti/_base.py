@@ -62,6 +62,12 @@ class _DeviceProblem:
         _lib.check(self._lib.bq_problem_dims(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
 
+    def layout(self):
+        """{'packed': the packed lower tile rows (kernel-built panels; a dense Q == Q') or row blocks, 'streamed', 'panel_bytes'}"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int64(0)
+        _lib.check(self._lib.bq_problem_layout(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {'packed': bool(a.value), 'streamed': bool(b.value), 'panel_bytes': c.value}
+
     def matvec(self, v):
         N = self.dims()[0]
         v = _lib.as_f64(v, N, 'v')
@@ -129,9 +135,15 @@ class Quadratic(OptimizationFunction):
     r"""f(x) = 1/2 x'Qx + q'x with a dense Hessian (same ctor and checks as optiml/opti/_base.py:230-256).
 
     `storage='f32'` keeps the device copy of Q in fp32 (fp64 accumulation); the default is fp64.
+
+    `symmetric=None` (default): the device copy is the packed lower triangle (half the memory, half the bytes per product) when
+    `Q == Q.T` holds exactly — compared on the device while Q is uploaded — and whole rows otherwise, so a Q that is not
+    symmetric keeps NumPy's `Q @ x` (the reference never checks, optiml/opti/_base.py:249-256).  `symmetric=True`: the caller
+    vouches for it, only the lower triangle of Q is read (LAPACK's uplo='L').  `symmetric=False`: whole rows whatever Q is.
+    `tune_placement=True`: as for `KernelQuadratic` (packed copies of >= 1 GB only).
     """
 
-    def __init__(self, Q, q, storage='f64'):
+    def __init__(self, Q, q, storage='f64', symmetric=None, tune_placement=False, expected_products=0):
         Q = np.array(Q, dtype=float)
         q = np.array(q, dtype=float)
         n = len(Q)
@@ -145,6 +157,9 @@ class Quadratic(OptimizationFunction):
             raise ValueError('q size does not match with Q')
         self.q = q
         self.storage = storage
+        self.symmetric = symmetric
+        self.tune_placement = bool(tune_placement)
+        self.expected_products = float(expected_products or 0)
         self._dev = None
 
     # -- device residency -------------------------------------------------------------------
@@ -152,8 +167,13 @@ class Quadratic(OptimizationFunction):
         lib = _lib.load()
         h = C.c_void_p()
         Qc = np.ascontiguousarray(self.Q)
-        _lib.check(lib.bq_problem_create_dense(ctx.handle, self.ndim, _lib.ptr(Qc), _lib.ptr(self.q.ravel()),
-                                               _lib.F32 if self.storage == 'f32' else _lib.F64, C.byref(h)))
+        flags = _lib.F32 if self.storage == 'f32' else _lib.F64
+        if self.symmetric is not None:
+            flags |= _lib.DENSE_LOWER if self.symmetric else _lib.DENSE_ROWS
+        if self.tune_placement:
+            ctx.set_placement_budget(self.expected_products)
+            flags |= _lib.PLACE_PANEL
+        _lib.check(lib.bq_problem_create_dense(ctx.handle, self.ndim, _lib.ptr(Qc), _lib.ptr(self.q.ravel()), flags, C.byref(h)))
         return _DeviceProblem(ctx, h)
 
     def device_problem(self, ctx=None):

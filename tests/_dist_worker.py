@@ -85,14 +85,35 @@ def gpu_mode(exchange, outdir, sym_exchange=None):
     quad = KernelQuadratic(Xr, np.hstack((-yr, yr)) + 0.1, 'svr', PolyKernel(3, 'scale', 1.))
     opt = FrankWolfe(quad=quad, ub=np.ones(600), max_iter=40).minimize()
     res['fw_x'], res['fw_f'] = opt.x, opt.f_x
-    # dense Quadratic: row-block panel + all-gather -> bit-identical for any world size
+    # dense Quadratic, Q == Q' exactly: the packed lower tile rows of the kernel panels (segments + all-gather of the segment
+    # partials) -> bit-identical for any world size
     from optiml_amd.opti import Quadratic
     rs = np.random.RandomState(4)
     G = rs.standard_normal((500, 520))
     Qd = G @ G.T / 500
+    Qd = (Qd + Qd.T) / 2
     dq = Quadratic(Qd, rs.standard_normal(500))
     res['dense_rows'] = np.array(dq.device_problem().dims()[2:])
-    res['dense_matvec'] = dq.device_problem().matvec(np.random.RandomState(12).standard_normal(500))
+    res['dense_packed'] = np.array(dq.device_problem().layout()['packed'])
+    # a dense Q that is NOT symmetric keeps whole row blocks + the all-gather of disjoint slices (NumPy's Q @ x)
+    vq = np.random.RandomState(12).standard_normal(500)
+    Qn = Qd + 0.01 * np.triu(rs.standard_normal((500, 500)), 1)
+    nq = Quadratic(Qn, rs.standard_normal(500))
+    res['rowsq_rows'] = np.array(nq.device_problem().dims()[2:])
+    res['rowsq_packed'] = np.array(nq.device_problem().layout()['packed'])
+    res['rowsq_matvec'] = nq.device_problem().matvec(vq)
+    res['rowsq_ref'] = Qn @ vq
+    res['rowsq_pg_x'] = ProjectedGradient(quad=nq, ub=np.ones(500), max_iter=40).minimize().x
+    # one element one ulp away from its mirror image, placed where only the rank that owns row 400 meets the pair (its
+    # column strip above its own rows): the ranks must AGREE on row blocks
+    Qh = Qd.copy()
+    Qh[10, 400] = np.nextafter(Qh[10, 400], np.inf)
+    hq = Quadratic(Qh, np.zeros(500))
+    res['hid_packed'] = np.array(hq.device_problem().layout()['packed'])
+    res['hid_matvec'] = hq.device_problem().matvec(vq)
+    res['hid_ref'] = Qh @ vq
+    hq.release()
+    res['dense_matvec'] = dq.device_problem().matvec(vq)
     opt = ProjectedGradient(quad=dq, ub=np.ones(500), max_iter=40).minimize()
     res['dense_pg_x'] = opt.x
     # augmented-Lagrangian dual: same sharded product, everything else replicated
@@ -113,7 +134,7 @@ def gpu_mode(exchange, outdir, sym_exchange=None):
     opt = FrankWolfe(quad=sq, ub=np.ones(n), max_iter=30).minimize()
     res['stream_fw_x'] = opt.x
     # ActiveSet with conjugate-gradient restricted solves: the only ActiveSet that shards (no dense factor); squared
-    # hinge dual of BASELINE config 5 (ub = +inf, x0 = 1) on the dense row-block panel -> bit-identical for any world
+    # hinge dual of BASELINE config 5 (ub = +inf, x0 = 1) on a dense (packed symmetric) panel -> bit-identical for any world
     from optiml_amd.opti.constrained import ActiveSetCG
     Qs = Qd + np.eye(500) / 2
     opt = ActiveSetCG(quad=Quadratic(Qs, -np.ones(500)), ub=np.full(500, np.inf), x=np.ones(500), max_iter=400).minimize()

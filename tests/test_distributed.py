@@ -130,7 +130,7 @@ def test_thread_ranks_primitives():
 
 SYM_KEYS = ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_dual', 'al_f', 'ascg_kernel_x',
             'ascg_kernel_f')
-ROW_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'ascg_x', 'ascg_iter', 'ascg_inner')
+ROW_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'ascg_x', 'ascg_iter', 'ascg_inner', 'rowsq_matvec', 'rowsq_pg_x', 'hid_matvec')
 # streamed kernel problems use the symmetric segment exchange since round 2b (every lower-triangle tile formed once)
 SYM_KEYS = SYM_KEYS + ('stream_matvec', 'stream_fw_x')
 
@@ -146,8 +146,14 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path, one_rank):
     two = _launch('gpu-host', 2, tmp_path / 'w2')
     # kernel panels: symmetric tile storage, balanced triangular partition (700 rows = 3 tile rows -> 2 + 1)
     assert tuple(two[0]['rows']) == (0, 512) and tuple(two[1]['rows']) == (512, 700)
-    # dense panels: equal 128-aligned row blocks
+    # a dense Q == Q': packed like a kernel panel (500 rows = 2 tile rows -> 1 + 1); any other dense Q: equal 128-aligned row
+    # blocks; a Q with one element one ulp off its mirror image, seen by rank 1 only: both ranks fall back to row blocks
     assert tuple(two[0]['dense_rows']) == (0, 256) and tuple(two[1]['dense_rows']) == (256, 500)
+    assert tuple(two[0]['rowsq_rows']) == (0, 256) and tuple(two[1]['rowsq_rows']) == (256, 500)
+    for r in two + [one]:
+        assert bool(r['dense_packed']) and not bool(r['rowsq_packed']) and not bool(r['hid_packed'])
+        np.testing.assert_allclose(r['rowsq_matvec'], r['rowsq_ref'], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(r['hid_matvec'], r['hid_ref'], rtol=1e-12, atol=1e-12)
     # streamed kernel problems: the segment partition of the tile rows, like the resident symmetric panels
     assert tuple(two[0]['stream_rows']) == (0, 512) and tuple(two[1]['stream_rows']) == (512, 700)
     np.testing.assert_allclose(one['stream_matvec'], one['matvec'], rtol=1e-11, atol=1e-11)

@@ -68,6 +68,89 @@ def test_dense_matvec_and_eval(amd, n, storage):
     quad.release()
 
 
+def _ulp_up(a):
+    return np.nextafter(a, np.inf)
+
+
+@pytest.mark.parametrize('storage', ['f64', 'f32'])
+@pytest.mark.parametrize('n', [5, 300, 777, 1400])
+def test_dense_layout_follows_exact_symmetry(amd, n, storage):
+    """A dense Q that equals its transpose exactly is kept as packed lower tile rows (half the bytes per product, the tile kernel
+    of the kernel panels); any other Q keeps whole rows and NumPy's `Q @ x` — the reference never checks symmetry
+    (optiml/opti/_base.py:249-256).  One element one ulp away from its mirror image is enough, wherever it sits: inside a diagonal
+    tile, in an off-diagonal tile, in the ragged last tile row."""
+    from optiml_amd.opti import Quadratic
+    rs = np.random.RandomState(7 * n)
+    G = rs.standard_normal((n, n + 2))
+    Q = G @ G.T / n
+    Q = (Q + Q.T) / 2
+    q = rs.standard_normal(n)
+    x = rs.standard_normal(n)
+    rnd = (lambda A: A.astype(np.float32).astype(np.float64)) if storage == 'f32' else (lambda A: A)
+    tol = dict(rtol=1e-12, atol=1e-12 * np.abs(Q).sum(1).max())
+
+    quad = Quadratic(Q, q, storage=storage)
+    dev = quad.device_problem()
+    assert dev.layout()['packed']
+    packed_bytes = dev.layout()['panel_bytes']
+    y_packed = dev.matvec(x)
+    np.testing.assert_allclose(y_packed, rnd(Q) @ x, **tol)
+    quad.release()
+    # the same Q forced into row blocks: the same operator, another summation order
+    rows = Quadratic(Q, q, storage=storage, symmetric=False)
+    assert not rows.device_problem().layout()['packed']
+    np.testing.assert_allclose(rows.device_problem().matvec(x), y_packed, **tol)
+    assert rows.device_problem().layout()['panel_bytes'] >= packed_bytes or n < 512
+    rows.release()
+
+    # one ulp of asymmetry, at places that meet different parts of the check
+    spots = {(1, 0), (n - 1, 0), (n - 1, n - 2), (n // 2, n // 2 - 1), (min(n - 1, 256), min(n - 2, 255)), (0, n - 1)}
+    for (i, j) in sorted(spots):
+        if i == j:
+            continue
+        Qa = Q.copy()
+        Qa[i, j] = _ulp_up(Qa[i, j]) if storage == 'f64' else Qa[i, j] * (1 + 2.0 ** -20)   # visible after rounding to fp32 too
+        qa = Quadratic(Qa, q, storage=storage)
+        assert not qa.device_problem().layout()['packed'], (i, j)
+        np.testing.assert_allclose(qa.device_problem().matvec(x), rnd(Qa) @ x, **tol)
+        qa.release()
+
+    # a Q that is not symmetric at all: NumPy's product, f = 1/2 x'Qx + q'x and g = Qx + q as the reference writes them
+    Qn = rs.standard_normal((n, n))
+    qn = Quadratic(Qn, q, storage=storage)
+    assert not qn.device_problem().layout()['packed']
+    f, g = qn.function_jacobian(x)
+    Qs = rnd(Qn)
+    np.testing.assert_allclose(g, Qs @ x + q, rtol=1e-12, atol=1e-11 * max(1.0, np.abs(Qs).sum(1).max()))
+    np.testing.assert_allclose(f, 0.5 * x @ Qs @ x + q @ x, rtol=1e-11, atol=1e-10 * n)
+    qn.release()
+
+    # symmetric=True: the caller vouches, only the lower triangle is read (uplo = 'L')
+    Ql = np.tril(Q) + np.triu(rs.standard_normal((n, n)), 1)
+    ql = Quadratic(Ql, q, storage=storage, symmetric=True)
+    assert ql.device_problem().layout()['packed']
+    np.testing.assert_array_equal(ql.device_problem().matvec(x), y_packed)
+    ql.release()
+
+
+def test_dense_symmetry_is_decided_on_the_bits(amd):
+    """The comparison is on the stored bits: +0 against -0 counts as a difference (row blocks: exactly what such a Q did before);
+    a NaN mirrored with the same payload is symmetric, and poisons the same outputs in either layout as it does in NumPy."""
+    from optiml_amd.opti import Quadratic
+    n = 300
+    x = np.random.RandomState(1).standard_normal(n)
+    Q = np.eye(n)
+    Q[200, 3] = -0.0
+    assert not Quadratic(Q, np.zeros(n)).device_problem().layout()['packed']
+    assert Quadratic(np.eye(n), np.zeros(n)).device_problem().layout()['packed']
+    Q = np.eye(n)
+    Q[3, 200] = Q[200, 3] = np.nan
+    for sym in (None, False):
+        out = Quadratic(Q, np.zeros(n), symmetric=sym).device_problem().matvec(x)
+        np.testing.assert_array_equal(np.isnan(out), np.isnan(Q @ x))
+        np.testing.assert_array_equal(out[~np.isnan(out)], x[~np.isnan(out)])
+
+
 X_STAR_CASES = ['nd2', 'nd5', 'nd64', 'rbf_svc200', 'lin_svc80', 'rbf_svr40', 'indef48']
 
 
