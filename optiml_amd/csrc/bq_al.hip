@@ -13,9 +13,22 @@
 // [A; -I; I] is never formed: every row is a coordinate or the single dense row a.  One panel product Q x per
 // iteration gives the value, the primal value and the gradient (the reference spends three).  All O(n) work and all
 // reductions are redundant per rank in a fixed order; only the panel product is sharded.
+//
+// An iteration is THREE launches with ONE chain of sums (round 6; six launches and two chains in rounds 2-5: prep, tiles, slab
+// reduction, finish, eval + decisions, update + decisions):
+//   the tile kernel;
+//   the kernel that closes the product (bq_epilogue.h, kind 2): Qx, the sums of this evaluation AND of the previous iteration's stop
+//   test per 256-row block; its last block closes the previous iteration (multiplier of the equality row, stop tests, iter += 1)
+//   and takes this one's value, record and epoch test;
+//   al_update_kernel: one elementwise pass — gradient, rule step, momentum, x, the multipliers of the bound rows, the per-element
+//   terms of the stop test (summed by the NEXT closing kernel) and the next product's input.
+// al_flush_kernel closes the last iteration of a bq_solver_run (same sums, same tree: the bits do not depend on how the iterations
+// are cut into runs).  BQ_SVR structure keeps a launch of its own for the product's input; Nesterov momentum moves x before the
+// gradient is taken, so its iterations are closed at once (flush after every update: five launches).
 #include <cmath>
 
 #include "bq_al.h"
+#include "bq_epilogue.h"
 
 #define VEC_LOOP(i)                                                             \
     const int64_t _base = (int64_t)blockIdx.x * BQ_VEC_TILE + threadIdx.x;      \
@@ -23,38 +36,6 @@
         for (int64_t i = _base + (int64_t)_j * BQ_VEC_BLOCK, _once = 1; _once; _once = 0)
 
 static inline dim3 vgrid(int64_t ldN) { return dim3((unsigned)(ldN / BQ_VEC_TILE)); }
-
-__device__ __forceinline__ double al_wsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-// NQ block sums in ONE round of barriers, and the NQ final sums over a launch's per-block partials (quantity q at part + q * nblk)
-// likewise: each quantity through the tree the one-quantity helpers of rounds 2-4 used (wave tree, four waves in order: same bits); NQ separate calls were 2 NQ barriers in kernels
-// whose length is their chain of dependent steps (round 5; config-2-sized AdaGrad: 42 -> 38 us beside the product)
-template <int NQ>
-__device__ __forceinline__ void al_bsum_n(double (&v)[NQ], double (*sh)[4]) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) v[q] = al_wsum(v[q]);
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) sh[q][threadIdx.x >> 6] = v[q];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) v[q] = ((sh[q][0] + sh[q][1]) + sh[q][2]) + sh[q][3];
-    __syncthreads();
-}
-template <int NQ>
-__device__ __forceinline__ void al_fsum_n(const double *part, int64_t nblk, double (&v)[NQ], double (*sh)[4]) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) v[q] = 0.0;
-    for (int64_t i = threadIdx.x; i < nblk; i += BQ_VEC_BLOCK) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) v[q] += part[q * nblk + i];
-    }
-    al_bsum_n<NQ>(v, sh);
-}
 
 // the block that takes the last ticket of a launch finishes the reduction and takes the scalar decisions in the same
 // kernel (same fixed-order final sums as a separate one-block kernel: results do not depend on which block is last)
@@ -68,11 +49,6 @@ __device__ __forceinline__ bool al_last_block(unsigned int *ticket) {
     if (last) __threadfence();
     return last != 0;
 }
-
-__device__ __forceinline__ void al_record_body(bq_scal *sc, const bq_al_params &prm, int has_eq, const double *part,
-                                               int64_t nblk, bq_iter_stat *stats);
-__device__ __forceinline__ void al_check_body(bq_scal *sc, const bq_al_params &prm, int has_eq, int has_rows,
-                                              const double *part, int64_t nblk, bq_iter_stat *stats);
 
 // nesterov: x += momentum * previous step, before the gradient is taken (gradient_descent.py:78-81 and the like)
 // value of a schedule at the current iteration (the last entry continues), or the constant
@@ -88,81 +64,31 @@ __global__ void al_jump_kernel(int64_t N, bq_al_vecs V, double mom_const, const 
     }
 }
 
-// partial sums of everything the value needs at x (Qx already computed)
-__global__ void al_eval_kernel(int64_t N, bq_al_vecs V, bq_scal *sc, double *part, int64_t nblk, bq_al_params prm,
-                               int has_eq, bq_iter_stat *stats) {
-    if (sc->done) return;
-    double xqx = 0.0, qx = 0.0, ax = 0.0, dc = 0.0, cl = 0.0;
-    VEC_LOOP(i) {
-        if (i < N) {
-            const double x = V.x[i];
-            xqx += x * V.Qx[i];
-            qx += V.q[i] * x;
-            if (V.a) ax += V.a[i] * x;
-            if (V.lb) {
-                const double c = V.lb[i] - x;
-                dc += V.llb[i] * c;
-                if (c > 0.0) cl += c * c;
-            }
-            if (V.ub) {
-                const double c = x - V.ub[i];
-                dc += V.lub[i] * c;
-                if (c > 0.0) cl += c * c;
-            }
-        }
-    }
-    __shared__ double sh5[5][4];
-    double v5[5] = {xqx, qx, ax, dc, cl};
-    al_bsum_n<5>(v5, sh5);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) part[q * nblk + blockIdx.x] = v5[q];
-    }
-    if (al_last_block(&sc->ticket[0])) {
-        al_record_body(sc, prm, has_eq, part, nblk, stats);
-        if (threadIdx.x == 0) sc->ticket[0] = 0;
-    }
+// The stand-alone closing kernel of an iteration's evaluation (bq_epilogue.h, kind 2) for the paths whose product has no closing
+// kernel of its own to carry it (dense row-block panels, the one-rank streamed product, BQ_SYM_EXCHANGE=allreduce): one workgroup
+// per 256 rows, the sums have the same bits whichever kernel closed the product.
+__global__ __launch_bounds__(256) void finish_al_kernel(const double *__restrict__ sv, bq_epilogue epi) {
+    if (epi.sc->done) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bq_al_pre pre = bq_al_epi_preload(epi, i, true, true);
+    bq_al_epi_finish<true>(epi, blockIdx.x, gridDim.x, bq_al_epi_element(epi, pre, i, i < epi.n ? sv[i] : 0.0, true), gridDim.x);
 }
 
-// last block of al_eval_kernel: value, primal value, iteration record, epoch test     (adagrad.py:85-101 and the like)
-__device__ __forceinline__ void al_record_body(bq_scal *sc, const bq_al_params &prm, int has_eq, const double *part,
-                                               int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh5[5][4];
-    double v5[5];
-    al_fsum_n<5>(part, nblk, v5, sh5);
-    const double xqx = v5[0], qx = v5[1], ax = v5[2], dc = v5[3], cl = v5[4];
-    if (threadIdx.x == 0) {
-        const double pf = 0.5 * xqx + qx;
-        double dual_c = dc, sq = cl;
-        if (has_eq) {
-            dual_c += sc->al_mu * ax;
-            sq += ax * ax;
-        }
-        const double f = pf + dual_c + 0.5 * prm.rho * sq;
-        sc->f = f;
-        sc->al_pf = pf;
-        sc->al_ax = ax;
-        const long long row = sc->iter - sc->stat_base;
-        if (row >= 0 && row < sc->stat_cap) {
-            stats[row].iter = sc->iter;
-            stats[row].f = f;
-            stats[row].r1 = pf;
-            stats[row].r2 = 0.0;
-            stats[row].r3 = 0.0;
-        }
-        sc->al_epoch += 1;
-        if (sc->al_epoch >= prm.epochs) {
-            sc->status = BQ_STATUS_STOPPED;
-            sc->done = 1;
-            sc->al_last = 1;   // the update kernel still owes g_x at this point (no step follows)
-        }
-    }
+// closes the iteration whose update has run but whose stop test is still pending (the end of a bq_solver_run; every iteration
+// with Nesterov momentum): the sums of bq_al_epi_finish without an evaluation
+__global__ __launch_bounds__(256) void al_flush_kernel(bq_epilogue epi) {
+    if (epi.sc->done || !epi.sc->al_pending) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bq_al_pre pre = bq_al_epi_preload(epi, i, true, false);
+    bq_al_epi_finish<false>(epi, blockIdx.x, gridDim.x, bq_al_epi_element(epi, pre, i, 0.0, false), gridDim.x);
 }
 
-// gradient, rule step, momentum, x update, multiplier update of the coordinate rows, and the partial sums the stop
-// test needs at the new point; the last block then updates the equality multiplier and runs the stop tests
-__global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_scal *sc, double *part, int64_t nblk,
-                                 int has_eq, int has_rows, bq_iter_stat *stats) {
+// gradient, rule step, momentum, x update, multiplier update of the coordinate rows, and the per-element terms of the stop test at
+// the new point (the next closing kernel, or al_flush_kernel, sums them, updates the equality multiplier and decides): one
+// elementwise pass, an element per thread
+// w_out (BQ_SVC without Nesterov momentum): the next product's input y o x_new, so that no prep launch precedes the tile kernel
+__global__ __launch_bounds__(256) void al_update_kernel(int64_t N, int64_t ldN, bq_al_vecs V, bq_al_params prm, bq_scal *sc,
+                                                        const double *__restrict__ sgn, double *__restrict__ w_out) {
     const bool last = sc->al_last != 0;   // 'stopped' at this evaluation: write its gradient, take no step
     if (sc->done && !last) return;
     const double ax = sc->al_ax, mu = sc->al_mu, rho = prm.rho;
@@ -173,35 +99,34 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
     double c1 = 1.0, c2 = 1.0;   // bias corrections 1 - beta^t
     if (prm.rule == BQ_RULE_ADAM || prm.rule == BQ_RULE_ADAMAX) c1 = 1.0 - pow(prm.beta1, t);
     if (prm.rule == BQ_RULE_ADAM) c2 = 1.0 - pow(prm.beta2, t);
-    double axn = 0.0, cn = 0.0, dl = 0.0, dx = 0.0;
-    VEC_LOOP(i) {
-        if (i < N) {
-            const double x = V.x[i];
-            // ---- gradient at x -------------------------------------------------------------------------------
-            double g = V.Qx[i] + V.q[i];
-            double dual_ag = 0.0, t3 = 0.0, t4 = 0.0;
-            if (V.a) {
-                dual_ag = __dmul_rn(mu, V.a[i]);
-                if (eq_act) t3 = __dmul_rn(V.a[i], ax);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) {
+        const double x = V.x[i];
+        // ---- gradient at x -------------------------------------------------------------------------------
+        double g = V.Qx[i] + V.q[i];
+        double dual_ag = 0.0, t3 = 0.0, t4 = 0.0;
+        if (V.a) {
+            dual_ag = __dmul_rn(mu, V.a[i]);
+            if (eq_act) t3 = __dmul_rn(V.a[i], ax);
+        }
+        if (V.lb) {
+            dual_ag -= V.llb[i];
+            if (V.lb[i] - x > 0.0) {
+                t3 += x;
+                t4 += V.lb[i];
             }
-            if (V.lb) {
-                dual_ag -= V.llb[i];
-                if (V.lb[i] - x > 0.0) {
-                    t3 += x;
-                    t4 += V.lb[i];
-                }
+        }
+        if (V.ub) {
+            dual_ag += V.lub[i];
+            if (x - V.ub[i] > 0.0) {
+                t3 += x;
+                t4 += V.ub[i];
             }
-            if (V.ub) {
-                dual_ag += V.lub[i];
-                if (x - V.ub[i] > 0.0) {
-                    t3 += x;
-                    t4 += V.ub[i];
-                }
-            }
-            g = ((g + dual_ag) + __dmul_rn(rho, t3)) - __dmul_rn(rho, t4);
-            V.g[i] = g;
-            V.xe[i] = x;
-            if (last) continue;
+        }
+        g = ((g + dual_ag) + __dmul_rn(rho, t3)) - __dmul_rn(rho, t4);
+        V.g[i] = g;
+        V.xe[i] = x;
+        if (!last) {
             // ---- rule step -----------------------------------------------------------------------------------
             const double d = -g, g2 = __dmul_rn(g, g);
             double s;
@@ -266,10 +191,11 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
             }
             V.step[i] = step;
             V.x[i] = xn;
-            if (prm.rule == BQ_RULE_ADADELTA)   // adadelta.py:122 (only reached when the stop test below fails)
+            if (w_out != nullptr) w_out[i] = sgn[i] * xn;
+            if (prm.rule == BQ_RULE_ADADELTA)   // adadelta.py:122 (only reached when the stop test fails: a stop ends the solve anyway)
                 V.s2[i] = __dmul_rn(prm.decay, V.s2[i]) + __dmul_rn(1.0 - prm.decay, __dmul_rn(step, step));
             // ---- constraints at the new point, multiplier update of the coordinate rows --------------------------
-            if (V.a) axn += V.a[i] * xn;
+            double cn = 0.0, dl = 0.0;
             if (V.lb) {
                 const double c = V.lb[i] - xn, old = V.llb[i];
                 const double nw = fmax(old + __dmul_rn(rho, c), 0.0);
@@ -284,7 +210,9 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
                 cn += c * c;
                 dl += (nw - old) * (nw - old);
             }
-            dx += (xn - x) * (xn - x);
+            V.chk[i] = cn;
+            V.chk[ldN + i] = dl;
+            V.chk[2 * ldN + i] = (xn - x) * (xn - x);
         }
     }
     if (last) {   // uniform: no step after the last evaluation; the flag is consumed by the block that finishes last
@@ -294,54 +222,44 @@ __global__ void al_update_kernel(int64_t N, bq_al_vecs V, bq_al_params prm, bq_s
         }
         return;
     }
-    __shared__ double sh4[4][4];
-    double v4[4] = {axn, cn, dl, dx};
-    al_bsum_n<4>(v4, sh4);
-    axn = v4[0];
-    cn = v4[1];
-    dl = v4[2];
-    dx = v4[3];
-    if (threadIdx.x == 0) {
-        part[0 * nblk + blockIdx.x] = axn;
-        part[1 * nblk + blockIdx.x] = cn;
-        part[2 * nblk + blockIdx.x] = dl;
-        part[3 * nblk + blockIdx.x] = dx;
-    }
-    if (al_last_block(&sc->ticket[1])) {
-        al_check_body(sc, prm, has_eq, has_rows, part, nblk, stats);
-        if (threadIdx.x == 0) sc->ticket[1] = 0;
-    }
+    if (i == 0) sc->al_pending = 1;   // read by the NEXT kernel (the closing kernel of the next product, or al_flush_kernel)
 }
 
-// last block of al_update_kernel: multiplier of the equality row, the two stop tests, iter += 1
-// (optiml/opti/_base.py:129-146)
-__device__ __forceinline__ void al_check_body(bq_scal *sc, const bq_al_params &prm, int has_eq, int has_rows,
-                                              const double *part, int64_t nblk, bq_iter_stat *stats) {
-    __shared__ double sh4[4][4];
-    double v4[4];
-    al_fsum_n<4>(part, nblk, v4, sh4);
-    const double axn = v4[0], dx = v4[3];
-    double cn = v4[1], dl = v4[2];
-    if (threadIdx.x == 0) {
-        if (has_eq) {
-            const double dmu = prm.rho * axn;
-            sc->al_mu = sc->al_mu + dmu;
-            cn += axn * axn;
-            dl += dmu * dmu;
-        }
-        const double cnorm = sqrt(cn), moved = sqrt(dl) + sqrt(dx);
-        const long long row = sc->iter - sc->stat_base;
-        if (row >= 0 && row < sc->stat_cap) {
-            stats[row].r2 = cnorm;
-            stats[row].r3 = moved;
-        }
-        if (has_rows && (moved <= prm.tol || cnorm <= prm.tol)) {
-            sc->status = BQ_STATUS_OPTIMAL;
-            sc->done = 1;
-        } else {
-            sc->iter += 1;
-        }
-    }
+static bq_epilogue al_epilogue(bq_solver *s) {
+    bq_al_state *al = s->al;
+    bq_problem *p = s->p;
+    bq_epilogue epi = {};
+    epi.structure = p->structure;
+    epi.kind = 2;
+    epi.n = p->n;
+    epi.N = p->N;
+    epi.diag_add = p->diag_add;
+    epi.x = al->V.x;
+    epi.q = al->V.q;
+    epi.lb = al->V.lb;
+    epi.ub = al->V.ub;
+    epi.sgn = p->sgn;
+    epi.Qd = al->V.Qx;
+    epi.sc = s->sc;
+    epi.part = s->partials;
+    epi.stats = s->stats;
+    epi.a = al->V.a;
+    epi.llb = al->V.llb;
+    epi.lub = al->V.lub;
+    epi.chk = al->V.chk;
+    epi.ldN = s->ldN;
+    epi.rho = al->prm.rho;
+    epi.tol = al->prm.tol;
+    epi.epochs = al->prm.epochs;
+    epi.has_rows = (al->V.a != nullptr || al->V.lb != nullptr || al->V.ub != nullptr) ? 1 : 0;
+    return epi;
+}
+
+// the end of a bq_solver_run: the last update's stop test must not stay pending across the call (its record leaves with this run)
+int bq_al_flush(bq_solver *s) {
+    al_flush_kernel<<<(unsigned)((s->p->n + 255) / 256), 256, 0, s->p->ctx->stream>>>(al_epilogue(s));
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
 }
 
 int bq_al_iterate(bq_solver *s) {
@@ -350,13 +268,25 @@ int bq_al_iterate(bq_solver *s) {
     hipStream_t st = p->ctx->stream;
     const int *done = &s->sc->done;
     const bq_al_params &prm = al->prm;
-    const int has_eq = al->V.a != nullptr, has_rows = has_eq || al->V.lb != nullptr || al->V.ub != nullptr;
-    if (prm.momentum_type == BQ_MOM_NESTEROV)
-        al_jump_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, prm.momentum, s->sc);
-    BQ_TRY(bq_problem_apply(p, al->V.x, al->V.Qx, done));
-    al_eval_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, s->sc, s->partials, s->nblk, prm, has_eq, s->stats);
-    al_update_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, prm, s->sc, s->partials, s->nblk, has_eq,
-                                                             has_rows, s->stats);
+    const bool nesterov = prm.momentum_type == BQ_MOM_NESTEROV;
+    if (nesterov) al_jump_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, al->V, prm.momentum, s->sc);
+    // the product's input: x itself (BQ_PLAIN), what the previous update kernel left in p->w (BQ_SVC, nothing has moved x since),
+    // else the structure map of x by a launch of its own
+    const double *w = al->V.x;
+    if (p->structure != BQ_PLAIN) {
+        if (!al->w_ready) BQ_TRY(bq_launch_prep(p, al->V.x, done));
+        w = p->w;
+    }
+    const bq_epilogue epi = al_epilogue(s);
+    bool fused = false;
+    BQ_TRY(bq_panel_product(p, p->add_one, w, done, &epi, &fused));
+    if (!fused) finish_al_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(p->s, epi);
+    double *w_out = (p->structure == BQ_SVC && !nesterov) ? p->w : nullptr;
+    al_update_kernel<<<(unsigned)((s->N + 255) / 256), 256, 0, st>>>(s->N, s->ldN, al->V, prm, s->sc, p->sgn, w_out);
+    al->w_ready = w_out != nullptr;
+    // Nesterov's jump of the NEXT iteration moves x before its gradient is taken: whether that iteration takes place must be known
+    // before the jump, so the iteration is closed here instead of inside the next closing kernel
+    if (nesterov) al_flush_kernel<<<(unsigned)((p->n + 255) / 256), 256, 0, st>>>(epi);
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

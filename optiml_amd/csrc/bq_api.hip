@@ -1013,7 +1013,7 @@ extern "C" int bq_solver_destroy(bq_solver *s) {
     delete s->resume;
     if (s->al) {
         bq_al_vecs &V = s->al->V;   // x, g, step (= s->d) and Qx (= s->Qd) are owned by the common slots above
-        for (void *ptr : {(void *)V.xe, (void *)V.s1, (void *)V.s2, (void *)V.s3, (void *)V.a, (void *)V.llb, (void *)V.lub,
+        for (void *ptr : {(void *)V.xe, (void *)V.chk, (void *)V.s1, (void *)V.s2, (void *)V.s3, (void *)V.a, (void *)V.llb, (void *)V.lub,
                           (void *)V.lr_sched, (void *)V.mom_sched})
             if (ptr) hipFree(ptr);
         delete s->al;
@@ -1165,6 +1165,11 @@ extern "C" int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const
     int rc = BQ_OK;
     for (double **v : {&s->x, &s->g, &s->d, &s->Qd, &V.xe, &V.s1})
         if (rc == BQ_OK) rc = alloc_vec(s, v);
+    if (rc == BQ_OK && hipMalloc(&V.chk, sizeof(double) * 3 * s->ldN) != hipSuccess) {
+        bq_set_error("cannot allocate the solver's vectors");
+        rc = BQ_ERR_NOMEM;
+    }
+    if (rc == BQ_OK) BQ_HIP(hipMemsetAsync(V.chk, 0, sizeof(double) * 3 * s->ldN, c->stream));
     const bool two = prm->rule == BQ_RULE_ADAM || prm->rule == BQ_RULE_AMSGRAD || prm->rule == BQ_RULE_ADAMAX ||
                      prm->rule == BQ_RULE_ADADELTA;
     if (rc == BQ_OK && two) rc = alloc_vec(s, &V.s2);
@@ -1341,6 +1346,7 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
             *s->flag_host = 0;
         }
     }
+    if (s->al) s->al->w_ready = false;   // p->w belongs to the problem: anything may have used it since the last run
     const long long base = s->host.iter;
     long long hdr[2] = {base, (long long)max_steps};
     BQ_HIP(hipMemcpyAsync(&s->sc->stat_base, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
@@ -1394,6 +1400,7 @@ extern "C" int bq_solver_run(bq_solver *s, int64_t max_steps, bq_iter_stat *stat
             }
         }
     }
+    if (s->al) BQ_TRY(bq_al_flush(s));
     BQ_HIP(hipMemcpyAsync(&s->host, s->sc, sizeof(bq_scal), hipMemcpyDeviceToHost, c->stream));
     BQ_SYNC(c);
     if (s->host.status < 0) {  // a kernel flagged a numerical failure (codes mirror BQ_ERR_*)

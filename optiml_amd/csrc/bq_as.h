@@ -75,6 +75,7 @@ struct as_pc {
     int top0 = 0, ntop = 0;       // the Phi_top columns (the projected order-2 directions) of the explicit model
     double *y1 = nullptr, *v2 = nullptr, *z2 = nullptr, *ones = nullptr;   // ldN each: y = P1^-1 r, R y, P1^-1 R y; weights 1
     double *ttop = nullptr;       // mp: Phi_top' y
+    long long lambda_nA = 0;      // size of the free set the spectrum bound of the remainder was estimated on (a larger set needs a new one)
 };
 
 struct as_ws {

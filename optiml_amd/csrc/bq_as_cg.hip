@@ -365,15 +365,23 @@ static int as_cg_solve_once(bq_solver *s, as_ws *w, int *pc_failed) {
 
 // A Woodbury system G that is not positive definite (or r'z <= 0) says something about the MODEL P, not about Q: its Gram matrix
 // has drifted under the rank-one updates, or the features do not fit this free set.  First G is summed afresh and the solve
-// repeated; if that fails too the preconditioner is dropped for the rest of the run (plain conjugate gradients).  Every rank
-// reads the same replicated scalars, so all ranks take the same turn here and stay in the same collectives.
+// repeated (with the spectrum bound of the implicit remainder estimated afresh on THIS free set: an underestimate is the other way
+// the operator turns indefinite); then the remainder is given up and the explicit model kept; if that fails too the preconditioner
+// is dropped for the rest of the run (plain conjugate gradients).  Every rank reads the same replicated scalars, so all ranks take
+// the same turn here and stay in the same collectives.
 static int as_cg_solve(bq_solver *s, as_ws *w) {
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         int pc_failed = 0;
         BQ_TRY(as_cg_solve_once(s, w, &pc_failed));
         if (!pc_failed) return BQ_OK;
         if (w->pc == nullptr) break;
         if (attempt == 0) {
+            w->pc->age = 0;
+            if (w->pc->r2) as_pc2_set_lambda(w->pc->r2, -1.0);
+            w->pc_rebuilds += 1;
+        } else if (w->pc->r2 != nullptr) {
+            as_pc2_free(w->pc->r2);
+            w->pc->r2 = nullptr;
             w->pc->age = 0;
             w->pc_rebuilds += 1;
         } else {

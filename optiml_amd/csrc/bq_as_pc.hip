@@ -390,7 +390,6 @@ constexpr int PC_FG = 8;   // features per butterfly group of the t kernel
 // eight sums), the four wave sums meet in LDS -> tpart[block][j]; the last workgroup to finish adds the blocks in block order.
 // Round 3 had one workgroup per FEATURE re-reading r and 1 / D for each of them: 2.5 GB of L2 traffic beside the 1 GB of
 // features, 0.40 ms per call at BASELINE config 5.  Fixed order throughout: the same bits on every rank.
-constexpr int PC_TSLICES_MAX = 4;   // feature slices of the t kernel (gridDim.y)
 __global__ __launch_bounds__(256) void as_pc_tphi_kernel(int m, int64_t m8, int64_t mp, int64_t N, int64_t ld,
                                                          const float *__restrict__ Phi, const double *__restrict__ dinv,
                                                          const double *__restrict__ r, double *__restrict__ tpart,
@@ -644,6 +643,20 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         want_r2 = v == 3 || (e == nullptr && p->n >= 65536);
     }
     std::vector<double> share((size_t)p->n);
+    // the sum over ranks of a flag, so that every rank takes the same turn (each product of the solve is a collective: a rank that fell
+    // back, or returned an error, alone would leave the others waiting in the next one for ever)
+    auto agree = [&](double *flag) -> int {
+        if (ctx->world <= 1 || ctx->comm_kind == BQ_COMM_SHARE) return BQ_OK;
+        hipError_t ae = hipMemcpyAsync(s->partials, flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        int arc = ae == hipSuccess ? bq_exchange_sum(ctx, s->partials, 1) : BQ_ERR_HIP;
+        if (arc == BQ_OK) ae = hipMemcpyAsync(flag, s->partials, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (arc == BQ_OK && ae == hipSuccess) arc = bq_ctx_sync(ctx);   // behind a collective: the bounded wait
+        if (arc == BQ_OK && ae != hipSuccess) {
+            bq_set_error("agreeing on the preconditioner across ranks failed: %s", hipGetErrorString(ae));
+            arc = BQ_ERR_HIP;
+        }
+        return arc;
+    };
     for (; fam2 >= 0; --fam2) {
         const bool classes = fam2 > 0;
         int m = p->kernel == BQ_KERNEL_RBF ? (int)p->d + 1 + fam2 * (int)p->d : (int)p->d;
@@ -681,6 +694,13 @@ int as_pc_create(bq_solver *s, as_pc **out) {
             e = hipMalloc(&pc->cls, sizeof(double) * (2 * p->d + 2));
             if (e == hipSuccess) e = hipMemsetAsync(pc->cls, 0, sizeof(double) * (2 * p->d + 2), ctx->stream);
         }
+        // fam2 == 2: per-sample numbers and the orthonormalising factor (set-up only) — allocated HERE, with everything else a rank may
+        // have no room for, so that their failure lands in the agreed flag (they used to come after the agreement)
+        double *raw = nullptr, *rinv_d = nullptr;
+        if (rc == BQ_OK && e == hipSuccess && fam2 == 2) {
+            e = hipMalloc(&raw, sizeof(double) * 3 * s->ldN);
+            if (e == hipSuccess) e = hipMalloc(&rinv_d, sizeof(double) * (size_t)(2 * p->d) * (size_t)(2 * p->d));
+        }
         // Do ALL ranks hold their features?  Every rank must run the SAME inner iteration (each product is a collective): a rank
         // that fell back to plain conjugate gradients alone — or returned an error alone — would leave the others waiting in the
         // next collective for ever.  So the outcome is agreed on (one all-reduce of a flag) and, if any rank has no room, every rank
@@ -707,19 +727,20 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         const bool r2_missing = fam2 == 2 && want_r2 && pc->r2 == nullptr;
         double failed = ((rc != BQ_OK || e != hipSuccess) ? 1.0 : 0.0) + (r2_missing ? 1e-3 : 0.0);
         if (failed >= 0.5) (void)hipGetLastError();
-        if (ctx->world > 1 && ctx->comm_kind != BQ_COMM_SHARE) {
-            hipError_t ae = hipMemcpyAsync(s->partials, &failed, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-            int arc = ae == hipSuccess ? bq_exchange_sum(ctx, s->partials, 1) : BQ_ERR_HIP;
-            if (arc == BQ_OK) ae = hipMemcpyAsync(&failed, s->partials, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-            if (arc == BQ_OK && ae == hipSuccess) arc = bq_ctx_sync(ctx);   // behind a collective: the bounded wait
-            if (arc != BQ_OK || ae != hipSuccess) {
+        {
+            const int arc = agree(&failed);
+            if (arc != BQ_OK) {
+                if (bdiag) hipFree(bdiag);
+                if (raw) hipFree(raw);
+                if (rinv_d) hipFree(rinv_d);
                 as_pc_free(pc);
-                if (arc == BQ_OK) bq_set_error("agreeing on the preconditioner across ranks failed: %s", hipGetErrorString(ae));
-                return arc != BQ_OK ? arc : BQ_ERR_HIP;
+                return arc;
             }
         }
         if (failed >= 0.5) {   // no room for the features on some rank: all ranks run plain conjugate gradients
             if (bdiag) hipFree(bdiag);
+            if (raw) hipFree(raw);
+            if (rinv_d) hipFree(rinv_d);
             as_pc_free(pc);
             return BQ_OK;
         }
@@ -727,7 +748,6 @@ int as_pc_create(bq_solver *s, as_pc **out) {
             as_pc2_free(pc->r2);
             pc->r2 = nullptr;
         }
-        double *raw = nullptr, *rinv_d = nullptr;   // fam2 == 2: per-sample numbers and the orthonormalising factor (setup only)
         hipError_t fe = hipSuccess;
         int frc = BQ_OK;
         if (classes) {
@@ -784,9 +804,7 @@ int as_pc_create(bq_solver *s, as_pc **out) {
                         Rinv[(size_t)ia * n2 + jb] = -v / R[(size_t)ia * n2 + ia];
                     }
                 }
-                fe = hipMalloc(&raw, sizeof(double) * 3 * s->ldN);
-                if (fe == hipSuccess) fe = hipMalloc(&rinv_d, sizeof(double) * (size_t)n2 * n2);
-                if (fe == hipSuccess) fe = hipMemcpyAsync(rinv_d, Rinv.data(), sizeof(double) * (size_t)n2 * n2, hipMemcpyHostToDevice, ctx->stream);
+                fe = hipMemcpyAsync(rinv_d, Rinv.data(), sizeof(double) * (size_t)n2 * n2, hipMemcpyHostToDevice, ctx->stream);
                 if (fe == hipSuccess) frc = bq_ctx_sync(ctx);   // Rinv leaves this scope
             }
         }
@@ -806,10 +824,20 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         if (raw) hipFree(raw);
         if (rinv_d) hipFree(rinv_d);
         if (bdiag) hipFree(bdiag);
-        if (fe != hipSuccess || frc != BQ_OK) {
+        // the feature build is rank-local work that can fail on one rank alone (a launch, a copy, a bounded wait): a second agreement,
+        // so that EVERY rank leaves solver creation with an error when any of them has one — none enters the solve's
+        // collectives without the others
+        double build_failed = (fe != hipSuccess || frc != BQ_OK) ? 1.0 : 0.0;
+        if (build_failed > 0.0) (void)hipGetLastError();
+        const int brc = agree(&build_failed);
+        if (brc != BQ_OK || build_failed > 0.0) {
             as_pc_free(pc);
-            if (fe != hipSuccess) bq_set_error("building the preconditioner features failed: %s", hipGetErrorString(fe));
-            return fe != hipSuccess ? BQ_ERR_HIP : frc;
+            if (brc != BQ_OK) return brc;
+            if (fe != hipSuccess)
+                bq_set_error("building the preconditioner features failed: %s", hipGetErrorString(fe));
+            else if (frc == BQ_OK)
+                bq_set_error("building the preconditioner features failed on another rank");
+            return frc != BQ_OK ? frc : BQ_ERR_HIP;
         }
         double lo = 1.0;
         for (double v : share) lo = std::min(lo, v);
@@ -932,9 +960,15 @@ int as_pc_update(bq_solver *s, as_ws *w) {
     } else {
         as_pc_sm_kernel<<<1, 1024, 0, st>>>(pc->m, pc->mp, s->ldN, pc->Phi, pc->dinv, pc->chg, pc->Ginv, pc->sm_fail);
     }
+    // the bound was estimated on a free set of lambda_nA samples: restricting to a smaller set only lowers lambda_max, a LARGER one (a
+    // resumed solve that starts from given masks, releases after an early estimate) may exceed it — and an underestimate is what
+    // turns the polynomial indefinite (profiles/r05/c5_lambda_scale.txt): estimate again.  Replicated numbers: every
+    // rank takes the same turn.
+    if (pc->r2 && rebuild && as_pc2_lambda(pc->r2) >= 0.0 && (long long)w->host_ints[0] > pc->lambda_nA + pc->lambda_nA / 8)
+        as_pc2_set_lambda(pc->r2, -1.0);
     if (pc->r2 && rebuild && as_pc2_lambda(pc->r2) < 0.0) {
         // lambda_max of P1^-1 R on this free set by a power iteration from the all-ones vector (twelve applications, two norms on the
-        // host; once per solver: restricting to a smaller free set later only lowers it).  Every rank computes the same bits.
+        // host; repeated only when the free set has grown by more than an eighth since).  Every rank computes the same bits.
         // The polynomial stays positive up to 1 + the assumed bound, so an estimate from BELOW must be widened, never trusted: at
         // config 5 six applications x 1.15 still gave 5.0 products per outer iteration, x 0.85 gave 8.0 and x 0.6 36 (the operator
         // turns indefinite); x 1.6 is as good as x 1.15 (profiles/r05/c5_lambda_scale.txt) — wide is cheap, narrow is not.
@@ -959,7 +993,10 @@ int as_pc_update(bq_solver *s, as_ws *w) {
 #ifndef BQ_PC2_LAMBDA_SCALE
 #define BQ_PC2_LAMBDA_SCALE 1.5   // a power iteration comes from below (swept at config 5: profiles/r05/c5_lambda_scale.txt)
 #endif
-        if (lam >= 0.0 && std::isfinite(lam)) as_pc2_set_lambda(pc->r2, BQ_PC2_LAMBDA_SCALE * lam);
+        if (lam >= 0.0 && std::isfinite(lam)) {
+            as_pc2_set_lambda(pc->r2, BQ_PC2_LAMBDA_SCALE * lam);
+            pc->lambda_nA = (long long)w->host_ints[0];
+        }
     }
     return BQ_OK;
 }

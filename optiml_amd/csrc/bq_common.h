@@ -59,7 +59,7 @@ constexpr int64_t BQ_PAD = 1024;
 constexpr int BQ_VEC_BLOCK = 256;                 // threads per block in the O(n) kernels
 constexpr int BQ_VEC_ITEMS = 4;                   // elements per thread
 constexpr int BQ_VEC_TILE = BQ_VEC_BLOCK * BQ_VEC_ITEMS;  // 1024 elements per block == BQ_PAD
-constexpr int BQ_MAX_PARTIAL_Q = 20;              // reduced quantities per block of 1024 elements (PG / FW: five per block of 256 rows)
+constexpr int BQ_MAX_PARTIAL_Q = 32;              // reduced quantities per block of 1024 elements (PG / FW: five per block of 256 rows; AL: eight)
 
 static inline int64_t bq_round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
 
@@ -180,7 +180,7 @@ struct bq_problem {
 // device-resident scalar state of a solver; one instance per solver, read back in one copy
 struct bq_scal {
     long long iter, max_iter, stat_base, stat_cap;
-    int status, done, fw_clip, pad0;
+    int status, done, fw_clip, al_pending;     // al_pending: an update has run whose stop test / multiplier step is still due (bq_epilogue.h, kind 2)
     double eps, fw_t;
     double f, ng, gd, max_t, den, t;          // PG / FW
     double low, best_lb, gap;                  // FW
@@ -197,6 +197,7 @@ struct bq_chol_ws;
 // augmented-Lagrangian driver (bq_al.hip): device vectors (null pointer = that constraint family is absent)
 struct bq_al_vecs {
     double *x, *xe, *g, *Qx, *q, *step, *s1, *s2, *s3;
+    double *chk;   // 3 x ldN: an update's per-element terms of the stop test (|c(x_new)|^2, |d dual|^2, |d x|^2), summed by the next closing kernel
     double *a, *lb, *ub, *llb, *lub;   // equality row; bounds; their multipliers
     const double *lr_sched, *mom_sched;   // optional per-iteration step sizes / momenta (index: iteration), else null
     long long sched_len;
@@ -204,6 +205,8 @@ struct bq_al_vecs {
 struct bq_al_state {
     bq_al_params prm;
     bq_al_vecs V;
+    bool w_ready = false;   // p->w holds the structure map of the current x (the last update kernel wrote it): cleared at the top of
+                            // every bq_solver_run, other calls on the problem use p->w too
 };
 
 struct bq_solver {
@@ -333,6 +336,7 @@ int bq_launch_gram_matrix(bq_ctx *ctx, int kernel, double gamma, double coef0, i
 
 // bq_vec.hip
 int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *done_flag);  // out = Q v, all ranks
+int bq_launch_prep(bq_problem *p, const double *v, const int *done_flag);   // p->w = the structure map of v (BQ_SVC: y o v; BQ_SVR: v+ - v-)
 int bq_vec_eval_f(bq_problem *p, const double *x, const double *Qx, double *g_out, double *f_dev);
 
 int bq_pgfw_start(bq_solver *s);
@@ -344,6 +348,7 @@ int bq_as_start(bq_solver *s);
 int bq_as_iterate(bq_solver *s);
 void bq_as_free(bq_solver *s);
 int bq_al_iterate(bq_solver *s);   // bq_al.hip
+int bq_al_flush(bq_solver *s);     // closes the last iteration of a run (its stop test is otherwise taken by the next closing kernel)
 const double *bq_as_view(bq_solver *s, int what);
 long long bq_as_inner_iters(bq_solver *s);
 long long bq_as_counter(bq_solver *s, int which);

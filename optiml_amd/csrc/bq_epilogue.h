@@ -21,7 +21,7 @@
 
 struct bq_epilogue {
     int structure;            // BQ_PLAIN / BQ_SVC / BQ_SVR
-    int kind;                 // 0: PG, 1: FW
+    int kind;                 // 0: PG, 1: FW, 2: the evaluation of an augmented-Lagrangian iteration (bq_al_epi_*, below)
     int do_update;            // a step is pending (every iteration but a solver's first): pgfw_update_kernel applies it
     long long n, N;
     double diag_add;
@@ -31,7 +31,18 @@ struct bq_epilogue {
     bq_scal *sc;
     double *part;             // 5 x nblocks partial sums (nblocks = the closing kernel's blocks of 256 rows)
     bq_iter_stat *stats;
+    // kind 2 only: x is the point (the product's input is its structure map), Qd receives Q x; lb / ub may be null there
+    const double *a, *llb, *lub;   // equality row; multipliers of the bound rows (null: that family is absent)
+    const double *chk;             // 3 x ldN: the last update's per-element terms of the stop test
+    long long ldN;
+    double rho, tol;
+    long long epochs;
+    int has_rows;                  // some constraint family is present (else nothing ever stops but the epoch count)
 };
+#define BQ_EPI_NONE 0
+#define BQ_EPI_PGFW 1
+#define BQ_EPI_AL 2
+static inline int bq_epi_mode(const bq_epilogue *e) { return e == nullptr ? BQ_EPI_NONE : (e->kind == 2 ? BQ_EPI_AL : BQ_EPI_PGFW); }
 
 __device__ __forceinline__ double bq_epi_wsum(double v) {
 #pragma unroll
@@ -267,5 +278,205 @@ __device__ __forceinline__ void bq_epi_finish(const bq_epilogue &e, long long a,
         if (row >= 0 && row < sc->stat_cap) e.stats[row] = st;
         if (!stop) sc->iter += 1;
         sc->ticket[1] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// kind 2: an augmented-Lagrangian iteration (optiml/opti/constrained/_base.py:326-340, the callback of optiml/opti/_base.py:96-117,
+// the epoch test of the stochastic rules, e.g. adagrad.py:85-101, and the multiplier step / stop tests of optiml/opti/_base.py:129-146)
+// in the kernel that closes the product Q x.  For the block's 256 rows: Qx = structure(s) (+ diag_add x), the partial sums of the
+// EVALUATION at x (x'Qx, q'x, a'x, dual'c, |max(c_in, 0)|^2) and of the STOP TEST the previous update left pending (|c(x)|^2 over
+// the bound rows, |d dual|^2, |d x|^2: per-element terms the update kernel stored; a'x is shared).  The LAST block first closes the
+// previous iteration — multiplier of the equality row, the two stop tests, iter += 1 — and then, unless that stopped the solve,
+// takes this iteration's value, primal value, record and epoch test.  Rounds 2-5 ran finish_kernel + al_eval_kernel behind the
+// closing kernel and a second reduce-and-decide chain inside the update kernel; now the update kernel is one elementwise pass and an
+// iteration has ONE chain of sums (the structure PG / FW got in round 5).  The price, as there: one product enqueued past the
+// iteration that stops.  Same partial-sum layout and tree in every closing kernel and in al_flush_kernel (which closes the last
+// iteration of a bq_solver_run): identical bits however the iterations are cut into runs, on any rank count.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int BQ_AL_NQ = 8;
+struct bq_al_pre {
+    double x[2], q[2], a[2], lb[2], ub[2], ll[2], lu[2], ck[2][3], sg;
+    bool live, pending;
+};
+// eval: the evaluation's operands too (the closing kernels); else only what the pending stop test needs (al_flush_kernel)
+__device__ __forceinline__ bq_al_pre bq_al_epi_preload(const bq_epilogue &e, long long i, bool active, bool eval) {
+    bq_al_pre p = {};
+    p.pending = e.sc->al_pending != 0;
+    p.live = active && i < e.n;
+    if (!p.live) return p;
+    const int halves = e.structure == BQ_SVR ? 2 : 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h < halves) {
+            const long long u = h == 0 ? i : e.n + i;
+            p.x[h] = e.x[u];
+            if (e.a) p.a[h] = e.a[u];
+            if (p.pending) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p.ck[h][k] = e.chk[k * e.ldN + u];
+            }
+            if (eval) {
+                p.q[h] = e.q[u];
+                if (e.lb) {
+                    p.lb[h] = e.lb[u];
+                    p.ll[h] = e.llb[u];
+                }
+                if (e.ub) {
+                    p.ub[h] = e.ub[u];
+                    p.lu[h] = e.lub[u];
+                }
+            }
+        }
+    }
+    p.sg = e.structure == BQ_SVC ? e.sgn[i] : 1.0;
+    return p;
+}
+
+struct bq_al_sums {
+    double v[BQ_AL_NQ];   // x'Qx, q'x, a'x, dual'c of the bound rows, |max(c_in, 0)|^2;  pending: |c|^2 of the bound rows, |d dual|^2, |d x|^2
+};
+__device__ __forceinline__ bq_al_sums bq_al_epi_element(const bq_epilogue &e, const bq_al_pre &p, long long i, double sv, bool eval) {
+    bq_al_sums c;
+#pragma unroll
+    for (int q = 0; q < BQ_AL_NQ; ++q) c.v[q] = 0.0;
+    if (!p.live) return c;
+    const bool two = e.structure == BQ_SVR;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 0 || two) {
+            const long long u = h == 0 ? i : e.n + i;
+            const double x = p.x[h];
+            if (e.a) c.v[2] += p.a[h] * x;
+            if (p.pending) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c.v[5 + k] += p.ck[h][k];
+            }
+            if (eval) {
+                double r;
+                if (two)
+                    r = h == 0 ? sv : -sv;
+                else
+                    r = e.structure == BQ_SVC ? p.sg * sv : sv;
+                if (e.diag_add != 0.0) r += e.diag_add * x;
+                e.Qd[u] = r;
+                c.v[0] += x * r;
+                c.v[1] += p.q[h] * x;
+                if (e.lb) {
+                    const double cc = p.lb[h] - x;
+                    c.v[3] += p.ll[h] * cc;
+                    if (cc > 0.0) c.v[4] += cc * cc;
+                }
+                if (e.ub) {
+                    const double cc = x - p.ub[h];
+                    c.v[3] += p.lu[h] * cc;
+                    if (cc > 0.0) c.v[4] += cc * cc;
+                }
+            }
+        }
+    }
+    return c;
+}
+
+// called by ALL threads of the workgroup (threads 0 .. 255 carry block `a`'s contributions), as bq_epi_finish.  EVAL: the closing
+// kernels (pending stop test, then the evaluation); else al_flush_kernel (the pending stop test alone)
+template <bool EVAL>
+__device__ __forceinline__ void bq_al_epi_finish(const bq_epilogue &e, long long a, long long nblocks, bq_al_sums c, unsigned int nwg) {
+    __shared__ double sh[BQ_AL_NQ][4];
+    __shared__ int last;
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+#pragma unroll
+        for (int q = 0; q < BQ_AL_NQ; ++q) c.v[q] = bq_epi_wsum(c.v[q]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < BQ_AL_NQ; ++q) sh[q][tid >> 6] = c.v[q];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < BQ_AL_NQ; ++q) e.part[q * nblocks + a] = ((sh[q][0] + sh[q][1]) + sh[q][2]) + sh[q][3];
+        __threadfence();
+        last = atomicAdd(&e.sc->ticket[0], 1u) == nwg - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double acc[BQ_AL_NQ];
+#pragma unroll
+    for (int q = 0; q < BQ_AL_NQ; ++q) acc[q] = 0.0;
+    if (tid < 256) {
+        for (long long k = tid; k < nblocks; k += 256) {
+#pragma unroll
+            for (int q = 0; q < BQ_AL_NQ; ++q) acc[q] += e.part[q * nblocks + k];
+        }
+#pragma unroll
+        for (int q = 0; q < BQ_AL_NQ; ++q) acc[q] = bq_epi_wsum(acc[q]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < BQ_AL_NQ; ++q) sh[q][tid >> 6] = acc[q];
+        }
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    double t[BQ_AL_NQ];
+#pragma unroll
+    for (int q = 0; q < BQ_AL_NQ; ++q) t[q] = ((sh[q][0] + sh[q][1]) + sh[q][2]) + sh[q][3];
+    bq_scal *sc = e.sc;
+    sc->ticket[0] = 0;
+    const double ax = t[2];
+    if (sc->al_pending) {
+        // the previous iteration's close (optiml/opti/_base.py:129-146): multiplier of the equality row from a'x at the new point
+        // (this very sum), the two stop tests, iter += 1
+        double cn = t[5], dl = t[6];
+        const double dx = t[7];
+        if (e.a) {
+            const double dmu = e.rho * ax;
+            sc->al_mu = sc->al_mu + dmu;
+            cn += ax * ax;
+            dl += dmu * dmu;
+        }
+        const double cnorm = sqrt(cn), moved = sqrt(dl) + sqrt(dx);
+        const long long row = sc->iter - sc->stat_base;
+        if (row >= 0 && row < sc->stat_cap) {
+            e.stats[row].r2 = cnorm;
+            e.stats[row].r3 = moved;
+        }
+        sc->al_pending = 0;
+        if (e.has_rows && (moved <= e.tol || cnorm <= e.tol)) {
+            sc->status = BQ_STATUS_OPTIMAL;
+            sc->done = 1;
+            return;   // the evaluation below belongs to an iteration that does not take place
+        }
+        sc->iter += 1;
+    }
+    if (!EVAL) return;
+    const double xqx = t[0], qx = t[1];
+    const double pf = 0.5 * xqx + qx;
+    double dual_c = t[3], sq = t[4];
+    if (e.a) {
+        dual_c += sc->al_mu * ax;
+        sq += ax * ax;
+    }
+    const double f = pf + dual_c + 0.5 * e.rho * sq;
+    sc->f = f;
+    sc->al_pf = pf;
+    sc->al_ax = ax;
+    const long long row = sc->iter - sc->stat_base;
+    if (row >= 0 && row < sc->stat_cap) {
+        bq_iter_stat st;
+        st.iter = sc->iter;
+        st.f = f;
+        st.r1 = pf;
+        st.r2 = 0.0;
+        st.r3 = 0.0;
+        e.stats[row] = st;
+    }
+    sc->al_epoch += 1;
+    if (sc->al_epoch >= e.epochs) {
+        sc->status = BQ_STATUS_STOPPED;
+        sc->done = 1;
+        sc->al_last = 1;   // the update kernel still owes g_x at this point (no step follows)
     }
 }

@@ -254,7 +254,7 @@ __device__ __forceinline__ double seg_partial(const double *__restrict__ p, int6
 // out[a*T + r] = sum over the segments [tab.lo, tab.hi) of their partial sums, in segment order — the canonical order of
 // the product: the same association whether the segments were summed here (one rank) or gathered from their owners
 // EPI: the PG / FW epilogue of bq_epilogue.h goes on from the summed product (out is still written: other consumers read p->s)
-template <int JG, bool EPI>
+template <int JG, int EPI>
 __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ slab, int64_t nb, bq_seg_table tab,
                                                            double *__restrict__ out, const int *__restrict__ done, bq_epilogue epi) {
     if (done != nullptr && *done) return;
@@ -266,7 +266,9 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
     const int r = threadIdx.x & (ST - 1), q = threadIdx.x >> 8;
     const double *p = slab + a * nb * ST + r;
     bq_epi_pre pre;
-    if constexpr (EPI) pre = bq_epi_preload(epi, a * ST + r, q == 0);   // in flight while the slab is walked
+    bq_al_pre apre;
+    if constexpr (EPI == BQ_EPI_PGFW) pre = bq_epi_preload(epi, a * ST + r, q == 0);   // in flight while the slab is walked
+    if constexpr (EPI == BQ_EPI_AL) apre = bq_al_epi_preload(epi, a * ST + r, q == 0, true);
     double acc = 0.0;
     for (int s0 = tab.lo; s0 < tab.hi; s0 += BQ_SYM_SEG) {
         const int ns = tab.hi - s0 < BQ_SYM_SEG ? tab.hi - s0 : BQ_SYM_SEG;
@@ -277,9 +279,8 @@ __global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restr
         __syncthreads();
     }
     if (q == 0) out[a * ST + r] = acc;
-    if constexpr (EPI) {
-        bq_epi_finish(epi, a, nb, bq_epi_element(epi, pre, a * ST + r, acc), gridDim.x);
-    }
+    if constexpr (EPI == BQ_EPI_PGFW) bq_epi_finish(epi, a, nb, bq_epi_element(epi, pre, a * ST + r, acc), gridDim.x);
+    if constexpr (EPI == BQ_EPI_AL) bq_al_epi_finish<true>(epi, a, nb, bq_al_epi_element(epi, apre, a * ST + r, acc, true), gridDim.x);
 }
 
 // the per-segment partial vectors of this rank's segments, each to its slot of the gathered buffer
@@ -296,13 +297,15 @@ __global__ __launch_bounds__(1024) void symv_reduce_seg_kernel(const double *__r
 }
 
 // out = sum of all S gathered segment vectors in segment order (every rank: identical bits); EPI: as symv_reduce_kernel
-template <bool EPI>
+template <int EPI>
 __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restrict__ gath, int64_t len, bq_seg_table tab,
                                                           double *__restrict__ out, const int *__restrict__ done, bq_epilogue epi) {
     if (done != nullptr && *done) return;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // len = nb * 256: always in range
     bq_epi_pre pre;
-    if constexpr (EPI) pre = bq_epi_preload(epi, i, true);
+    bq_al_pre apre;
+    if constexpr (EPI == BQ_EPI_PGFW) pre = bq_epi_preload(epi, i, true);
+    if constexpr (EPI == BQ_EPI_AL) apre = bq_al_epi_preload(epi, i, true, true);
     double acc = 0.0;
     int s = 0;
     for (; s + 8 <= tab.count; s += 8) {   // the canonical eight segments: eight loads in flight, added in segment order
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(256) void symv_segsum_kernel(const double *__restri
     }
     for (; s < tab.count; ++s) acc += gath[(int64_t)tab.slot[s] * len + i];
     out[i] = acc;
-    if constexpr (EPI) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, pre, i, acc), gridDim.x);
+    if constexpr (EPI == BQ_EPI_PGFW) bq_epi_finish(epi, blockIdx.x, gridDim.x, bq_epi_element(epi, pre, i, acc), gridDim.x);
+    if constexpr (EPI == BQ_EPI_AL) bq_al_epi_finish<true>(epi, blockIdx.x, gridDim.x, bq_al_epi_element(epi, apre, i, acc, true), gridDim.x);
 }
 
 // The timed launch: when the context is profiling, the kernel's own dispatch carries the two timestamps (hipExtLaunchKernelGGL with a
@@ -374,10 +378,12 @@ static int launch_variant(bq_ctx *ctx, const void *panel, int storage, bool add_
                           const double *w, double *slab, double *out, int mode, const int *done, const bq_epilogue *epi) {
     constexpr int JG = JG_DEFAULT;
     BQ_TRY((launch_tiles<JG, SR>(ctx, panel, storage, add_one, tab.cut[tab.lo], tab.cut[tab.hi], nb, w, slab, done)));
-    if (mode == 0 && epi != nullptr)
-        symv_reduce_kernel<JG, true><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, *epi);
+    if (mode == 0 && bq_epi_mode(epi) == BQ_EPI_PGFW)
+        symv_reduce_kernel<JG, BQ_EPI_PGFW><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, *epi);
+    else if (mode == 0 && bq_epi_mode(epi) == BQ_EPI_AL)
+        symv_reduce_kernel<JG, BQ_EPI_AL><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, *epi);
     else if (mode == 0)
-        symv_reduce_kernel<JG, false><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, bq_epilogue{});
+        symv_reduce_kernel<JG, BQ_EPI_NONE><<<(unsigned)nb, 1024, 0, ctx->stream>>>(slab, nb, tab, out, done, bq_epilogue{});
     else if (tab.hi > tab.lo)
         symv_reduce_seg_kernel<JG><<<dim3((unsigned)nb, (unsigned)(tab.hi - tab.lo)), 1024, 0, ctx->stream>>>(slab, nb, tab, out, done);
     BQ_HIP(hipGetLastError());
@@ -418,10 +424,12 @@ int bq_launch_symv_segments(bq_ctx *ctx, const void *panel, int storage, bool ad
 int bq_launch_symv_segsum(bq_ctx *ctx, int64_t nb, const bq_seg_table &tab, const double *gath, double *out, const int *done,
                           const bq_epilogue *epi) {
     const int64_t len = nb * ST;
-    if (epi != nullptr)
-        symv_segsum_kernel<true><<<(unsigned)nb, 256, 0, ctx->stream>>>(gath, len, tab, out, done, *epi);
+    if (bq_epi_mode(epi) == BQ_EPI_PGFW)
+        symv_segsum_kernel<BQ_EPI_PGFW><<<(unsigned)nb, 256, 0, ctx->stream>>>(gath, len, tab, out, done, *epi);
+    else if (bq_epi_mode(epi) == BQ_EPI_AL)
+        symv_segsum_kernel<BQ_EPI_AL><<<(unsigned)nb, 256, 0, ctx->stream>>>(gath, len, tab, out, done, *epi);
     else
-        symv_segsum_kernel<false><<<(unsigned)nb, 256, 0, ctx->stream>>>(gath, len, tab, out, done, bq_epilogue{});
+        symv_segsum_kernel<BQ_EPI_NONE><<<(unsigned)nb, 256, 0, ctx->stream>>>(gath, len, tab, out, done, bq_epilogue{});
     BQ_HIP(hipGetLastError());
     return BQ_OK;
 }

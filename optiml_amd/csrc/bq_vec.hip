@@ -125,6 +125,12 @@ int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *do
     return BQ_OK;
 }
 
+int bq_launch_prep(bq_problem *p, const double *v, const int *done) {
+    prep_kernel<<<vec_grid(p->ld), BQ_VEC_BLOCK, 0, p->ctx->stream>>>(p->structure, p->n, v, p->sgn, p->w, done);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
+}
+
 int bq_problem_apply(bq_problem *p, const double *v, double *out, const int *done) {
     bq_ctx *ctx = p->ctx;
     const double *w = v;

@@ -144,6 +144,9 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys, tmp_pa
 
     def fake_child(argv, timeout):
         calls.append((list(argv), timeout))
+        if '--dense' in argv:
+            lay = lambda v, f: {'value': v, 'roofline': {'frac': f, 'avg_launch_ms': 0.3}}
+            return {'what': 'dense_quadratic', 'n': 20000, 'layouts': {'packed': lay(3500.0, 0.81), 'rows': lay(2000.0, 0.85)}}, None, 5.0
         if '--collective-floor' in argv:
             return {'what': 'collective_floor', 'headline': {'gather_8_segments': {'mean_us': 5.0}, 'allreduce': {'mean_us': 4.0}}}, None, 1.0
         if '--emulate-shares' in argv:
@@ -167,9 +170,15 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys, tmp_pa
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
     bench.orchestrate(args)
     lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
-    # the LAST stdout line is the compact record and the only one (r04's 25.6 KB line overflowed the driver's 12.8 KB tail)
-    assert len(lines) == 1 and len(lines[-1]) < bench.LINE_LIMIT == 4096
+    # the LAST stdout line is the compact record (r04's 25.6 KB line overflowed the driver's 12.8 KB tail); the one before it is the
+    # same record as it stood when the headline child returned (a run cut during the side records leaves THAT as its last line)
+    assert len(lines) == 2 and all(len(l) < bench.LINE_LIMIT == 4096 for l in lines)
+    first = json.loads(lines[0])
+    assert first['value'] == 160.0 and first['roofline']['frac'] == 0.82 and first['cpu_baseline']['value'] == 0.2
+    assert 'side' not in first and 'headline record only' in first['state']
     line = json.loads(lines[-1])
+    assert 'state' not in line
+    assert line['side']['dense_c2_packed_rows_iter_s'] == [3500.0, 2000.0] and line['side']['dense_c2_packed_rows_frac'] == [0.81, 0.85]
     assert line['value'] == 160.0 and line['steps'] == 20 and line['warmup'] == 5 and line['n_gpus'] == 1
     assert line['roofline']['frac'] == 0.82 and line['cpu_baseline']['value'] == 0.2
     assert line['side']['c2_iter_s'] == 10.0 and line['side']['c5_products_per_outer_it'] == 10.0 and line['side']['as_c2_s'] == 10.0
@@ -197,6 +206,47 @@ def test_default_line_is_composed_from_child_records(monkeypatch, capsys, tmp_pa
     rec = json.load(open(args.records_file))
     assert len(calls) == 1 and all('skipped' in v for v in rec['configs'].values())
     assert line['value'] == 160.0 and 'skipped' not in line and all('budget left' in line['side'][f'{c}_iter_s'] for c in ('c2', 'c4', 'c5'))
+
+
+def test_a_run_cut_after_the_headline_child_leaves_a_parseable_last_line(monkeypatch, capsys, tmp_path):
+    """The driver's limit (or a slow box) can end the default run while the side records are being measured — round 4 lost its whole
+    record that way.  The line is therefore printed as soon as the headline record exists: here the first side record's child never
+    returns (the parent is interrupted inside it), and the last stdout line still parses with every contract field."""
+    sys.path.insert(0, REPO)
+    import bench
+    args = bench.parse(['--gpus', '1', '--steps', '20', '--warmup', '5'])
+    args.records_file = str(tmp_path / 'bench_records.json')
+    head = {'metric': 'dual_qp_iterations_per_sec', 'value': 163.0, 'unit': 'iter/s', 'n_gpus': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 6.13,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'svc_hinge_rbf_pg_dual_n100000_d128', 'n': 100000, 'd': 128, 'panel_placement_ms': [6.3312345, 6.0912345],
+                       'placement_budget': 'steady state: up to 5 s (SVC.fit: 2 % of max_iter products, 0.2 s at least)', 'device': 'X (gfx950)'},
+            'roofline': {'bound': 'hbm', 'achieved': 6650.0, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.83, 'traffic': None, 'avg_launch_ms': 6.06,
+                         'frac_first_placement': 0.795},
+            'cpu_baseline': {'value': 0.23, 'unit': 'iter/s', 'cores': 64, 'kind': 'port', 'sample': 'oracle PG'}}
+    calls = []
+
+    def child(argv, timeout):
+        calls.append(list(argv))
+        if len(calls) == 1:
+            return dict(head), None, 100.0
+        raise KeyboardInterrupt   # the cut: what a SIGINT / the end of the caller's patience looks like from inside the parent
+
+    monkeypatch.setattr(bench, '_run_child', child)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
+    with pytest.raises(KeyboardInterrupt):
+        bench.orchestrate(args)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(calls) == 2 and len(lines) == 1
+    line = json.loads(lines[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line
+    assert line['value'] == 163.0 and line['roofline']['frac'] == 0.83 and line['cpu_baseline']['value'] == 0.23
+    # the line says which placement it is and what the first allocation would have read (VERDICT r5 item 2)
+    assert line['config']['panel_placement_ms'] == [6.331, 6.091] and line['config']['placement_budget'] == 'steady state'
+    assert line['roofline']['frac_first_placement'] == 0.795
+    assert 'headline record only' in line['state']
+    assert json.load(open(args.records_file))['value'] == 163.0
 
 
 def test_compact_line_stays_under_the_limit_whatever_the_record_holds():
