@@ -20,6 +20,9 @@
 
 constexpr int GT = BQ_GT;
 constexpr int GK = BQ_GK;
+#ifndef BQ_STREAM_FOLD
+#define BQ_STREAM_FOLD 0
+#endif
 
 __global__ void transpose_pad_kernel(const double *__restrict__ X, int64_t n, int64_t d, double *__restrict__ Xt,
                                      int64_t np, int64_t dp) {
@@ -151,6 +154,9 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
         const int64_t pitch = P.lower_only ? bq_sym_pitch(arow / BQ_SYM_TILE) : P.ld;
         const int64_t tile0 = P.lower_only ? bq_sym_addr(arow, 0, I0) : (arow - P.arow0) * P.ld;   // uniform
         T *const lane_base = out + tile0 + (int64_t)(wr * 64 + 2 * crow) * pitch + bcol + wc * 64 + 2 * ccol;
+        double bj[4];   // the squared norms of this lane's four columns, once per tile (b2 is padded to the image pitch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bj[j] = KIND == BQ_KERNEL_RBF ? P.b2[bcol + bq_acc_col(2 * (j >> 1)) + (j & 1)] : 0.0;
         auto epilogue = [&](auto on_diag, auto on_edge, auto deg) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(gram_params P, T *__r
                             if (KIND == BQ_KERNEL_RBF) {
                                 double dist = -2.0 * dot;
                                 dist += ai;
-                                dist += P.b2[gj + h];   // padded to the image pitch
+                                dist += bj[2 * jp + h];
                                 dist = fmax(dist, 0.0);
                                 if (decltype(on_diag)::value && P.same && gi == gj + h) dist = 0.0;
                                 kv[h] = bq_exp(-P.gamma * dist);
@@ -541,6 +547,24 @@ __global__ __launch_bounds__(256, 2) void gram_stream_sym_kernel(gram_params P, 
         int64_t opaque = 0;
         asm volatile("" : "+s"(opaque));
         const double one = add_one ? 1.0 : 0.0;
+        // the squared norms of this lane's four columns, once per tile (round 6: read per element they were 64 dependent loads per
+        // lane and tile between the accumulators and the exponentials: profiles/r06/gram_epilogue_variants.txt)
+        double bj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bj[j] = KIND == BQ_KERNEL_RBF ? P.b2[bcol + bq_acc_col(j)] : 0.0;
+        double wj[4];   // ... and the product's input over them (zero beyond n: padded to the panel pitch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wj[j] = w[bcol + bq_acc_col(j)];
+#if BQ_STREAM_FOLD
+        // MEASURED VARIANT, not the product (build with -DBQ_STREAM_FOLD=1): the argument of the exponential as
+        // fma(2 gamma, x.y, c_i + c_j), c = -gamma |x|^2 per row / per column, clamped from above at 0 — three vector instructions per
+        // element instead of five, another rounding of the distances than sklearn's (-2 x.y + |x|^2 + |y|^2, clamped at 0).
+        // profiles/r06/gram_epilogue_variants.txt has what it buys.
+        const double g2 = 2.0 * P.gamma;
+        double cj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cj[j] = -P.gamma * bj[j];
+#endif
         auto epilogue = [&](auto on_diag, auto deg) {
             double col[4] = {0.0, 0.0, 0.0, 0.0};
             double part[16];   // one per accumulator row of this lane; folded over the 16 lanes of a row after the maps
@@ -558,12 +582,19 @@ __global__ __launch_bounds__(256, 2) void gram_stream_sym_kernel(gram_params P, 
                         const double dot = acc[i][j][v];
                         double kv;
                         if (KIND == BQ_KERNEL_RBF) {
+#if BQ_STREAM_FOLD
+                            double arg = fma(g2, dot, -P.gamma * ai + cj[j]);   // (-gamma a_i: once per row, hoisted by the compiler)
+                            arg = fmin(arg, 0.0);
+                            if (decltype(on_diag)::value && gi == gj) arg = 0.0;
+                            kv = bq_exp(arg);
+#else
                             double dist = -2.0 * dot;
                             dist += ai;
-                            dist += P.b2[gj];
+                            dist += bj[j];
                             dist = fmax(dist, 0.0);
                             if (decltype(on_diag)::value && gi == gj) dist = 0.0;
                             kv = bq_exp(-P.gamma * dist);
+#endif
                         } else if (KIND == BQ_KERNEL_POLY) {
                             kv = bq_poly_map<decltype(deg)::value>(P.gamma * dot + P.coef0, P.degree);
                         } else if (KIND == BQ_KERNEL_SIGMOID) {
@@ -572,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void gram_stream_sym_kernel(gram_params P, 
                             kv = dot;
                         }
                         kv += one;
-                        pr = fma(kv, w[gj], pr);   // w is zero beyond n (padded to the panel pitch)
+                        pr = fma(kv, wj[j], pr);
                         if (!decltype(on_diag)::value) col[j] = fma(kv, wi, col[j]);   // the diagonal tile is used once
                         if ((KIND == BQ_KERNEL_RBF || (KIND == BQ_KERNEL_POLY && decltype(deg)::value == 0)) && ((j + 1) % STREAM_SYM_EXP_ILP == 0))
                             __builtin_amdgcn_sched_barrier(0);
