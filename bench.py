@@ -147,6 +147,9 @@ def parse(argv=None):
                     help='dense Quadratic(Q, q) of --samples variables (optiml/opti/_base.py:228-300; a banded symmetric Q whose product '
                          'is known in closed form): the product and ProjectedGradient iterations on the packed lower-triangle copy the '
                          'library keeps when Q == Q\' exactly, and on the row blocks it keeps otherwise (forced), each with its roofline')
+    ap.add_argument('--wall-limit', type=float, default=0.0,
+                    help='--solver ip | as: stop the fit after this many seconds (0: none) and report how far it got — for the fits that '
+                         'need ~n outer iterations at the headline size (tools/profile_kkt_headline.sh)')
     ap.add_argument('--cpu-study', action='store_true',
                     help='CPU only (SURVEY 8d): the oracle timed at three sizes to check the n^2 (PG) / n^3 (Cholesky) laws '
                          'behind the extrapolated baseline, plus a blocked Gram-streaming product at the full n')
@@ -517,7 +520,7 @@ def kkt_smo(n, d, sigma, X=None, y=None, cpu=True, cpu_n=12000):
     return rec
 
 
-def kkt_box(solver, n, d, sigma, cpu=True):
+def kkt_box(solver, n, d, sigma, cpu=True, wall_limit=0.0):
     """SVC.fit(optimizer=InteriorPoint | ActiveSet) end to end on one GPU, to the solver's own stop test.  roofline: fp64 MFMA
     fraction of the Cholesky factorisations (n^3/3 flop each, HIP-event time of the factorisation kernels).  CPU: the oracle's
     per-iteration cost at a bounded n scaled by the n^3 law to THIS n, times the iteration count — labelled."""
@@ -530,6 +533,19 @@ def kkt_box(solver, n, d, sigma, cpu=True):
     ctx = device.get_context()
     X, y = make_blobs(n, d, seed=0, sigma=sigma)
     cls = InteriorPoint if solver == 'ip' else ActiveSet
+    if wall_limit > 0:
+        base = cls
+
+        class cls(base):   # the same solver; its callback also looks at the clock every 256th iteration
+            def callback(self, args=()):
+                base.callback(self, args)
+                if not self.iter % 256:
+                    if not self.iter % 4096:
+                        print(f'[bench] {base.__name__} n={n}: iteration {self.iter}, f = {self.f_x:.8g}, {time.perf_counter() - t0:.0f} s',
+                              file=sys.stderr, flush=True)
+                    if time.perf_counter() - t0 > wall_limit:
+                        raise StopIteration
+        cls.__name__ = base.__name__
     ctx.profile(True)
     ctx.profile_read(_lib.PROF_CHOL, reset=True)
     import threading
@@ -552,6 +568,13 @@ def kkt_box(solver, n, d, sigma, cpu=True):
            'status': o.status, 'f': float(o.f_x), 'n_sv': int(len(est.support_)), 's_per_iteration': dt / max(o.iter, 1),
            'stop_test': 'relative gap <= 1e-10' if solver == 'ip' else 'no wrong-sign multiplier (exact)',
            'includes': 'Gram build + iterations + intercept'}
+    if wall_limit > 0:
+        rec['wall_limit_s'] = wall_limit
+        rec['cut_at_wall_limit'] = o.status == 'unknown'
+    if solver == 'as':
+        rec['bounds_at_the_end'] = {'at_lower': int(o.L.sum()), 'at_upper': int(o.U.sum()), 'free': int(n - o.L.sum() - o.U.sum())}
+        rec['counters'] = {'minres_iterations': int(o.minres_iterations), 'product_free_iterations': int(o.product_free_iterations),
+                           'base_factorisations': int(ch_cnt)}
     if solver == 'ip' and ch_cnt:
         flops = n ** 3 / 3.0
         tf = flops / (ch_ms / ch_cnt * 1e-3) / 1e12
@@ -610,7 +633,7 @@ def bench_kkt_line(args):
     if args.solver == 'smo':
         rec = kkt_smo(args.n, args.d, args.sigma, cpu=not args.no_cpu)
     else:
-        rec = kkt_box(args.solver, args.n, args.d, args.sigma, cpu=not args.no_cpu)
+        rec = kkt_box(args.solver, args.n, args.d, args.sigma, cpu=not args.no_cpu, wall_limit=args.wall_limit)
     steps = rec.get('iterations', rec.get('outer_iterations', 0))
     out = {'metric': 'time_to_kkt_tol', 'value': rec['value'], 'unit': 's', 'n_gpus': 1, 'steps': int(steps), 'warmup': 0,
            'ms_per_step': 1e3 * rec['value'] / max(steps, 1), 'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None,
@@ -994,13 +1017,14 @@ def orchestrate(args):
                         # panel's placement moves it by +-3 % from process to process: a difference of two processes' numbers is
                         # noise); the share run contributes only what a product costs beside its tile kernel (slab reduction, O(n))
                         p1 = one['roofline']['avg_launch_ms'] + (g1['slowest_share_ms_per_step'] - g1['slowest_share_symv_tiles_ms'])
-                        # ... of which the implicit order-2 remainder of the preconditioner is sharded by samples (round 5): it costs
-                        # 1 / G of its one-GPU time (HIP events around it in the c5 record) + two more collectives per application
+                        # ... of which the preconditioner's applications are sharded by samples (round 5: the implicit remainder; round 6:
+                        # the explicit model's passes too): 1 / G of their one-GPU time (HIP events around them in the c5 record) + their
+                        # collectives (preconditioner_collectives_per_call per application)
                         shard = one.get('preconditioner_sharded_ms_per_step', 0.0)
                         calls = one.get('preconditioner_sharded_calls_per_step', 0.0)
                         repl = one['ms_per_step'] - prods * p1 - shard
                         share_ms = part['slowest_share_ms_per_step'] + tab['assumed_exchange_us'] * 1e-3
-                        part['ascg_outer_iteration_ms_predicted'] = prods * share_ms + repl + shard / part['G'] + 2 * calls * tab['assumed_exchange_us'] * 1e-3
+                        part['ascg_outer_iteration_ms_predicted'] = prods * share_ms + repl + shard / part['G'] + one.get('preconditioner_collectives_per_call', 2) * calls * tab['assumed_exchange_us'] * 1e-3
                         part['ascg_replicated_ms_per_outer_iteration'] = repl
                         part['ascg_sample_sharded_ms_per_outer_iteration_one_gpu'] = shard
                         part['ascg_one_gpu_product_step_ms'] = p1
@@ -1500,20 +1524,24 @@ def main():
         if ascg:
             out['inner_products_per_step'] = inner / max(done, 1)
             out['inner_tol'] = args.inner_tol
-            fam = os.environ.get('BQ_AS_CG_PC_CLASS', '2')
+            hooks = dict(h.split('=', 1) for h in os.environ.get('BQ_TEST_HOOKS', '').split(',') if '=' in h)
+            fam = hooks.get('as_cg_pc_class', '2')
             out['inner_preconditioner'] = 'none (BQ_AS_CG_PC=0)' if os.environ.get('BQ_AS_CG_PC') == '0' else \
                 'diagonal + Taylor features of the RBF kernel through Woodbury: orders 0-1 (d + 2 columns)' + \
                 {'2': ' + the order-2 term projected onto the 2d class-mean directions (3d + 2 columns in all)' +
-                      (', the rest of the order-2 term applied without features behind a degree-1 Chebyshev polynomial' if n >= 65536 and 'BQ_AS_CG_PC_CLASS' not in os.environ else ''),
+                      (', the rest of the order-2 term applied without features behind a degree-1 Chebyshev polynomial' if n >= 65536 and 'as_cg_pc_class' not in hooks else ''),
                  '3': ' + the order-2 term projected onto the 2d class-mean directions + its implicit remainder (forced)',
                  '1': ' + the class-mean cross term of rounds 3-4 (2d + 2 columns in all)'}.get(fam, '')
             out['time_to_kkt_projected'] = c5_projection(n, d, 1e3 * elapsed / max(done, 1))
-            out['inner_warm_start'] = os.environ.get('BQ_AS_CG_WARM') != '0'
+            out['inner_warm_start'] = hooks.get('as_cg_warm') != '0'
             out['products_per_sec'] = mv_cnt / elapsed
-            # the sample-sharded part of the preconditioner (the implicit order-2 remainder: moment slices, x'Mx, v of a rank's own
-            # samples): HIP events around it; on G ranks it costs 1/G of this + two more collectives per application
+            # one application of the preconditioner (HIP events around it): every pass over samples in it is sharded since round 6 — the
+            # explicit model's two passes over the features and the implicit order-2 remainder; on G ranks it costs 1/G of this + its
+            # collectives (2 for the explicit model alone; 6 with the remainder: t, z, M + Phi_top'y, v, t, z)
+            remainder = fam == '3' or (n >= 65536 and 'as_cg_pc_class' not in hooks and fam == '2')
             out['preconditioner_sharded_ms_per_step'] = pcs_ms / max(done, 1)
             out['preconditioner_sharded_calls_per_step'] = pcs_cnt / max(done, 1)
+            out['preconditioner_collectives_per_call'] = 6 if remainder else 2
         traffic = measured_traffic(workload, world) if args.storage == 'f64' else None
         if traffic:
             out['roofline']['traffic'] = traffic['hbm_bytes']

@@ -249,7 +249,7 @@ int bq_ctx_release_held_memory(bq_ctx *ctx, int64_t *bytes);
  * BQ_AS (active_set.py:82-237): same masks, candidate / ratio step, Bland release and tolerances as the reference; the
  * restricted system of line :141 is solved from a Cholesky factor that is KEPT across iterations (the free set moves by
  * one index at a time: the changes are carried through a Schur complement on a base factor, which is rebuilt every 96 to 512
- * changes; environment BQ_AS_SCHUR=0 re-factorises in every iteration like the reference).  A non-positive pivot takes
+ * changes; hook as_schur=0 re-factorises in every iteration like the reference).  A non-positive pivot takes
  * the reference's minres branch (:142-151). */
 int bq_solver_create(bq_problem *p, int kind, const double *lb, const double *ub, const double *x0,
                      double eps, int64_t max_iter, double fw_t, bq_solver **out);
@@ -270,7 +270,7 @@ int bq_solver_inner_iters(bq_solver *s, int64_t *total);
  *   BQ_COUNT_REFACTOR  base-set factorisations of the kept-factor path;  BQ_COUNT_REUSED  iterations solved through a kept factor
  *   BQ_COUNT_INNER     = bq_solver_inner_iters
  *   BQ_COUNT_NO_PRODUCT  ratio-step iterations (active_set.py:152-176) whose f(x) came from the line-search identity
- *                      f(x + t d) = f(x) + (t - t^2/2) g_A'd_A instead of a product with Q (BQ_AS_F_CHAIN=0: none) */
+ *                      f(x + t d) = f(x) + (t - t^2/2) g_A'd_A instead of a product with Q (hook as_f_chain=0: none) */
 #define BQ_COUNT_INNER 0
 #define BQ_COUNT_MINRES 1
 #define BQ_COUNT_REFACTOR 2

@@ -98,13 +98,27 @@ void bq_ctx_cache_put(bq_ctx *c, void *panel, size_t bytes) {
     c->panel_cache_bytes = bytes;
 }
 
+// BQ_TEST_HOOKS="name=value,...": bq_common.h
+bool bq_hook(const char *name, double *value) {
+    const char *e = getenv("BQ_TEST_HOOKS");
+    if (e == nullptr) return false;
+    const size_t len = strlen(name);
+    for (const char *p = e; *p;) {
+        const char *end = strchr(p, ',');
+        const size_t item = end ? (size_t)(end - p) : strlen(p);
+        if (item > len && strncmp(p, name, len) == 0 && p[len] == '=') {
+            if (value) *value = atof(p + len + 1);
+            return true;
+        }
+        p += item + (end ? 1 : 0);
+    }
+    return false;
+}
+
 hipError_t bq_device_malloc(void **ptr, size_t bytes) {
-    // BQ_TEST_ALLOC_FAIL_ABOVE=<bytes>: test hook — requests above the threshold fail ONCE per request while a cached
+    // hook alloc_fail_above=<bytes>: requests above the threshold fail ONCE per request while a cached
     // panel exists, so that the drop-and-retry path is exercised without exhausting a 288 GB device
-    static const long long fail_above = [] {
-        const char *e = getenv("BQ_TEST_ALLOC_FAIL_ABOVE");
-        return e ? atoll(e) : -1ll;
-    }();
+    const long long fail_above = (long long)bq_hook_value("alloc_fail_above", -1.0);
     hipError_t e = hipSuccess;
     bool simulated = false;
     if (fail_above >= 0 && (long long)bytes > fail_above) {

@@ -531,9 +531,8 @@ static int place_panel(bq_problem *p, double first_alloc_ms) {
     bq_ctx *c = p->ctx;
     if (!p->symmetric || p->streamed || p->panel == nullptr || p->panel_bytes < ((size_t)1 << 30) || p->I1 <= p->I0) return BQ_OK;
     const int want = 3;   // allocations tried at most (a 4th never won in round 4's sweeps: profiles/r04/placement_*.txt)
-    const char *e = getenv("BQ_PANEL_GOOD_GBS");
-    const double good_gbs = e ? atof(e) : 6500.0;
-    e = getenv("BQ_PLACE_BUDGET_MS");
+    const double good_gbs = bq_hook_value("panel_good_gbs", 6500.0);
+    const char *e = getenv("BQ_PLACE_BUDGET_MS");
     const double budget_min = c->place_min_ms >= 0.0 ? c->place_min_ms : (e ? atof(e) : 200.0);
     double budget_ms = budget_min;   // grows with the work the caller expects once the product's time is known (below)
     const auto t_start = std::chrono::steady_clock::now();

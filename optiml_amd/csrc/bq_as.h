@@ -38,6 +38,14 @@ struct as_cg_scal {
     int pc, pad;
 };
 
+// the sample segments of the sharded parts of the preconditioner (bq_as_pc.hip, bq_as_pc2.hip): segment k = sample blocks [blk[k], blk[k + 1]) of 1024 samples,
+// this rank owns [lo, hi); gathered buffers hold world * cmax slots of maxlen blocks (a kernel argument: plain data)
+struct as_pc_part {
+    int S, lo, hi, cmax;
+    int slot[BQ_SYM_SEG_MAX];
+    long long blk[BQ_SYM_SEG_MAX + 1];
+    long long maxlen;
+};
 // Preconditioner of the inner conjugate gradients: P = D + Phi Phi' restricted to the free set, Phi (N x m, m << N) an
 // explicit low-rank factor (stored in fp32) of the smooth part of the Hessian and D the diagonal left over.  Applied through Woodbury:
 //   P_AA^-1 r = D^-1 r - D^-1 Phi_A G^-1 Phi_A' D^-1 r,   G = I + Phi_A' D_A^-1 Phi_A  (m x m, factorised once per outer iteration).
@@ -53,7 +61,6 @@ struct as_pc {
                              // over Phi per inner iteration move half the bytes (round 4)
     int64_t m8 = 0;          // m rounded up to the feature group of the t = Phi' D^-1 r kernel
     double *tpart = nullptr; // nblk x mp: per-sample-block partial sums of t
-    unsigned int *tticket = nullptr;
     double *dinv = nullptr;  // ldN: 1 / D_i
     double *z = nullptr;     // ldN: preconditioned residual
     double *Gpart = nullptr; // slices x mp x mp partial Gram sums
@@ -75,6 +82,12 @@ struct as_pc {
     int top0 = 0, ntop = 0;       // the Phi_top columns (the projected order-2 directions) of the explicit model
     double *y1 = nullptr, *v2 = nullptr, *z2 = nullptr, *ones = nullptr;   // ldN each: y = P1^-1 r, R y, P1^-1 R y; weights 1
     double *ttop = nullptr;       // mp: Phi_top' y
+    // the explicit model's two passes over Phi are sums over / values of SAMPLES: sharded by the canonical sample segments like the
+    // remainder (round 6) — a rank walks its own sample blocks, the per-segment sums of t (S x mp doubles) and the rank's z are
+    // gathered, everything is added / unpacked in segment order on every rank (and in the same order on one rank)
+    as_pc_part part;
+    double *tg = nullptr;         // (world * cmax) x mp: per-segment sums of t = Phi' D^-1 r, gathered
+    double *zg = nullptr;         // (world * cmax) x maxlen x 1024: z in the gathered layout
     long long lambda_nA = 0;      // size of the free set the spectrum bound of the remainder was estimated on (a larger set needs a new one)
 };
 
@@ -97,7 +110,7 @@ struct as_ws {
     // host_scal (and the kept-factor path's small_pin) are MAPPED, coherent pinned memory; the kernel that completes a record stores
     // it there itself and then posts a sequence number into `mail` — [0] top of the iteration (as_top_kernel), [1] the dot
     // products of a new slot (as_schur_dots_kernel), [2] the candidate's feasibility (as_cand_scatter_kernel) — on which the host
-    // spins (bq_ctx_wait_flag).  BQ_AS_MAILBOX=0: copies + hipStreamSynchronize as before.
+    // spins (bq_ctx_wait_flag).  hook as_mailbox=0: copies + hipStreamSynchronize as before.
     int *mail = nullptr;
     int *mail_d = nullptr, *host_ints_d = nullptr, *host_scal_d = nullptr;   // the device's addresses of mail / host_ints / host_scal
     int mail_seq[3] = {0, 0, 0};
@@ -127,7 +140,7 @@ struct as_ws {
     hipEvent_t cg_event = nullptr; // recorded behind the copy of the flag (lagged polling of the inner iteration)
     long long cg_iters = 0;
     double *Qdl = nullptr, *Qcand = nullptr;   // Q delta accumulated over the inner iterations; Q cand = Q z + Q delta
-    bool incq = true;              // BQ_AS_CG_INCQ=0: a fresh product Q x after every outer iteration (round 2)
+    bool incq = true;              // hook as_cg_incq=0: a fresh product Q x after every outer iteration (round 2)
     bool colq = false;             // the start product of a warm-started solve is Q cand + a few columns of Q formed from X
     double *sq = nullptr;          // ldN: squared row norms of X (the columns' RBF distances)
     int *zchg = nullptr;           // [0] count, [1] 1 = columns suffice (the start product is skipped), [2 ..] indices
@@ -137,7 +150,7 @@ struct as_ws {
     long long pc_rebuilds = 0, pc_dropped = 0;   // Woodbury system not positive definite: G summed afresh / preconditioner given up
     as_pc *pc = nullptr;           // null: plain conjugate gradients
     bool have_cand = false;        // w->cand holds the candidate of the previous outer iteration (the warm start)
-    bool warm = true;              // BQ_AS_CG_WARM=0: start every inner solve from the current point
+    bool warm = true;              // hook as_cg_warm=0: start every inner solve from the current point
 };
 
 
@@ -286,7 +299,7 @@ static __global__ void as_cand_scatter_idx_kernel(const int *__restrict__ idx, i
 }
 // ---- host-side helpers ----------------------------------------------------------------------------------------
 static inline as_ws *get_ws(bq_solver *s) { return reinterpret_cast<as_ws *>(s->as_ws); }
-static inline bool as_env_on(const char *name) {
+static inline bool as_env_on(const char *name) {   // a user-level switch: BQ_AS_CG_PC=0
     const char *e = getenv(name);
     return !(e && atoi(e) == 0);
 }
@@ -360,16 +373,10 @@ int as_cg_iterate(bq_solver *s, as_ws *w);     // the body of one outer iteratio
 
 // ---- preconditioner (bq_as_pc.hip, bq_as_pc2.hip) ------------------------------------------------------------
 constexpr int PC_MAX_M = 1024;   // features the apply kernels keep in LDS
-// the sample segments of the sharded order-2 remainder (bq_as_pc2.hip): segment k = sample blocks [blk[k], blk[k + 1]) of 1024 samples,
-// this rank owns [lo, hi); gathered buffers hold world * cmax slots of maxlen blocks (a kernel argument: plain data)
-struct as_pc_part {
-    int S, lo, hi, cmax;
-    int slot[BQ_SYM_SEG_MAX];
-    long long blk[BQ_SYM_SEG_MAX + 1];
-    long long maxlen;
-};
 typedef float as_f4 __attribute__((ext_vector_type(4)));
-int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out);
+void as_pc_make_part(const bq_ctx *ctx, int64_t nblk, as_pc_part *pt);   // the canonical sample segments of nblk blocks of 1024 samples
+int as_pc2_create(bq_solver *s, double *bdiag_out, int64_t tail, as_pc2 **out);
+double *as_pc2_tail(const as_pc2 *r, int64_t *gstride);
 void as_pc2_free(as_pc2 *r);
 int as_pc2_bpart(bq_solver *s, as_pc2 *r, const double *y, const as_cg_scal *cg);
 const double *as_pc2_ypart(const as_pc2 *r, int *tiles);

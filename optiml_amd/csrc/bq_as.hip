@@ -17,7 +17,7 @@
 // silently switches to scipy's minres on the normal equations (:142-151): here a persistent single-workgroup MINRES
 // kernel (bq_minres.hip) takes over for |A| <= 8192.
 //
-// Factor re-use (default for every non-empty free set; BQ_AS_SCHUR=0 re-factorises every iteration as the reference does): between
+// Factor re-use (default for every non-empty free set; hook as_schur=0 re-factorises every iteration as the reference does): between
 // two consecutive iterations the free set changes by one or a few indices, so the Cholesky factor of a BASE set A0 is
 // kept and the current restricted system is solved through its Schur complement — variables of A0 that have reached a
 // bound since are pinned by a multiplier row (x_k = bound), variables released since are bordered on:
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void as_write_free_kernel(int64_t N, const uns
 // free set (fixed order: per block, then over the blocks) and its last block moves f and gamma (sc->aux[0]; as_release_mb_kernel
 // sets it back to 1).  The host asks for this only while every candidate since that release came from a factorisation (not from
 // the minimum-residual branch) and forms f by a product again every 64th step of a run (chain == 2: only gamma moves; as_finish_iteration);
-// BQ_AS_F_CHAIN=0: never.
+// hook as_f_chain=0: never.
 __global__ __launch_bounds__(256) void as_step_min_kernel(int64_t N, const unsigned char *__restrict__ mL,
                                                           const unsigned char *__restrict__ mU, const double *__restrict__ cand,
                                                           const double *__restrict__ lb, const double *__restrict__ ub,
@@ -434,8 +434,8 @@ int bq_as_start(bq_solver *s) {
     w->host_scal_d = reinterpret_cast<int *>(as_dev(w->host_scal));
     BQ_HIP(hipMalloc(&w->mail_ticket, sizeof(unsigned int) * 2));
     BQ_HIP(hipMemsetAsync(w->mail_ticket, 0, sizeof(unsigned int) * 2, s->p->ctx->stream));
-    w->mailbox = !s->as_cg && as_env_on("BQ_AS_MAILBOX");
-    w->f_chain = !s->as_cg && as_env_on("BQ_AS_F_CHAIN");
+    w->mailbox = !s->as_cg && bq_hook_on("as_mailbox");
+    w->f_chain = !s->as_cg && bq_hook_on("as_f_chain");
 #ifdef BQ_AS_TIMING   // diagnostic build (BQ_EXTRA_CXXFLAGS=-DBQ_AS_TIMING): where the host's time goes per iteration, printed by bq_as_free
     w->timing = true;
 #endif
@@ -577,7 +577,7 @@ int bq_as_iterate(bq_solver *s) {
 
     if (s->as_cg) return as_cg_iterate(s, w);
     bool solved = false;
-    // (an empty free set has nothing to keep: with BQ_AS_SCHUR_MIN=0 it reached the kept-factor path and launched empty grids)
+    // (an empty free set has nothing to keep: with hook as_schur_min=0 it reached the kept-factor path and launched empty grids)
     if (as_schur_enabled() && nA > 0 && nA >= as_schur_min()) BQ_TRY(as_schur_step(s, w, nA, &solved));
     if (!solved && w->sch) w->sch->valid = false;   // the classic path below overwrites the kept factor
     if (solved) {

@@ -271,7 +271,7 @@ __global__ void as_cg_gather_kernel(const int *__restrict__ ints, const int *__r
 // the restricted solve of one outer iteration by conjugate gradients; leaves the candidate in w->cand and the
 // feasibility flag in w->host_ints[2].
 //   start: the candidate of the previous outer iteration (the free set has moved by one index since, so it solves the new
-//   system up to one column of Q), else the current point;  BQ_AS_CG_WARM=0: always the current point
+//   system up to one column of Q), else the current point;  hook as_cg_warm=0: always the current point
 //   preconditioner: struct as_pc (RBF and linear panels);   BQ_AS_CG_PC=0: none
 static int as_cg_solve_once(bq_solver *s, as_ws *w, int *pc_failed) {
     *pc_failed = 0;
@@ -443,11 +443,11 @@ int as_cg_create(bq_solver *s, as_ws *w) {
     BQ_HIP(hipMemsetAsync(w->cg, 0, sizeof(as_cg_scal), ctx->stream));
     BQ_HIP(hipHostMalloc(&w->cg_flag_host, 2 * sizeof(int)));
     BQ_HIP(hipEventCreateWithFlags(&w->cg_event, hipEventDisableTiming));
-    w->warm = as_env_on("BQ_AS_CG_WARM");
-    w->incq = as_env_on("BQ_AS_CG_INCQ");
+    w->warm = bq_hook_on("as_cg_warm");
+    w->incq = bq_hook_on("as_cg_incq");
     {
         bq_problem *p = s->p;
-        w->colq = w->warm && as_env_on("BQ_AS_CG_COLQ") && p->X != nullptr && !p->streamed &&
+        w->colq = w->warm && bq_hook_on("as_cg_colq") && p->X != nullptr && !p->streamed &&
                   (p->structure == BQ_PLAIN || p->structure == BQ_SVC) && p->kernel >= BQ_KERNEL_LINEAR &&
                   p->kernel <= BQ_KERNEL_SIGMOID;
         if (w->colq) {

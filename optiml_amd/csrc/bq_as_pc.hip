@@ -390,14 +390,15 @@ constexpr int PC_FG = 8;   // features per butterfly group of the t kernel
 // eight sums), the four wave sums meet in LDS -> tpart[block][j]; the last workgroup to finish adds the blocks in block order.
 // Round 3 had one workgroup per FEATURE re-reading r and 1 / D for each of them: 2.5 GB of L2 traffic beside the 1 GB of
 // features, 0.40 ms per call at BASELINE config 5.  Fixed order throughout: the same bits on every rank.
-__global__ __launch_bounds__(256) void as_pc_tphi_kernel(int m, int64_t m8, int64_t mp, int64_t N, int64_t ld,
+// blockIdx.x counts this rank's sample blocks from block0 on (round 6: the pass is sharded by samples, as_pc_part).
+__global__ __launch_bounds__(256) void as_pc_tphi_kernel(int m, int64_t m8, int64_t mp, int64_t N, int64_t ld, int64_t block0,
                                                          const float *__restrict__ Phi, const double *__restrict__ dinv,
-                                                         const double *__restrict__ r, double *__restrict__ tpart,
-                                                         double *__restrict__ tvec, unsigned int *ticket, const as_cg_scal *cg) {
+                                                         const double *__restrict__ r, double *__restrict__ tpart, const as_cg_scal *cg) {
     if (cg->done) return;
     __shared__ double wsum[4][PC_MAX_M];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + 4 * tid;   // ld is a multiple of the tile: always in range
+    const int64_t blk = block0 + blockIdx.x;
+    const int64_t base = blk * BQ_VEC_TILE + 4 * tid;   // ld is a multiple of the tile: always in range
     // this workgroup's feature groups: a contiguous quarter of the m8 / 8 groups
     const int64_t ngroups = m8 / PC_FG;
     const int64_t g_lo = ngroups * blockIdx.y / gridDim.y, g_hi = ngroups * (blockIdx.y + 1) / gridDim.y;
@@ -438,51 +439,64 @@ __global__ __launch_bounds__(256) void as_pc_tphi_kernel(int m, int64_t m8, int6
         if ((lane & 7) == 0) wsum[wv][j0 - j_lo + rho] = s1;
     }
     __syncthreads();
-    double *mine = tpart + (int64_t)blockIdx.x * mp;
+    double *mine = tpart + blk * mp;
     for (int64_t j = j_lo + tid; j < j_hi; j += 256) {
         const int64_t c = j - j_lo;
         mine[j] = j < m ? ((wsum[0][c] + wsum[1][c]) + wsum[2][c]) + wsum[3][c] : 0.0;
     }
-    (void)tvec;
-    (void)ticket;
 }
 
-// t[j] = the sample blocks' partial sums added in block order: 16 features x 16 interleaved runs of blocks per workgroup (a run's
-// loads are independent of each other: ~15 in flight per lane), the 16 runs then combined in run order.  (As the tail of the
-// kernel above, one workgroup walking 245 dependent, 5 KB-strided loads per feature, it cost more than the pass over Phi.)
-__global__ __launch_bounds__(256) void as_pc_treduce_kernel(int64_t m8, int64_t mp, int64_t nb, const double *__restrict__ tpart,
-                                                            double *__restrict__ tvec, const as_cg_scal *cg) {
+// The sample blocks' partial sums of t, per canonical sample SEGMENT (blockIdx.y counts this rank's segments): 16 features x 16
+// interleaved runs of the segment's blocks per workgroup (a run's loads are independent of each other), the 16 runs then combined
+// in run order -> the segment's slot of the gathered buffer.  (Round 5 added ALL blocks in one such pass on every rank; the
+// association is per segment now, then over the segments in order: as_pc_tsum_kernel — the same on one rank and on eight.)
+__global__ __launch_bounds__(256) void as_pc_tseg_kernel(int64_t m8, int64_t mp, as_pc_part part, const double *__restrict__ tpart,
+                                                         double *__restrict__ tg, int64_t gstride, const as_cg_scal *cg) {
     if (cg->done) return;
     __shared__ double red[16][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t j = (int64_t)blockIdx.x * 16 + tx;
+    const int k = part.lo + (int)blockIdx.y;
     double acc = 0.0;
     if (j < m8)
-        for (int64_t b = ty; b < nb; b += 16) acc += tpart[b * mp + j];
+        for (int64_t b = part.blk[k] + ty; b < part.blk[k + 1]; b += 16) acc += tpart[b * mp + j];
     red[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && j < mp) {
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][tx];
-        tvec[j] = v;
+        for (int q = 0; q < 16; ++q) v += red[q][tx];
+        tg[(int64_t)part.slot[k] * gstride + j] = v;
     }
 }
+// t = the gathered per-segment sums added in segment order (every rank: the same bits)
+__global__ __launch_bounds__(256) void as_pc_tsum_kernel(int64_t mp, as_pc_part part, const double *__restrict__ tg, int64_t gstride,
+                                                         double *__restrict__ tvec, const as_cg_scal *cg) {
+    if (cg->done) return;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= mp) return;
+    double a = 0.0;
+    for (int k = 0; k < part.S; ++k) a += tg[(int64_t)part.slot[k] * gstride + j];
+    tvec[j] = a;
+}
 
-// z = P^-1 r on the free set: z_i = (r_i - Phi_i . u) / D_i, u = G^-1 t;  rz = r'z;  beta = rz / rz_old (first: 0).
+// z = P^-1 r on the free set for THIS RANK's sample blocks (block0 on): z_i = (r_i - Phi_i . u) / D_i, u = G^-1 t, written in the
+// gathered layout (the slot of the block's segment); as_pc_zunpack_kernel brings every rank's part home and takes r'z.
 // A lane owns four consecutive samples (one 16-byte load per feature row), eight feature rows in flight.
-__global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int64_t N, int64_t ld, const float *__restrict__ Phi,
-                                                          const double *__restrict__ dinv, const unsigned char *__restrict__ mL,
-                                                          const unsigned char *__restrict__ mU, const double *__restrict__ r,
-                                                          const double *__restrict__ u, double *__restrict__ z, double *part,
-                                                          int64_t nblk, as_cg_scal *cg, int first, int fin) {
-    // fin == 0: z only (an inner application of P1^-1 inside the polynomial of the order-2 remainder: as_pc_apply)
+__global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int64_t N, int64_t ld, int64_t block0, as_pc_part part,
+                                                          const float *__restrict__ Phi, const double *__restrict__ dinv,
+                                                          const unsigned char *__restrict__ mL, const unsigned char *__restrict__ mU,
+                                                          const double *__restrict__ r, const double *__restrict__ u,
+                                                          double *__restrict__ zg, const as_cg_scal *cg) {
     if (cg->done) return;
     __shared__ double us[PC_MAX_M];
-    __shared__ double sh[4];
     for (int j = threadIdx.x; j < m8; j += BQ_VEC_BLOCK) us[j] = j < m ? u[j] : 0.0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * BQ_VEC_TILE + 4 * threadIdx.x;
+    const int64_t blk = block0 + blockIdx.x;
+    int k = part.lo;
+    while (k + 1 < part.hi && blk >= part.blk[k + 1]) ++k;
+    double *dst = zg + ((int64_t)part.slot[k] * part.maxlen + (blk - part.blk[k])) * BQ_VEC_TILE + 4 * threadIdx.x;
+    const int64_t base = blk * BQ_VEC_TILE + 4 * threadIdx.x;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t j0 = 0; j0 < m8; j0 += PC_FG) {
         as_f4 v[PC_FG];
@@ -497,22 +511,38 @@ __global__ __launch_bounds__(256) void as_pc_apply_kernel(int m, int64_t m8, int
             acc[3] = fma((double)v[f].w, uj, acc[3]);
         }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = base + q;
+        double zi = 0.0;
+        if (i < N && !(mL[i] | mU[i])) zi = dinv[i] * (r[i] - acc[q]);
+        dst[q] = zi;
+    }
+}
+// z (contiguous, every sample) from the gathered layout;  fin: rz = r'z and beta = rz / rz_old (first: 0) of the conjugate gradients
+// (fin == 0: z only — an inner application of P1^-1 inside the polynomial of the order-2 remainder: as_pc_apply)
+__global__ __launch_bounds__(256) void as_pc_zunpack_kernel(int64_t N, as_pc_part part, const double *__restrict__ zg,
+                                                            const double *__restrict__ r, double *__restrict__ z, double *pt_sums,
+                                                            int64_t nblk, as_cg_scal *cg, int first, int fin) {
+    if (cg->done) return;
+    __shared__ double sh[4];
+    const int64_t blk = blockIdx.x;
+    int k = 0;
+    while (k + 1 < part.S && blk >= part.blk[k + 1]) ++k;
+    const double *src = zg + ((int64_t)part.slot[k] * part.maxlen + (blk - part.blk[k])) * BQ_VEC_TILE + 4 * threadIdx.x;
+    const int64_t base = blk * BQ_VEC_TILE + 4 * threadIdx.x;
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int64_t i = base + k;
-        double zi = 0.0;
-        if (i < N && !(mL[i] | mU[i])) {
-            zi = dinv[i] * (r[i] - acc[k]);
-            s += __dmul_rn(r[i], zi);
-        }
-        z[i] = zi;
+    for (int q = 0; q < 4; ++q) {
+        const double zi = src[q];
+        z[base + q] = zi;
+        if (base + q < N) s += __dmul_rn(r[base + q], zi);   // z vanishes outside the free set
     }
     if (!fin) return;
     s = as_block_sum(s, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) pt_sums[blockIdx.x] = s;
     if (as_last_block(&cg->ticket[0])) {
-        const double rz = as_final_sum(part, nblk, sh);
+        const double rz = as_final_sum(pt_sums, nblk, sh);
         if (threadIdx.x == 0) {
             cg->ticket[0] = 0;
             cg->beta = (first || !(cg->rz > 0.0)) ? 0.0 : rz / cg->rz;
@@ -619,6 +649,23 @@ __global__ void as_pc_mask_ones_kernel(int64_t N, int64_t ld, const unsigned cha
 // range (2 g |x|^2 not small) and would make P far worse conditioned than Q itself.
 constexpr double PC_MIN_DIAG_SHARE = 0.1;
 
+// the canonical sample segments (as many as the panel's: 8 up to 8 ranks) in blocks of 1024 samples, this rank's run of them and the
+// slot of every segment in the gathered buffers — a function of the block count and the rank count only
+void as_pc_make_part(const bq_ctx *ctx, int64_t nblk, as_pc_part *out) {
+    as_pc_part &pt = *out;
+    pt.S = bq_sym_segments(ctx->world);
+    pt.lo = bq_sym_seg_first(ctx->rank, ctx->world, pt.S);
+    pt.hi = bq_sym_seg_first(ctx->rank + 1, ctx->world, pt.S);
+    pt.cmax = (pt.S + ctx->world - 1) / ctx->world;
+    pt.maxlen = 0;
+    for (int k = 0; k <= pt.S; ++k) pt.blk[k] = (long long)((int64_t)k * nblk / pt.S);
+    for (int k = 0; k < pt.S; ++k) pt.maxlen = std::max(pt.maxlen, pt.blk[k + 1] - pt.blk[k]);
+    for (int q = 0; q < ctx->world; ++q) {
+        const int lo = bq_sym_seg_first(q, ctx->world, pt.S), hi = bq_sym_seg_first(q + 1, ctx->world, pt.S);
+        for (int k = lo; k < hi; ++k) pt.slot[k] = q * pt.cmax + (k - lo);
+    }
+}
+
 // build the preconditioner's features once per solver (null: the panel's kernel has none, the features do not fit this data,
 // or BQ_AS_CG_PC=0)
 int as_pc_create(bq_solver *s, as_pc **out) {
@@ -629,18 +676,19 @@ int as_pc_create(bq_solver *s, as_pc **out) {
     if (p->kernel != BQ_KERNEL_RBF && !(p->kernel == BQ_KERNEL_LINEAR && p->diag_add > 0.0)) return BQ_OK;
     bq_ctx *ctx = p->ctx;
     // family 2 of the RBF features on BQ_SVC panels: 2 = projected order-2 directions (2d columns), 1 = the class-mean cross term of
-    // rounds 3-4 (d columns), 0 = none.  BQ_AS_CG_PC_CLASS=0|1|2 caps it (tests compare them); a family that does not fit PC_MAX_M
+    // rounds 3-4 (d columns), 0 = none.  hook as_cg_pc_class=0|1|2 caps it (tests compare them); a family that does not fit PC_MAX_M
     // features, or whose model leaves a sample too little of its diagonal, steps down.  With family 2 the REST of the order-2 term is
     // applied without features behind a degree-1 Chebyshev polynomial (bq_as_pc2.hip) where its bulk stands out of the diagonal —
     // n >= 65 536 (its eigenvalues grow like n / (d (d + 1) / 2); below, it costs more launches than it saves products) or
-    // BQ_AS_CG_PC_CLASS=3 (tests).
+    // hook as_cg_pc_class=3 (tests).
     int fam2 = 0;
     bool want_r2 = false;
     if (p->kernel == BQ_KERNEL_RBF && p->structure == BQ_SVC) {
-        const char *e = getenv("BQ_AS_CG_PC_CLASS");
-        const int v = e ? std::max(0, std::min(atoi(e), 3)) : 2;
+        double hv = 2.0;
+        const bool forced = bq_hook("as_cg_pc_class", &hv);
+        const int v = std::max(0, std::min((int)hv, 3));
         fam2 = std::min(v, 2);
-        want_r2 = v == 3 || (e == nullptr && p->n >= 65536);
+        want_r2 = v == 3 || (!forced && p->n >= 65536);
     }
     std::vector<double> share((size_t)p->n);
     // the sum over ranks of a flag, so that every rank takes the same turn (each product of the solve is a collective: a rank that fell
@@ -675,8 +723,15 @@ int as_pc_create(bq_solver *s, as_pc **out) {
         if (rc == BQ_OK) e = hipMalloc(&pc->Phi, sizeof(float) * (size_t)(pc->m8 + PC_FG) * s->ldN);
         if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->Phi, 0, sizeof(float) * (size_t)(pc->m8 + PC_FG) * s->ldN, ctx->stream);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->tpart, sizeof(double) * (size_t)s->nblk * pc->mp);
-        if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->tticket, sizeof(unsigned int));
-        if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->tticket, 0, sizeof(unsigned int), ctx->stream);
+        as_pc_make_part(ctx, s->nblk, &pc->part);
+        {
+            const size_t tgl = sizeof(double) * (size_t)ctx->world * pc->part.cmax * pc->mp;
+            const size_t zgl = sizeof(double) * (size_t)ctx->world * pc->part.cmax * pc->part.maxlen * BQ_VEC_TILE;
+            if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->tg, tgl);
+            if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->tg, 0, tgl, ctx->stream);
+            if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->zg, zgl);
+            if (rc == BQ_OK && e == hipSuccess) e = hipMemsetAsync(pc->zg, 0, zgl, ctx->stream);
+        }
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->dinv, sizeof(double) * s->ldN);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->z, sizeof(double) * s->ldN);
         if (rc == BQ_OK && e == hipSuccess) e = hipMalloc(&pc->Gpart, sizeof(double) * PC_SLICES * pc->mp * pc->mp);
@@ -713,7 +768,7 @@ int as_pc_create(bq_solver *s, as_pc **out) {
             for (double **v : {&pc->y1, &pc->v2, &pc->z2, &pc->ones})
                 if (re == hipSuccess) re = hipMalloc(v, sizeof(double) * s->ldN);
             if (re == hipSuccess) re = hipMalloc(&pc->ttop, sizeof(double) * pc->mp);
-            if (re == hipSuccess && as_pc2_create(s, bdiag, &pc->r2) != BQ_OK) re = hipErrorOutOfMemory;
+            if (re == hipSuccess && as_pc2_create(s, bdiag, pc->mp, &pc->r2) != BQ_OK) re = hipErrorOutOfMemory;
             if (re == hipSuccess && pc->r2 != nullptr) {
                 as_pc_fill_kernel<<<(unsigned)(s->ldN / 256), 256, 0, ctx->stream>>>(s->ldN, 1.0, pc->ones);
                 pc->top0 = (int)p->d + 1;
@@ -857,35 +912,59 @@ void as_pc_free(as_pc *pc) {
     for (void *ptr : {(void *)pc->y1, (void *)pc->v2, (void *)pc->z2, (void *)pc->ones, (void *)pc->ttop})
         if (ptr) hipFree(ptr);
     for (void *ptr : {(void *)pc->Phi, (void *)pc->dinv, (void *)pc->z, (void *)pc->Gpart, (void *)pc->cls, (void *)pc->Ginv,
-                      (void *)pc->u, (void *)pc->sm_fail, (void *)pc->prev, (void *)pc->chg, (void *)pc->tpart, (void *)pc->tticket})
+                      (void *)pc->u, (void *)pc->sm_fail, (void *)pc->prev, (void *)pc->chg, (void *)pc->tpart, (void *)pc->tg, (void *)pc->zg})
         if (ptr) hipFree(ptr);
     delete pc;
 }
 
-// out = P1_AA^-1 in (in vanishes outside the free set); fin: also r'z and beta of the conjugate gradients (in is their residual)
-static void as_pc_solve1(bq_solver *s, as_ws *w, const double *in, double *out, int first, int fin) {
+// t = Phi' (dinv o in) over `m` feature rows of `Phi`, sharded by samples: this rank's blocks -> per-segment sums into its slots of
+// the gathered buffer `tg` (slot pitch gstride); the caller gathers and then adds the segments in order (as_pc_tsum_kernel)
+static void as_pc_tpart(bq_solver *s, as_ws *w, int m, int64_t m8, const float *Phi, const double *dinv, const double *in, double *tg,
+                        int64_t gstride) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
-    const dim3 g1(vgrid(s->ldN).x, 1);
-    as_pc_tphi_kernel<<<g1, BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, pc->mp, s->N, s->ldN, pc->Phi, pc->dinv, in, pc->tpart, pc->ws->rhs, pc->tticket, w->cg);
-    as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(pc->m8, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ws->rhs, w->cg);
+    const as_pc_part &pt = pc->part;
+    const int64_t b0 = pt.blk[pt.lo], b1 = pt.blk[pt.hi];
+    if (b1 <= b0) return;
+    as_pc_tphi_kernel<<<dim3((unsigned)(b1 - b0), 1), BQ_VEC_BLOCK, 0, st>>>(m, m8, pc->mp, s->N, s->ldN, b0, Phi, dinv, in, pc->tpart, w->cg);
+    as_pc_tseg_kernel<<<dim3((unsigned)(pc->mp / 16), (unsigned)(pt.hi - pt.lo)), 256, 0, st>>>(m8, pc->mp, pt, pc->tpart, tg, gstride, w->cg);
+}
+
+// out = P1_AA^-1 in (in vanishes outside the free set); fin: also r'z and beta of the conjugate gradients (in is their residual).
+// Two passes over Phi, both over THIS RANK's samples only; two collectives: the per-segment sums of t (S x mp doubles) and z.
+static int as_pc_solve1(bq_solver *s, as_ws *w, const double *in, double *out, int first, int fin) {
+    as_pc *pc = w->pc;
+    bq_ctx *ctx = s->p->ctx;
+    hipStream_t st = ctx->stream;
+    const as_pc_part &pt = pc->part;
+    const int64_t b0 = pt.blk[pt.lo], b1 = pt.blk[pt.hi];
+    as_pc_tpart(s, w, pc->m, pc->m8, pc->Phi, pc->dinv, in, pc->tg, pc->mp);
+    BQ_HIP(hipGetLastError());
+    BQ_TRY(bq_exchange_gather(ctx, pc->tg, (int64_t)pt.cmax * pc->mp));
+    as_pc_tsum_kernel<<<(unsigned)((pc->mp + 255) / 256), 256, 0, st>>>(pc->mp, pt, pc->tg, pc->mp, pc->ws->rhs, w->cg);
     as_pc_gemv_kernel<<<(unsigned)((pc->mp + 3) / 4), 256, 0, st>>>(pc->mp, pc->Ginv, pc->ws->rhs, pc->u, w->cg);   // u = G^-1 t
-    as_pc_apply_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, s->N, s->ldN, pc->Phi, pc->dinv, s->mL, s->mU, in, pc->u, out,
-                                                               s->partials, s->nblk, w->cg, first, fin);
+    if (b1 > b0)
+        as_pc_apply_kernel<<<(unsigned)(b1 - b0), BQ_VEC_BLOCK, 0, st>>>(pc->m, pc->m8, s->N, s->ldN, b0, pt, pc->Phi, pc->dinv, s->mL, s->mU, in,
+                                                                       pc->u, pc->zg, w->cg);
+    BQ_HIP(hipGetLastError());
+    BQ_TRY(bq_exchange_gather(ctx, pc->zg, (int64_t)pt.cmax * pt.maxlen * BQ_VEC_TILE));
+    as_pc_zunpack_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, pt, pc->zg, in, out, s->partials, s->nblk, w->cg, first, fin);
+    BQ_HIP(hipGetLastError());
+    return BQ_OK;
 }
 
 // v2 = R y on the free set, R = B - Phi_top Phi_top' (y vanishes outside the free set)
 static int as_pc_r_apply(bq_solver *s, as_ws *w, const double *y) {
     as_pc *pc = w->pc;
     hipStream_t st = s->p->ctx->stream;
-    hipEvent_t pe0 = nullptr, pe1 = nullptr;   // profiling: the part of the preconditioner that is sharded by samples (BQ_PROF_PCSHARD)
-    BQ_TRY(bq_prof_begin(s->p->ctx, BQ_PROF_PCSHARD, &pe0, &pe1));
-    BQ_TRY(as_pc2_bpart(s, pc->r2, y, w->cg));
+    // Phi_top' y: this rank's samples, per-segment sums into the TAIL of the remainder's gathered slots — they ride on its all-gather
     const float *Phitop = pc->Phi + (int64_t)pc->top0 * s->ldN;
     const int64_t m8t = bq_round_up(pc->ntop, PC_FG);   // (Phi carries PC_FG spare zero rows behind its last feature)
-    as_pc_tphi_kernel<<<dim3(vgrid(s->ldN).x, 1), BQ_VEC_BLOCK, 0, st>>>(pc->ntop, m8t, pc->mp, s->N, s->ldN, Phitop, pc->ones, y, pc->tpart,
-                                                                         pc->ttop, pc->tticket, w->cg);
-    as_pc_treduce_kernel<<<(unsigned)(pc->mp / 16), 256, 0, st>>>(m8t, pc->mp, (int64_t)vgrid(s->ldN).x, pc->tpart, pc->ttop, w->cg);
+    int64_t gstride = 0;
+    double *tail = as_pc2_tail(pc->r2, &gstride);
+    as_pc_tpart(s, w, pc->ntop, m8t, Phitop, pc->ones, y, tail, gstride);
+    BQ_TRY(as_pc2_bpart(s, pc->r2, y, w->cg));   // (gathers M's per-segment sums and the tail)
+    as_pc_tsum_kernel<<<(unsigned)((pc->mp + 255) / 256), 256, 0, st>>>(pc->mp, pc->part, tail, gstride, pc->ttop, w->cg);
     int tiles = 0;
     const double *ypart = as_pc2_ypart(pc->r2, &tiles);
     const as_pc_part pt = *as_pc2_part(pc->r2);
@@ -898,7 +977,7 @@ static int as_pc_r_apply(bq_solver *s, as_ws *w, const double *y) {
     BQ_TRY(bq_exchange_gather(s->p->ctx, vg, (int64_t)pt.cmax * pt.maxlen * BQ_VEC_TILE));
     as_pc_unpack_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->ldN, pt, vg, pc->v2, w->cg);
     BQ_HIP(hipGetLastError());
-    return bq_prof_end(s->p->ctx, BQ_PROF_PCSHARD, pe0, pe1);
+    return BQ_OK;
 }
 
 // z = P_AA^-1 r (+ r'z and beta on the device).  Explicit model: one Woodbury application.  With the order-2 remainder:
@@ -911,16 +990,21 @@ int as_pc_apply(bq_solver *s, as_ws *w, int first) {
     hipStream_t st = s->p->ctx->stream;
     double alpha = 1.0, beta = 0.0;
     if (pc->r2) as_pc2_coefs(pc->r2, &alpha, &beta);
+    // profiling (BQ_PROF_PCSHARD): one application of the preconditioner — all of its passes over samples are sharded since round 6
+    // (what stays replicated inside it: the m x m product, the segment sums and the unpacking of two n-vectors: microseconds)
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    BQ_TRY(bq_prof_begin(s->p->ctx, BQ_PROF_PCSHARD, &pe0, &pe1));
     if (pc->r2 == nullptr || beta == 0.0) {
-        as_pc_solve1(s, w, w->r, pc->z, first, 1);
-        return BQ_OK;
+        BQ_TRY(as_pc_solve1(s, w, w->r, pc->z, first, 1));   // two collectives
+    } else {
+        BQ_TRY(as_pc_solve1(s, w, w->r, pc->y1, first, 0));
+        BQ_TRY(as_pc_r_apply(s, w, pc->y1));                 // six collectives in all
+        BQ_TRY(as_pc_solve1(s, w, pc->v2, pc->z2, first, 0));
+        as_pc_combine_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, alpha, beta, w->r, pc->y1, pc->z2, pc->z, s->partials, s->nblk, w->cg,
+                                                                     first);
+        BQ_HIP(hipGetLastError());
     }
-    as_pc_solve1(s, w, w->r, pc->y1, first, 0);
-    BQ_TRY(as_pc_r_apply(s, w, pc->y1));
-    as_pc_solve1(s, w, pc->v2, pc->z2, first, 0);
-    as_pc_combine_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(s->N, alpha, beta, w->r, pc->y1, pc->z2, pc->z, s->partials, s->nblk, w->cg, first);
-    BQ_HIP(hipGetLastError());
-    return BQ_OK;
+    return bq_prof_end(s->p->ctx, BQ_PROF_PCSHARD, pe0, pe1);
 }
 
 // which samples entered / left the free set since the preconditioner's G^-1 was brought up to date: the list (and whether it is short
@@ -929,7 +1013,7 @@ int as_pc_apply(bq_solver *s, as_ws *w, int first) {
 void as_pc_track(bq_solver *s, as_ws *w, hipStream_t st) {
     as_pc *pc = w->pc;
     const int64_t N = s->N;
-    const int force = (pc->age == 0 || pc->age >= 128 || !as_env_on("BQ_AS_CG_PC_INCR")) ? 1 : 0;
+    const int force = (pc->age == 0 || pc->age >= 128 || !bq_hook_on("as_cg_pc_incr")) ? 1 : 0;
     int *lcnt = reinterpret_cast<int *>(s->partials + s->nblk);
     as_pc_diff_count_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, pc->prev, lcnt, &s->sc->pad1[0], pc->chg, force);
     as_pc_diff_write_kernel<<<vgrid(s->ldN), BQ_VEC_BLOCK, 0, st>>>(N, s->mL, s->mU, pc->prev, lcnt, pc->chg);
@@ -980,7 +1064,7 @@ int as_pc_update(bq_solver *s, as_ws *w) {
         for (int it = 0; it < 12; ++it) {
             if (it == 11) BQ_HIP(hipMemcpyAsync(a.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
             BQ_TRY(as_pc_r_apply(s, w, pc->y1));
-            as_pc_solve1(s, w, pc->v2, pc->y1, 1, 0);
+            BQ_TRY(as_pc_solve1(s, w, pc->v2, pc->y1, 1, 0));
         }
         BQ_HIP(hipMemcpyAsync(b.data(), pc->y1, sizeof(double) * N, hipMemcpyDeviceToHost, st));
         BQ_TRY(bq_ctx_sync(s->p->ctx));

@@ -30,7 +30,9 @@ struct as_pc2 {
     int nsl = 0, own_sl_lo = 0, own_sl_hi = 0;   // slices in all; this rank's (its segments are a contiguous run)
     long long *sl_row = nullptr, *sl_k = nullptr; // device: first row and length (samples) of slice s
     int *sl_first = nullptr;                      // device: first slice of segment k (k = S: nsl)
-    double *Mg = nullptr;     // (world * cmax) x dp x dp: the per-segment sums, gathered
+    int64_t gstride = 0;      // doubles per slot of Mg: dp x dp + the caller's tail (as_pc_r_apply: the segment sums of Phi_top' y ride on
+                              // the same all-gather)
+    double *Mg = nullptr;     // (world * cmax) x gstride: the per-segment sums of M (+ tail), gathered
     double *vg = nullptr;     // (world * cmax) x maxlen x 1024: v in the gathered layout
     double *Xp = nullptr;     // rows x dp, row-major, zero padded: the k-major image of X with k = sample
     double *Xt = nullptr;     // dp x ld: the k-major image with k = feature
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void pc2_moment_kernel(int64_t dp, int sl0,
 }
 
 // Mg[slot(k)] = the slices of segment k added in slice order (blockIdx.y = k - first own segment); tiles above the diagonal mirrored
-__global__ __launch_bounds__(256) void pc2_moment_seg_kernel(int64_t dp, as_pc_part part, const int *__restrict__ sl_first,
+__global__ __launch_bounds__(256) void pc2_moment_seg_kernel(int64_t dp, int64_t gstride, as_pc_part part, const int *__restrict__ sl_first,
                                                              const double *__restrict__ Mpart, double *__restrict__ Mg, const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -114,16 +116,16 @@ __global__ __launch_bounds__(256) void pc2_moment_seg_kernel(int64_t dp, as_pc_p
         a1 += Mpart[(int64_t)(sl + 1) * dp * dp + e];
     }
     if (sl < end) a0 += Mpart[(int64_t)sl * dp * dp + e];
-    Mg[(int64_t)part.slot[k] * dp * dp + o] = a0 + a1;
+    Mg[(int64_t)part.slot[k] * gstride + o] = a0 + a1;
 }
 // M = the gathered per-segment sums added in segment order (every rank: the same bits)
-__global__ __launch_bounds__(256) void pc2_moment_final_kernel(int64_t dp, as_pc_part part, const double *__restrict__ Mg, double *__restrict__ M,
-                                                               const as_cg_scal *cg) {
+__global__ __launch_bounds__(256) void pc2_moment_final_kernel(int64_t dp, int64_t gstride, as_pc_part part, const double *__restrict__ Mg,
+                                                               double *__restrict__ M, const as_cg_scal *cg) {
     if (cg != nullptr && cg->done) return;
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= dp * dp) return;
     double a = 0.0;
-    for (int k = 0; k < part.S; ++k) a += Mg[(int64_t)part.slot[k] * dp * dp + o];
+    for (int k = 0; k < part.S; ++k) a += Mg[(int64_t)part.slot[k] * gstride + o];
     M[o] = a;
 }
 
@@ -190,7 +192,7 @@ void as_pc2_free(as_pc2 *r) {
 }
 
 // buffers and images; bdiag_out (device, ldN): the diagonal of B, which the caller takes out of D
-int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out) {
+int as_pc2_create(bq_solver *s, double *bdiag_out, int64_t tail, as_pc2 **out) {
     *out = nullptr;
     bq_problem *p = s->p;
     hipStream_t st = p->ctx->stream;
@@ -201,23 +203,14 @@ int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out) {
     r->ld = s->ldN;
     const int64_t T = r->dp / BQ_GT;
     r->rows = r->ld;
+    r->gstride = r->dp * r->dp + tail;
     // the canonical sample segments (as many as the panel's: 8 up to 8 ranks), in blocks of 1024 samples, this rank's run of them
     // and the slot of every segment in the gathered buffers; slices of at most two blocks (2 048 samples: ~3 x 123 workgroups at
     // config 5) inside every segment
     bq_ctx *ctx = p->ctx;
     as_pc_part &pt = r->part;
     const int64_t nblk = r->ld / BQ_VEC_TILE;
-    pt.S = bq_sym_segments(ctx->world);
-    pt.lo = bq_sym_seg_first(ctx->rank, ctx->world, pt.S);
-    pt.hi = bq_sym_seg_first(ctx->rank + 1, ctx->world, pt.S);
-    pt.cmax = (pt.S + ctx->world - 1) / ctx->world;
-    pt.maxlen = 0;
-    for (int k = 0; k <= pt.S; ++k) pt.blk[k] = (long long)((int64_t)k * nblk / pt.S);
-    for (int k = 0; k < pt.S; ++k) pt.maxlen = std::max(pt.maxlen, pt.blk[k + 1] - pt.blk[k]);
-    for (int q = 0; q < ctx->world; ++q) {
-        const int lo = bq_sym_seg_first(q, ctx->world, pt.S), hi = bq_sym_seg_first(q + 1, ctx->world, pt.S);
-        for (int k = lo; k < hi; ++k) pt.slot[k] = q * pt.cmax + (k - lo);
-    }
+    as_pc_make_part(ctx, nblk, &pt);
     std::vector<long long> sl_row, sl_k;
     std::vector<int> sl_first((size_t)pt.S + 1, 0);
     for (int k = 0; k < pt.S; ++k) {
@@ -237,8 +230,8 @@ int as_pc2_create(bq_solver *s, double *bdiag_out, as_pc2 **out) {
     if (e == hipSuccess) e = hipMalloc(&r->sl_row, sizeof(long long) * nsl1);
     if (e == hipSuccess) e = hipMalloc(&r->sl_k, sizeof(long long) * nsl1);
     if (e == hipSuccess) e = hipMalloc(&r->sl_first, sizeof(int) * ((size_t)pt.S + 1));
-    if (e == hipSuccess) e = hipMalloc(&r->Mg, sizeof(double) * (size_t)ctx->world * pt.cmax * r->dp * r->dp);
-    if (e == hipSuccess) e = hipMemsetAsync(r->Mg, 0, sizeof(double) * (size_t)ctx->world * pt.cmax * r->dp * r->dp, st);
+    if (e == hipSuccess) e = hipMalloc(&r->Mg, sizeof(double) * (size_t)ctx->world * pt.cmax * r->gstride);
+    if (e == hipSuccess) e = hipMemsetAsync(r->Mg, 0, sizeof(double) * (size_t)ctx->world * pt.cmax * r->gstride, st);
     if (e == hipSuccess) e = hipMalloc(&r->vg, sizeof(double) * (size_t)ctx->world * pt.cmax * pt.maxlen * BQ_VEC_TILE);
     if (e == hipSuccess) e = hipMemsetAsync(r->vg, 0, sizeof(double) * (size_t)ctx->world * pt.cmax * pt.maxlen * BQ_VEC_TILE, st);
     if (e == hipSuccess && r->nsl > 0) e = hipMemcpyAsync(r->sl_row, sl_row.data(), sizeof(long long) * r->nsl, hipMemcpyHostToDevice, st);
@@ -283,10 +276,10 @@ int as_pc2_bpart(bq_solver *s, as_pc2 *r, const double *y, const as_cg_scal *cg)
     if (own_sl > 0)
         pc2_moment_kernel<<<dim3((unsigned)(T * (T + 1) / 2), (unsigned)own_sl), 256, 0, st>>>(r->dp, r->own_sl_lo, r->sl_row, r->sl_k, r->Xp, r->W,
                                                                                             r->Mpart, cg);
-    if (own_seg > 0) pc2_moment_seg_kernel<<<dim3(ge, (unsigned)own_seg), 256, 0, st>>>(r->dp, pt, r->sl_first, r->Mpart, r->Mg, cg);
+    if (own_seg > 0) pc2_moment_seg_kernel<<<dim3(ge, (unsigned)own_seg), 256, 0, st>>>(r->dp, r->gstride, pt, r->sl_first, r->Mpart, r->Mg, cg);
     BQ_HIP(hipGetLastError());
-    BQ_TRY(bq_exchange_gather(ctx, r->Mg, (int64_t)pt.cmax * r->dp * r->dp));
-    pc2_moment_final_kernel<<<ge, 256, 0, st>>>(r->dp, pt, r->Mg, r->M, cg);
+    BQ_TRY(bq_exchange_gather(ctx, r->Mg, (int64_t)pt.cmax * r->gstride));
+    pc2_moment_final_kernel<<<ge, 256, 0, st>>>(r->dp, r->gstride, pt, r->Mg, r->M, cg);
     if (row1 > row0)
         pc2_bilinear_kernel<<<dim3((unsigned)((row1 - row0) / BQ_GT), (unsigned)T), 256, 0, st>>>(r->dp, r->ld, row0 / BQ_GT, r->Xt, r->Xp, r->M,
                                                                                                r->ypart, cg);
@@ -294,6 +287,10 @@ int as_pc2_bpart(bq_solver *s, as_pc2 *r, const double *y, const as_cg_scal *cg)
     return BQ_OK;
 }
 const as_pc_part *as_pc2_part(const as_pc2 *r) { return &r->part; }
+double *as_pc2_tail(const as_pc2 *r, int64_t *gstride) {   // the caller's tail of slot 0 of the gathered per-segment buffer
+    *gstride = r->gstride;
+    return r->Mg + r->dp * r->dp;
+}
 double *as_pc2_vg(const as_pc2 *r) { return r->vg; }
 const double *as_pc2_ypart(const as_pc2 *r, int *tiles) {
     *tiles = (int)(r->dp / BQ_GT);

@@ -48,7 +48,8 @@ __global__ void as_cand_scatter_kernel(int64_t n0, int m, const int *__restrict_
 // changed indices carried before the base is re-factorised: the larger the factor, the longer it is worth keeping
 // (n^3/3 to rebuild against one more small-system row per carried index)
 static int as_schur_limit(int64_t np0) {
-    if (const char *e = getenv("BQ_AS_SCHUR_LIMIT")) return std::max(1, std::min(atoi(e), AS_SCHUR_MAX));   // tests
+    double hv = 0.0;
+    if (bq_hook("as_schur_limit", &hv)) return std::max(1, std::min((int)hv, AS_SCHUR_MAX));   // tests
     // (re-tuned in round 2 for the two-launches-per-1024-rows sweeps: a solve is ~4x cheaper, so the n^3/3 of a rebuild is
     // amortised over more iterations: n = 50 000: 0.77 s per rebuild = 3 ms per iteration at 256 carried changes)
     // (below |A| = 8 192: 96 through round 4's first half; swept again once every free set went through the kept factor and the
@@ -341,12 +342,10 @@ static bool as_small_solve(int m, const std::vector<double> &C, const double *t,
 // per iteration: 3 921 of the 22 897 iterations of BASELINE config 2's shape, 0.67 ms each.  Measured to 'optimal' at n = 20 000
 // (profiles/r04/as_schur_min_sweep.txt): 1024 17.5 s, 256 16.5 s, 64 16.3 s, 16 16.1 s, 0 16.1 s — any non-empty free set now.
 int as_schur_min() {   // read per iteration: tests switch it between solves
-    const char *e = getenv("BQ_AS_SCHUR_MIN");
-    return e ? atoi(e) : 1;
+    return (int)bq_hook_value("as_schur_min", 1.0);
 }
 bool as_schur_enabled() {
-    const char *e = getenv("BQ_AS_SCHUR");
-    return e ? atoi(e) != 0 : true;
+    return bq_hook_on("as_schur");
 }
 
 #define AS_PANEL_ARGS(T) p->structure, (const T *)p->panel, p->ld, p->symmetric ? 1 : 0, p->n, p->sgn, p->diag_add

@@ -40,6 +40,21 @@ void bq_set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// test hooks: ONE environment variable, BQ_TEST_HOOKS="name=value,name=value", read at every use (the tests switch hooks between
+// solves of one process).  They force paths that a heuristic would not take at test sizes, or switch a shortcut off so that a test
+// can hold it against the long way — nothing a user of the library needs (round 6: these were eighteen BQ_* variables).
+//   rows_per_step=4|8  stream_unit=U  minres_big_min=N  as_schur=0  as_schur_min=N  as_schur_limit=N  as_mailbox=0  as_f_chain=0
+//   as_cg_warm=0  as_cg_incq=0  as_cg_colq=0  as_cg_pc_incr=0  as_cg_pc_class=0..3  ip_svr_reduced=0  smo_helpers=N
+//   panel_good_gbs=G  alloc_fail_above=BYTES
+// ---------------------------------------------------------------------------------------------
+bool bq_hook(const char *name, double *value);                       // true (and *value) when the hook is set
+static inline double bq_hook_value(const char *name, double dflt) {
+    double v = dflt;
+    return bq_hook(name, &v) ? v : dflt;
+}
+static inline bool bq_hook_on(const char *name) { return bq_hook_value(name, 1.0) != 0.0; }   // default on; "name=0" switches off
+
+// ---------------------------------------------------------------------------------------------
 // device allocation: EVERY hipMalloc of the library goes through bq_device_malloc, which on failure gives the panels the
 // live contexts keep cached (bq_ctx.panel_cache) back to the driver and tries once more
 // ---------------------------------------------------------------------------------------------
@@ -343,7 +358,7 @@ int bq_pgfw_start(bq_solver *s);
 int bq_pgfw_iterate(bq_solver *s);
 int bq_ip_start(bq_solver *s);
 int bq_ip_iterate(bq_solver *s);
-bool bq_ip_svr_reduced();   // n x n Schur reduction of the SVR Newton system (default; BQ_IP_SVR_REDUCED=0 disables)
+bool bq_ip_svr_reduced();   // n x n Schur reduction of the SVR Newton system (default; hook ip_svr_reduced=0 disables)
 int bq_as_start(bq_solver *s);
 int bq_as_iterate(bq_solver *s);
 void bq_as_free(bq_solver *s);

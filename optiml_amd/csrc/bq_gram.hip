@@ -710,7 +710,10 @@ int bq_stream_prepare(bq_ctx *ctx, const double *Xdev, int64_t n, int64_t d, int
         // depend on the rank count)
         const int64_t target = 24 * 512 * 8;
         int64_t U = total / target > 0 ? (total + target - 1) / target : 1;
-        if (const char *e = getenv("BQ_STREAM_UNIT")) U = atoll(e) > 0 ? atoll(e) : U;   // tests: several tiles per unit at small n
+        {   // hook stream_unit: several tiles per unit at small n (tests)
+            double hv = 0.0;
+            if (bq_hook("stream_unit", &hv) && hv >= 1.0) U = (int64_t)hv;
+        }
         const int64_t kmax = (T + U - 1) / U;
         // launch order: column range by column range, rows descending inside a range — the workgroups in flight walk the SAME
         // column tiles at about the same time, like the row-block form (measured equal to row-major unit order at n = 100 000:

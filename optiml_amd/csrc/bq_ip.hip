@@ -264,14 +264,10 @@ __global__ void ip_svr_expand_kernel(int64_t n, const double *__restrict__ hd, c
 }
 
 // Default ON: on the reference's SVR fixtures the reduced system reproduces the 2n x 2n trajectory (same iteration
-// count, objective to 1e-14, alpha+ - alpha- to 1e-11).  BQ_IP_SVR_REDUCED=0 selects the reference's own 2n x 2n
+// count, objective to 1e-14, alpha+ - alpha- to 1e-11).  hook ip_svr_reduced=0 selects the reference's own 2n x 2n
 // factorisation instead.
 bool bq_ip_svr_reduced() {
-    static const bool on = [] {
-        const char *e = getenv("BQ_IP_SVR_REDUCED");
-        return e == nullptr || atoi(e) != 0;
-    }();
-    return on;
+    return bq_hook_on("ip_svr_reduced");
 }
 
 static ipv ip_vecs(bq_solver *s) {

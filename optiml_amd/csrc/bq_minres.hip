@@ -445,11 +445,10 @@ static int minres_normal_big(bq_chol_ws *ws, const int *nA_dev, int64_t nA, int6
     return BQ_OK;
 }
 
-// nA: |A| on the host.  Up to BQ_MINRES_BIG_MIN (default 4096) rows the single persistent workgroup is faster (no launches at
+// nA: |A| on the host.  Up to hook minres_big_min (default 4096) rows the single persistent workgroup is faster (no launches at
 // all); beyond that — and for any size the one workgroup could not hold — the multi-workgroup form.
 int bq_minres_normal(bq_chol_ws *ws, const int *nA_dev, int64_t nA, int64_t np, double *vec, int *iters_dev) {
-    const char *e = getenv("BQ_MINRES_BIG_MIN");   // read per call: tests switch the form inside one process
-    const long long big_min = e ? atoll(e) : 4096ll;
+    const long long big_min = (long long)bq_hook_value("minres_big_min", 4096.0);   // read per call: tests switch the form inside one process
     if (nA >= big_min) return minres_normal_big(ws, nA_dev, nA, np, vec, iters_dev);
     minres_normal_kernel<<<1, MT, 0, ws->ctx->stream>>>(ws->H, ws->ldh, nA_dev, ws->rhs, vec, np, 1e-5, iters_dev);
     BQ_HIP(hipGetLastError());

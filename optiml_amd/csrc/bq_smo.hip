@@ -1430,13 +1430,13 @@ extern "C" int bq_smo_create(bq_problem *p, int task, const double *y, double C,
     if (e == hipSuccess) e = hipMalloc(&s->nz, sizeof(int) * n);
     if (e == hipSuccess) e = hipMalloc(&s->cf, sizeof(double) * n);
     if (e == hipSuccess) e = hipMalloc(&s->sc, sizeof(bq_smo_scal));
-    // helper workgroups of the full sweeps: BQ_SMO_HELPERS (0 = the walker alone).  Default 48: measured at n = 100 000
+    // helper workgroups of the full sweeps: hook smo_helpers (0 = the walker alone).  Default 48: measured at n = 100 000
     // the sweeps take 455 / 357 / 344 / 355 / 365 / 380 / 433 / 479 ms with 16 / 32 / 48 / 64 / 96 / 128 / 192 / 255
     // helpers — past ~48 the extra pollers of the control line cost the walker more than the extra gather rate brings
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
     s->helpers = std::min(48, cus / 4);
-    if (const char *env = getenv("BQ_SMO_HELPERS")) s->helpers = atoi(env);
+    s->helpers = (int)bq_hook_value("smo_helpers", (double)s->helpers);
     s->helpers = std::max(0, std::min(s->helpers, cus - 1));
     if (s->helpers < SMO_T / 64) s->helpers = 0;   // the first batch after a pair step wants one CU per sample
     if (e == hipSuccess && s->helpers) {

@@ -399,10 +399,7 @@ static int launch_any(bq_ctx *ctx, const void *panel, int storage, bool add_one,
     // 1 650 strips (n = 40 000) 1.07 -> 1.02 ms; grids whose last round is well filled are 2-6 % faster with 4, long grids do not
     // care.  The rows of a step are independent sums and the lane butterfly pairs the same lanes in the same order: the bits do
     // not depend on the choice (tests/test_distributed.py::test_rows_per_step_variants_are_bit_identical).
-    static const int force = [] {
-        const char *e = getenv("BQ_SYMV_ROWS_PER_STEP");   // 4 or 8: no heuristic (the bit-identity test switches it)
-        return e ? atoi(e) : 0;
-    }();
+    const int force = (int)bq_hook_value("rows_per_step", 0.0);   // 4 or 8: no heuristic (the bit-identity test switches it)
     const int64_t strips = strips_before<JG_DEFAULT>(tab.cut[tab.hi]) - strips_before<JG_DEFAULT>(tab.cut[tab.lo]);
     const int64_t slots = 2 * (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256);
     const bool sparse_tail = strips >= slots && strips < 8 * slots && 2 * (strips % slots) < slots;

@@ -22,3 +22,37 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+# ---- the library's test hooks: ONE environment variable, BQ_TEST_HOOKS="name=value,..." (csrc/bq_common.h) ----------------------
+def _hooks_now():
+    return dict(item.split('=', 1) for item in os.environ.get('BQ_TEST_HOOKS', '').split(',') if '=' in item)
+
+
+def _hooks_str(cur):
+    return ','.join(f'{k}={v}' for k, v in cur.items())
+
+
+def set_hooks(monkeypatch, **kw):
+    """set_hooks(monkeypatch, as_schur_min=0, as_schur=None): set / remove (None) hooks for the rest of the test."""
+    cur = _hooks_now()
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv('BQ_TEST_HOOKS', _hooks_str(cur))
+    else:
+        monkeypatch.delenv('BQ_TEST_HOOKS', raising=False)
+
+
+def hooks_env(**kw):
+    """{'BQ_TEST_HOOKS': ...} for a child process: the hooks of this process + kw."""
+    cur = _hooks_now()
+    cur.update({k: str(v) for k, v in kw.items() if v is not None})
+    return {'BQ_TEST_HOOKS': _hooks_str(cur)}
+
+
+def hook_value(name, default=None):
+    return _hooks_now().get(name, default)

@@ -7,6 +7,8 @@ import sys
 
 import pytest
 
+from conftest import set_hooks, hooks_env, hook_value
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(REPO, 'bench.py')
 
@@ -308,7 +310,7 @@ def test_products_that_returned_on_the_done_flag_are_not_counted():
     """ActiveSetCG enqueues one inner iteration more than it needs per solve (the `done` flag is looked at one iteration late);
     that launch returns at once and says so itself (bq_prof_skip_arg).  The profiled launch count of the bench record is exactly
     the number of products the solver needed — not a guess from durations."""
-    if os.environ.get('BQ_AS_CG_INCQ') == '0' or os.environ.get('BQ_AS_CG_COLQ') == '0':
+    if hook_value('as_cg_incq') == '0' or hook_value('as_cg_colq') == '0':
         pytest.skip('with the product-free bookkeeping switched off every outer iteration has products of its own')
     r = _run(['--config', 'c5', '--samples', '6000', '--features', '32', '--steps', '6', '--warmup', '2', '--no-cpu', '--kkt', 'none'])
     assert r.returncode == 0, r.stderr[-2000:]

@@ -14,6 +14,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import set_hooks, hooks_env, hook_value
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, '_dist_worker.py')
 
@@ -272,7 +274,7 @@ def test_rows_per_step_variants_are_bit_identical(tmp_path, one_rank):
     (bq_symv.hip).  The choice must not change a bit — otherwise a rank count that changes the grid would change the iterates:
     products, PG / FW / augmented-Lagrangian / ActiveSetCG runs forced to 4 and to 8 rows per step equal the default run."""
     for rows in ('4', '8'):
-        res = _launch('gpu-host', 1, tmp_path / f'rows{rows}', extra_env={'BQ_SYMV_ROWS_PER_STEP': rows})[0]
+        res = _launch('gpu-host', 1, tmp_path / f'rows{rows}', extra_env=hooks_env(rows_per_step=rows))[0]
         for key in ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_f', 'ascg_kernel_x', 'ascg_kernel_f'):
             assert np.array_equal(res[key], one_rank[key]), (rows, key)
 
@@ -282,12 +284,12 @@ def test_order2_remainder_of_the_preconditioner_is_replicated_bitwise(tmp_path):
     """The implicit order-2 remainder of ActiveSetCG's preconditioner (csrc/bq_as_pc2.hip: two MFMA products with a split-K sum, a
     power-iteration spectrum bound, a Chebyshev polynomial) is sharded by sample segments — a rank forms the moment slices and the
     x'Mx values of its own samples, the per-segment sums and v are gathered and added in segment order: forced on
-    (BQ_AS_CG_PC_CLASS=3), one, two and three ranks give the same bits — and the same outer trajectory as without it."""
-    env = {'BQ_AS_CG_PC_CLASS': '3'}
+    (hook as_cg_pc_class=3), one, two and three ranks give the same bits — and the same outer trajectory as without it."""
+    env = hooks_env(as_cg_pc_class=3)
     one = _launch('gpu-host', 1, tmp_path / 'one', extra_env=env)[0]
     two = _launch('gpu-host', 2, tmp_path / 'two', extra_env=env)
     three = _launch('gpu-host', 3, tmp_path / 'three', extra_env=env)     # uneven runs of the eight sample segments: 2 / 3 / 3
-    plain = _launch('gpu-host', 1, tmp_path / 'plain', extra_env={'BQ_AS_CG_PC_CLASS': '2'})[0]
+    plain = _launch('gpu-host', 1, tmp_path / 'plain', extra_env=hooks_env(as_cg_pc_class='2'))[0]
     for key in ('ascg_kernel_x', 'ascg_kernel_f'):
         for r in two + three:
             assert np.array_equal(r[key], one[key]), key

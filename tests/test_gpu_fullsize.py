@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import set_hooks, hooks_env, hook_value
+
 pytestmark = pytest.mark.gpu
 
 
@@ -121,11 +123,11 @@ def test_active_set_kept_factor_at_config2_shape(monkeypatch):
     X, y = make_blobs(n, d, seed=0)
     runs = []
     for mode, limit in (('0', None), ('1', None), ('1', '512')):   # 512: what factors of 80 000 rows and more carry
-        monkeypatch.setenv('BQ_AS_SCHUR', mode)
+        set_hooks(monkeypatch, as_schur=mode)
         if limit is None:
-            monkeypatch.delenv('BQ_AS_SCHUR_LIMIT', raising=False)
+            set_hooks(monkeypatch, as_schur_limit=None)
         else:
-            monkeypatch.setenv('BQ_AS_SCHUR_LIMIT', limit)
+            set_hooks(monkeypatch, as_schur_limit=limit)
         hist = []
         cb = lambda o: hist.append((o.f_x, o.n_bound))
         cb._bq_needs_state = False
@@ -443,7 +445,7 @@ def test_config5_squared_hinge_active_set_cg_at_full_size():
     # one cold solve from x0 = 1 and two warm ones: 22 inner iterations with round 5's preconditioner (the order-2 term: its 2d large
     # directions as features, the rest implicitly), 32 without the implicit part, 40 with rounds 3-4's features (tools/c5_first_iterations.py)
     # (the suite is also run with the older feature families forced, profiles/rNN/pytest_gpu_shortcuts_off.log: their own counts then)
-    bound = {'0': 80, '1': 44, '2': 35}.get(os.environ.get('BQ_AS_CG_PC_CLASS', ''), 26)
+    bound = {'0': 80, '1': 44, '2': 35}.get(hook_value('as_cg_pc_class', ''), 26)
     assert opt.inner_iters <= bound, opt.inner_iters
     f = [r['f'] for r in rec]
     assert all(b <= a for a, b in zip(f, f[1:]))

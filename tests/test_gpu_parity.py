@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, set_hooks, hooks_env, hook_value
 
 pytestmark = pytest.mark.gpu
 
@@ -37,11 +37,11 @@ AS_KINDS = ['as', 'ascg']
 def as_factor_mode(request, monkeypatch):
     """The dense-factor ActiveSet either re-factorises Q[A,A] in every iteration (what the reference does) or keeps the
     factor of a base set and carries the changes through a Schur complement (csrc/bq_as.hip; the default for every non-empty
-    free set since round 4 — BQ_AS_SCHUR_MIN=0 states it).  Both must follow the reference's trajectory."""
+    free set since round 4 — hook as_schur_min=0 states it).  Both must follow the reference's trajectory."""
     if request.param == 'reuse':
-        monkeypatch.setenv('BQ_AS_SCHUR_MIN', '0')
+        set_hooks(monkeypatch, as_schur_min='0')
     else:
-        monkeypatch.setenv('BQ_AS_SCHUR', '0')
+        set_hooks(monkeypatch, as_schur='0')
     return request.param
 
 
@@ -220,7 +220,7 @@ def test_panel_placement_selection(amd, monkeypatch):
     plain = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y)
     ref = plain.device_problem().matvec(v)
     assert plain.device_problem().placement() == []
-    monkeypatch.setenv('BQ_PANEL_GOOD_GBS', '1e9')         # nothing is good enough ...
+    set_hooks(monkeypatch, panel_good_gbs='1e9')         # nothing is good enough ...
     monkeypatch.setenv('BQ_PLACE_BUDGET_MS', '60000')      # ... and there is time: all three candidates are tried
     tuned = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)   # (`plain` still holds its panel: a fresh allocation)
     ms = tuned.device_problem().placement()
@@ -771,7 +771,7 @@ def test_active_set_factor_reuse_across_refreshes(amd, monkeypatch, storage):
     for x0, iters in ((None, 450), (x_near, 300)):
         runs = []
         for mode in ('0', '1'):
-            monkeypatch.setenv('BQ_AS_SCHUR', mode)
+            set_hooks(monkeypatch, as_schur=mode)
             hist = []
             cb = lambda o: hist.append((o.f_x, o.n_bound))
             cb._bq_needs_state = False
@@ -823,7 +823,7 @@ def test_active_set_cg_preconditioner_and_warm_start(amd, monkeypatch):
 
     def run(kernel, n, d, iters, pc, warm):
         monkeypatch.setenv('BQ_AS_CG_PC', pc)
-        monkeypatch.setenv('BQ_AS_CG_WARM', warm)
+        set_hooks(monkeypatch, as_cg_warm=warm)
         X, y = make_blobs(n, d, seed=0, sigma=8.0)
         hist = []
         cb = lambda o: hist.append((o.f_x, o.n_bound))
@@ -871,8 +871,7 @@ def test_active_set_cg_product_free_bookkeeping_does_not_drift_over_hundreds_of_
     X, y = make_blobs(n, d, seed=11, sigma=8.0)
 
     def run(shortcuts):
-        for var in ('BQ_AS_CG_INCQ', 'BQ_AS_CG_COLQ'):
-            monkeypatch.setenv(var, '1' if shortcuts else '0')
+        set_hooks(monkeypatch, as_cg_incq=1 if shortcuts else 0, as_cg_colq=1 if shortcuts else 0)
         hist = []
         cb = lambda o: hist.append((o.f_x, o.n_bound))
         cb._bq_needs_state = False
@@ -890,9 +889,9 @@ def test_active_set_cg_product_free_bookkeeping_does_not_drift_over_hundreds_of_
     # the preconditioner's G^-1 is carried through these 260 free-set changes by Sherman-Morrison updates (rebuilt every 128):
     # against the same run with G summed afresh and factorised in EVERY outer iteration the inner iteration counts agree —
     # the carried inverse is as good a preconditioner as the fresh one — and the outer path is the same
-    monkeypatch.setenv('BQ_AS_CG_PC_INCR', '0')
+    set_hooks(monkeypatch, as_cg_pc_incr='0')
     h2, x2, it2, in2 = run(True)
-    monkeypatch.delenv('BQ_AS_CG_PC_INCR')
+    set_hooks(monkeypatch, as_cg_pc_incr=None)
     assert np.array_equal(h2[:, 1], h1[:, 1])
     np.testing.assert_allclose(h2[:, 0], h1[:, 0], rtol=1e-9)
     assert abs(in2 - in1) <= 0.03 * in2 + 5, (in1, in2)
@@ -945,7 +944,7 @@ def test_active_set_cg_feature_families_agree_and_the_projected_one_is_the_cheap
     ref = bo.active_set(Q, -np.ones(n), np.full(n, np.inf), x0=np.ones(n), max_iter=30)
     inner = {}
     for fam in ('0', '1', '2', '3'):   # 3: family 2 + the implicit order-2 remainder behind a Chebyshev polynomial (csrc/bq_as_pc2.hip)
-        monkeypatch.setenv('BQ_AS_CG_PC_CLASS', fam)
+        set_hooks(monkeypatch, as_cg_pc_class=fam)
         quad = KernelQuadratic(X, -np.ones(n), 'svc', GaussianKernel('scale'), y=y, diag=0.5)
         opt = _solvers()['ascg'](quad=quad, ub=np.full(n, np.inf), x=np.ones(n), max_iter=30).minimize()
         assert opt.iter == ref['iter'] and opt.status == ref['status']
@@ -990,8 +989,8 @@ def test_minres_forms_agree(amd, monkeypatch):
     n = len(y)
     runs = []
     for big_min in ('1000000', '0'):
-        monkeypatch.setenv('BQ_MINRES_BIG_MIN', big_min)
-        monkeypatch.setenv('BQ_AS_SCHUR', '0')
+        set_hooks(monkeypatch, minres_big_min=big_min)
+        set_hooks(monkeypatch, as_schur='0')
         hist = []
         cb = lambda o: hist.append(o.f_x)
         cb._bq_needs_state = False
@@ -1030,7 +1029,7 @@ def test_active_set_objective_without_a_product_on_ratio_steps(amd, as_factor_mo
     """INTEGRATION.md "Deviations": after a ratio step the reference evaluates f(x) with products by Q (active_set.py:172-176); the
     device uses the step's own identity f(x + t d) = f(x) + (t - t^2/2) g_A'd_A (d is a Newton step on the free set) and forms f by a
     product only at release iterations and every 64th step of a run (bq_as.hip, as_step_min_kernel).  Same iterates by construction;
-    here: the recorded objective follows the ORACLE's (a product per iteration) and the run with BQ_AS_F_CHAIN=0, on a dual whose
+    here: the recorded objective follows the ORACLE's (a product per iteration) and the run with hook as_f_chain=0, on a dual whose
     trajectory has long runs of ratio steps (hundreds of iterations before the first release) and on one with lower bounds != 0."""
     from oracle import bcqp_oracle as bo
     from optiml_amd import _lib
@@ -1056,7 +1055,7 @@ def test_active_set_objective_without_a_product_on_ratio_steps(amd, as_factor_mo
     for name, Q, q, lb, ub in cases:
         runs = {}
         for chain in ('1', '0'):
-            monkeypatch.setenv('BQ_AS_F_CHAIN', chain)
+            set_hooks(monkeypatch, as_f_chain=chain)
             hist = []
             cb = lambda o: hist.append(o.f_x)
             cb._bq_needs_state = False
@@ -1081,7 +1080,7 @@ def test_active_set_objective_without_a_product_on_ratio_steps(amd, as_factor_mo
 
 def test_active_set_mailbox_looks_change_nothing(amd, monkeypatch):
     """The dense ActiveSet's three looks per iteration are records the kernels post into mapped pinned memory (as_ws::mail,
-    bq_ctx_wait_flag; slot table and coefficients read by the kernels from the host's buffers).  BQ_AS_MAILBOX=0 is the round-3 way
+    bq_ctx_wait_flag; slot table and coefficients read by the kernels from the host's buffers).  hook as_mailbox=0 is the round-3 way
     (hipMemcpyAsync + hipStreamSynchronize, device copies of the tables): how the host learns a record must not move a bit."""
     from optiml_amd.opti import Quadratic
     from optiml_amd.opti.constrained import ActiveSet
@@ -1093,7 +1092,7 @@ def test_active_set_mailbox_looks_change_nothing(amd, monkeypatch):
     ub = np.full(n, 1.0)
     runs = {}
     for mail in ('1', '0'):
-        monkeypatch.setenv('BQ_AS_MAILBOX', mail)
+        set_hooks(monkeypatch, as_mailbox=mail)
         hist = []
         cb = lambda o: hist.append(o.f_x)
         cb._bq_needs_state = False
@@ -1390,7 +1389,7 @@ def test_kernel_map_exp_on_the_device_matches_numpy_over_its_whole_range(amd):
 
 def test_svr_ip_full_2n_system_matches_the_reduced_default(amd, tmp_path):
     """SVR + InteriorPoint factorises the n x n system in u = dx+ - dx- by default (symmetric elimination, bq_ip.hip);
-    BQ_IP_SVR_REDUCED=0 selects the reference's own 2n x 2n factorisation (interior_point.py:235).  Both must follow
+    hook ip_svr_reduced=0 selects the reference's own 2n x 2n factorisation (interior_point.py:235).  Both must follow
     the reference's trajectory: same iteration count, objective to 1e-9, alpha+ - alpha- to 1e-8 (the default path is
     held to the same bar by test_fit_svr_ip / test_trajectory_svr_structured_ip)."""
     import subprocess, sys, os, json
@@ -1408,7 +1407,7 @@ print(json.dumps({'iter': est.optimizer.iter, 'status': est.optimizer.status, 'f
                   'alphas': est.alphas_.tolist()}))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
        os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fit_svr_n400.npz'))
-    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, BQ_IP_SVR_REDUCED='0'),
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **hooks_env(ip_svr_reduced=0)),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
@@ -1450,7 +1449,7 @@ def test_streamed_product_matches_the_resident_panel(amd, structure, kname, n):
 
 @pytest.mark.parametrize('unit', ['2', '3', '5'])
 def test_streamed_product_with_several_tiles_per_unit(amd, monkeypatch, unit):
-    """At test sizes a work unit of the streamed product is one tile; BQ_STREAM_UNIT forces the shape of the large-n case (a unit
+    """At test sizes a work unit of the streamed product is one tile; hook stream_unit forces the shape of the large-n case (a unit
     = several column tiles whose row sums accumulate in LDS, truncated units next to the diagonal, several units per row)."""
     from optiml_amd.ml.svm.kernels import gaussian
     from optiml_amd.opti import KernelQuadratic
@@ -1460,7 +1459,7 @@ def test_streamed_product_with_several_tiles_per_unit(amd, monkeypatch, unit):
     y = np.where(rs.standard_normal(n) > 0, 1., -1.)
     q = -np.ones(n)
     a = KernelQuadratic(X, q, 'svc', gaussian, y=y)
-    monkeypatch.setenv('BQ_STREAM_UNIT', unit)
+    set_hooks(monkeypatch, stream_unit=unit)
     b = KernelQuadratic(X, q, 'svc', gaussian, y=y, storage='stream')
     try:
         for seed in (0, 1):
@@ -1550,7 +1549,7 @@ def test_ragged_sizes_kernel_panels(amd, n, monkeypatch):
     from optiml_amd.datasets import make_blobs, make_regression
     from optiml_amd.opti import KernelQuadratic
     from optiml_amd.ml.svm.kernels import gaussian
-    monkeypatch.setenv('BQ_AS_SCHUR_MIN', '0')
+    set_hooks(monkeypatch, as_schur_min='0')
     X, y = make_blobs(n, 7, seed=n)
     Q, q, ub = so.svc_dual(so.gram('rbf', X), y, 1.0)
     for s, fn, iters in (('fw', bo.frank_wolfe, 50), ('ip', bo.interior_point, 200), ('as', bo.active_set, 120)):
@@ -1614,7 +1613,7 @@ print('ok')
 
 def test_panel_cache_is_reused_and_dropped_when_an_allocation_fails(amd):
     """A context keeps ONE released panel >= 1 GB for the next problem of about that size (bq_ctx.panel_cache); any failing
-    device allocation of the library drops it and retries (BQ_TEST_ALLOC_FAIL_ABOVE simulates the failure)."""
+    device allocation of the library drops it and retries (hook alloc_fail_above simulates the failure)."""
     code = '''
 import os
 
@@ -1645,4 +1644,4 @@ check(16400, 4)          # a fresh allocation again
 print('ok')
 '''
     assert 'ok' in _run_child(code)
-    assert 'ok' in _run_child(code, {'BQ_TEST_ALLOC_FAIL_ABOVE': str(1 << 20)})
+    assert 'ok' in _run_child(code, hooks_env(alloc_fail_above=1 << 20))

@@ -19,7 +19,7 @@ the reference's.
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, set_hooks, hooks_env, hook_value
 from test_oracle_golden import SMO_SVC, SMO_SVR
 
 pytestmark = pytest.mark.gpu
@@ -283,9 +283,9 @@ def test_helper_workgroups_do_not_change_the_path(amd, monkeypatch, attempt):
     runs = []
     for h in ('0', '16', None, '128', '255'):
         if h is None:
-            monkeypatch.delenv('BQ_SMO_HELPERS', raising=False)
+            set_hooks(monkeypatch, smo_helpers=None)
         else:
-            monkeypatch.setenv('BQ_SMO_HELPERS', h)
+            set_hooks(monkeypatch, smo_helpers=h)
         quad = KernelQuadratic(X, -np.ones(n), 'svc', _kernel('rbf'), y=yb, rank_one=False)
         c = SMOClassifier(quad, X, yb, None, _kernel('rbf'), 1., 1e-3).minimize()
         quad = KernelQuadratic(Xr, np.hstack((-yr, yr)) + 0.1, 'svr', _kernel('rbf'), rank_one=False)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dense ActiveSet: the f(x) of ratio-step iterations from the line-search identity (bq_as.hip, as_step_min_kernel) against the same
-fit with a panel product per iteration (BQ_AS_F_CHAIN=0).  Two child processes (the switch is read when the solver starts), same
+fit with a panel product per iteration (BQ_TEST_HOOKS=as_f_chain=0).  Two child processes (the switch is read when the solver starts), same
 seeded problem; prints iterations, status, how many iterations went without a product and the largest relative difference of the
 recorded f along the trajectory.
 
@@ -41,7 +41,7 @@ print(json.dumps({'fit_s': dt, 'iter': int(opt.iter), 'status': opt.status, 'f':
 
 
 def run(n, d, max_iter, chain, out):
-    env = dict(os.environ, BQ_AS_F_CHAIN='1' if chain else '0')
+    env = dict(os.environ, BQ_TEST_HOOKS='as_f_chain=%d' % (1 if chain else 0))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = CHILD % {'root': root, 'n': n, 'd': d, 'max_iter': max_iter, 'out': out}
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)

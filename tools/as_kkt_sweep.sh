@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/as_kkt_sweep.sh NAME VAR v1 v2 ...: dense ActiveSet at BASELINE config 2's shape (n = 20 000, d = 64) to 'optimal' once per value of the
-# environment variable VAR (e.g. BQ_AS_SCHUR_MIN 64 256 1024), with BQ_AS_TIMING's host-side breakdown; one line per run in NAME/sweep.txt
+# environment variable VAR (e.g. BQ_TEST_HOOKS as_schur_min=64 as_schur_min=256), with BQ_AS_TIMING's host-side breakdown; one line per run in NAME/sweep.txt
 out=gpurun_out/$1; var=$2; shift; shift; mkdir -p "$out"
 for v in "$@"; do
     env "$var=$v" BQ_AS_TIMING=1 python3 bench.py --solver as --samples 20000 --features 64 --no-cpu --records none > "$out/kkt_$v.json" 2> "$out/kkt_$v.err"

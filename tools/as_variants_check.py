@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dense ActiveSet's product-free objective (BQ_AS_F_CHAIN, INTEGRATION.md "Deviations") on the panel kinds the parity tests do not
+"""Dense ActiveSet's product-free objective (hook as_f_chain, INTEGRATION.md "Deviations") on the panel kinds the parity tests do not
 sweep for it: an fp32-stored panel and an SVR dual (2n variables on an n x n panel), beside the fp64 SVC dual.  Each fit once with
 the identity and once with a product per iteration (fresh process each); prints iterations, status, the number of iterations without
 a product and the largest difference of the recorded objective relative to its scale.      python tools/as_variants_check.py
@@ -33,7 +33,7 @@ print(json.dumps(out))
 '''
 res = {}
 for chain in ("1", "0"):
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}], env=dict(os.environ, BQ_AS_F_CHAIN=chain), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}], env=dict(os.environ, BQ_TEST_HOOKS='as_f_chain=' + chain), capture_output=True, text=True)
     if r.returncode: print(r.stderr[-1500:]); sys.exit(1)
     res[chain] = json.loads(r.stdout.strip().splitlines()[-1])
 import numpy as np

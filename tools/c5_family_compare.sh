@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/c5fam}; steps=${2:-20}
 mkdir -p "$out"
 for fam in ${FAMILIES:-1 2 3}; do
-    BQ_AS_CG_PC_CLASS=$fam python3 bench.py --config c5 --steps "$steps" --warmup 2 --no-cpu --kkt none --line full > "$out/c5_fam$fam.json" 2> "$out/c5_fam$fam.err" || exit 1
+    BQ_TEST_HOOKS=as_cg_pc_class=$fam python3 bench.py --config c5 --steps "$steps" --warmup 2 --no-cpu --kkt none --line full > "$out/c5_fam$fam.json" 2> "$out/c5_fam$fam.err" || exit 1
     python3 - "$out/c5_fam$fam.json" "$fam" <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -63,6 +63,7 @@ def work(workload, kernel):
 
 def main(d):
     w = csv.writer(sys.stdout)
+    # launches / avg_ms: the launches that did their work (rocpd_stats.py: CallsFull / AverageFullNs), not those that returned on a `done` flag
     w.writerow(['workload', 'kernel', 'launches', 'avg_ms', 'min_ms', 'share_of_gpu_time_pct', 'bound', 'algorithmic_per_launch', 'unit',
                 'achieved', 'achieved_unit', 'peak', 'frac_of_peak', 'bench_value', 'bench_unit'])
     for path in sorted(glob.glob(os.path.join(d, '*_kernel_stats.csv'))):
@@ -80,7 +81,7 @@ def main(d):
             short = re.sub(r'\(.*', '', name)[:70]
             if float(r['Percentage']) < 0.05 and not short.startswith(('symv', 'gemv', 'gram', 'pgfw', 'al_')):
                 continue
-            calls, avg, mn = int(float(r['Calls'])), float(r['AverageNs']) / 1e6, float(r['MinNs']) / 1e6
+            calls, avg, mn = int(float(r.get('CallsFull') or r['Calls'])), float(r.get('AverageFullNs') or r['AverageNs']) / 1e6, float(r['MinNs']) / 1e6
             k = work(workload, short)
             if k:
                 bound, alg, unit = k

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: SMO runs for several helper-workgroup counts must give the same path (BQ_SMO_HELPERS)."""
+"""Diagnostic: SMO runs for several helper-workgroup counts must give the same path (BQ_TEST_HOOKS=smo_helpers=N)."""
 import os
 import sys
 
@@ -22,7 +22,7 @@ else:
     X, yr = make_regression(n, 8, seed=4)
     yr = (yr - yr.mean()) / yr.std()
 for h in (sys.argv[3].split(',') if len(sys.argv) > 3 else ('0', '0', '16', '16', '128', '128', '128', '255', '255')):
-    os.environ['BQ_SMO_HELPERS'] = h
+    os.environ['BQ_TEST_HOOKS'] = 'smo_helpers=' + h
     if task == 'both':   # the sequence of tests/test_gpu_smo.py: a classifier run first, then the regression
         quad = KernelQuadratic(Xc, -np.ones(6000), 'svc', gaussian, y=ycb, rank_one=False)
         o = SMOClassifier(quad, Xc, ycb, None, gaussian, 1., 1e-3).minimize()

@@ -14,7 +14,7 @@ for name in ('fit_svr_n400.npz', 'fit_svr_n150.npz'):
     keys = [k for k in g.files if 'ip' in k]
     a = est.alphas_; n = len(a) // 2
     ref = g['rbf_ip_alphas'] if 'rbf_ip_alphas' in g.files else None
-    out = dict(name=name, mode=os.environ.get('BQ_IP_SVR_REDUCED', '0'), iter=int(est.optimizer.iter), status=est.optimizer.status,
+    out = dict(name=name, mode=os.environ.get('BQ_TEST_HOOKS', 'ip_svr_reduced=1'), iter=int(est.optimizer.iter), status=est.optimizer.status,
                f=float(est.optimizer.f_x), ref_iter=int(g['rbf_ip_iter']) if 'rbf_ip_iter' in g.files else None,
                ref_f=float(g['rbf_ip_f_x']) if 'rbf_ip_f_x' in g.files else None)
     if ref is not None:
