@@ -692,7 +692,10 @@ extern "C" int bq_problem_create_kernel(bq_ctx *c, int structure, int64_t n, int
         bq_problem_destroy(p);
         return rc;
     }
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail(e);
+    if (const int src = bq_ctx_sync(c)) {   // (bounded on a multi-rank context)
+        bq_problem_destroy(p);
+        return src;
+    }
     *out = p;
     return BQ_OK;
 }
@@ -1091,7 +1094,13 @@ extern "C" int bq_solver_create(bq_problem *p, int kind, const double *lb, const
         s->host.f = NAN;
         e = hipMemcpyAsync(s->sc, &s->host, sizeof(bq_scal), hipMemcpyHostToDevice, c->stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) {   // may sit behind a collective of an earlier solve: the bounded wait
+        const int src = bq_ctx_sync(c);
+        if (src != BQ_OK) {
+            bq_solver_destroy(s);
+            return src;
+        }
+    }
     if (e != hipSuccess) {
         bq_set_error("solver setup failed: %s", hipGetErrorString(e));
         bq_solver_destroy(s);
@@ -1222,7 +1231,13 @@ extern "C" int bq_al_solver_create(bq_problem *p, const bq_al_params *prm, const
         s->host.al_pf = NAN;
         e = hipMemcpyAsync(s->sc, &s->host, sizeof(bq_scal), hipMemcpyHostToDevice, c->stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) {   // may sit behind a collective of an earlier solve: the bounded wait
+        const int src = bq_ctx_sync(c);
+        if (src != BQ_OK) {
+            bq_solver_destroy(s);
+            return src;
+        }
+    }
     if (e != hipSuccess) {
         bq_set_error("solver setup failed: %s", hipGetErrorString(e));
         bq_solver_destroy(s);

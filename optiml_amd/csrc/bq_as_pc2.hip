@@ -237,7 +237,7 @@ int as_pc2_create(bq_solver *s, double *bdiag_out, int64_t tail, as_pc2 **out) {
     if (e == hipSuccess && r->nsl > 0) e = hipMemcpyAsync(r->sl_row, sl_row.data(), sizeof(long long) * r->nsl, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && r->nsl > 0) e = hipMemcpyAsync(r->sl_k, sl_k.data(), sizeof(long long) * r->nsl, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(r->sl_first, sl_first.data(), sizeof(int) * ((size_t)pt.S + 1), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);   // the three tables leave this scope
+    if (e == hipSuccess && bq_ctx_sync(ctx) != BQ_OK) e = hipErrorUnknown;   // the three tables leave this scope (the bounded wait: the stream may hold collectives)
     if (e == hipSuccess) e = hipMalloc(&r->Xt, sizeof(double) * r->dp * r->ld);
     if (e == hipSuccess) e = hipMalloc(&r->W, sizeof(double) * r->rows * r->dp);
     if (e == hipSuccess) e = hipMalloc(&r->Mpart, sizeof(double) * nsl1 * r->dp * r->dp);

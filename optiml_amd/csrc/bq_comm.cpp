@@ -79,8 +79,8 @@ struct stage_scope {
         }();
         if (dt > 5.0 || verbose) fprintf(stderr, "[bcqp] RCCL start-up: %s took %.3f s\n", name, dt);
         char buf[160];
+        std::lock_guard<std::mutex> lk(g_stages.m);   // the separator looks at the text: under the lock too
         snprintf(buf, sizeof(buf), "%s%s %.3f s", g_stages.text.empty() ? "" : "; ", name, dt);
-        std::lock_guard<std::mutex> lk(g_stages.m);
         g_stages.text += buf;
     }
 };

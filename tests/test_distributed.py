@@ -281,10 +281,13 @@ def test_rows_per_step_variants_are_bit_identical(tmp_path, one_rank):
 
 @pytest.mark.gpu
 def test_order2_remainder_of_the_preconditioner_is_replicated_bitwise(tmp_path):
-    """The implicit order-2 remainder of ActiveSetCG's preconditioner (csrc/bq_as_pc2.hip: two MFMA products with a split-K sum, a
-    power-iteration spectrum bound, a Chebyshev polynomial) is sharded by sample segments — a rank forms the moment slices and the
-    x'Mx values of its own samples, the per-segment sums and v are gathered and added in segment order: forced on
-    (hook as_cg_pc_class=3), one, two and three ranks give the same bits — and the same outer trajectory as without it."""
+    """ActiveSetCG's preconditioner is sharded by sample segments: the implicit order-2 remainder (csrc/bq_as_pc2.hip: two MFMA
+    products with a split-K sum, a power-iteration spectrum bound, a Chebyshev polynomial — a rank forms the moment slices and the
+    x'Mx values of its own samples) and, since round 6, the explicit model's two passes over the features too (csrc/bq_as_pc.hip:
+    t = Phi' D^-1 r over a rank's own sample blocks, z for its own samples); the per-segment sums of M, of t and of Phi_top' y and
+    the vectors v and z are gathered and added / unpacked in segment order — six collectives per application.  Forced on (hook
+    as_cg_pc_class=3), one, two and three ranks give the same bits — and the same outer trajectory as without the remainder.
+    (The explicit model alone, two collectives per application, is what every `ascg_kernel_*` key of the tests above runs.)"""
     env = hooks_env(as_cg_pc_class=3)
     one = _launch('gpu-host', 1, tmp_path / 'one', extra_env=env)[0]
     two = _launch('gpu-host', 2, tmp_path / 'two', extra_env=env)

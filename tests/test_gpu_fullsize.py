@@ -534,7 +534,9 @@ def test_config5_full_size_over_eight_ranks():
     """C5 at its own size and rank count: squared-hinge RBF dual, ActiveSet with conjugate-gradient restricted solves,
     n = 250 000, d = 256, fp32 panel (125 GB in all) split over EIGHT ranks = eight threads / contexts / streams of this
     process on the one GPU (the box allows six processes on the card), host-callback exchange.  One product and two outer
-    iterations (each tens of masked panel products + one collective each) are bit-identical to one rank."""
+    iterations (each tens of masked panel products with one collective each, and as many applications of the preconditioner with
+    six: every pass over samples in it — explicit features and implicit order-2 remainder — is sharded by the canonical sample
+    segments since round 6) are bit-identical to one rank."""
     from test_distributed import run_thread_ranks
     from optiml_amd import _lib
     from optiml_amd.datasets import make_blobs
