@@ -113,6 +113,28 @@ def gpu_mode(exchange, outdir, sym_exchange=None):
     res['hid_matvec'] = hq.device_problem().matvec(vq)
     res['hid_ref'] = Qh @ vq
     hq.release()
+    # six tile rows (ranks own several, and rows above their own): a symmetric Q is packed on every rank count, and ONE element one
+    # ulp off its mirror image sends every rank to row blocks wherever the pair sits — inside a rank's own tile rows (compared while
+    # that rank's rows go up) or between two ranks' rows (met only in the later rank's column strip)
+    nd = 1300
+    G2 = np.random.RandomState(21).standard_normal((nd, 40))
+    Q6 = G2 @ G2.T / nd + np.eye(nd)
+    Q6 = (Q6 + Q6.T) / 2
+    v6 = np.random.RandomState(22).standard_normal(nd)
+    q6 = Quadratic(Q6, np.zeros(nd))
+    res['six_packed'] = np.array(q6.device_problem().layout()['packed'])
+    res['six_rows'] = np.array(q6.device_problem().dims()[2:])
+    res['six_matvec'] = q6.device_problem().matvec(v6)
+    res['six_ref'] = Q6 @ v6
+    q6.release()
+    for tag, (i, j) in (('a', (300, 1290)), ('b', (1100, 1101)), ('c', (520, 700)), ('d', (5, 260))):
+        Qx = Q6.copy()
+        Qx[i, j] = np.nextafter(Qx[i, j], np.inf)
+        qx = Quadratic(Qx, np.zeros(nd))
+        res[f'six_{tag}_packed'] = np.array(qx.device_problem().layout()['packed'])
+        res[f'six_{tag}_matvec'] = qx.device_problem().matvec(v6)
+        res[f'six_{tag}_ref'] = Qx @ v6
+        qx.release()
     res['dense_matvec'] = dq.device_problem().matvec(vq)
     opt = ProjectedGradient(quad=dq, ub=np.ones(500), max_iter=40).minimize()
     res['dense_pg_x'] = opt.x

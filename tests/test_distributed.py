@@ -132,7 +132,11 @@ def test_thread_ranks_primitives():
 
 SYM_KEYS = ('matvec', 'gram_matvec', 'pg_x', 'pg_hist', 'fw_x', 'fw_f', 'al_x', 'al_dual', 'al_f', 'ascg_kernel_x',
             'ascg_kernel_f')
-ROW_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'ascg_x', 'ascg_iter', 'ascg_inner', 'rowsq_matvec', 'rowsq_pg_x', 'hid_matvec')
+# dense Hessians: a Q == Q' is packed like a kernel panel since round 6 (segments + all-gather of segment partials), any other Q keeps
+# row blocks (all-gather of disjoint slices)
+DENSE_SYM_KEYS = ('dense_matvec', 'dense_pg_x', 'dense_al_x', 'ascg_x', 'ascg_iter', 'ascg_inner', 'six_matvec')
+DENSE_ROW_KEYS = ('rowsq_matvec', 'rowsq_pg_x', 'hid_matvec', 'six_a_matvec', 'six_b_matvec', 'six_c_matvec', 'six_d_matvec')
+ROW_KEYS = DENSE_SYM_KEYS + DENSE_ROW_KEYS
 # streamed kernel problems use the symmetric segment exchange since round 2b (every lower-triangle tile formed once)
 SYM_KEYS = SYM_KEYS + ('stream_matvec', 'stream_fw_x')
 
@@ -152,8 +156,12 @@ def test_two_ranks_reproduce_single_rank_bitwise(tmp_path, one_rank):
     # blocks; a Q with one element one ulp off its mirror image, seen by rank 1 only: both ranks fall back to row blocks
     assert tuple(two[0]['dense_rows']) == (0, 256) and tuple(two[1]['dense_rows']) == (256, 500)
     assert tuple(two[0]['rowsq_rows']) == (0, 256) and tuple(two[1]['rowsq_rows']) == (256, 500)
+    assert tuple(two[0]['six_rows']) == (0, 1024) and tuple(two[1]['six_rows']) == (1024, 1300)   # six tile rows: 4 + 2
     for r in two + [one]:
         assert bool(r['dense_packed']) and not bool(r['rowsq_packed']) and not bool(r['hid_packed'])
+        assert bool(r['six_packed']) and not any(bool(r[f'six_{t}_packed']) for t in 'abcd')
+        for t in ('', 'a_', 'b_', 'c_', 'd_'):
+            np.testing.assert_allclose(r[f'six_{t}matvec'], r[f'six_{t}ref'], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(r['rowsq_matvec'], r['rowsq_ref'], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(r['hid_matvec'], r['hid_ref'], rtol=1e-12, atol=1e-12)
     # streamed kernel problems: the segment partition of the tile rows, like the resident symmetric panels
@@ -188,6 +196,7 @@ def test_three_ranks_uneven_partitions(tmp_path, one_rank):
     three = _launch('gpu-host', 3, tmp_path / 'w3')
     assert [tuple(r['rows']) for r in three] == [(0, 512), (512, 512), (512, 700)]
     for r in three:
+        assert bool(r['six_packed']) and not any(bool(r[f'six_{t}_packed']) for t in 'abcd') and not bool(r['hid_packed'])
         for key in ROW_KEYS + SYM_KEYS:
             assert np.array_equal(r[key], one_rank[key]), key
 
@@ -199,6 +208,7 @@ def test_four_ranks_two_segments_each(tmp_path, one_rank):
     four = _launch('gpu-host', 4, tmp_path / 'w4')
     assert [tuple(r['rows']) for r in four] == [(0, 512), (512, 512), (512, 700), (700, 700)]
     for r in four:
+        assert bool(r['six_packed']) and not any(bool(r[f'six_{t}_packed']) for t in 'abcd') and not bool(r['hid_packed'])
         for key in ROW_KEYS + SYM_KEYS:
             assert np.array_equal(r[key], one_rank[key]), key
 
@@ -224,8 +234,10 @@ def test_allreduce_variant_of_the_symmetric_exchange(tmp_path, one_rank):
     two = _launch('gpu-host-allreduce', 2, tmp_path / 'w2ar')
     for r in two:
         assert str(r['sym_exchange']) == 'allreduce'
-        for key in ROW_KEYS:
+        for key in DENSE_ROW_KEYS:   # row blocks end in an all-gather of disjoint slices whatever the symmetric exchange is
             assert np.array_equal(r[key], one_rank[key]), key
+        for key in DENSE_SYM_KEYS:   # packed dense Hessians take the symmetric exchange: the rank sum's association is the transport's
+            np.testing.assert_allclose(r[key], one_rank[key], rtol=1e-9, atol=1e-11, err_msg=key)
         for key in ('matvec', 'gram_matvec', 'pg_hist', 'fw_f', 'al_f', 'stream_matvec'):
             np.testing.assert_allclose(r[key], one_rank[key], rtol=1e-12, atol=1e-12, err_msg=key)
         for key in ('pg_x', 'fw_x', 'al_x', 'al_dual', 'stream_fw_x'):

@@ -226,6 +226,13 @@ def test_panel_placement_selection(amd, monkeypatch):
     ms = tuned.device_problem().placement()
     assert len(ms) == 3 and all(t > 0 for t in ms)
     assert np.array_equal(tuned.device_problem().matvec(v), ref)
+    # the two candidates that were not kept are HELD until the solve is over; a caller that needs the memory for something the
+    # library does not see takes it back at once (bq_ctx_release_held_memory), and then nothing is left to give
+    from optiml_amd import device as _device
+    panel_bytes = tuned.device_problem().layout()['panel_bytes']
+    assert _device.get_context().release_held_memory() == 2 * panel_bytes
+    assert _device.get_context().release_held_memory() == 0
+    assert np.array_equal(tuned.device_problem().matvec(v), ref)
     monkeypatch.setenv('BQ_PLACE_BUDGET_MS', '0')          # no time for anything but the first timing (another fresh allocation)
     hurried = KernelQuadratic(X, -np.ones(n), 'svc', gaussian, y=y, tune_placement=True)
     assert len(hurried.device_problem().placement()) == 1
