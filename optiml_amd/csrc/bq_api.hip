@@ -485,15 +485,27 @@ extern "C" int bq_problem_create_dense(bq_ctx *c, int64_t n, const double *Q, co
     // every rank is handed the same Q, so the look at the host matrix sends them all the same way
     bool try_sym = !force_rows && (trust_lower || bq_dense_host_spot_symmetric(Q, n));
     if (try_sym) {
-        BQ_TRY(dense_new(c, n, q, storage, true, place, &p));
+        // rank-local steps (the packed panel's allocation, the upload, the comparison), then ONE agreement on a multi-rank context:
+        // "some rank failed" ends the call with an error on EVERY rank, "some rank saw a difference" sends every rank to row blocks
+        int rc = dense_new(c, n, q, storage, true, place, &p);
         int is_sym = 1;
-        int rc = bq_dense_upload_sym(p, Q, !trust_lower, &is_sym);
+        if (rc == BQ_OK) rc = bq_dense_upload_sym(p, Q, !trust_lower, &is_sym);
         if (rc == BQ_OK) rc = bq_ctx_sync(c);
-        if (rc != BQ_OK) {
-            bq_problem_destroy(p);
+        bool any_failed = rc != BQ_OK, any_asym = !is_sym;
+        if (!trust_lower || c->world > 1) {
+            int arc = bq_dense_agree(c, rc != BQ_OK, &any_failed);
+            if (arc == BQ_OK && !any_failed && !trust_lower) arc = bq_dense_agree(c, !is_sym, &any_asym);
+            if (rc == BQ_OK && arc != BQ_OK) rc = arc;
+        }
+        if (rc != BQ_OK || any_failed) {
+            if (p) bq_problem_destroy(p);
+            if (rc == BQ_OK) {
+                bq_set_error("the dense Hessian could not be set up on another rank");
+                rc = BQ_ERR_HIP;
+            }
             return rc;
         }
-        if (is_sym) {
+        if (!any_asym) {
             *out = p;
             return BQ_OK;
         }

@@ -323,6 +323,7 @@ int bq_panel_product(bq_problem *p, bool add_one, const double *w, const int *do
 // while uploading, agreed across ranks), else row blocks
 bool bq_dense_host_spot_symmetric(const double *Q, int64_t n);
 int bq_dense_upload_sym(bq_problem *p, const double *Q, bool check, int *symmetric);
+int bq_dense_agree(bq_ctx *c, bool mine, bool *any);   // a flag summed over the ranks (one all-reduce; no-op on one rank)
 int bq_dense_upload_rows(bq_problem *p, const double *Q);
 
 // bq_gemv.hip: s[r0 + i] = sum_j elem(panel[i][j]) * w[j], i in [0, nrows)

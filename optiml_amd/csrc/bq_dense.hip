@@ -76,8 +76,6 @@ __global__ __launch_bounds__(256) void dense_symcheck_kernel(const double *__res
     if (bad) *flag = 1;
 }
 
-__global__ void flag_to_double_kernel(const int *flag, double *out) { *out = *flag ? 1.0 : 0.0; }
-
 template <typename T>
 int upload_sym_t(bq_problem *p, const double *Q, bool check, int *symmetric) {
     bq_ctx *c = p->ctx;
@@ -173,32 +171,33 @@ bool bq_dense_host_spot_symmetric(const double *Q, int64_t n) {
     return true;
 }
 
-// p: a dense problem laid out symmetric (problem_layout); fills the packed panel from Q.  check: compare with the transpose while
-// uploading and agree across ranks — *symmetric == 0 means the caller must fall back to row blocks (the panel is then partial).
-int bq_dense_upload_sym(bq_problem *p, const double *Q, bool check, int *symmetric) {
-    bq_ctx *c = p->ctx;
-    int mine = 1;
-    int rc = p->storage == BQ_F64 ? upload_sym_t<double>(p, Q, check, &mine) : upload_sym_t<float>(p, Q, check, &mine);
-    // every rank reaches the agreement, whatever happened to it before: a rank that failed alone must not leave the others waiting
-    if (check && c->comm_kind != BQ_COMM_NONE && c->comm_kind != BQ_COMM_SHARE) {
-        double *fd = nullptr;
-        const double bad = (rc != BQ_OK || !mine) ? 1.0 : 0.0;
-        int rc2 = BQ_OK;
-        if (hipMalloc(&fd, sizeof(double)) != hipSuccess) {
-            bq_set_error("cannot allocate the symmetry flag");
-            return BQ_ERR_HIP;
-        }
-        if (hipMemcpyAsync(fd, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc2 = BQ_ERR_HIP;
-        if (rc2 == BQ_OK) rc2 = bq_exchange_sum(c, fd, 1);
-        double total = 0.0;
-        if (rc2 == BQ_OK && hipMemcpyAsync(&total, fd, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc2 = BQ_ERR_HIP;
-        if (rc2 == BQ_OK) rc2 = bq_ctx_sync(c);
-        hipFree(fd);
-        if (rc == BQ_OK) rc = rc2;
-        if (total > 0.0) mine = 0;
+// One flag summed over the ranks of a multi-rank context (no-op elsewhere): *any = some rank raised it.  Every rank that entered
+// bq_problem_create_dense's packed attempt reaches this, whatever happened to it before — a rank that failed alone must not leave the
+// others waiting in the collective.
+int bq_dense_agree(bq_ctx *c, bool mine, bool *any) {
+    *any = mine;
+    if (c->comm_kind == BQ_COMM_NONE || c->comm_kind == BQ_COMM_SHARE) return BQ_OK;
+    double *fd = nullptr;
+    const double bad = mine ? 1.0 : 0.0;
+    if (hipMalloc(&fd, sizeof(double)) != hipSuccess) {
+        bq_set_error("cannot allocate the agreement flag");
+        return BQ_ERR_HIP;
     }
-    *symmetric = mine;
+    int rc = BQ_OK;
+    if (hipMemcpyAsync(fd, &bad, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = BQ_ERR_HIP;
+    if (rc == BQ_OK) rc = bq_exchange_sum(c, fd, 1);
+    double total = 0.0;
+    if (rc == BQ_OK && hipMemcpyAsync(&total, fd, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = BQ_ERR_HIP;
+    if (rc == BQ_OK) rc = bq_ctx_sync(c);
+    hipFree(fd);
+    if (rc == BQ_OK) *any = total > 0.0;
     return rc;
+}
+
+// p: a dense problem laid out symmetric (problem_layout); fills the packed panel from Q.  check: compare with the transpose while
+// uploading — *symmetric == 0 means this rank saw a difference (the caller agrees across ranks and falls back to row blocks)
+int bq_dense_upload_sym(bq_problem *p, const double *Q, bool check, int *symmetric) {
+    return p->storage == BQ_F64 ? upload_sym_t<double>(p, Q, check, symmetric) : upload_sym_t<float>(p, Q, check, symmetric);
 }
 
 __global__ void f64_to_f32_rows_kernel(const double *__restrict__ src, int64_t n, float *__restrict__ dst, int64_t ld) {
