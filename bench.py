@@ -1306,6 +1306,8 @@ def main():
     if args.cpu_study:
         return cpu_study(args)
     if args.dense:
+        if args.gpus != 1 or 'WORLD_SIZE' in os.environ:
+            raise SystemExit('--dense is a one-GPU record (the sharding of a packed dense Hessian is that of the kernel panels: --gpus N on the default workload)')
         return dense_record(args)
     if args.emulate_shares:
         return share_timing(args)
