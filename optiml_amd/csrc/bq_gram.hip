@@ -385,14 +385,23 @@ int bq_launch_gram(bq_ctx *ctx, const double *X, int64_t n, int64_t d, int64_t r
     return BQ_OK;
 }
 
-// out[t] = sum_m coef[m] * kernel(SV[m], Xt[t]) + intercept : the m x t cross-Gram goes through the same MFMA
-// kernel (A = Xt rows, B = SV rows -> panel t x m), then the panel product with coef.
+// out[t] = sum_m coef[m] * kernel(SV[m], Xt[t]) + intercept : the cross-Gram goes through the same MFMA kernel (A = Xt rows,
+// B = SV rows -> panel rows x m), then the row-block product with coef — in CHUNKS of test points, so that the t x m panel is never
+// held whole (round 6: 10^6 test points against 50 000 support vectors would have asked for 400 GB; a chunk's panel is <= 2 GiB).
+// Every output row is formed by the same kernels on the same operands whatever the chunking: the values do not depend on it
+// (hook decision_chunk_rows forces small chunks in the tests).
 int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int degree, int64_t m, int64_t d,
                        const double *SV, const double *coef, double intercept, int64_t t, const double *Xt,
                        double *out) {
     gram_images A, B;
     double *dSV = nullptr, *dXt = nullptr, *panel = nullptr, *w = nullptr, *s = nullptr;
     const int64_t ld = bq_round_up(m, BQ_PAD);
+    int64_t chunk = std::max<int64_t>(GT, ((int64_t)1 << 28) / ld / GT * GT);   // rows of test points per pass: <= 2 GiB of panel
+    {
+        double hv = 0.0;
+        if (bq_hook("decision_chunk_rows", &hv) && hv >= 1.0) chunk = bq_round_up((int64_t)hv, GT);
+    }
+    chunk = std::min(chunk, bq_round_up(t, GT));
     int rc = BQ_OK;
     auto cleanup = [&]() {
         free_image(&A);
@@ -414,21 +423,24 @@ int bq_launch_decision(bq_ctx *ctx, int kernel, double gamma, double coef0, int 
     } while (0)
     DEC_HIP(hipMalloc(&dSV, sizeof(double) * m * d));
     DEC_HIP(hipMalloc(&dXt, sizeof(double) * t * d));
-    DEC_HIP(hipMalloc(&panel, sizeof(double) * t * ld));
+    DEC_HIP(hipMalloc(&panel, sizeof(double) * chunk * ld));
     DEC_HIP(hipMalloc(&w, sizeof(double) * ld));
-    DEC_HIP(hipMalloc(&s, sizeof(double) * t));
+    DEC_HIP(hipMalloc(&s, sizeof(double) * bq_round_up(t, GT)));
     DEC_HIP(hipMemcpyAsync(dSV, SV, sizeof(double) * m * d, hipMemcpyHostToDevice, ctx->stream));
     DEC_HIP(hipMemcpyAsync(dXt, Xt, sizeof(double) * t * d, hipMemcpyHostToDevice, ctx->stream));
-    DEC_HIP(hipMemsetAsync(panel, 0, sizeof(double) * t * ld, ctx->stream));
+    DEC_HIP(hipMemsetAsync(panel, 0, sizeof(double) * chunk * ld, ctx->stream));   // the pad columns m .. ld stay zero: the row product reads them
     DEC_HIP(hipMemsetAsync(w, 0, sizeof(double) * ld, ctx->stream));
     DEC_HIP(hipMemcpyAsync(w, coef, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = make_image(ctx, dXt, t, d, &A)) != BQ_OK || (rc = make_image(ctx, dSV, m, d, &B)) != BQ_OK) {
         cleanup();
         return rc;
     }
-    // kernel(SV, Xt)[m][t] == kernel(Xt, SV)[t][m] for all three kernels (gamma is passed in resolved)
-    rc = run_gram(ctx, A, B, 0, t, m, false, kernel, gamma, coef0, degree, panel, BQ_F64, ld);
-    if (rc == BQ_OK) rc = bq_launch_gemv(ctx, panel, BQ_F64, false, t, ld, w, s, nullptr);
+    // kernel(SV, Xt)[m][t] == kernel(Xt, SV)[t][m] for all the kernels (gamma is passed in resolved)
+    for (int64_t r0 = 0; rc == BQ_OK && r0 < t; r0 += chunk) {
+        const int64_t r1 = std::min(t, r0 + chunk);
+        rc = run_gram(ctx, A, B, r0, r1, m, false, kernel, gamma, coef0, degree, panel, BQ_F64, ld);
+        if (rc == BQ_OK) rc = bq_launch_gemv(ctx, panel, BQ_F64, false, r1 - r0, ld, w, s + r0, nullptr);
+    }
     if (rc != BQ_OK) {
         cleanup();
         return rc;

@@ -1345,6 +1345,38 @@ def test_reference_integration_test_iris(amd, s):
     assert svc.score(X_test, y_test) >= 0.97
 
 
+def test_decision_function_is_chunked_over_test_points(amd, monkeypatch):
+    """`decision_function` (optiml/ml/svm/_base.py:284-287: kernel(SV, X) contracted with dual_coef_) goes through the cross-Gram in
+    chunks of test points, so that the t x m panel is never held whole; every row is formed by the same kernels on the same operands
+    whatever the chunking: forced to 256-row chunks (ragged last chunk, ragged last tile) the values are the same BITS, and they
+    are the oracle's."""
+    import ctypes as C
+    from optiml_amd import _lib
+    from optiml_amd.device import get_context
+    from oracle import svm_oracle as so
+    rs = np.random.RandomState(5)
+    m, t, d = 700, 1000 + 37, 12
+    SV, Xt = rs.standard_normal((m, d)), rs.standard_normal((t, d))
+    coef, b = rs.standard_normal(m), 0.25
+    lib = _lib.load()
+
+    def run(kind, gamma, coef0, degree):
+        out = np.empty(t)
+        _lib.check(lib.bq_decision_function(get_context().handle, kind, gamma, coef0, degree, m, d, _lib.ptr(SV), _lib.ptr(coef), b, t,
+                                            _lib.ptr(Xt), _lib.ptr(out)))
+        return out
+
+    gamma = 1.0 / (d * SV.var())
+    for kind, name, c0, deg in ((_lib.KERNEL_RBF, 'rbf', 0.0, 0), (_lib.KERNEL_POLY, 'poly', 1.0, 3), (_lib.KERNEL_LINEAR, 'linear', 0.0, 0)):
+        set_hooks(monkeypatch, decision_chunk_rows=None)
+        whole = run(kind, gamma, c0, deg)
+        set_hooks(monkeypatch, decision_chunk_rows=256)
+        chunked = run(kind, gamma, c0, deg)
+        np.testing.assert_array_equal(chunked, whole)
+        K = so.gram(name, Xt, SV, gamma=gamma, coef0=c0, degree=deg or 3)
+        np.testing.assert_allclose(whole, K @ coef + b, rtol=1e-11, atol=1e-11 * np.abs(K).sum(1).max())
+
+
 def test_laplacian_and_sigmoid_kernels(amd):
     """the remaining kernel functors (optiml/ml/svm/kernels.py:132-201) against the reference fixture."""
     from optiml_amd.ml.svm import SVC
