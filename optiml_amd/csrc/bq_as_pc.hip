@@ -1038,7 +1038,7 @@ int as_pc_update(bq_solver *s, as_ws *w) {
         as_pc_gram_reduce_kernel<<<gtri, 256, 0, st>>>(pc->m, pc->mp, pc->Gpart, pc->ws->H, pc->ws->ldh);
         BQ_TRY(bq_chol_factor(pc->ws, pc->mp));
         BQ_TRY(bq_chol_prepare_sweeps(pc->ws, pc->mp));   // the explicit inverse factor (mp <= 1024: one block)
-        as_pc_ginv_kernel<<<dim3((unsigned)(pc->mp / 16), (unsigned)(pc->mp / 16)), 256, 0, st>>>(pc->mp, pc->ws->bigMT, 1024, pc->Ginv);
+        as_pc_ginv_kernel<<<dim3((unsigned)(pc->mp / 16), (unsigned)(pc->mp / 16)), 256, 0, st>>>(pc->mp, pc->ws->bigMT, pc->ws->bb, pc->Ginv);
         BQ_HIP(hipMemsetAsync(pc->sm_fail, 0, sizeof(int), st));
         pc->rebuilds += 1;
     } else {

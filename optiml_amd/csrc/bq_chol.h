@@ -24,6 +24,7 @@ struct bq_chol_ws {
     // they were prepared for (0: not prepared; bq_chol_solve then walks the 128-row blocks)
     double *bigM = nullptr, *bigMT = nullptr, *big_scratch = nullptr, *sw_t = nullptr;
     int64_t big_cap = 0, sweep_np = 0;
+    int64_t bb = 1024;        // rows of a big block of the prepared sweeps (bq_chol_prepare_sweeps chooses it)
     // look-ahead: the narrow work of pass p+1 (diagonal blocks, TRSM, column update) runs on a side stream that owns
     // a few reserved CUs while the wide trailing update of pass p runs on the rest of the chip
     hipStream_t s_main = nullptr, s_side = nullptr;

@@ -474,18 +474,19 @@ int bq_chol_factor(bq_chol_ws *ws, int64_t np) {
 // iterations, each with one or two solves).  The block-by-block solves above take one dependent launch per 128 rows and
 // direction (782 launches for a 10 GB factor at n = 50 000: ~10 % of the HBM rate).  bq_chol_prepare_sweeps() spends one
 // pass over the factor to make every sweep a short chain of full-chip row-panel products instead:
-//   * the 1024 x 1024 diagonal blocks of L are inverted once (M_K = L_KK^-1, built from the 128 x 128 inverses the
+//   * the bb x bb (1024 ... 4096) diagonal blocks of L are inverted once (M_K = L_KK^-1, built from the 128 x 128 inverses the
 //     factorisation left behind: X_ij = -Linv_ii sum_{j <= k < i} L_ik X_kj on the MFMA tile kernel) and kept together with
 //     their transposes;
 //   * L^T is mirrored into the (unused) upper triangle of H, so that the backward sweep reads contiguous rows too.
-// A sweep then takes two launches per 1024 rows: t = b_K - L[K, :K] y (all CUs streaming the row panel once) and
+// A sweep then takes two launches per bb rows: t = b_K - L[K, :K] y (all CUs streaming the row panel once) and
 // y_K = M_K t.  n = 20 000: 40 launches instead of 154 per direction; the factor is streamed once per direction at the
 // product's rate.  Every sum has a fixed order (no atomics): results do not depend on the launch geometry.
 // ---------------------------------------------------------------------------------------------
-constexpr int64_t BB = 1024;   // rows of a big block
+// rows of a big block: bq_chol_ws::bb, chosen when the sweeps are prepared (1024 for small workspaces, 2048 from order 4096, 4096
+// from order 8192 on: a quarter of the launches of a sweep for four times the inverse-block traffic — profiles/r06/as_sweep_block.txt)
 
 // X_ij blocks of one big block's inverse, one workgroup per (column j of sub-blocks, big block)
-__global__ __launch_bounds__(256, 2) void big_inverse_kernel(const double *__restrict__ H, int64_t ldh, int64_t np,
+__global__ __launch_bounds__(256, 2) void big_inverse_kernel(const double *__restrict__ H, int64_t ldh, int64_t np, int64_t BB,
                                                              const double *__restrict__ LinvT, double *__restrict__ M,
                                                              double *__restrict__ scratch) {
     __shared__ __attribute__((aligned(16))) bq_tile_smem sm;
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void big_inverse_kernel(const double *__res
 }
 
 // MT_K = M_K^T (32 x 32 tiles through LDS)
-__global__ __launch_bounds__(256) void big_transpose_kernel(const double *__restrict__ M, double *__restrict__ MT) {
+__global__ __launch_bounds__(256) void big_transpose_kernel(const double *__restrict__ M, double *__restrict__ MT, int64_t BB) {
     __shared__ double tile[32][33];
     const double *src = M + (int64_t)blockIdx.z * BB * BB;
     double *dst = MT + (int64_t)blockIdx.z * BB * BB;
@@ -595,8 +596,17 @@ __global__ void sweep_copy_kernel(const double *__restrict__ src, double *__rest
 
 int bq_chol_prepare_sweeps(bq_chol_ws *ws, int64_t np) {
     hipStream_t st = ws->ctx->stream;
+    // the big block: a sweep is two launches per block and direction, so fewer, larger blocks shorten the launch chain of a sweep at
+    // the price of more inverse-block traffic (np * bb * 8 B per direction); hook sweep_block forces it (tests, the sweep)
+    // measured (profiles/r06/as_sweep_block.txt, dense ActiveSet to 'optimal'): n = 20 000 9.91 / 9.16 / 9.07 / 10.18 s and n = 50 000
+    // 79.2 / 72.2 / 70.6 / 73.5 s with 1024 / 2048 / 4096 / 8192
+    int64_t BB = ws->cap >= 8192 ? 4096 : (ws->cap >= 4096 ? 2048 : 1024);
+    {
+        double hv = 0.0;
+        if (bq_hook("sweep_block", &hv) && (hv == 1024.0 || hv == 2048.0 || hv == 4096.0 || hv == 8192.0)) BB = (int64_t)hv;
+    }
     const int64_t nbb = (np + BB - 1) / BB;
-    if (ws->big_cap < nbb) {
+    if (ws->big_cap < nbb || ws->bb != BB) {
         for (double **p : {&ws->bigM, &ws->bigMT, &ws->big_scratch, &ws->sw_t})
             if (*p) {
                 hipFree(*p);
@@ -606,13 +616,14 @@ int bq_chol_prepare_sweeps(bq_chol_ws *ws, int64_t np) {
         const int64_t want = (ws->cap + BB - 1) / BB;
         BQ_HIP(hipMalloc(&ws->bigM, sizeof(double) * want * BB * BB));
         BQ_HIP(hipMalloc(&ws->bigMT, sizeof(double) * want * BB * BB));
-        BQ_HIP(hipMalloc(&ws->big_scratch, sizeof(double) * want * 8 * NB * NB));
+        BQ_HIP(hipMalloc(&ws->big_scratch, sizeof(double) * want * (BB / NB) * NB * NB));
         BQ_HIP(hipMalloc(&ws->sw_t, sizeof(double) * BB));
         ws->big_cap = want;
+        ws->bb = BB;
     }
     BQ_HIP(hipMemsetAsync(ws->bigM, 0, sizeof(double) * nbb * BB * BB, st));
-    big_inverse_kernel<<<dim3(8, (unsigned)nbb), 256, 0, st>>>(ws->H, ws->ldh, np, ws->LinvT, ws->bigM, ws->big_scratch);
-    big_transpose_kernel<<<dim3(32, 32, (unsigned)nbb), 256, 0, st>>>(ws->bigM, ws->bigMT);
+    big_inverse_kernel<<<dim3((unsigned)(BB / NB), (unsigned)nbb), 256, 0, st>>>(ws->H, ws->ldh, np, BB, ws->LinvT, ws->bigM, ws->big_scratch);
+    big_transpose_kernel<<<dim3((unsigned)(BB / 32), (unsigned)(BB / 32), (unsigned)nbb), 256, 0, st>>>(ws->bigM, ws->bigMT, BB);
     mirror_lower_kernel<<<dim3((unsigned)(np / 32), (unsigned)(np / 32)), 256, 0, st>>>(ws->H, ws->ldh, np);
     BQ_HIP(hipGetLastError());
     ws->sweep_np = np;
@@ -621,6 +632,7 @@ int bq_chol_prepare_sweeps(bq_chol_ws *ws, int64_t np) {
 
 static int chol_solve_fast(bq_chol_ws *ws, int64_t np, int64_t first_nonzero, double *also) {
     hipStream_t st = ws->ctx->stream;
+    const int64_t BB = ws->bb;
     const int64_t ldh = ws->ldh, nbb = (np + BB - 1) / BB;
     auto rows_of = [&](int64_t K) { return np - K * BB < BB ? np - K * BB : BB; };
     double *rhs = ws->rhs, *t = ws->sw_t;

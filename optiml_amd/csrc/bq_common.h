@@ -45,7 +45,7 @@ void bq_set_error(const char *fmt, ...);
 // can hold it against the long way — nothing a user of the library needs (round 6: these were eighteen BQ_* variables).
 //   rows_per_step=4|8  stream_unit=U  minres_big_min=N  as_schur=0  as_schur_min=N  as_schur_limit=N  as_mailbox=0  as_f_chain=0
 //   as_cg_warm=0  as_cg_incq=0  as_cg_colq=0  as_cg_pc_incr=0  as_cg_pc_class=0..3  ip_svr_reduced=0  smo_helpers=N
-//   panel_good_gbs=G  alloc_fail_above=BYTES  decision_chunk_rows=R
+//   panel_good_gbs=G  alloc_fail_above=BYTES  decision_chunk_rows=R  sweep_block=1024|2048|4096
 // ---------------------------------------------------------------------------------------------
 bool bq_hook(const char *name, double *value);                       // true (and *value) when the hook is set
 static inline double bq_hook_value(const char *name, double dflt) {

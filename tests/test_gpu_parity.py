@@ -33,15 +33,19 @@ def _solvers():
 AS_KINDS = ['as', 'ascg']
 
 
-@pytest.fixture(params=['refactor', 'reuse'])
+@pytest.fixture(params=['refactor', 'reuse', 'reuse-block4096'])
 def as_factor_mode(request, monkeypatch):
     """The dense-factor ActiveSet either re-factorises Q[A,A] in every iteration (what the reference does) or keeps the
     factor of a base set and carries the changes through a Schur complement (csrc/bq_as.hip; the default for every non-empty
-    free set since round 4 — hook as_schur_min=0 states it).  Both must follow the reference's trajectory."""
+    free set since round 4 — hook as_schur_min=0 states it).  Both must follow the reference's trajectory.  'reuse-block4096': the
+    kept factor's sweeps with the big block large workspaces get (round 6: 4096 rows from order 8192 on; forced here, where a
+    factor is a fraction of one block)."""
     if request.param == 'reuse':
-        set_hooks(monkeypatch, as_schur_min='0')
+        set_hooks(monkeypatch, as_schur_min=0)
+    elif request.param == 'reuse-block4096':
+        set_hooks(monkeypatch, as_schur_min=0, sweep_block=4096)
     else:
-        set_hooks(monkeypatch, as_schur='0')
+        set_hooks(monkeypatch, as_schur=0)
     return request.param
 
 
